@@ -1,0 +1,958 @@
+/*
+ * paf_oracle.c -- TEST INFRASTRUCTURE ONLY (see paf_oracle.h).
+ *
+ * Scalar CPU restatement of the reference paffy hot path. Each function names
+ * the reference lines whose behaviour it restates (paths relative to
+ * /root/reference). Nothing here is shipped or called by the product path.
+ *
+ * Data model: one record = fixed numeric fields + two name slices that point
+ * into the input buffer + a window [lo, lo+n) over an array of (length, op)
+ * pairs. Lengths are kept in the reference's 56-bit signed range (wrap56).
+ */
+#include "paf_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ */
+/* small utilities                                                      */
+/* ------------------------------------------------------------------ */
+
+enum { OP_M = 0, OP_I = 1, OP_D = 2, OP_EQ = 3, OP_X = 4 }; /* inc/paf.h:52-58 */
+
+typedef struct {
+    int64_t len;
+    int32_t op;
+} oop;
+
+/* CigarRecord.length is a 56-bit signed bitfield (inc/paf.h:61-64). */
+static inline int64_t wrap56(int64_t v) { return (int64_t)((uint64_t)v << 8) >> 8; }
+
+typedef struct {
+    char *p;
+    int64_t n, cap;
+} obuf;
+
+static void ob_need(obuf *b, int64_t extra) {
+    if (b->n + extra <= b->cap) return;
+    int64_t c = b->cap ? b->cap : 4096;
+    while (c < b->n + extra) c *= 2;
+    b->p = (char *)realloc(b->p, (size_t)c);
+    b->cap = c;
+}
+static void ob_bytes(obuf *b, const char *s, int64_t n) {
+    ob_need(b, n);
+    memcpy(b->p + b->n, s, (size_t)n);
+    b->n += n;
+}
+static void ob_char(obuf *b, char c) {
+    ob_need(b, 1);
+    b->p[b->n++] = c;
+}
+/* int64_to_str, impl/paf.c:10-34: '0' for zero, '-' prefix, plain decimal. */
+static void ob_int(obuf *b, int64_t v) {
+    char tmp[24];
+    int k = 0;
+    uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+    if (u == 0) tmp[k++] = '0';
+    while (u) {
+        tmp[k++] = (char)('0' + u % 10);
+        u /= 10;
+    }
+    ob_need(b, k + 1);
+    if (v < 0) b->p[b->n++] = '-';
+    while (k) b->p[b->n++] = tmp[--k];
+}
+
+/* str_to_int64, impl/paf.c:37-48: optional '-', digits, no validation, wraps. */
+static int64_t parse_i64(const char *s, const char *e) {
+    uint64_t v = 0;
+    int neg = 0;
+    if (s < e && *s == '-') {
+        neg = 1;
+        s++;
+    }
+    while (s < e && *s >= '0' && *s <= '9') v = v * 10 + (uint64_t)(*s++ - '0');
+    return (int64_t)(neg ? (uint64_t)0 - v : v);
+}
+
+/* ------------------------------------------------------------------ */
+/* record                                                               */
+/* ------------------------------------------------------------------ */
+
+typedef struct {
+    const char *qname, *tname; /* slices (not NUL terminated) */
+    int64_t qname_len, tname_len;
+    int64_t qlen, qs, qe, tlen, ts, te;
+    int64_t nmatch, nbases, mapq;
+    int64_t score, tile_level, chain_id, chain_score;
+    int same_strand;
+    char type;
+    int has_cigar; /* parsed cigar present (non-NULL in the reference) */
+    oop *ops;      /* owned */
+    int64_t lo, n, cap;
+    const char *cg_str; /* unparsed cigar text (tile mode), NULL if no cg tag */
+    int64_t cg_str_len;
+} rec;
+
+static void rec_free(rec *r) {
+    free(r->ops);
+    r->ops = NULL;
+}
+
+static int op_code(char c) {
+    switch (c) { /* impl/paf.c:96-103 */
+        case 'M': return OP_M;
+        case '=': return OP_EQ;
+        case 'X': return OP_X;
+        case 'I': return OP_I;
+        case 'D': return OP_D;
+        default: return -1;
+    }
+}
+static char op_char(int op) { /* impl/paf.c:372-379 */
+    switch (op) {
+        case OP_M: return 'M';
+        case OP_I: return 'I';
+        case OP_D: return 'D';
+        case OP_EQ: return '=';
+        case OP_X: return 'X';
+        default: return 'N';
+    }
+}
+
+/*
+ * cigar_parse, impl/paf.c:70-111. Empty text -> no cigar (returns 0 and
+ * *present=0). Every character that is not a digit ends an op; anything
+ * outside MID=X aborts, as does a trailing digit run (the reference's switch
+ * then sees the terminating NUL).
+ */
+static int cigar_from_text(const char *s, const char *e, oop **ops_out, int64_t *n_out, int *present, int64_t *bad) {
+    *ops_out = NULL;
+    *n_out = 0;
+    *present = 0;
+    if (s == e) return PO_OK;
+    int64_t cnt = 0;
+    for (const char *c = s; c < e; c++)
+        if ((unsigned)(*c - '0') > 9u) cnt++;
+    oop *ops = (oop *)malloc(sizeof(oop) * (size_t)(cnt + 1));
+    int64_t k = 0;
+    const char *c = s;
+    while (c < e) {
+        uint64_t len = 0;
+        while (c < e && *c >= '0' && *c <= '9') len = len * 10 + (uint64_t)(*c++ - '0');
+        int op = c < e ? op_code(*c) : -1;
+        if (op < 0) {
+            *bad = c < e ? (unsigned char)*c : 0;
+            free(ops);
+            return PO_ERR_CIGAR_CHAR;
+        }
+        ops[k].len = wrap56((int64_t)len);
+        ops[k].op = op;
+        k++;
+        c++;
+    }
+    *ops_out = ops;
+    *n_out = k;
+    *present = 1;
+    return PO_OK;
+}
+
+/*
+ * paf_parse, impl/paf.c:137-209, on the byte range [p, e) of one line.
+ * strtok_r(.., "\t") semantics: tokens are maximal runs of non-tab bytes.
+ * Deviation (documented): a tag token shorter than 5 bytes is never
+ * recognised; the reference would read past the token terminator there.
+ */
+static int parse_line(const char *p, const char *e, int parse_cigar, rec *r, int64_t *aux) {
+    memset(r, 0, sizeof(*r));
+    r->tile_level = -1;
+    r->chain_id = -1;
+    r->chain_score = -1;
+    int field = 0;
+    const char *c = p;
+    for (;;) {
+        while (c < e && *c == '\t') c++;
+        if (c >= e) break;
+        const char *t = c;
+        while (c < e && *c != '\t') c++;
+        const char *te = c;
+        switch (field) {
+            case 0: r->qname = t; r->qname_len = te - t; break;
+            case 1: r->qlen = parse_i64(t, te); break;
+            case 2: r->qs = parse_i64(t, te); break;
+            case 3: r->qe = parse_i64(t, te); break;
+            case 4:
+                if (*t != '+' && *t != '-') {
+                    *aux = (unsigned char)*t;
+                    return PO_ERR_STRAND;
+                }
+                r->same_strand = *t == '+';
+                break;
+            case 5: r->tname = t; r->tname_len = te - t; break;
+            case 6: r->tlen = parse_i64(t, te); break;
+            case 7: r->ts = parse_i64(t, te); break;
+            case 8: r->te = parse_i64(t, te); break;
+            case 9: r->nmatch = parse_i64(t, te); break;
+            case 10: r->nbases = parse_i64(t, te); break;
+            case 11: r->mapq = parse_i64(t, te); break;
+            default: {
+                if (te - t < 5 || t[2] != ':' || t[4] != ':') break;
+                const char *v = t + 5;
+                if (t[0] == 't' && t[1] == 'p') {
+                    r->type = v < te ? *v : '\0';
+                    if (r->type != 'P' && r->type != 'S' && r->type != 'I') {
+                        *aux = (unsigned char)r->type;
+                        return PO_ERR_TP_ASSERT;
+                    }
+                } else if (t[0] == 'A' && t[1] == 'S') {
+                    r->score = parse_i64(v, te);
+                } else if (t[0] == 'c' && t[1] == 'g') {
+                    if (parse_cigar) {
+                        free(r->ops); /* duplicate tag: last one wins (impl/paf.c:193-198) */
+                        r->ops = NULL;
+                        int rc = cigar_from_text(v, te, &r->ops, &r->n, &r->has_cigar, aux);
+                        r->lo = 0;
+                        r->cap = r->n;
+                        if (rc) return rc;
+                    } else {
+                        r->cg_str = v;
+                        r->cg_str_len = te - v;
+                    }
+                } else if (t[0] == 't' && t[1] == 'l') {
+                    r->tile_level = parse_i64(v, te);
+                } else if (t[0] == 'c' && t[1] == 'n') {
+                    r->chain_id = parse_i64(v, te);
+                } else if (t[0] == 's' && t[1] == '1') {
+                    r->chain_score = parse_i64(v, te);
+                }
+            }
+        }
+        field++;
+    }
+    if (field < 12) return PO_ERR_FEW_FIELDS;
+    return PO_OK;
+}
+
+/* paf_write_to_buffer, impl/paf.c:317-389 (grammar: SURVEY Appendix B). */
+static void write_rec(const rec *r, obuf *b) {
+    ob_bytes(b, r->qname, r->qname_len);
+    ob_char(b, '\t');
+    ob_int(b, r->qlen); ob_char(b, '\t');
+    ob_int(b, r->qs); ob_char(b, '\t');
+    ob_int(b, r->qe); ob_char(b, '\t');
+    ob_char(b, r->same_strand ? '+' : '-'); ob_char(b, '\t');
+    ob_bytes(b, r->tname, r->tname_len);
+    ob_char(b, '\t');
+    ob_int(b, r->tlen); ob_char(b, '\t');
+    ob_int(b, r->ts); ob_char(b, '\t');
+    ob_int(b, r->te); ob_char(b, '\t');
+    ob_int(b, r->nmatch); ob_char(b, '\t');
+    ob_int(b, r->nbases); ob_char(b, '\t');
+    ob_int(b, r->mapq);
+    if (r->type != '\0' || r->tile_level != -1) {
+        char t = r->type;
+        if (t == '\0') t = r->tile_level > 1 ? 'S' : 'P';
+        ob_bytes(b, "\ttp:A:", 6);
+        ob_char(b, t);
+    }
+    /* score != INT_MAX is the only guard (impl/paf.c:349): AS is always written */
+    if (r->score != 2147483647LL) {
+        ob_bytes(b, "\tAS:i:", 6);
+        ob_int(b, r->score);
+    }
+    if (r->tile_level != -1) { ob_bytes(b, "\ttl:i:", 6); ob_int(b, r->tile_level); }
+    if (r->chain_id != -1) { ob_bytes(b, "\tcn:i:", 6); ob_int(b, r->chain_id); }
+    if (r->chain_score != -1) { ob_bytes(b, "\ts1:i:", 6); ob_int(b, r->chain_score); }
+    if (r->has_cigar) {
+        ob_bytes(b, "\tcg:Z:", 6);
+        for (int64_t i = 0; i < r->n; i++) {
+            ob_int(b, r->ops[r->lo + i].len);
+            ob_char(b, op_char(r->ops[r->lo + i].op));
+        }
+    } else if (r->cg_str) {
+        ob_bytes(b, "\tcg:Z:", 6);
+        ob_bytes(b, r->cg_str, r->cg_str_len);
+    }
+    ob_char(b, '\n');
+}
+
+/* paf_check, impl/paf.c:427-461. */
+static int check_rec(const rec *r) {
+    if (r->qs < 0 || r->qs >= r->qlen) return PO_ERR_CHECK_QSTART;
+    if (r->qs > r->qe || r->qe > r->qlen) return PO_ERR_CHECK_QEND;
+    if (r->ts < 0 || r->ts >= r->tlen) return PO_ERR_CHECK_TSTART;
+    if (r->ts > r->te || r->te > r->tlen) return PO_ERR_CHECK_TEND;
+    if (r->has_cigar) {
+        int64_t i = 0, j = 0;
+        for (int64_t k = 0; k < r->n; k++) {
+            const oop *o = &r->ops[r->lo + k];
+            if (o->op != OP_D) i += o->len;
+            if (o->op != OP_I) j += o->len;
+        }
+        if (i != r->qe - r->qs) return PO_ERR_CHECK_CIGAR_Q;
+        if (j != r->te - r->ts) return PO_ERR_CHECK_CIGAR_T;
+    }
+    return PO_OK;
+}
+
+/* paf_invert + cigar_reverse, impl/paf.c:124-135,469-490. */
+static void invert_rec(rec *r) {
+    int64_t t;
+    const char *s;
+    t = r->qs; r->qs = r->ts; r->ts = t;
+    t = r->qe; r->qe = r->te; r->te = t;
+    t = r->qlen; r->qlen = r->tlen; r->tlen = t;
+    s = r->qname; r->qname = r->tname; r->tname = s;
+    t = r->qname_len; r->qname_len = r->tname_len; r->tname_len = t;
+    if (!r->has_cigar) return;
+    for (int64_t k = 0; k < r->n; k++) {
+        oop *o = &r->ops[r->lo + k];
+        if (o->op == OP_I) o->op = OP_D;
+        else if (o->op == OP_D) o->op = OP_I;
+    }
+    if (!r->same_strand) {
+        int64_t a = r->lo, b = r->lo + r->n - 1;
+        while (a < b) {
+            oop tmp = r->ops[a];
+            r->ops[a] = r->ops[b];
+            r->ops[b] = tmp;
+            a++;
+            b--;
+        }
+    }
+}
+
+/* ---- identity trim: impl/paf.c:811-953, arithmetic per SURVEY Appendix A 13-18 ---- */
+
+/* paf_trim_unreliable_ends2, impl/paf.c:811-840 (less_than is always 1 at its call sites). */
+static int64_t trim_scan(const rec *r, int64_t *m_out, int64_t *x_out, double thr, int64_t max_trim) {
+    int64_t m = 0, x = 0, idx_found = -1;
+    for (int64_t k = 0; k < r->n; k++) {
+        const oop *o = &r->ops[r->lo + k];
+        if (o->op == OP_EQ || o->op == OP_M) m += o->len;
+        else x += o->len; /* X, I and D all count as mismatches */
+        if (max_trim >= 0 && m + x > max_trim) break;
+        volatile float fm = (float)m, fd = (float)(m + x);
+        volatile float q = fm / fd; /* float32 divide, widened afterwards (impl/paf.c:832) */
+        double pid = (double)q;
+        if (pid < thr) idx_found = k;
+    }
+    *m_out = m;
+    *x_out = x;
+    return idx_found;
+}
+
+/* paf_trim_upto, impl/paf.c:842-861. */
+static void trim_upto(rec *r, int64_t count) {
+    for (int64_t k = 0; k < count; k++) {
+        const oop *o = &r->ops[r->lo + k];
+        if (o->op != OP_I) r->ts += o->len;
+        if (o->op != OP_D) {
+            if (r->same_strand) r->qs += o->len;
+            else r->qe -= o->len;
+        }
+    }
+    r->lo += count;
+    r->n -= count;
+}
+
+/* paf_trim_unreliable_prefix, impl/paf.c:863-904: both thresholds arrive as float32. */
+static void trim_prefix(rec *r, float thr_f, float id_f, int64_t max_trim) {
+    int64_t m, x;
+    int64_t trim_idx = trim_scan(r, &m, &x, (double)thr_f, max_trim);
+    if (trim_idx < 0) return;
+    int64_t sm = 0, sx = 0, best = -1;
+    for (int64_t k = trim_idx; k >= 0; k--) {
+        const oop *o = &r->ops[r->lo + k];
+        if (o->op == OP_EQ || o->op == OP_M) sm += o->len;
+        else sx += o->len;
+        volatile float fm = (float)sm, fd = (float)(sm + sx);
+        volatile float q = fm / fd;
+        double sid = (double)q;
+        if (sid >= (double)id_f) best = k;
+    }
+    int64_t count = best >= 0 ? best : trim_idx + 1;
+    if (count > 0) trim_upto(r, count);
+}
+
+/* paf_trim_unreliable_tails, impl/paf.c:906-953. */
+static int trim_identity(rec *r, float score_fraction, float max_fraction) {
+    int64_t m, x;
+    trim_scan(r, &m, &x, 0.0, -1);
+    volatile float fm = (float)m, fd = (float)(m + x);
+    volatile float q = fm / fd;
+    double identity = (double)q;
+    volatile double prod = identity * (double)score_fraction;
+    double thr = identity - prod;
+    volatile float ft = (float)(m + x);
+    volatile float fmt = ft * max_fraction;
+    int64_t max_trim = (int64_t)fmt;
+    trim_prefix(r, (float)thr, (float)identity, max_trim);
+    invert_rec(r);
+    trim_prefix(r, (float)thr, (float)identity, max_trim);
+    invert_rec(r);
+    int64_t m2, x2;
+    trim_scan(r, &m2, &x2, 0.0, -1);
+    volatile float fm2 = (float)m2, fd2 = (float)(m2 + x2);
+    volatile float q2 = fm2 / fd2;
+    double final_identity = (double)q2;
+    if (!(final_identity >= identity)) return PO_ERR_TRIM_IDENTITY_ASSERT;
+    return PO_OK;
+}
+
+/* ---- fixed trim: impl/paf.c:507-598 ---- */
+
+static int is_aligned_op(int op) { return op == OP_M || op == OP_EQ || op == OP_X; }
+
+static int64_t aligned_bases(const rec *r) { /* impl/paf.c:507-516 */
+    int64_t a = 0;
+    for (int64_t k = 0; k < r->n; k++)
+        if (is_aligned_op(r->ops[r->lo + k].op)) a += r->ops[r->lo + k].len;
+    return a;
+}
+
+/* cigar_trim, impl/paf.c:518-545 (front == 1) and cigar_trim_back, :547-576 (front == 0). */
+static void trim_one_end(rec *r, int64_t *qc, int64_t *tc, int64_t end, int qsign, int tsign, int front) {
+    int64_t done = 0;
+    while (r->n > 0) {
+        oop *o = &r->ops[front ? r->lo : r->lo + r->n - 1];
+        int al = is_aligned_op(o->op);
+        if (al && !(done < end)) break;
+        if (al) {
+            if (done + o->len > end) {
+                int64_t i = end - done;
+                o->len = wrap56(o->len - i);
+                *qc += qsign * i;
+                *tc += tsign * i;
+                break;
+            }
+            done += o->len;
+            *qc += qsign * o->len;
+            *tc += tsign * o->len;
+        } else if (o->op == OP_I) {
+            *qc += qsign * o->len;
+        } else {
+            *tc += tsign * o->len;
+        }
+        if (front) r->lo++;
+        r->n--;
+    }
+}
+
+/* paf_trim_ends, impl/paf.c:578-587. */
+static int trim_ends(rec *r, int64_t end) {
+    if (!r->has_cigar) return PO_ERR_NULL_CIGAR; /* reference dereferences the NULL cigar */
+    if (r->same_strand) {
+        trim_one_end(r, &r->qs, &r->ts, end, 1, 1, 1);
+        trim_one_end(r, &r->qe, &r->te, end, -1, -1, 0);
+    } else {
+        trim_one_end(r, &r->qe, &r->ts, end, -1, 1, 1);
+        trim_one_end(r, &r->qs, &r->te, end, 1, -1, 0);
+    }
+    return PO_OK;
+}
+
+/* paf_trim_end_fraction, impl/paf.c:589-598. */
+static int trim_fixed(rec *r, float pct) {
+    if (!(pct >= 0 && pct <= 1.0)) return PO_ERR_TRIM_FIXED_ASSERT;
+    int64_t a = aligned_bases(r);
+    volatile float prod = (float)a * pct; /* int64 * float -> float32 multiply */
+    double half = (double)prod / 2.0;
+    int64_t end = (int64_t)half;
+    return trim_ends(r, end);
+}
+
+/* ---- mismatch encoding: impl/paf.c:739-809 ---- */
+
+/* stString_reverseComplementChar [sonLib, absent]: A<->T, C<->G in both cases; every other
+ * byte maps to itself (parity unpinned for non-ACGT letters). */
+static char rc_char(char c) {
+    switch (c) {
+        case 'A': return 'T'; case 'T': return 'A'; case 'C': return 'G'; case 'G': return 'C';
+        case 'a': return 't'; case 't': return 'a'; case 'c': return 'g'; case 'g': return 'c';
+        default: return c;
+    }
+}
+static int up(char c) { return (c >= 'a' && c <= 'z') ? c - 32 : (unsigned char)c; } /* toupper, C locale */
+
+/* paf_encode_mismatches, impl/paf.c:739-784. */
+static int encode_mismatches(rec *r, const po_seq *q, const po_seq *t) {
+    if (!r->has_cigar) return PO_OK;
+    int64_t cap = r->n * 2 + 16, out = 0;
+    oop *nw = (oop *)malloc(sizeof(oop) * (size_t)cap);
+    int64_t qi = 0, tj = r->ts;
+    for (int64_t k = 0; k < r->n; k++) {
+        const oop *o = &r->ops[r->lo + k];
+        if (o->op == OP_M) {
+            int64_t toff = tj;
+            int64_t qoff = r->same_strand ? r->qs + qi : r->qe - (qi + 1);
+            int prev = 0, first = 1;
+            for (int64_t i = 0; i < o->len; i++) {
+                int64_t tp = toff + i, qp = r->same_strand ? qoff + i : qoff - i;
+                if (tp < 0 || tp >= t->len || qp < 0 || qp >= q->len) {
+                    free(nw);
+                    return PO_ERR_SEQ_RANGE;
+                }
+                char qc = r->same_strand ? q->seq[qp] : rc_char(q->seq[qp]);
+                int is_match = up(t->seq[tp]) == up(qc);
+                if (first || is_match != prev) {
+                    if (out >= cap) {
+                        cap *= 2;
+                        nw = (oop *)realloc(nw, sizeof(oop) * (size_t)cap);
+                    }
+                    nw[out].op = is_match ? OP_EQ : OP_X;
+                    nw[out].len = 1;
+                    out++;
+                    first = 0;
+                } else {
+                    nw[out - 1].len = wrap56(nw[out - 1].len + 1);
+                }
+                prev = is_match;
+            }
+            qi += o->len;
+            tj += o->len;
+        } else {
+            if (out >= cap) {
+                cap *= 2;
+                nw = (oop *)realloc(nw, sizeof(oop) * (size_t)cap);
+            }
+            nw[out++] = *o;
+            if (o->op == OP_I) qi += o->len;
+            else if (o->op == OP_D) tj += o->len;
+            else { qi += o->len; tj += o->len; }
+        }
+    }
+    free(r->ops);
+    r->ops = nw;
+    r->lo = 0;
+    r->n = out;
+    r->cap = cap;
+    return PO_OK;
+}
+
+/* paf_remove_mismatches, impl/paf.c:786-809. */
+static void remove_mismatches(rec *r) {
+    if (!r->has_cigar) return;
+    int64_t w = 0;
+    for (int64_t k = 0; k < r->n; k++) {
+        oop o = r->ops[r->lo + k];
+        if (o.op == OP_EQ || o.op == OP_X || o.op == OP_M) {
+            if (w > 0 && r->ops[r->lo + w - 1].op == OP_M) {
+                r->ops[r->lo + w - 1].len = wrap56(r->ops[r->lo + w - 1].len + o.len);
+            } else {
+                r->ops[r->lo + w].len = o.len;
+                r->ops[r->lo + w].op = OP_M;
+                w++;
+            }
+        } else {
+            r->ops[r->lo + w] = o;
+            w++;
+        }
+    }
+    r->n = w;
+}
+
+/* ------------------------------------------------------------------ */
+/* stream driver                                                        */
+/* ------------------------------------------------------------------ */
+
+typedef struct {
+    const po_stage *stages;
+    int32_t n_stages;
+    const po_seq *seqs;
+    int64_t n_seqs;
+    obuf out;
+    po_error *err;
+    int64_t record;
+} run_ctx;
+
+static int fail(run_ctx *c, int code, int stage, int64_t aux) {
+    if (c->err) {
+        c->err->code = code;
+        c->err->stage = stage;
+        c->err->record = c->record;
+        c->err->aux = aux;
+    }
+    return code;
+}
+
+static const po_seq *find_seq(const run_ctx *c, const char *name, int64_t len) {
+    for (int64_t i = 0; i < c->n_seqs; i++)
+        if ((int64_t)strlen(c->seqs[i].name) == len && memcmp(c->seqs[i].name, name, (size_t)len) == 0) return &c->seqs[i];
+    return NULL;
+}
+
+/*
+ * What a later process sees after `paf_write | paf_parse` of this record:
+ * an empty cigar text parses to "no cigar" (impl/paf.c:71-73) and a
+ * synthesised tp letter (impl/paf.c:343-348) becomes a stored one.
+ */
+static void reparse_normalise(rec *r) {
+    if (r->has_cigar && r->n == 0) r->has_cigar = 0;
+    if (r->type == '\0' && r->tile_level != -1) r->type = r->tile_level > 1 ? 'S' : 'P';
+}
+
+static int run_from(run_ctx *c, rec *r, int32_t s);
+
+/* paf_shatter + paf_shatter2, impl/paf.c:600-663, then the driver loop impl/paf_shatter.c:88-95. */
+static int shatter_stage(run_ctx *c, rec *r, int32_t s) {
+    int64_t qc = r->same_strand ? r->qs : r->qe;
+    int64_t tc = r->ts;
+    int64_t nkids = 0, kcap = r->has_cigar ? r->n : 0;
+    rec *kids = (rec *)malloc(sizeof(rec) * (size_t)(kcap + 1));
+    int rc = PO_OK;
+    for (int64_t k = 0; r->has_cigar && k < r->n; k++) {
+        const oop *o = &r->ops[r->lo + k];
+        if (!(o->len >= 1)) { rc = PO_ERR_SHATTER_ZERO_LEN; break; }
+        if (o->op == OP_M) {
+            int64_t qstart;
+            if (r->same_strand) {
+                qstart = qc;
+                qc += o->len;
+            } else {
+                qc -= o->len;
+                qstart = qc;
+            }
+            rec *kid = &kids[nkids];
+            memset(kid, 0, sizeof(*kid)); /* calloc: chain_score stays 0, impl/paf.c:601 */
+            kid->qname = r->qname; kid->qname_len = r->qname_len;
+            kid->qlen = r->qlen; kid->qs = qstart; kid->qe = qstart + o->len;
+            kid->tname = r->tname; kid->tname_len = r->tname_len;
+            kid->tlen = r->tlen; kid->ts = tc; kid->te = tc + o->len;
+            kid->same_strand = r->same_strand;
+            kid->has_cigar = 1;
+            kid->ops = (oop *)malloc(sizeof(oop));
+            kid->ops[0].len = o->len;
+            kid->ops[0].op = OP_M;
+            kid->lo = 0; kid->n = 1; kid->cap = 1;
+            kid->score = r->score;
+            kid->mapq = r->mapq;
+            kid->nmatch = o->len;
+            kid->nbases = o->len;
+            kid->tile_level = r->tile_level;
+            kid->type = r->type;
+            kid->chain_id = r->chain_id;
+            nkids++;
+            rc = check_rec(kid);
+            if (rc) break;
+            tc += o->len;
+        } else if (o->op == OP_I) {
+            qc += r->same_strand ? o->len : -o->len;
+        } else {
+            if (o->op != OP_D) { rc = PO_ERR_SHATTER_BAD_OP; break; }
+            tc += o->len;
+        }
+    }
+    if (!rc) {
+        if (tc != r->te) rc = PO_ERR_SHATTER_END;
+        else if (r->same_strand ? qc != r->qe : qc != r->qs) rc = PO_ERR_SHATTER_END;
+    }
+    if (rc) rc = fail(c, rc, s, 0);
+    for (int64_t k = 0; k < nkids; k++) {
+        if (!rc) rc = run_from(c, &kids[k], s + 1);
+        rec_free(&kids[k]);
+    }
+    free(kids);
+    return rc;
+}
+
+static int run_from(run_ctx *c, rec *r, int32_t s) {
+    for (; s < c->n_stages; s++) {
+        const po_stage *st = &c->stages[s];
+        int rc = PO_OK;
+        if (s > 0) reparse_normalise(r);
+        switch (st->kind) {
+            case PO_INVERT:
+                invert_rec(r);
+                rc = check_rec(r);
+                break;
+            case PO_TRIM_IDENTITY:
+                rc = trim_identity(r, st->p0, st->p1);
+                if (!rc) rc = check_rec(r);
+                break;
+            case PO_TRIM_FIXED:
+                rc = trim_fixed(r, st->p1);
+                if (!rc) rc = check_rec(r);
+                break;
+            case PO_SHATTER:
+                return shatter_stage(c, r, s);
+            case PO_ADD_MISMATCHES: {
+                const po_seq *q = find_seq(c, r->qname, r->qname_len);
+                if (!q) { rc = PO_ERR_MISSING_QUERY_SEQ; break; }
+                const po_seq *t = find_seq(c, r->tname, r->tname_len);
+                if (!t) { rc = PO_ERR_MISSING_TARGET_SEQ; break; }
+                rc = encode_mismatches(r, q, t);
+                if (!rc) rc = check_rec(r);
+                break;
+            }
+            case PO_REMOVE_MISMATCHES:
+                remove_mismatches(r);
+                rc = check_rec(r);
+                break;
+            case PO_PASS:
+                break;
+            default:
+                rc = -1;
+        }
+        if (rc) return fail(c, rc, s, 0);
+    }
+    write_rec(r, &c->out);
+    return PO_OK;
+}
+
+int po_run(const po_stage *stages, int32_t n_stages, const char *in, int64_t in_len, const po_seq *seqs,
+           int64_t n_seqs, char **out, int64_t *out_len, po_error *err) {
+    run_ctx c;
+    memset(&c, 0, sizeof(c));
+    c.stages = stages;
+    c.n_stages = n_stages;
+    c.seqs = seqs;
+    c.n_seqs = n_seqs;
+    c.err = err;
+    if (err) memset(err, 0, sizeof(*err));
+    int rc = PO_OK;
+    const char *p = in, *end = in + in_len;
+    /* paf_read_with_buffer, impl/paf.c:211-218: a final line without '\n' is still a record */
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        rec r;
+        int64_t aux = 0;
+        rc = parse_line(p, le, 1, &r, &aux);
+        if (rc) {
+            fail(&c, rc, -1, aux);
+            rec_free(&r);
+            break;
+        }
+        rc = run_from(&c, &r, 0);
+        rec_free(&r);
+        if (rc) break;
+        c.record++;
+        p = nl ? nl + 1 : end;
+    }
+    *out = c.out.p;
+    *out_len = c.out.n;
+    return rc;
+}
+
+/* ------------------------------------------------------------------ */
+/* tile: impl/paf_tile.c:28-93,156-178 and impl/paf.c:675-709          */
+/* ------------------------------------------------------------------ */
+
+typedef struct {
+    const char *name;
+    int64_t name_len, length;
+    uint16_t *counts;
+} count_array;
+
+static const rec *g_sort_recs;
+/* paf_cmp_by_descending_score, impl/paf_tile.c:28-34; input index as the final key restates the
+ * stable glibc-2.35 qsort the survey ran against (parity unpinned). */
+static int cmp_rank(const void *a, const void *b) {
+    int64_t i = *(const int64_t *)a, j = *(const int64_t *)b;
+    const rec *x = &g_sort_recs[i], *y = &g_sort_recs[j];
+    if (x->chain_score != y->chain_score) return x->chain_score > y->chain_score ? -1 : 1;
+    if (x->score != y->score) return x->score > y->score ? -1 : 1;
+    return i < j ? -1 : (i > j ? 1 : 0);
+}
+
+int po_tile(const char *in, int64_t in_len, char **out, int64_t *out_len, po_error *err) {
+    run_ctx c;
+    memset(&c, 0, sizeof(c));
+    c.err = err;
+    if (err) memset(err, 0, sizeof(*err));
+    int rc = PO_OK;
+    int64_t nrec = 0, rcap = 1024;
+    rec *recs = (rec *)malloc(sizeof(rec) * (size_t)rcap);
+    const char *p = in, *end = in + in_len;
+    while (p < end) { /* read_pafs(input, 0), impl/paf.c:492-499 */
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        if (nrec == rcap) {
+            rcap *= 2;
+            recs = (rec *)realloc(recs, sizeof(rec) * (size_t)rcap);
+        }
+        int64_t aux = 0;
+        c.record = nrec;
+        rc = parse_line(p, le, 0, &recs[nrec], &aux);
+        if (rc) {
+            fail(&c, rc, -1, aux);
+            break;
+        }
+        nrec++;
+        p = nl ? nl + 1 : end;
+    }
+    int64_t *order = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nrec + 1));
+    count_array *arrs = NULL;
+    int64_t narr = 0, acap = 0;
+    int64_t *hist = (int64_t *)calloc(65536 + 2, sizeof(int64_t));
+    if (!rc) {
+        for (int64_t i = 0; i < nrec; i++) order[i] = i;
+        g_sort_recs = recs;
+        qsort(order, (size_t)nrec, sizeof(int64_t), cmp_rank);
+        for (int64_t k = 0; k < nrec && !rc; k++) {
+            rec *r = &recs[order[k]];
+            c.record = order[k];
+            if (!r->cg_str) { rc = fail(&c, PO_ERR_NULL_CIGAR, 0, 0); break; }
+            oop *ops; int64_t n; int present; int64_t aux = 0;
+            rc = cigar_from_text(r->cg_str, r->cg_str + r->cg_str_len, &ops, &n, &present, &aux);
+            if (rc) { fail(&c, rc, 0, aux); break; }
+            /* get_alignment_count_array, impl/paf.c:675-688 */
+            count_array *ca = NULL;
+            for (int64_t a = 0; a < narr; a++)
+                if (arrs[a].name_len == r->qname_len && memcmp(arrs[a].name, r->qname, (size_t)r->qname_len) == 0) { ca = &arrs[a]; break; }
+            if (!ca) {
+                if (narr == acap) { acap = acap ? acap * 2 : 64; arrs = (count_array *)realloc(arrs, sizeof(count_array) * (size_t)acap); }
+                ca = &arrs[narr++];
+                ca->name = r->qname; ca->name_len = r->qname_len; ca->length = r->qlen;
+                ca->counts = (uint16_t *)calloc((size_t)(r->qlen > 0 ? r->qlen : 1), sizeof(uint16_t));
+            } else if (ca->length != r->qlen) { free(ops); rc = fail(&c, PO_ERR_TILE_ASSERT, 0, 1); break; }
+            /* increase_alignment_level_counts, impl/paf.c:690-709: walks upward from query_start
+             * in cigar order whatever the strand; saturates at INT16_MAX-1 */
+            int64_t i = r->qs;
+            int bad = 0;
+            for (int64_t o = 0; o < n && !bad; o++) {
+                if (ops[o].op == OP_D) continue;
+                if (ops[o].op != OP_I) {
+                    for (int64_t j = 0; j < ops[o].len; j++) {
+                        int64_t pos = i + j;
+                        if (!(pos < r->qe && pos >= 0 && pos < r->qlen)) { bad = 1; break; }
+                        if (ca->counts[pos] < 32767 - 1) ca->counts[pos]++;
+                    }
+                }
+                i += ops[o].len;
+            }
+            if (bad || i != r->qe) { free(ops); rc = fail(&c, PO_ERR_TILE_ASSERT, 0, 2); break; }
+            /* get_median_alignment_level, impl/paf_tile.c:36-93 */
+            int64_t maxlev = 0, matches = 0;
+            for (int64_t q = r->qs; q < r->qe; q++) if (ca->counts[q] > maxlev) maxlev = ca->counts[q];
+            memset(hist, 0, sizeof(int64_t) * (size_t)(maxlev + 2));
+            i = r->qs;
+            for (int64_t o = 0; o < n; o++) {
+                if (ops[o].op == OP_D) continue;
+                if (ops[o].op != OP_I)
+                    for (int64_t j = 0; j < ops[o].len; j++) { hist[ca->counts[i + j]]++; matches++; }
+                i += ops[o].len;
+            }
+            int64_t level = 32767; /* matches == 0 -> INT16_MAX */
+            if (matches != 0) {
+                int64_t acc = 0, lv;
+                for (lv = 0; lv <= maxlev; lv++) {
+                    acc += hist[lv];
+                    if ((double)acc >= (double)matches / 2.0) break;
+                }
+                level = lv;
+                if (lv > maxlev || !(lv > 0)) { free(ops); rc = fail(&c, PO_ERR_TILE_ASSERT, 0, 3); break; }
+            }
+            r->tile_level = level;
+            free(ops);
+        }
+        if (!rc)
+            for (int64_t k = 0; k < nrec; k++) write_rec(&recs[order[k]], &c.out); /* write_pafs, impl/paf.c:501-505 */
+    }
+    for (int64_t a = 0; a < narr; a++) free(arrs[a].counts);
+    free(arrs);
+    free(hist);
+    free(order);
+    free(recs);
+    *out = c.out.p;
+    *out_len = c.out.n;
+    return rc;
+}
+
+void po_free(void *p) { free(p); }
+
+int po_error_exit_status(int32_t code) {
+    switch (code) {
+        case PO_OK: return 0;
+        case PO_ERR_STRAND: case PO_ERR_CIGAR_CHAR:
+        case PO_ERR_CHECK_QSTART: case PO_ERR_CHECK_QEND: case PO_ERR_CHECK_TSTART: case PO_ERR_CHECK_TEND:
+        case PO_ERR_CHECK_CIGAR_Q: case PO_ERR_CHECK_CIGAR_T:
+        case PO_ERR_MISSING_QUERY_SEQ: case PO_ERR_MISSING_TARGET_SEQ:
+            return 1; /* st_errAbort / exit(1) */
+        case PO_ERR_FEW_FIELDS: case PO_ERR_NULL_CIGAR: case PO_ERR_SEQ_RANGE:
+            return 139; /* NULL / wild dereference in the reference */
+        default:
+            return 134; /* assert -> abort() */
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* library-level probes for the known-answer tests                      */
+/* ------------------------------------------------------------------ */
+
+int64_t po_cigar_parse(const char *cigar, int64_t *lens, int32_t *ops, int64_t cap) {
+    oop *o; int64_t n; int present; int64_t bad = 0;
+    int rc = cigar_from_text(cigar, cigar + strlen(cigar), &o, &n, &present, &bad);
+    if (rc) return -2;
+    if (!present) return -1;
+    for (int64_t i = 0; i < n && i < cap; i++) { lens[i] = o[i].len; ops[i] = o[i].op; }
+    free(o);
+    return n;
+}
+
+int po_cigar_stats(const char *cigar, int64_t *s, int zero_counts) {
+    oop *o; int64_t n; int present; int64_t bad = 0;
+    int rc = cigar_from_text(cigar, cigar + strlen(cigar), &o, &n, &present, &bad);
+    if (rc) return rc;
+    if (zero_counts) memset(s, 0, sizeof(int64_t) * 6);
+    for (int64_t i = 0; i < n; i++) { /* paf_stats_calc, impl/paf.c:236-260 */
+        if (o[i].op == OP_EQ || o[i].op == OP_M) s[0] += o[i].len;
+        else if (o[i].op == OP_X) s[1] += o[i].len;
+        else if (o[i].op == OP_I) { s[2]++; s[4] += o[i].len; }
+        else { s[3]++; s[5] += o[i].len; }
+    }
+    free(o);
+    return PO_OK;
+}
+
+int64_t po_cigar_aligned_bases(const char *cigar) {
+    rec r;
+    memset(&r, 0, sizeof(r));
+    int64_t bad = 0;
+    if (cigar_from_text(cigar, cigar + strlen(cigar), &r.ops, &r.n, &r.has_cigar, &bad)) return -1;
+    int64_t a = aligned_bases(&r);
+    rec_free(&r);
+    return a;
+}
+
+int po_trim_ends_line(const char *line, int64_t line_len, int64_t end_bases, char **out, int64_t *out_len) {
+    rec r; int64_t aux = 0;
+    const char *e = line + line_len;
+    if (line_len && e[-1] == '\n') e--;
+    int rc = parse_line(line, e, 1, &r, &aux);
+    obuf b = {0, 0, 0};
+    if (!rc) rc = trim_ends(&r, end_bases);
+    if (!rc) write_rec(&r, &b);
+    rec_free(&r);
+    *out = b.p;
+    *out_len = b.n;
+    return rc;
+}
+
+int64_t po_coverage_counts(const char *in, int64_t in_len, const char *name, uint16_t *counts, int64_t len) {
+    const char *p = in, *end = in + in_len;
+    int64_t applied = 0, nl_name = (int64_t)strlen(name);
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        rec r; int64_t aux = 0;
+        if (parse_line(p, le, 1, &r, &aux) == PO_OK && r.qname_len == nl_name && memcmp(r.qname, name, (size_t)nl_name) == 0 &&
+            r.qlen == len) {
+            int64_t i = r.qs;
+            for (int64_t o = 0; o < r.n; o++) {
+                const oop *op = &r.ops[r.lo + o];
+                if (op->op == OP_D) continue;
+                if (op->op != OP_I)
+                    for (int64_t j = 0; j < op->len; j++)
+                        if (i + j >= 0 && i + j < len && counts[i + j] < 32767 - 1) counts[i + j]++;
+                i += op->len;
+            }
+            applied++;
+        }
+        rec_free(&r);
+        p = nl ? nl + 1 : end;
+    }
+    return applied;
+}

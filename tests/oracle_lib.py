@@ -1,0 +1,133 @@
+"""ctypes binding of oracle/libpaf_oracle.so -- the CPU checker (test infrastructure only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "libpaf_oracle.so")
+
+INVERT, TRIM_IDENTITY, TRIM_FIXED, SHATTER, ADD_MISMATCHES, REMOVE_MISMATCHES, PASS = 1, 2, 3, 4, 5, 6, 7
+
+
+class Stage(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("p0", C.c_float), ("p1", C.c_float)]
+
+
+class Seq(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("seq", C.c_char_p), ("len", C.c_int64)]
+
+
+class Error(C.Structure):
+    _fields_ = [("code", C.c_int32), ("stage", C.c_int32), ("record", C.c_int64), ("aux", C.c_int64)]
+
+
+def build(force=False):
+    src = [os.path.join(ORACLE_DIR, f) for f in ("paf_oracle.c", "paf_oracle.h")]
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        L.po_run.restype = C.c_int
+        L.po_run.argtypes = [C.POINTER(Stage), C.c_int32, C.c_char_p, C.c_int64, C.POINTER(Seq), C.c_int64,
+                             C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(Error)]
+        L.po_tile.restype = C.c_int
+        L.po_tile.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(Error)]
+        L.po_free.argtypes = [C.c_void_p]
+        L.po_error_exit_status.argtypes = [C.c_int32]
+        L.po_cigar_parse.restype = C.c_int64
+        L.po_cigar_parse.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int64]
+        L.po_cigar_stats.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.c_int]
+        L.po_cigar_aligned_bases.restype = C.c_int64
+        L.po_cigar_aligned_bases.argtypes = [C.c_char_p]
+        L.po_trim_ends_line.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.po_coverage_counts.restype = C.c_int64
+        L.po_coverage_counts.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.POINTER(C.c_uint16), C.c_int64]
+        _lib = L
+    return _lib
+
+
+def stage(kind, p0=0.05, p1=1.0):
+    """p0 = trim -r (trimIdentity, default 0.05), p1 = trim -t (trimFraction, default 1.0)."""
+    return Stage(kind, p0, p1)
+
+
+def _take(ptr, n):
+    data = C.string_at(ptr, n.value) if ptr.value else b""
+    if ptr.value:
+        lib().po_free(ptr)
+    return data
+
+
+def run(stages, data, seqs=None):
+    """Apply a chain of stream commands; returns (output bytes, Error)."""
+    L = lib()
+    arr = (Stage * max(1, len(stages)))(*stages)
+    sarr, ns = None, 0
+    keep = []
+    if seqs:
+        ns = len(seqs)
+        sarr = (Seq * ns)()
+        for i, (name, seq) in enumerate(seqs.items()):
+            nb = name if isinstance(name, bytes) else name.encode()
+            sb = seq if isinstance(seq, bytes) else seq.encode()
+            keep += [nb, sb]
+            sarr[i] = Seq(nb, sb, len(sb))
+    out, n, err = C.c_void_p(), C.c_int64(), Error()
+    L.po_run(arr, len(stages), data, len(data), sarr, ns, C.byref(out), C.byref(n), C.byref(err))
+    return _take(out, n), err
+
+
+def tile(data):
+    L = lib()
+    out, n, err = C.c_void_p(), C.c_int64(), Error()
+    L.po_tile(data, len(data), C.byref(out), C.byref(n), C.byref(err))
+    return _take(out, n), err
+
+
+def exit_status(code):
+    return lib().po_error_exit_status(code)
+
+
+def cigar_parse(text):
+    cap = max(16, len(text))
+    lens, ops = (C.c_int64 * cap)(), (C.c_int32 * cap)()
+    n = lib().po_cigar_parse(text.encode() if isinstance(text, str) else text, lens, ops, cap)
+    if n < 0:
+        return n
+    return [(ops[i], lens[i]) for i in range(n)]
+
+
+def cigar_stats(text, acc=None, zero=True):
+    s = (C.c_int64 * 6)(*(acc or [0] * 6))
+    rc = lib().po_cigar_stats(text.encode(), s, 1 if zero else 0)
+    assert rc == 0
+    return list(s)
+
+
+def aligned_bases(text):
+    return lib().po_cigar_aligned_bases(text.encode())
+
+
+def trim_ends_line(line, end_bases):
+    out, n = C.c_void_p(), C.c_int64()
+    rc = lib().po_trim_ends_line(line, len(line), end_bases, C.byref(out), C.byref(n))
+    return rc, _take(out, n)
+
+
+def coverage_counts(data, name, length):
+    counts = (C.c_uint16 * length)()
+    applied = lib().po_coverage_counts(data, len(data), name.encode(), counts, length)
+    return applied, list(counts)

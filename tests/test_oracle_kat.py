@@ -1,0 +1,207 @@
+"""Pins the CPU oracle to the reference's own known-answer tests.
+
+Every case restates one test of /root/reference/tests/paf_unit_test.c (lines cited) at the
+text level: the record the reference test builds with make_paf()/parse_str() is written as a
+PAF line, pushed through the oracle, and compared with the line paf_write would give for the
+fields the reference test asserts (SURVEY.md Appendix B grammar: AS:i:<n> is always written).
+"""
+import oracle_lib as O
+
+S = O.stage
+M, I, D, EQ, X = 0, 1, 2, 3, 4
+
+
+def line(q, qlen, qs, qe, strand, t, tlen, ts, te, nm, nb, mq, cigar=None, tags=""):
+    s = f"{q}\t{qlen}\t{qs}\t{qe}\t{strand}\t{t}\t{tlen}\t{ts}\t{te}\t{nm}\t{nb}\t{mq}"
+    if tags:
+        s += "\t" + tags
+    if cigar is not None:
+        s += "\tcg:Z:" + cigar
+    return (s + "\n").encode()
+
+
+def out_line(q, qlen, qs, qe, strand, t, tlen, ts, te, nm, nb, mq, cigar=None, tags="AS:i:0"):
+    return line(q, qlen, qs, qe, strand, t, tlen, ts, te, nm, nb, mq, cigar, tags)
+
+
+def run1(stages, data, seqs=None):
+    out, err = O.run(stages, data, seqs)
+    assert err.code == 0, (err.code, err.stage, err.record)
+    return out
+
+
+# ---- 1/2. cigar parsing, paf_unit_test.c:51-106 ----
+def test_cigar_parse():
+    assert O.cigar_parse("") == -1  # NULL
+    assert O.cigar_parse("10M") == [(M, 10)]
+    assert O.cigar_parse("5M3I2D4=1X") == [(M, 5), (I, 3), (D, 2), (EQ, 4), (X, 1)]
+    assert O.cigar_parse("1000000M") == [(M, 1000000)]
+    assert O.cigar_parse("3M2I") == [(M, 3), (I, 2)]
+
+
+# ---- 3. paf_parse, paf_unit_test.c:110-182 ----
+def test_parse_minimal():
+    src = b"query1\t100\t0\t50\t+\ttarget1\t200\t10\t60\t50\t50\t255"
+    assert run1([S(O.PASS)], src) == src + b"\tAS:i:0\n"  # no cigar, no cg tag
+
+
+def test_parse_with_cigar_and_tags():
+    src = line("q1", 100, 0, 8, "+", "t1", 200, 0, 7, 8, 10, 60, "5M3I2D")
+    assert run1([S(O.PASS)], src) == out_line("q1", 100, 0, 8, "+", "t1", 200, 0, 7, 8, 10, 60, "5M3I2D")
+    src = line("q1", 100, 0, 50, "+", "t1", 200, 0, 50, 50, 50, 60, None, "tp:A:P\tAS:i:42\ttl:i:2\tcn:i:5\ts1:i:100")
+    assert run1([S(O.PASS)], src) == src
+    # tag order on output is fixed whatever the input order (impl/paf.c:343-385)
+    shuffled = line("q1", 100, 0, 50, "+", "t1", 200, 0, 50, 50, 50, 60, None, "s1:i:100\tcn:i:5\ttl:i:2\tAS:i:42\ttp:A:P")
+    assert run1([S(O.PASS)], shuffled) == src
+
+
+def test_parse_strand():
+    for st in "+-":
+        src = line("q1", 100, 0, 50, st, "t1", 200, 0, 50, 50, 50, 60)
+        assert run1([S(O.PASS)], src).split(b"\t")[4] == st.encode()
+
+
+# ---- 4. print(parse(print(parse(x)))) == print(parse(x)), paf_unit_test.c:186-230 ----
+def test_roundtrip_idempotent():
+    for src in (b"query1\t100\t0\t50\t+\ttarget1\t200\t10\t60\t50\t50\t255\n",
+                line("q1", 100, 0, 8, "+", "t1", 200, 0, 7, 8, 10, 60, "5M3I2D")):
+        once = run1([S(O.PASS)], src)
+        assert run1([S(O.PASS)], once) == once
+
+
+# ---- 5. file I/O, paf_unit_test.c:234-291 ----
+def test_read_three_records_then_eof():
+    src = (b"q1\t100\t0\t50\t+\tt1\t200\t0\t50\t50\t50\t60\n"
+           b"q2\t200\t10\t60\t-\tt2\t300\t20\t70\t50\t50\t30\n"
+           b"q3\t150\t5\t55\t+\tt3\t250\t15\t65\t50\t50\t40\n")
+    out = run1([S(O.PASS)], src).splitlines()
+    assert len(out) == 3
+    assert [l.split(b"\t")[0] for l in out] == [b"q1", b"q2", b"q3"]
+    assert out[1].split(b"\t")[4] == b"-" and out[2].split(b"\t")[2] == b"5"
+    # a final line without '\n' is still a record and is written with one (impl/paf.c:213,387)
+    assert run1([S(O.PASS)], src[:-1]).splitlines() == out
+
+
+# ---- 6. paf_stats_calc, paf_unit_test.c:295-330 ----
+def test_stats():
+    assert O.cigar_stats("10M") == [10, 0, 0, 0, 0, 0]
+    assert O.cigar_stats("3=2X1I2D") == [3, 2, 1, 1, 1, 2]
+    acc = O.cigar_stats("5M", O.cigar_stats("5M", zero=False), zero=False)
+    assert acc[0] == 10
+    assert O.cigar_stats("5M", acc, zero=True)[0] == 5
+
+
+# ---- 7. paf_invert, paf_unit_test.c:334-393 ----
+def test_invert():
+    src = line("query", 100, 10, 18, "+", "target", 200, 20, 27, 8, 10, 60, "5M3I2D")
+    assert run1([S(O.INVERT)], src) == out_line("target", 200, 20, 27, "+", "query", 100, 10, 18, 8, 10, 60, "5M3D2I")
+    src = line("query", 100, 10, 18, "-", "target", 200, 20, 25, 5, 8, 60, "5M3I")
+    assert run1([S(O.INVERT)], src) == out_line("target", 200, 20, 25, "-", "query", 100, 10, 18, 5, 8, 60, "3D5M")
+    src = line("query", 100, 10, 18, "+", "target", 200, 20, 27, 8, 10, 60, "5M3I2D")
+    assert run1([S(O.INVERT), S(O.INVERT)], src) == run1([S(O.PASS)], src)
+
+
+# ---- 8. aligned bases, paf_unit_test.c:397-403 ----
+def test_aligned_bases():
+    assert O.aligned_bases("5M3I2D4=1X") == 10
+
+
+# ---- 9. trimming, paf_unit_test.c:407-456 ----
+def test_trim_ends():
+    rc, out = O.trim_ends_line(line("q", 100, 5, 15, "+", "t", 100, 5, 15, 10, 10, 60, "10M"), 0)
+    assert rc == 0 and out == out_line("q", 100, 5, 15, "+", "t", 100, 5, 15, 10, 10, 60, "10M")
+    rc, out = O.trim_ends_line(line("q", 100, 0, 10, "+", "t", 100, 0, 10, 10, 10, 60, "10M"), 2)
+    assert rc == 0 and out == out_line("q", 100, 2, 8, "+", "t", 100, 2, 8, 10, 10, 60, "6M")
+    rc, out = O.trim_ends_line(line("q", 100, 0, 8, "+", "t", 100, 0, 7, 7, 8, 60, "2M1I5M"), 3)
+    assert rc == 0 and out == out_line("q", 100, 4, 5, "+", "t", 100, 3, 4, 7, 8, 60, "1M")
+
+
+def test_trim_end_fraction():
+    src = line("q", 100, 0, 10, "+", "t", 100, 0, 10, 10, 10, 60, "10M")
+    assert run1([S(O.TRIM_FIXED, 0.05, 0.4)], src) == out_line("q", 100, 2, 8, "+", "t", 100, 2, 8, 10, 10, 60, "6M")
+
+
+# ---- 10. shatter, paf_unit_test.c:460-521 (+ Appendix A-12: children carry s1:i:0) ----
+def test_shatter():
+    kid = lambda qs, qe, st, ts, te, L: out_line("q", 100, qs, qe, st, "t", 100, ts, te, L, L, 60, f"{L}M", "AS:i:0\ts1:i:0")
+    assert run1([S(O.SHATTER)], line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M")) == kid(0, 5, "+", 0, 5, 5)
+    assert run1([S(O.SHATTER)], line("q", 100, 0, 7, "+", "t", 100, 0, 9, 7, 9, 60, "3M2D4M")) == \
+        kid(0, 3, "+", 0, 3, 3) + kid(3, 7, "+", 5, 9, 4)
+    assert run1([S(O.SHATTER)], line("q", 100, 0, 7, "-", "t", 100, 0, 9, 7, 9, 60, "3M2D4M")) == \
+        kid(4, 7, "-", 0, 3, 3) + kid(0, 4, "-", 5, 9, 4)
+
+
+# ---- 11. mismatch encoding, paf_unit_test.c:525-572 ----
+def test_encode_and_remove_mismatches():
+    enc = lambda q, t, nm, L: run1([S(O.ADD_MISMATCHES)], line("q", L, 0, L, "+", "t", L, 0, L, nm, L, 60, f"{L}M"), {"q": q, "t": t})
+    assert enc("AAAAA", "AAAAA", 5, 5) == out_line("q", 5, 0, 5, "+", "t", 5, 0, 5, 5, 5, 60, "5=")
+    assert enc("AAAAA", "CCCCC", 0, 5) == out_line("q", 5, 0, 5, "+", "t", 5, 0, 5, 0, 5, 60, "5X")
+    assert enc("AATT", "AACC", 2, 4) == out_line("q", 4, 0, 4, "+", "t", 4, 0, 4, 2, 4, 60, "2=2X")
+    src = line("q", 100, 0, 6, "+", "t", 100, 0, 5, 5, 6, 60, "3=2X1I")
+    assert run1([S(O.REMOVE_MISMATCHES)], src) == out_line("q", 100, 0, 6, "+", "t", 100, 0, 5, 5, 6, 60, "5M1I")
+
+
+# ---- 12. coverage counters, paf_unit_test.c:576-603 ----
+def test_coverage_counts():
+    applied, counts = O.coverage_counts(line("seq1", 10, 2, 5, "+", "t", 100, 0, 3, 3, 3, 60, "3M"), "seq1", 10)
+    assert applied == 1 and counts == [0, 0, 1, 1, 1, 0, 0, 0, 0, 0]
+
+
+# ---- 14. paf_trim_unreliable_tails, paf_unit_test.c:634-687 ----
+def test_trim_unreliable_tails():
+    src = line("q", 9, 0, 9, "-", "t", 9, 0, 9, 5, 9, 60, "2X5=2X")
+    assert run1([S(O.TRIM_IDENTITY, 0.0, 1.0)], src) == out_line("q", 9, 2, 7, "-", "t", 9, 2, 7, 5, 9, 60, "5=")
+    src = line("q", 9, 0, 9, "+", "t", 9, 0, 9, 5, 9, 60, "2X5=2X")
+    assert run1([S(O.TRIM_IDENTITY, 1.0, 1.0)], src) == out_line("q", 9, 0, 9, "+", "t", 9, 0, 9, 5, 9, 60, "2X5=2X")
+    src = line("q", 9, 0, 7, "-", "t", 9, 0, 7, 5, 7, 60, "2X5=")
+    assert run1([S(O.TRIM_IDENTITY, 0.0, 1.0)], src) == out_line("q", 9, 0, 5, "-", "t", 9, 2, 7, 5, 7, 60, "5=")
+    # a '+' record has its prefix trimmed twice and its suffix never
+    src = line("q", 9, 0, 9, "+", "t", 9, 0, 9, 5, 9, 60, "2X5=2X")
+    assert run1([S(O.TRIM_IDENTITY, 0.0, 1.0)], src) == out_line("q", 9, 2, 9, "+", "t", 9, 2, 9, 5, 9, 60, "5=2X")
+
+
+# ---- 16. paf_check positive path, paf_unit_test.c:705-731 (invert's driver calls paf_check) ----
+def test_check_valid_records():
+    for src in (line("q", 100, 0, 50, "+", "t", 200, 10, 60, 50, 50, 60),
+                line("q", 100, 0, 50, "-", "t", 200, 10, 60, 50, 50, 60),
+                line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5="),
+                line("q", 100, 0, 6, "+", "t", 100, 0, 7, 5, 8, 60, "3=2X1I2D")):
+        _, err = O.run([S(O.INVERT), S(O.INVERT)], src)
+        assert err.code == 0
+
+
+# ---- error behaviour read off the reference sources ----
+def test_error_paths():
+    ok = line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M")
+    cases = [
+        (b"q\t100\t0\t5\t*\tt\t100\t0\t5\t5\t5\t60\n", [S(O.PASS)], 2, 1),            # bad strand -> st_errAbort
+        (line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M", "tp:A:i"), [S(O.PASS)], 3, 134),  # tp assert
+        (line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M2S"), [S(O.PASS)], 4, 1),  # bad cigar char
+        (line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M3"), [S(O.PASS)], 4, 1),   # trailing digits
+        (line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5="), [S(O.SHATTER)], 12, 134),
+        (line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "0M5M"), [S(O.SHATTER)], 11, 134),
+        (line("q", 100, 0, 6, "+", "t", 100, 0, 5, 5, 5, 60, "5M"), [S(O.SHATTER)], 13, 134),
+        (line("q", 100, 0, 6, "+", "t", 100, 0, 5, 5, 5, 60, "5M"), [S(O.INVERT)], 10, 1),
+        (b"q\t100\t0\t5\t+\tt\t100\t0\n", [S(O.PASS)], 1, 139),
+        (b"\n", [S(O.PASS)], 1, 139),
+    ]
+    for src, stages, code, status in cases:
+        out, err = O.run(stages, ok + src + ok)
+        assert err.code == code and err.record == 1, (src, err.code)
+        assert O.exit_status(err.code) == status
+        assert out == O.run(stages, ok)[0]  # the records before the failing one were written
+
+
+def test_writer_quirks():
+    # every unknown tag is dropped, AS:i:0 appears when AS is absent (Appendix A-4, A-8)
+    src = line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M", "NM:i:3\tms:i:9\tde:f:0.01\tzd:i:3")
+    assert run1([S(O.PASS)], src) == out_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M")
+    # consecutive tabs collapse (strtok_r) and an empty cg:Z: yields no cg tag (A-1, A-6)
+    src = b"q\t\t100\t0\t5\t+\tt\t100\t0\t5\t5\t5\t60\t\tcg:Z:\n"
+    assert run1([S(O.PASS)], src) == out_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60)
+    # tl without tp synthesises tp from the level (A-9); shatter children inherit tp/AS/tl/cn, not s1 (A-12)
+    src = line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M", "tl:i:2\ts1:i:99\tcn:i:4\tAS:i:7")
+    assert run1([S(O.SHATTER)], src) == out_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M", "tp:A:S\tAS:i:7\ttl:i:2\tcn:i:4\ts1:i:0")
+    # negative and duplicate tags: last cg wins (A-7)
+    src = line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, None, "AS:i:-12\tcg:Z:9M\tcg:Z:5M")
+    assert run1([S(O.PASS)], src) == out_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M", "AS:i:-12")
