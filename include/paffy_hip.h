@@ -1,0 +1,152 @@
+/*
+ * paffy_hip.h -- C-ABI of the MI355X (gfx950) PAF hot path.
+ *
+ * Boundary: the reference has no FFI; its hot path is the per-command loop
+ *     while ((paf = paf_read_with_buffer(..)) != NULL) { <transform>; paf_check; paf_write_with_buffer; }
+ * in impl/paf_{shatter,invert,trim,add_mismatches}.c and the whole-file body of
+ * impl/paf_tile.c. Each entry point below replaces that loop for a whole batch of PAF text
+ * at once; the host drivers (host/paffy_*.c, same `paffy <cmd>` CLI and flags) call nothing
+ * else. Signatures are plain pointers and sizes: no HIP or torch types.
+ *
+ * Data stays text at the boundary (the PAF line grammar of impl/paf.c:317-389 is the wire
+ * format between paffy processes), so a batch is: device pointer to '\n'-separated lines in,
+ * device pointer to the output lines out, byte-exact to what the reference command(s) write.
+ *
+ * Two-phase protocol, mirroring paf_estimate_buffer_size -> realloc -> paf_write_to_buffer
+ * (impl/paf.c:391-406): paffy_hip_plan() parses and transforms the batch and reports the exact
+ * output size and the first failing record; paffy_hip_emit() writes the bytes.
+ */
+#ifndef PAFFY_HIP_H_
+#define PAFFY_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct paffy_hip_ctx paffy_hip_ctx;
+
+/* One stage = one reference command in a `paffy a | paffy b | ...` chain. */
+enum {
+    PAFFY_INVERT = 1,            /* impl/paf_invert.c:84-89: paf_invert, paf_check, write            */
+    PAFFY_TRIM_IDENTITY = 2,     /* impl/paf_trim.c:117-119: paf_trim_unreliable_tails(p0=-r, p1=-t)  */
+    PAFFY_TRIM_FIXED = 3,        /* impl/paf_trim.c:120-122: paf_trim_end_fraction(p1=-t)             */
+    PAFFY_SHATTER = 4,           /* impl/paf_shatter.c:88-95: paf_shatter, write each block (last stage only) */
+    PAFFY_ADD_MISMATCHES = 5,    /* impl/paf_add_mismatches.c:113-131: paf_encode_mismatches          */
+    PAFFY_REMOVE_MISMATCHES = 6, /* impl/paf_add_mismatches.c:110-112: paf_remove_mismatches          */
+    PAFFY_PASS = 7               /* paf_read -> paf_write only (normalises tags, impl/paf.c:317-389)  */
+};
+#define PAFFY_MAX_STAGES 8
+
+typedef struct {
+    int32_t kind;
+    float p0; /* trim: trim_by_identity_fraction, a float as in impl/paf_trim.c:16 (default 0.05) */
+    float p1; /* trim: trim_end_fraction, a float as in impl/paf_trim.c:14 (default 1.0)          */
+} paffy_stage;
+
+/* Record-level failures: what the reference turns into st_errAbort / assert / a crash. */
+enum {
+    PAFFY_OK = 0,
+    PAFFY_ERR_FEW_FIELDS = 1,          /* impl/paf.c:144-172 (NULL token dereferenced)  */
+    PAFFY_ERR_STRAND = 2,              /* impl/paf.c:155-157 st_errAbort                */
+    PAFFY_ERR_TP_ASSERT = 3,           /* impl/paf.c:190 assert                         */
+    PAFFY_ERR_CIGAR_CHAR = 4,          /* impl/paf.c:102 st_errAbort                    */
+    PAFFY_ERR_CHECK_QSTART = 5,        /* impl/paf.c:428                                */
+    PAFFY_ERR_CHECK_QEND = 6,          /* impl/paf.c:431                                */
+    PAFFY_ERR_CHECK_TSTART = 7,        /* impl/paf.c:434                                */
+    PAFFY_ERR_CHECK_TEND = 8,          /* impl/paf.c:437                                */
+    PAFFY_ERR_CHECK_CIGAR_Q = 9,       /* impl/paf.c:452                                */
+    PAFFY_ERR_CHECK_CIGAR_T = 10,      /* impl/paf.c:456                                */
+    PAFFY_ERR_SHATTER_ZERO_LEN = 11,   /* impl/paf.c:635 assert                         */
+    PAFFY_ERR_SHATTER_BAD_OP = 12,     /* impl/paf.c:650 assert                         */
+    PAFFY_ERR_SHATTER_END = 13,        /* impl/paf.c:654-660 asserts                    */
+    PAFFY_ERR_TRIM_IDENTITY_ASSERT = 14, /* impl/paf.c:952 assert                       */
+    PAFFY_ERR_TRIM_FIXED_ASSERT = 15,  /* impl/paf.c:591 assert                         */
+    PAFFY_ERR_NULL_CIGAR = 16,         /* impl/paf.c:520 (NULL cigar dereferenced)      */
+    PAFFY_ERR_MISSING_QUERY_SEQ = 17,  /* impl/paf_add_mismatches.c:117-120 exit(1)     */
+    PAFFY_ERR_MISSING_TARGET_SEQ = 18, /* impl/paf_add_mismatches.c:123-127 exit(1)     */
+    PAFFY_ERR_TILE_ASSERT = 19,        /* impl/paf.c:685,698,708; impl/paf_tile.c:57,86,171 */
+    PAFFY_ERR_SEQ_RANGE = 21           /* paf_encode_mismatches would read outside a sequence */
+};
+
+/* Call-level failures (negative return values). */
+enum {
+    PAFFY_E_HIP = -1,         /* a HIP runtime call failed; see paffy_hip_last_error()         */
+    PAFFY_E_ARG = -2,         /* bad argument (NULL, misaligned pointer, in_len >= 4 GiB - 64) */
+    PAFFY_E_UNSUPPORTED = -3, /* stage list this build cannot fuse (run the stages one by one)  */
+    PAFFY_E_CAPACITY = -4,    /* output buffer smaller than the planned size                   */
+    PAFFY_E_STATE = -5        /* emit without a successful plan                                */
+};
+
+typedef struct {
+    int32_t code;   /* PAFFY_ERR_*, 0 = none */
+    int32_t stage;  /* index into the stage list, -1 = while parsing */
+    int64_t record; /* zero-based record in the batch */
+    int64_t aux;    /* offending character for STRAND / TP / CIGAR_CHAR */
+} paffy_error;
+
+typedef struct {
+    int64_t n_records; /* lines in the batch                                              */
+    int64_t n_rows;    /* lines emit will write                                           */
+    int64_t in_bytes;
+    int64_t out_bytes; /* bytes emit will write: all records before the first failing one */
+    paffy_error error; /* first failure in stream order (code 0 = none)                   */
+} paffy_plan_info;
+
+/* Lifetime. `device` < 0 keeps the current HIP device. */
+int paffy_hip_create(paffy_hip_ctx **ctx, int device);
+void paffy_hip_destroy(paffy_hip_ctx *ctx);
+/* Stream all kernels of this context are launched on (a hipStream_t; NULL = default stream). */
+int paffy_hip_set_stream(paffy_hip_ctx *ctx, void *hip_stream);
+
+/*
+ * plan: index the lines of d_in[0, in_len) (16-byte aligned device pointer; the allocation
+ * must be readable up to the next multiple of 16), parse every record, run the stage list,
+ * and compute each record's exact output size. Blocks until the numbers are known.
+ * A final line without '\n' is a record (impl/paf.c:213).
+ */
+int paffy_hip_plan(paffy_hip_ctx *ctx, const paffy_stage *stages, int32_t n_stages, const void *d_in, int64_t in_len,
+                   paffy_plan_info *info);
+
+/*
+ * emit: write the planned output to d_out (16-byte aligned, out_cap >= info.out_bytes). Returns
+ * after enqueueing; paffy_hip_sync() or any synchronisation of the stream completes it.
+ */
+int paffy_hip_emit(paffy_hip_ctx *ctx, void *d_out, int64_t out_cap);
+int paffy_hip_sync(paffy_hip_ctx *ctx);
+
+/* Host-buffer convenience used by the CLI drivers: H2D, plan, emit, D2H. *h_out is malloc'ed. */
+int paffy_hip_run_host(paffy_hip_ctx *ctx, const paffy_stage *stages, int32_t n_stages, const char *h_in, int64_t in_len,
+                       char **h_out, int64_t *out_len, paffy_plan_info *info);
+
+/* Exit status the reference process ends with for a record error (1, 134 or 139). */
+int paffy_hip_error_exit_status(int32_t code);
+const char *paffy_hip_error_string(int32_t code);
+const char *paffy_hip_last_error(paffy_hip_ctx *ctx);
+
+/* Per-kernel timing with HIP events on the context's stream (for bench.py's roofline line). */
+int paffy_hip_profile_enable(paffy_hip_ctx *ctx, int on);
+/* Fills up to cap entries; returns the number of distinct kernels seen since the last reset. */
+int paffy_hip_profile_read(paffy_hip_ctx *ctx, const char **names, double *total_ms, int64_t *launches, int cap);
+int paffy_hip_profile_reset(paffy_hip_ctx *ctx);
+
+/* Plain device-memory helpers so that C hosts need no HIP headers. */
+int paffy_hip_malloc(void **d_ptr, int64_t bytes);
+int paffy_hip_free(void *d_ptr);
+int paffy_hip_memcpy_h2d(void *d_dst, const void *h_src, int64_t bytes);
+int paffy_hip_memcpy_d2h(void *h_dst, const void *d_src, int64_t bytes);
+int paffy_hip_device_count(void);
+
+/*
+ * Synthetic workload of SURVEY.md section 8d, generated on the device (same bytes as
+ * tools/paf_synth.c): records [r0, r0+n) of (seed, mean_ops). With d_out == NULL only the
+ * byte count is returned in *bytes.
+ */
+int paffy_hip_synth(paffy_hip_ctx *ctx, uint64_t seed, uint32_t mean_ops, uint64_t r0, uint64_t n, void *d_out,
+                    int64_t out_cap, int64_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

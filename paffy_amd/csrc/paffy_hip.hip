@@ -1,0 +1,673 @@
+/*
+ * paffy_hip.hip -- gfx950 implementation of include/paffy_hip.h.
+ *
+ * Kernels, in launch order for one batch of PAF text resident in HBM:
+ *   k_sep_count / k_sep_write  one coalesced pass each over the bytes (16 B per lane): '\t' and
+ *                              '\n' positions are compacted into sep_pos[], newline ranks into
+ *                              nl_idx[] (replaces stFile_getLine + strtok_r, impl/paf.c:144-212)
+ *   k_header                   one lane per record: fixed fields and tags (paf_parse, impl/paf.c:137-209)
+ *   k_record_lds<false>        one workgroup per record: cigar -> LDS ops -> transforms -> exact size
+ *   k_record_arena<false>      same for records whose ops do not fit LDS (ops in an HBM arena)
+ *   k_scan_records             exclusive prefix sum of the sizes up to the first failing record
+ *   k_record_lds<true> / k_record_arena<true>   the lines, through the LDS ring, 16 B coalesced stores
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/paffy_hip.h"
+#include "paf_synth_core.h"
+#include "record_kernel.h"
+
+#define SEP_TILE 65536u /* bytes per workgroup in the separator passes */
+
+/* ------------------------------------------------------------------ */
+/* separators                                                           */
+/* ------------------------------------------------------------------ */
+
+__device__ __forceinline__ void sep_masks(const uint8_t *in, uint32_t in_len, uint32_t g, uint32_t &tabs_nl, uint32_t &nl) {
+    /* 16 bytes at g (multiple of 16): bit j of tabs_nl set for '\t' or '\n', of nl for '\n' */
+    tabs_nl = nl = 0;
+    if (g >= in_len) return;
+    uint4 v = *reinterpret_cast<const uint4 *>(in + g);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        uint32_t c = (w[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+        bool valid = g + j < in_len;
+        if (valid && c == '\n') {
+            nl |= 1u << j;
+            tabs_nl |= 1u << j;
+        } else if (valid && c == '\t') {
+            tabs_nl |= 1u << j;
+        }
+    }
+}
+
+__global__ __launch_bounds__(PAFFY_NT) void k_sep_count(const uint8_t *in, uint32_t in_len, uint2 *tile_counts) {
+    __shared__ int64_t scratch[16];
+    const uint32_t tile0 = blockIdx.x * SEP_TILE;
+    int64_t acc[2] = {0, 0};
+    for (uint32_t off = threadIdx.x * 16; off < SEP_TILE; off += PAFFY_NT * 16) {
+        uint32_t a, b;
+        sep_masks(in, in_len, tile0 + off, a, b);
+        acc[0] += __popc(a);
+        acc[1] += __popc(b);
+    }
+    block_sum<2>(acc, scratch);
+    if (threadIdx.x == 0) {
+        /* a final line without '\n' still is a record (impl/paf.c:213): virtual newline at in_len */
+        if (blockIdx.x == gridDim.x - 1 && in_len > 0 && in[in_len - 1] != '\n') {
+            acc[0] += 1;
+            acc[1] += 1;
+        }
+        tile_counts[blockIdx.x] = make_uint2((uint32_t)acc[0], (uint32_t)acc[1]);
+    }
+}
+
+/* single workgroup: exclusive scan of the per-tile counts */
+__global__ __launch_bounds__(PAFFY_NT) void k_scan_tiles(uint2 *tile_counts, uint32_t n_tiles, DevInfo *info) {
+    __shared__ int64_t scratch[16];
+    int64_t carry0 = 0, carry1 = 0;
+    for (uint32_t base = 0; base < n_tiles; base += PAFFY_NT) {
+        uint32_t i = base + threadIdx.x;
+        uint2 c = i < n_tiles ? tile_counts[i] : make_uint2(0, 0);
+        int64_t v[2] = {c.x, c.y}, tot[2];
+        block_excl_scan<2>(v, tot, scratch);
+        if (i < n_tiles) tile_counts[i] = make_uint2((uint32_t)(carry0 + v[0]), (uint32_t)(carry1 + v[1]));
+        carry0 += tot[0];
+        carry1 += tot[1];
+    }
+    if (threadIdx.x == 0) {
+        info->n_seps = (uint32_t)carry0;
+        info->n_lines = (uint32_t)carry1;
+    }
+}
+
+__global__ __launch_bounds__(PAFFY_NT) void k_sep_write(const uint8_t *in, uint32_t in_len, const uint2 *tile_off, uint32_t *sep_pos,
+                                                         uint32_t *nl_idx) {
+    __shared__ int64_t scratch[16];
+    const uint32_t tile0 = blockIdx.x * SEP_TILE;
+    uint2 base = tile_off[blockIdx.x];
+    uint32_t sbase = base.x, lbase = base.y;
+    for (uint32_t off = threadIdx.x * 16; off < SEP_TILE; off += PAFFY_NT * 16) {
+        uint32_t a, b;
+        const uint32_t g = tile0 + off;
+        sep_masks(in, in_len, g, a, b);
+        int64_t v[2] = {__popc(a), __popc(b)}, tot[2];
+        block_excl_scan<2>(v, tot, scratch);
+        uint32_t si = sbase + (uint32_t)v[0], li = lbase + (uint32_t)v[1];
+        while (a) {
+            int j = __ffs((int)a) - 1;
+            a &= a - 1;
+            sep_pos[si] = g + j;
+            if (b & (1u << j)) nl_idx[li++] = si;
+            si++;
+        }
+        sbase += (uint32_t)tot[0];
+        lbase += (uint32_t)tot[1];
+    }
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && in_len > 0 && in[in_len - 1] != '\n') {
+        sep_pos[sbase] = in_len;
+        nl_idx[lbase] = sbase;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* header fields                                                        */
+/* ------------------------------------------------------------------ */
+
+/* str_to_int64, impl/paf.c:37-48 */
+__device__ int64_t parse_i64_dev(const uint8_t *in, uint32_t p, uint32_t e) {
+    uint64_t v = 0;
+    bool neg = false;
+    if (p < e && in[p] == '-') {
+        neg = true;
+        p++;
+    }
+    while (p < e) {
+        uint32_t d = (uint32_t)in[p] - '0';
+        if (d > 9u) break;
+        v = v * 10 + d;
+        p++;
+    }
+    return (int64_t)(neg ? (uint64_t)0 - v : v);
+}
+
+/*
+ * paf_parse, impl/paf.c:137-209: tokens are the non-empty gaps between consecutive separators of
+ * the line (strtok_r collapses runs of tabs). Tag tokens shorter than 5 bytes are never
+ * recognised (documented deviation: the reference reads past the token there).
+ */
+__global__ __launch_bounds__(PAFFY_NT) void k_header(const uint8_t *in, const uint32_t *sep_pos, const uint32_t *nl_idx, uint32_t n_lines,
+                                                      RecMeta *meta) {
+    const uint32_t r = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (r >= n_lines) return;
+    const uint32_t s_end = nl_idx[r];
+    const uint32_t s_begin = r == 0 ? 0 : nl_idx[r - 1] + 1;
+    uint32_t tok = r == 0 ? 0 : sep_pos[nl_idx[r - 1]] + 1;
+    RecMeta m;
+    memset(&m, 0, sizeof(m));
+    m.tile_level = -1;
+    m.chain_id = -1;
+    m.chain_score = -1;
+    int field = 0;
+    for (uint32_t si = s_begin; si <= s_end && m.err == 0; si++) {
+        const uint32_t te = sep_pos[si];
+        const uint32_t t = tok;
+        tok = te + 1;
+        if (te == t) continue; /* empty token */
+        switch (field) {
+            case 0: m.qname_off = t; m.qname_len = te - t; break;
+            case 1: m.qlen = parse_i64_dev(in, t, te); break;
+            case 2: m.qs = parse_i64_dev(in, t, te); break;
+            case 3: m.qe = parse_i64_dev(in, t, te); break;
+            case 4: {
+                uint8_t c = in[t];
+                if (c != '+' && c != '-') {
+                    m.err = PAFFY_ERR_STRAND;
+                    m.err_aux = c;
+                }
+                m.same_strand = c == '+';
+                break;
+            }
+            case 5: m.tname_off = t; m.tname_len = te - t; break;
+            case 6: m.tlen = parse_i64_dev(in, t, te); break;
+            case 7: m.ts = parse_i64_dev(in, t, te); break;
+            case 8: m.te = parse_i64_dev(in, t, te); break;
+            case 9: m.nmatch = parse_i64_dev(in, t, te); break;
+            case 10: m.nbases = parse_i64_dev(in, t, te); break;
+            case 11: m.mapq = parse_i64_dev(in, t, te); break;
+            default: {
+                if (te - t < 5 || in[t + 2] != ':' || in[t + 4] != ':') break;
+                const uint8_t t0 = in[t], t1 = in[t + 1];
+                const uint32_t v = t + 5;
+                if (t0 == 't' && t1 == 'p') {
+                    m.type = v < te ? in[v] : 0;
+                    if (m.type != 'P' && m.type != 'S' && m.type != 'I') {
+                        m.err = PAFFY_ERR_TP_ASSERT;
+                        m.err_aux = m.type;
+                    }
+                } else if (t0 == 'A' && t1 == 'S') {
+                    m.score = parse_i64_dev(in, v, te);
+                } else if (t0 == 'c' && t1 == 'g') {
+                    m.has_cg = 1; /* last cg tag wins (impl/paf.c:193-198) */
+                    m.cg_off = v;
+                    m.cg_len = te - v;
+                } else if (t0 == 't' && t1 == 'l') {
+                    m.tile_level = parse_i64_dev(in, v, te);
+                } else if (t0 == 'c' && t1 == 'n') {
+                    m.chain_id = parse_i64_dev(in, v, te);
+                } else if (t0 == 's' && t1 == '1') {
+                    m.chain_score = parse_i64_dev(in, v, te);
+                }
+            }
+        }
+        field++;
+    }
+    if (m.err == 0 && field < 12) m.err = PAFFY_ERR_FEW_FIELDS;
+    meta[r] = m;
+}
+
+/* ------------------------------------------------------------------ */
+/* record sizes -> offsets                                              */
+/* ------------------------------------------------------------------ */
+
+/* single workgroup; records at or after the first failing one contribute nothing */
+__global__ __launch_bounds__(PAFFY_NT) void k_scan_records(const int64_t *out_len, const int64_t *out_rows, uint32_t n, int64_t *out_off,
+                                                            DevInfo *info) {
+    __shared__ int64_t scratch[16];
+    const uint32_t first_err = (uint32_t)(info->first_err_key >> 16);
+    int64_t cb = 0, cr = 0;
+    for (uint32_t base = 0; base < n; base += PAFFY_NT) {
+        uint32_t i = base + threadIdx.x;
+        bool live = i < n && i < first_err;
+        int64_t v[2] = {live ? out_len[i] : 0, live ? out_rows[i] : 0}, tot[2];
+        block_excl_scan<2>(v, tot, scratch);
+        if (i < n) out_off[i] = cb + v[0];
+        cb += tot[0];
+        cr += tot[1];
+    }
+    if (threadIdx.x == 0) {
+        info->out_bytes = (unsigned long long)cb;
+        info->out_rows = (unsigned long long)cr;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* synthetic workload, one lane per record                   */
+/* ------------------------------------------------------------------ */
+
+__global__ __launch_bounds__(PAFFY_NT) void k_synth_size(psynth_cfg cfg, uint64_t r0, uint32_t n, int64_t *sizes) {
+    uint32_t i = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (i < n) sizes[i] = psynth_emit_record(&cfg, r0 + i, nullptr);
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_synth_fill(psynth_cfg cfg, uint64_t r0, uint32_t n, const int64_t *off, uint8_t *out) {
+    uint32_t i = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (i < n) psynth_emit_record(&cfg, r0 + i, reinterpret_cast<char *>(out) + off[i]);
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_scan_i64(const int64_t *in, uint32_t n, int64_t *out_excl, int64_t *total) {
+    __shared__ int64_t scratch[16];
+    int64_t carry = 0;
+    for (uint32_t base = 0; base < n; base += PAFFY_NT) {
+        uint32_t i = base + threadIdx.x;
+        int64_t v[1] = {i < n ? in[i] : 0}, tot[1];
+        block_excl_scan<1>(v, tot, scratch);
+        if (i < n) out_excl[i] = carry + v[0];
+        carry += tot[0];
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+/* ------------------------------------------------------------------ */
+/* host side                                                            */
+/* ------------------------------------------------------------------ */
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct ProfEntry {
+    std::string name;
+    double ms = 0;
+    int64_t launches = 0;
+};
+
+struct paffy_hip_ctx {
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, arena, info, synth_sizes;
+    DevInfo *h_info = nullptr; /* pinned */
+    /* plan state */
+    bool planned = false;
+    KParams kp;
+    paffy_plan_info plan;
+    /* profiling */
+    bool profile = false;
+    std::vector<ProfEntry> prof;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+    std::vector<std::string> name_store;
+};
+
+#define HIPCHK(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);          \
+            return PAFFY_E_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+static int ensure(paffy_hip_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) HIPCHK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    HIPCHK(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+static int prof_slot(paffy_hip_ctx *c, const char *name) {
+    for (size_t i = 0; i < c->prof.size(); i++)
+        if (c->prof[i].name == name) return (int)i;
+    ProfEntry e;
+    e.name = name;
+    c->prof.push_back(e);
+    return (int)c->prof.size() - 1;
+}
+static void prof_collect(paffy_hip_ctx *c) {
+    for (auto &p : c->pending) {
+        float ms = 0;
+        (void)hipEventSynchronize(p.second.second);
+        (void)hipEventElapsedTime(&ms, p.second.first, p.second.second);
+        c->prof[p.first].ms += ms;
+        c->prof[p.first].launches += 1;
+        (void)hipEventDestroy(p.second.first);
+        (void)hipEventDestroy(p.second.second);
+    }
+    c->pending.clear();
+}
+
+/* launch wrapper: optional HIP events on the context's stream around each kernel */
+#define LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                                  \
+    do {                                                                                    \
+        hipEvent_t e0_ = nullptr, e1_ = nullptr;                                            \
+        if ((ctx)->profile) {                                                               \
+            (void)hipEventCreate(&e0_);                                                           \
+            (void)hipEventCreate(&e1_);                                                           \
+            (void)hipEventRecord(e0_, (ctx)->stream);                                             \
+        }                                                                                   \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);         \
+        if ((ctx)->profile) {                                                               \
+            (void)hipEventRecord(e1_, (ctx)->stream);                                             \
+            (ctx)->pending.push_back({prof_slot(ctx, name), {e0_, e1_}});                   \
+        }                                                                                   \
+        HIPCHK(ctx, hipGetLastError());                                                     \
+    } while (0)
+
+extern "C" {
+
+int paffy_hip_create(paffy_hip_ctx **out, int device) {
+    if (!out) return PAFFY_E_ARG;
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) return PAFFY_E_HIP;
+    paffy_hip_ctx *c = new paffy_hip_ctx();
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_info), sizeof(DevInfo)) != hipSuccess) {
+        delete c;
+        return PAFFY_E_HIP;
+    }
+    if (ensure(c, c->info, sizeof(DevInfo))) {
+        delete c;
+        return PAFFY_E_HIP;
+    }
+    /* the record kernels use more than the default 64 KiB of LDS */
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_record_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_record_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_record_arena<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_record_arena<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_LDS_BYTES);
+    *out = c;
+    return 0;
+}
+
+void paffy_hip_destroy(paffy_hip_ctx *c) {
+    if (!c) return;
+    prof_collect(c);
+    DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
+                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->arena, &c->info, &c->synth_sizes};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (c->h_info) (void)hipHostFree(c->h_info);
+    delete c;
+}
+
+int paffy_hip_set_stream(paffy_hip_ctx *c, void *s) {
+    if (!c) return PAFFY_E_ARG;
+    c->stream = reinterpret_cast<hipStream_t>(s);
+    return 0;
+}
+
+const char *paffy_hip_last_error(paffy_hip_ctx *c) { return c ? c->last_error.c_str() : "null context"; }
+
+static int fetch_info(paffy_hip_ctx *c) {
+    HIPCHK(c, hipMemcpyAsync(c->h_info, c->info.p, sizeof(DevInfo), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages, const void *d_in, int64_t in_len,
+                   paffy_plan_info *info) {
+    if (!c || !info || (n_stages > 0 && !stages) || n_stages < 0 || n_stages > PAFFY_MAX_STAGES) return PAFFY_E_ARG;
+    if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
+    for (int32_t i = 0; i < n_stages; i++) {
+        int k = stages[i].kind;
+        bool ok = k == PAFFY_INVERT || k == PAFFY_TRIM_IDENTITY || k == PAFFY_TRIM_FIXED || k == PAFFY_PASS ||
+                  (k == PAFFY_SHATTER && i == n_stages - 1);
+        if (!ok) {
+            c->last_error = "stage list not fusable in this build";
+            return PAFFY_E_UNSUPPORTED;
+        }
+    }
+    c->planned = false;
+    memset(info, 0, sizeof(*info));
+    info->in_bytes = in_len;
+    memset(&c->plan, 0, sizeof(c->plan));
+    c->plan.in_bytes = in_len;
+    KParams &kp = c->kp;
+    memset(&kp, 0, sizeof(kp));
+    if (in_len == 0) {
+        c->planned = true;
+        kp.n_rec = 0;
+        return 0;
+    }
+    const uint8_t *in = static_cast<const uint8_t *>(d_in);
+    const uint32_t len = (uint32_t)in_len;
+    const uint32_t n_tiles = (len + SEP_TILE - 1) / SEP_TILE;
+
+    DevInfo zero;
+    memset(&zero, 0, sizeof(zero));
+    zero.first_err_key = ~0ull;
+    HIPCHK(c, hipMemcpyAsync(c->info.p, &zero, sizeof(zero), hipMemcpyHostToDevice, c->stream));
+    if (ensure(c, c->tile_counts, sizeof(uint2) * n_tiles)) return PAFFY_E_HIP;
+    LAUNCH(c, "k_sep_count", k_sep_count, dim3(n_tiles), dim3(PAFFY_NT), 0, in, len, static_cast<uint2 *>(c->tile_counts.p));
+    LAUNCH(c, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(PAFFY_NT), 0, static_cast<uint2 *>(c->tile_counts.p), n_tiles,
+           static_cast<DevInfo *>(c->info.p));
+    if (fetch_info(c)) return PAFFY_E_HIP;
+    const uint32_t n_seps = c->h_info->n_seps, n_lines = c->h_info->n_lines;
+
+    if (ensure(c, c->sep_pos, sizeof(uint32_t) * (size_t)(n_seps + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->nl_idx, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->meta, sizeof(RecMeta) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->out_len, sizeof(int64_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->out_rows, sizeof(int64_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->out_off, sizeof(int64_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->status, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->err_aux, sizeof(int32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->n_ops, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->arena_off, sizeof(uint64_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->w_list, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+    if (c->arena.cap == 0 && ensure(c, c->arena, (size_t)8 << 20)) return PAFFY_E_HIP;
+
+    LAUNCH(c, "k_sep_write", k_sep_write, dim3(n_tiles), dim3(PAFFY_NT), 0, in, len, static_cast<const uint2 *>(c->tile_counts.p),
+           static_cast<uint32_t *>(c->sep_pos.p), static_cast<uint32_t *>(c->nl_idx.p));
+    if (n_lines > 0)
+        LAUNCH(c, "k_header", k_header, dim3((n_lines + PAFFY_NT - 1) / PAFFY_NT), dim3(PAFFY_NT), 0, in,
+               static_cast<const uint32_t *>(c->sep_pos.p), static_cast<const uint32_t *>(c->nl_idx.p), n_lines,
+               static_cast<RecMeta *>(c->meta.p));
+
+    kp.in = in;
+    kp.in_len = len;
+    kp.n_rec = n_lines;
+    kp.meta = static_cast<const RecMeta *>(c->meta.p);
+    for (int32_t i = 0; i < n_stages; i++) kp.stages[i] = stages[i];
+    kp.n_stages = n_stages;
+    kp.out_len = static_cast<int64_t *>(c->out_len.p);
+    kp.out_rows = static_cast<int64_t *>(c->out_rows.p);
+    kp.status = static_cast<uint32_t *>(c->status.p);
+    kp.err_aux = static_cast<int32_t *>(c->err_aux.p);
+    kp.n_ops = static_cast<uint32_t *>(c->n_ops.p);
+    kp.arena_off = static_cast<uint64_t *>(c->arena_off.p);
+    kp.out_off = static_cast<const int64_t *>(c->out_off.p);
+    kp.w_list = static_cast<uint32_t *>(c->w_list.p);
+    kp.info = static_cast<DevInfo *>(c->info.p);
+
+    if (n_lines > 0) {
+        LAUNCH(c, "k_record_lds<size>", k_record_lds<false>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_LDS_BYTES, kp);
+        for (int attempt = 0; attempt < 2; attempt++) {
+            kp.arena = static_cast<uint64_t *>(c->arena.p);
+            kp.arena_cap = c->arena.cap / 8;
+            LAUNCH(c, "k_record_arena<size>", k_record_arena<false>, dim3(512), dim3(PAFFY_NT), PAFFY_LDS_BYTES, kp);
+            if (fetch_info(c)) return PAFFY_E_HIP;
+            if (c->h_info->arena_used <= kp.arena_cap) break;
+            /* arena too small: grow to the exact demand and redo the arena records */
+            size_t need = (size_t)c->h_info->arena_used * 8;
+            if (ensure(c, c->arena, need)) return PAFFY_E_HIP;
+            unsigned long long z = 0;
+            HIPCHK(c, hipMemcpyAsync(&static_cast<DevInfo *>(c->info.p)->arena_used, &z, sizeof(z), hipMemcpyHostToDevice, c->stream));
+        }
+        LAUNCH(c, "k_scan_records", k_scan_records, dim3(1), dim3(PAFFY_NT), 0, kp.out_len, kp.out_rows, n_lines,
+               static_cast<int64_t *>(c->out_off.p), kp.info);
+    }
+    if (fetch_info(c)) return PAFFY_E_HIP;
+    if (c->profile) prof_collect(c);
+    if (c->h_info->internal) {
+        char buf[128];
+        snprintf(buf, sizeof(buf), "internal limit hit (flags 0x%x): record pieces longer than the LDS staging area", c->h_info->internal);
+        c->last_error = buf;
+        return PAFFY_E_UNSUPPORTED;
+    }
+    paffy_plan_info &pl = c->plan;
+    pl.n_records = n_lines;
+    pl.n_rows = (int64_t)c->h_info->out_rows;
+    pl.out_bytes = (int64_t)c->h_info->out_bytes;
+    if (c->h_info->first_err_key != ~0ull) {
+        unsigned long long k = c->h_info->first_err_key;
+        pl.error.code = (int32_t)(k & 0xff);
+        pl.error.stage = (int32_t)((k >> 8) & 0xff) - 1;
+        pl.error.record = (int64_t)(k >> 16);
+        int32_t aux = 0;
+        HIPCHK(c, hipMemcpy(&aux, static_cast<int32_t *>(c->err_aux.p) + pl.error.record, sizeof(aux), hipMemcpyDeviceToHost));
+        pl.error.aux = aux;
+    }
+    *info = pl;
+    c->planned = true;
+    return 0;
+}
+
+int paffy_hip_emit(paffy_hip_ctx *c, void *d_out, int64_t out_cap) {
+    if (!c) return PAFFY_E_ARG;
+    if (!c->planned) return PAFFY_E_STATE;
+    if (c->plan.out_bytes == 0 || c->kp.n_rec == 0) return 0;
+    if (!d_out || (reinterpret_cast<uintptr_t>(d_out) & 15)) return PAFFY_E_ARG;
+    if (out_cap < c->plan.out_bytes) return PAFFY_E_CAPACITY;
+    KParams kp = c->kp;
+    kp.out = static_cast<uint8_t *>(d_out);
+    LAUNCH(c, "k_record_lds<emit>", k_record_lds<true>, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_LDS_BYTES, kp);
+    if (c->h_info->w_count > 0)
+        LAUNCH(c, "k_record_arena<emit>", k_record_arena<true>, dim3(512), dim3(PAFFY_NT), PAFFY_LDS_BYTES, kp);
+    return 0;
+}
+
+int paffy_hip_sync(paffy_hip_ctx *c) {
+    if (!c) return PAFFY_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->profile) prof_collect(c);
+    return 0;
+}
+
+int paffy_hip_run_host(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages, const char *h_in, int64_t in_len, char **h_out,
+                       int64_t *out_len, paffy_plan_info *info) {
+    if (!c || !h_out || !out_len || !info) return PAFFY_E_ARG;
+    *h_out = nullptr;
+    *out_len = 0;
+    void *d_in = nullptr, *d_out = nullptr;
+    int rc = 0;
+    if (in_len > 0) {
+        HIPCHK(c, hipMalloc(&d_in, (size_t)in_len + 64));
+        if (hipMemcpy(d_in, h_in, (size_t)in_len, hipMemcpyHostToDevice) != hipSuccess) rc = PAFFY_E_HIP;
+    }
+    if (!rc) rc = paffy_hip_plan(c, stages, n_stages, d_in, in_len, info);
+    if (!rc && info->out_bytes > 0) {
+        if (hipMalloc(&d_out, (size_t)info->out_bytes + 64) != hipSuccess) rc = PAFFY_E_HIP;
+        if (!rc) rc = paffy_hip_emit(c, d_out, info->out_bytes + 64);
+        if (!rc) rc = paffy_hip_sync(c);
+        if (!rc) {
+            *h_out = static_cast<char *>(malloc((size_t)info->out_bytes));
+            if (hipMemcpy(*h_out, d_out, (size_t)info->out_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = PAFFY_E_HIP;
+            *out_len = info->out_bytes;
+        }
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+int paffy_hip_error_exit_status(int32_t code) {
+    switch (code) {
+        case PAFFY_OK: return 0;
+        case PAFFY_ERR_STRAND: case PAFFY_ERR_CIGAR_CHAR:
+        case PAFFY_ERR_CHECK_QSTART: case PAFFY_ERR_CHECK_QEND: case PAFFY_ERR_CHECK_TSTART: case PAFFY_ERR_CHECK_TEND:
+        case PAFFY_ERR_CHECK_CIGAR_Q: case PAFFY_ERR_CHECK_CIGAR_T:
+        case PAFFY_ERR_MISSING_QUERY_SEQ: case PAFFY_ERR_MISSING_TARGET_SEQ:
+            return 1; /* st_errAbort / exit(1) */
+        case PAFFY_ERR_FEW_FIELDS: case PAFFY_ERR_NULL_CIGAR: case PAFFY_ERR_SEQ_RANGE:
+            return 139; /* the reference dereferences NULL / reads out of bounds */
+        default:
+            return 134; /* assert -> abort() */
+    }
+}
+
+const char *paffy_hip_error_string(int32_t code) {
+    switch (code) {
+        case PAFFY_OK: return "ok";
+        case PAFFY_ERR_FEW_FIELDS: return "Paf line has fewer than 12 fields";
+        case PAFFY_ERR_STRAND: return "Got an unexpected strand character in a paf string";
+        case PAFFY_ERR_TP_ASSERT: return "tp tag is not P, S or I";
+        case PAFFY_ERR_CIGAR_CHAR: return "Got an unexpected character paf cigar string";
+        case PAFFY_ERR_CHECK_QSTART: return "Paf query start coordinates are invalid";
+        case PAFFY_ERR_CHECK_QEND: return "Paf query end coordinates are invalid";
+        case PAFFY_ERR_CHECK_TSTART: return "Paf target start coordinates are invalid";
+        case PAFFY_ERR_CHECK_TEND: return "Paf target end coordinates are invalid";
+        case PAFFY_ERR_CHECK_CIGAR_Q: return "Paf cigar alignment does not match query length";
+        case PAFFY_ERR_CHECK_CIGAR_T: return "Paf cigar alignment does not match target length";
+        case PAFFY_ERR_SHATTER_ZERO_LEN: return "shatter: cigar op of length < 1";
+        case PAFFY_ERR_SHATTER_BAD_OP: return "shatter: cigar op other than M, I or D";
+        case PAFFY_ERR_SHATTER_END: return "shatter: cigar does not end on the record's end coordinates";
+        case PAFFY_ERR_TRIM_IDENTITY_ASSERT: return "trim: final identity below the starting identity";
+        case PAFFY_ERR_TRIM_FIXED_ASSERT: return "trim: fraction outside [0, 1]";
+        case PAFFY_ERR_NULL_CIGAR: return "record has no cigar";
+        case PAFFY_ERR_MISSING_QUERY_SEQ: return "No query sequence found";
+        case PAFFY_ERR_MISSING_TARGET_SEQ: return "No target sequence found";
+        case PAFFY_ERR_TILE_ASSERT: return "tile: coverage assertion failed";
+        case PAFFY_ERR_SEQ_RANGE: return "alignment reaches outside a sequence";
+        default: return "unknown error";
+    }
+}
+
+int paffy_hip_profile_enable(paffy_hip_ctx *c, int on) {
+    if (!c) return PAFFY_E_ARG;
+    c->profile = on != 0;
+    return 0;
+}
+int paffy_hip_profile_reset(paffy_hip_ctx *c) {
+    if (!c) return PAFFY_E_ARG;
+    prof_collect(c);
+    for (auto &e : c->prof) {
+        e.ms = 0;
+        e.launches = 0;
+    }
+    return 0;
+}
+int paffy_hip_profile_read(paffy_hip_ctx *c, const char **names, double *total_ms, int64_t *launches, int cap) {
+    if (!c) return PAFFY_E_ARG;
+    prof_collect(c);
+    int n = (int)c->prof.size();
+    for (int i = 0; i < n && i < cap; i++) {
+        if (names) names[i] = c->prof[i].name.c_str();
+        if (total_ms) total_ms[i] = c->prof[i].ms;
+        if (launches) launches[i] = c->prof[i].launches;
+    }
+    return n;
+}
+
+int paffy_hip_malloc(void **p, int64_t bytes) { return hipMalloc(p, (size_t)bytes + 64) == hipSuccess ? 0 : PAFFY_E_HIP; }
+int paffy_hip_free(void *p) { return hipFree(p) == hipSuccess ? 0 : PAFFY_E_HIP; }
+int paffy_hip_memcpy_h2d(void *d, const void *h, int64_t n) { return hipMemcpy(d, h, (size_t)n, hipMemcpyHostToDevice) == hipSuccess ? 0 : PAFFY_E_HIP; }
+int paffy_hip_memcpy_d2h(void *h, const void *d, int64_t n) { return hipMemcpy(h, d, (size_t)n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : PAFFY_E_HIP; }
+int paffy_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int paffy_hip_synth(paffy_hip_ctx *c, uint64_t seed, uint32_t mean_ops, uint64_t r0, uint64_t n, void *d_out, int64_t out_cap,
+                    int64_t *bytes) {
+    if (!c || !bytes || n >= (1ull << 31)) return PAFFY_E_ARG;
+    *bytes = 0;
+    if (n == 0) return 0;
+    psynth_cfg cfg;
+    cfg.seed = seed;
+    cfg.mean_ops = mean_ops;
+    cfg.n_contigs = 24;
+    if (ensure(c, c->synth_sizes, sizeof(int64_t) * (size_t)(2 * n + 2))) return PAFFY_E_HIP;
+    int64_t *sizes = static_cast<int64_t *>(c->synth_sizes.p), *offs = sizes + n, *total = offs + n;
+    const uint32_t nn = (uint32_t)n, grid = (nn + PAFFY_NT - 1) / PAFFY_NT;
+    LAUNCH(c, "k_synth_size", k_synth_size, dim3(grid), dim3(PAFFY_NT), 0, cfg, r0, nn, sizes);
+    LAUNCH(c, "k_scan_i64", k_scan_i64, dim3(1), dim3(PAFFY_NT), 0, sizes, nn, offs, total);
+    int64_t h_total = 0;
+    HIPCHK(c, hipMemcpyAsync(&h_total, total, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *bytes = h_total;
+    if (!d_out) return 0;
+    if (out_cap < h_total) return PAFFY_E_CAPACITY;
+    LAUNCH(c, "k_synth_fill", k_synth_fill, dim3(grid), dim3(PAFFY_NT), 0, cfg, r0, nn, offs, static_cast<uint8_t *>(d_out));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+} /* extern "C" */

@@ -1,0 +1,1085 @@
+/*
+ * record_kernel.h -- one workgroup per PAF record: cigar text -> ops in LDS -> transforms on a
+ * view -> byte-exact lines through an LDS ring -> coalesced 16-byte global stores.
+ *
+ * The same code runs twice per batch: the sizing pass (EMIT = false) computes every record's
+ * exact output length and first failing check; after a prefix sum over the lengths the emit
+ * pass (EMIT = true) re-derives the record and writes it at its offset. Nothing but the raw
+ * text is read from HBM and nothing but the final text is written (algorithmic bytes only).
+ *
+ * Reference behaviour restated here (paths relative to /root/reference):
+ *   cigar_parse impl/paf.c:70-111 | paf_check :427-461 | paf_invert :469-490 |
+ *   paf_trim_end_fraction/paf_trim_ends/cigar_trim(_back) :518-598 | paf_shatter :600-663 |
+ *   paf_trim_unreliable_tails/_prefix/_ends2/paf_trim_upto :811-953 | paf_write_to_buffer :317-389
+ * Transforms never move ops: invert / trims are edits of a View (window, direction, I<->D
+ * relabel, shortened end ops) over the parsed array.
+ */
+#ifndef PAFFY_RECORD_KERNEL_H_
+#define PAFFY_RECORD_KERNEL_H_
+
+#include "device_util.h"
+#include "record_types.h"
+
+#define INTERNAL_TMPL_TOO_LONG 1u
+#define INTERNAL_ROW_TOO_LONG 2u
+#define INTERNAL_DIGIT_RUN 4u
+
+/* ---------------- op stores ---------------- */
+
+struct OpsLds { /* 4-byte ops in LDS: len << 3 | op, len < 2^29 */
+    uint32_t *p;
+    static constexpr bool kNarrow = true;
+    __device__ __forceinline__ void get(uint32_t i, int64_t &len, int &op) const {
+        uint32_t w = p[i];
+        op = (int)(w & 7u);
+        len = (int64_t)(w >> 3);
+    }
+    __device__ __forceinline__ void set(uint32_t i, int64_t len, int op) const { p[i] = ((uint32_t)len << 3) | (uint32_t)op; }
+};
+struct OpsArena { /* 8-byte ops in HBM: the CigarRecord layout, inc/paf.h:61-64 */
+    uint64_t *p;
+    static constexpr bool kNarrow = false;
+    __device__ __forceinline__ void get(uint32_t i, int64_t &len, int &op) const {
+        uint64_t w = p[i];
+        op = (int)(w & 0xffu);
+        len = (int64_t)w >> 8; /* 56-bit signed */
+    }
+    __device__ __forceinline__ void set(uint32_t i, int64_t len, int op) const { p[i] = ((uint64_t)len << 8) | (uint64_t)op; }
+};
+
+template <class OPS>
+struct View {
+    OPS ops;
+    uint32_t lo, n;
+    bool rev, swp;
+    int64_t sub_lo, sub_hi; /* bases cut from the raw first / last op of the window (fixed trim) */
+    __device__ __forceinline__ void get(uint32_t i, int64_t &len, int &op) const {
+        uint32_t raw = rev ? lo + n - 1 - i : lo + i;
+        ops.get(raw, len, op);
+        if (swp && (op == OP_I || op == OP_D)) op ^= 3;
+        if (raw == lo) len -= sub_lo;
+        if (raw == lo + n - 1) len -= sub_hi;
+    }
+    __device__ __forceinline__ void drop_front(uint32_t k) {
+        if (k == 0) return;
+        if (!rev) {
+            lo += k;
+            sub_lo = 0;
+        } else {
+            sub_hi = 0;
+        }
+        n -= k;
+        if (n == 0) sub_lo = sub_hi = 0;
+    }
+    __device__ __forceinline__ void shorten_front(int64_t amt) {
+        if (!rev) sub_lo += amt;
+        else sub_hi += amt;
+    }
+};
+
+struct RecState {
+    int64_t qlen, qs, qe, tlen, ts, te, nmatch, nbases, mapq, score, tile_level, chain_id, chain_score;
+    uint32_t qn_off, qn_len, tn_off, tn_len;
+    bool same;
+    uint8_t type;
+    bool has_cigar;
+};
+
+struct Shared { /* small workgroup-shared words */
+    uint32_t err_pos;
+    uint32_t flags;
+    int64_t bcast[4];
+};
+
+__device__ __forceinline__ int op_code_of(uint32_t c) { /* impl/paf.c:96-103 */
+    return c == 'M' ? OP_M : c == 'I' ? OP_I : c == 'D' ? OP_D : c == '=' ? OP_EQ : c == 'X' ? OP_X : -1;
+}
+__device__ __forceinline__ uint32_t op_char_of(int op) { /* impl/paf.c:372-379 */
+    return op == OP_M ? 'M' : op == OP_I ? 'I' : op == OP_D ? 'D' : op == OP_EQ ? '=' : op == OP_X ? 'X' : 'N';
+}
+
+/* chunk of the view owned by this thread for whole-record sweeps (odd stride: no LDS bank conflicts) */
+__device__ __forceinline__ void sweep_bounds(uint32_t n, uint32_t &b, uint32_t &e) {
+    uint32_t c = ((n + PAFFY_NT - 1) / PAFFY_NT) | 1u;
+    uint64_t bb = (uint64_t)threadIdx.x * c;
+    b = bb < n ? (uint32_t)bb : n;
+    e = (bb + c) < n ? (uint32_t)(bb + c) : n;
+}
+
+/* ---------------- cigar text -> ops ---------------- */
+
+/*
+ * cigar_parse, impl/paf.c:70-111, workgroup-parallel: 4 KiB text tiles staged in LDS; every byte
+ * that is not a digit ends an op; the digits before it are read backwards (mod 2^64, like the
+ * reference's forward accumulate). Returns the op count; *fits is false when the ops do not
+ * fit `cap` or (narrow store) a length needs more than 29 bits. err_pos: smallest text offset
+ * holding a character outside MID=X, or cg_off+cg_len for a trailing digit run.
+ */
+template <class OPS>
+__device__ uint32_t parse_cigar(const uint8_t *in, uint32_t cg_off, uint32_t cg_len, const OPS &ops, uint32_t cap, uint8_t *txt,
+                                int64_t *scratch, Shared *sh, bool *fits, uint32_t *err_pos) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t end = cg_off + cg_len;
+    const uint32_t a0 = cg_off & ~15u;
+    if (tid == 0) {
+        sh->err_pos = 0xffffffffu;
+        sh->flags = 0;
+    }
+    uint32_t n = 0;
+    for (uint32_t tb = a0; tb < end; tb += PAFFY_NT * 16) {
+        uint4 h = make_uint4(0, 0, 0, 0);
+        if (tb != a0 && tid < 2) h = reinterpret_cast<uint4 *>(txt + PAFFY_HALO + PAFFY_NT * 16 - 32)[tid];
+        __syncthreads();
+        if (tb != a0 && tid < 2) reinterpret_cast<uint4 *>(txt)[tid] = h;
+        const uint32_t g = tb + tid * 16;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g < end) v = *reinterpret_cast<const uint4 *>(in + g);
+        reinterpret_cast<uint4 *>(txt + PAFFY_HALO)[tid] = v;
+        __syncthreads();
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t opmask = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            uint32_t c = (w[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+            uint32_t pos = g + j;
+            bool inr = pos >= cg_off && pos < end;
+            bool dig = (c - '0') < 10u;
+            if (inr && !dig) opmask |= 1u << j;
+            if (inr && dig && pos == end - 1) atomicMin(&sh->err_pos, end); /* trailing digits: switch sees NUL */
+        }
+        int64_t cnt[1] = {(int64_t)__popc(opmask)}, tot[1];
+        block_excl_scan<1>(cnt, tot, scratch);
+        uint32_t idx = n + (uint32_t)cnt[0];
+        while (opmask) {
+            int j = __ffs((int)opmask) - 1;
+            opmask &= opmask - 1;
+            uint32_t c = (w[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+            int code = op_code_of(c);
+            if (code < 0) {
+                atomicMin(&sh->err_pos, g + j);
+                code = 0;
+            }
+            int p = (int)(PAFFY_HALO + tid * 16 + j) - 1;
+            uint32_t avail = g + j - cg_off; /* cigar bytes before this character */
+            uint32_t reach = (uint32_t)(p + 1);
+            if (tb == a0 && reach > tid * 16 + j) reach = tid * 16 + j; /* no halo before the first tile */
+            uint32_t lim = avail < reach ? avail : reach;
+            uint64_t len = 0, pw = 1;
+            uint32_t k = 0;
+            for (; k < lim; k++) {
+                uint32_t d = (uint32_t)txt[p - (int)k] - '0';
+                if (d > 9u) break;
+                len += d * pw;
+                pw *= 10;
+            }
+            if (k == lim && lim < avail) atomicOr(&sh->flags, INTERNAL_DIGIT_RUN); /* run longer than the halo */
+            int64_t l56 = (int64_t)(len << 8) >> 8;
+            if (OPS::kNarrow && (l56 < 0 || l56 >= (1ll << 29))) atomicOr(&sh->flags, 0x100u);
+            if (idx < cap) ops.set(idx, l56, code);
+            idx++;
+        }
+        n += (uint32_t)tot[0];
+    }
+    __syncthreads();
+    *err_pos = sh->err_pos;
+    uint32_t fl = sh->flags;
+    *fits = n <= cap && !(fl & 0x100u);
+    __syncthreads();
+    return n | ((fl & INTERNAL_DIGIT_RUN) ? 0x80000000u : 0u);
+}
+
+/* Sequential fallback for digit runs longer than the LDS halo (leading zeros etc.). */
+template <class OPS>
+__device__ uint32_t parse_cigar_serial(const uint8_t *in, uint32_t cg_off, uint32_t cg_len, const OPS &ops, uint32_t cap, Shared *sh,
+                                       bool *fits, uint32_t *err_pos) {
+    if (threadIdx.x == 0) {
+        uint32_t n = 0, ep = 0xffffffffu, wide = 0;
+        uint32_t p = cg_off, end = cg_off + cg_len;
+        while (p < end) {
+            uint64_t len = 0;
+            while (p < end && (uint32_t)(in[p] - '0') < 10u) len = len * 10 + (uint32_t)(in[p++] - '0');
+            int code = p < end ? op_code_of(in[p]) : -1;
+            if (code < 0) {
+                if (ep == 0xffffffffu) ep = p;
+                code = 0;
+                if (p >= end) break;
+            }
+            int64_t l56 = (int64_t)(len << 8) >> 8;
+            if (OPS::kNarrow && (l56 < 0 || l56 >= (1ll << 29))) wide = 1;
+            if (n < cap) ops.set(n, l56, code);
+            n++;
+            p++;
+        }
+        sh->err_pos = ep;
+        sh->flags = wide;
+        sh->bcast[0] = n;
+    }
+    __syncthreads();
+    uint32_t n = (uint32_t)sh->bcast[0];
+    *err_pos = sh->err_pos;
+    *fits = n <= cap && !sh->flags;
+    __syncthreads();
+    return n;
+}
+
+/* ---------------- transforms on a view ---------------- */
+
+__device__ __forceinline__ void invert_state(RecState &s) { /* paf_invert, impl/paf.c:469-474 */
+    int64_t t;
+    uint32_t u;
+    t = s.qs; s.qs = s.ts; s.ts = t;
+    t = s.qe; s.qe = s.te; s.te = t;
+    t = s.qlen; s.qlen = s.tlen; s.tlen = t;
+    u = s.qn_off; s.qn_off = s.tn_off; s.tn_off = u;
+    u = s.qn_len; s.qn_len = s.tn_len; s.tn_len = u;
+}
+template <class OPS>
+__device__ __forceinline__ void invert_view(const RecState &s, View<OPS> &v) { /* impl/paf.c:476-489 */
+    v.swp = !v.swp;
+    if (!s.same) v.rev = !v.rev;
+}
+
+/* paf_check, impl/paf.c:427-461. Returns 0 or the PAFFY_ERR_CHECK_* code. */
+template <class OPS>
+__device__ int check_record(const RecState &s, const View<OPS> &v, int64_t *scratch) {
+    if (s.qs < 0 || s.qs >= s.qlen) return PAFFY_ERR_CHECK_QSTART;
+    if (s.qs > s.qe || s.qe > s.qlen) return PAFFY_ERR_CHECK_QEND;
+    if (s.ts < 0 || s.ts >= s.tlen) return PAFFY_ERR_CHECK_TSTART;
+    if (s.ts > s.te || s.te > s.tlen) return PAFFY_ERR_CHECK_TEND;
+    if (s.has_cigar) {
+        uint32_t b, e;
+        sweep_bounds(v.n, b, e);
+        int64_t acc[2] = {0, 0};
+        for (uint32_t i = b; i < e; i++) {
+            int64_t len;
+            int op;
+            v.get(i, len, op);
+            if (op != OP_D) acc[0] += len;
+            if (op != OP_I) acc[1] += len;
+        }
+        block_sum<2>(acc, scratch);
+        if (acc[0] != s.qe - s.qs) return PAFFY_ERR_CHECK_CIGAR_Q;
+        if (acc[1] != s.te - s.ts) return PAFFY_ERR_CHECK_CIGAR_T;
+    }
+    return 0;
+}
+
+/* float32 quotient widened to double: `((float)a)/(a + b)` of impl/paf.c:832,886,923,937 */
+__device__ __forceinline__ double ratio_f32(int64_t num, int64_t den) {
+    return (double)__fdiv_rn(__ll2float_rn(num), __ll2float_rn(den));
+}
+
+/* matches / mismatches of the whole view: paf_trim_unreliable_ends2(.., 0, 1, -1), impl/paf.c:811-840 */
+template <class OPS>
+__device__ void match_stats(const View<OPS> &v, int64_t &m, int64_t &x, int64_t *scratch) {
+    uint32_t b, e;
+    sweep_bounds(v.n, b, e);
+    int64_t acc[2] = {0, 0};
+    for (uint32_t i = b; i < e; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        if (op == OP_EQ || op == OP_M) acc[0] += len;
+        else acc[1] += len; /* X, I and D all count as mismatches */
+    }
+    block_sum<2>(acc, scratch);
+    m = acc[0];
+    x = acc[1];
+}
+
+/* paf_trim_unreliable_prefix + paf_trim_upto, impl/paf.c:842-904 (thresholds arrive as float32). */
+template <class OPS>
+__device__ void trim_prefix(RecState &s, View<OPS> &v, float thr_f, float id_f, int64_t max_trim, int64_t *scratch, Shared *sh) {
+    const double thr = (double)thr_f, idd = (double)id_f;
+    uint32_t b, e;
+    sweep_bounds(v.n, b, e);
+    /* sweep A: per-thread (matches, mismatches) -> exclusive prefix */
+    int64_t c[2] = {0, 0}, tot[2];
+    for (uint32_t i = b; i < e; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        if (op == OP_EQ || op == OP_M) c[0] += len;
+        else c[1] += len;
+    }
+    block_excl_scan<2>(c, tot, scratch);
+    /* sweep B: last index (while cumulative <= max_trim) whose prefix identity < threshold */
+    int64_t cm = c[0], cx = c[1], found = -1;
+    for (uint32_t i = b; i < e; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        if (op == OP_EQ || op == OP_M) cm += len;
+        else cx += len;
+        if (max_trim >= 0 && cm + cx > max_trim) break;
+        if (ratio_f32(cm, cm + cx) < thr) found = i;
+    }
+    int64_t trim_idx = block_max_i64(found, scratch);
+    if (trim_idx < 0) return;
+    /* inclusive cumulative at trim_idx, broadcast by its owner */
+    if (trim_idx >= (int64_t)b && trim_idx < (int64_t)e) {
+        int64_t am = c[0], ax = c[1];
+        for (uint32_t i = b; i <= (uint32_t)trim_idx; i++) {
+            int64_t len;
+            int op;
+            v.get(i, len, op);
+            if (op == OP_EQ || op == OP_M) am += len;
+            else ax += len;
+        }
+        sh->bcast[0] = am;
+        sh->bcast[1] = ax;
+    }
+    __syncthreads();
+    const int64_t tm = sh->bcast[0], tx = sh->bcast[1];
+    __syncthreads();
+    /* sweep C: smallest i <= trim_idx whose suffix [i, trim_idx] has identity >= identity */
+    int64_t em = c[0], ex = c[1], best = INT64_MAX;
+    for (uint32_t i = b; i < e && (int64_t)i <= trim_idx; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        int64_t sm = tm - em, sx = tx - ex;
+        if (best == INT64_MAX && ratio_f32(sm, sm + sx) >= idd) best = i;
+        if (op == OP_EQ || op == OP_M) em += len;
+        else ex += len;
+    }
+    best = block_min_i64(best, scratch);
+    int64_t count = best != INT64_MAX ? best : trim_idx + 1;
+    if (count <= 0) return;
+    /* paf_trim_upto: advance coordinates over the dropped ops */
+    int64_t d[2] = {0, 0};
+    for (uint32_t i = b; i < e && (int64_t)i < count; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        if (op != OP_I) d[0] += len;
+        if (op != OP_D) d[1] += len;
+    }
+    block_sum<2>(d, scratch);
+    s.ts += d[0];
+    if (s.same) s.qs += d[1];
+    else s.qe -= d[1];
+    v.drop_front((uint32_t)count);
+}
+
+/* paf_trim_unreliable_tails, impl/paf.c:906-953. Returns 0 or PAFFY_ERR_TRIM_IDENTITY_ASSERT. */
+template <class OPS>
+__device__ int trim_identity(RecState &s, View<OPS> &v, float score_fraction, float max_fraction, int64_t *scratch, Shared *sh) {
+    int64_t m, x;
+    match_stats(v, m, x, scratch);
+    const double identity = ratio_f32(m, m + x);
+    const double thr = __dsub_rn(identity, __dmul_rn(identity, (double)score_fraction));
+    const int64_t max_trim = __float2ll_rz(__fmul_rn(__ll2float_rn(m + x), max_fraction));
+    const float thr_f = __double2float_rn(thr), id_f = __double2float_rn(identity);
+    trim_prefix(s, v, thr_f, id_f, max_trim, scratch, sh);
+    invert_state(s);
+    invert_view(s, v);
+    trim_prefix(s, v, thr_f, id_f, max_trim, scratch, sh);
+    invert_state(s);
+    invert_view(s, v);
+    int64_t m2, x2;
+    match_stats(v, m2, x2, scratch);
+    const double final_identity = ratio_f32(m2, m2 + x2);
+    return final_identity >= identity ? 0 : PAFFY_ERR_TRIM_IDENTITY_ASSERT;
+}
+
+__device__ __forceinline__ bool is_aligned_op(int op) { return op == OP_M || op == OP_EQ || op == OP_X; }
+
+/*
+ * cigar_trim / cigar_trim_back, impl/paf.c:518-576, on the front of the view (call on the
+ * reversed view for the back). Ops are popped while the front op is an indel or fewer than
+ * `end` aligned bases are gone; the op that crosses `end` is shortened. dq/dt: bases consumed.
+ */
+template <class OPS>
+__device__ void trim_front_fixed(View<OPS> &v, int64_t end, int64_t &dq, int64_t &dt, int64_t *scratch, Shared *sh) {
+    uint32_t b, e;
+    sweep_bounds(v.n, b, e);
+    int64_t c[1] = {0}, tot[1];
+    for (uint32_t i = b; i < e; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        if (is_aligned_op(op)) c[0] += len;
+    }
+    block_excl_scan<1>(c, tot, scratch);
+    int64_t tb = c[0], stop = INT64_MAX, stop_tb = 0;
+    for (uint32_t i = b; i < e; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        if (is_aligned_op(op)) {
+            if (!(tb < end) || tb + len > end) {
+                stop = i;
+                stop_tb = tb;
+                break;
+            }
+            tb += len;
+        }
+    }
+    int64_t s_idx = block_min_i64(stop, scratch);
+    if (s_idx != INT64_MAX && s_idx >= (int64_t)b && s_idx < (int64_t)e) sh->bcast[0] = stop_tb;
+    __syncthreads();
+    int64_t tb_s = s_idx != INT64_MAX ? sh->bcast[0] : 0;
+    __syncthreads();
+    uint32_t drop = s_idx == INT64_MAX ? v.n : (uint32_t)s_idx;
+    int64_t d[2] = {0, 0};
+    for (uint32_t i = b; i < e && i < drop; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        if (op != OP_D) d[0] += len;
+        if (op != OP_I) d[1] += len;
+    }
+    block_sum<2>(d, scratch);
+    dq = d[0];
+    dt = d[1];
+    v.drop_front(drop);
+    if (s_idx != INT64_MAX && tb_s < end) {
+        int64_t amt = end - tb_s;
+        v.shorten_front(amt);
+        dq += amt;
+        dt += amt;
+    }
+}
+
+/* paf_trim_end_fraction + paf_trim_ends, impl/paf.c:578-598. */
+template <class OPS>
+__device__ int trim_fixed(RecState &s, View<OPS> &v, float pct, int64_t *scratch, Shared *sh) {
+    if (!(pct >= 0.0f && pct <= 1.0f)) return PAFFY_ERR_TRIM_FIXED_ASSERT;
+    uint32_t b, e;
+    sweep_bounds(v.n, b, e);
+    int64_t a[1] = {0};
+    for (uint32_t i = b; i < e; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        if (is_aligned_op(op)) a[0] += len;
+    }
+    block_sum<1>(a, scratch);
+    const int64_t end = __double2ll_rz((double)__fmul_rn(__ll2float_rn(a[0]), pct) / 2.0);
+    if (!s.has_cigar) return PAFFY_ERR_NULL_CIGAR;
+    int64_t dq, dt;
+    trim_front_fixed(v, end, dq, dt, scratch, sh);
+    if (s.same) s.qs += dq;
+    else s.qe -= dq;
+    s.ts += dt;
+    v.rev = !v.rev;
+    trim_front_fixed(v, end, dq, dt, scratch, sh);
+    v.rev = !v.rev;
+    if (s.same) s.qe -= dq;
+    else s.qs += dq;
+    s.te -= dt;
+    return 0;
+}
+
+/* ---------------- line pieces ---------------- */
+
+/* Serial LDS byte builder used by one lane per piece. */
+struct Piece {
+    uint8_t *p;
+    uint32_t n, cap;
+    bool over;
+    __device__ __forceinline__ void ch(uint32_t c) {
+        if (n < cap) p[n] = (uint8_t)c;
+        else over = true;
+        n++;
+    }
+    __device__ __forceinline__ void str(const char *s) {
+        while (*s) ch((uint8_t)*s++);
+    }
+    __device__ void num(int64_t v) {
+        char tmp[24];
+        int k = 0;
+        uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+        if (u == 0) tmp[k++] = '0';
+        while (u) {
+            uint64_t q = u / 10;
+            tmp[k++] = (char)('0' + (int)(u - q * 10));
+            u = q;
+        }
+        if (v < 0) ch('-');
+        while (k) ch((uint8_t)tmp[--k]);
+    }
+    __device__ void name(const uint8_t *in, uint32_t off, uint32_t len) {
+        for (uint32_t i = 0; i < len; i++) ch(in[off + i]);
+    }
+};
+
+/* Optional tags in the fixed order of impl/paf.c:343-365; `s1` is the chain_score to print. */
+__device__ void piece_tags(Piece &w, const RecState &s, int64_t s1) {
+    if (s.type != 0 || s.tile_level != -1) {
+        uint32_t t = s.type;
+        if (t == 0) t = s.tile_level > 1 ? 'S' : 'P';
+        w.str("\ttp:A:");
+        w.ch(t);
+    }
+    if (s.score != 2147483647ll) { /* INT_MAX guard, impl/paf.c:349 */
+        w.str("\tAS:i:");
+        w.num(s.score);
+    }
+    if (s.tile_level != -1) { w.str("\ttl:i:"); w.num(s.tile_level); }
+    if (s.chain_id != -1) { w.str("\tcn:i:"); w.num(s.chain_id); }
+    if (s1 != -1) { w.str("\ts1:i:"); w.num(s1); }
+}
+__device__ uint32_t tags_len(const RecState &s, int64_t s1) {
+    uint32_t n = 0;
+    if (s.type != 0 || s.tile_level != -1) n += 7;
+    if (s.score != 2147483647ll) n += 6 + dec_len(s.score);
+    if (s.tile_level != -1) n += 6 + dec_len(s.tile_level);
+    if (s.chain_id != -1) n += 6 + dec_len(s.chain_id);
+    if (s1 != -1) n += 6 + dec_len(s1);
+    return n;
+}
+
+/* ---------------- ring -> HBM ---------------- */
+
+/* Store ring bytes [from, to) (from, to multiples of 16) to out; bytes outside [lo, hi) are not ours. */
+__device__ __forceinline__ void ring_flush(const uint8_t *ring, uint8_t *out, uint64_t from, uint64_t to, uint64_t lo, uint64_t hi) {
+    for (uint64_t c = from + 16ull * threadIdx.x; c < to; c += 16ull * PAFFY_NT) {
+        uint4 v = *reinterpret_cast<const uint4 *>(ring + ((uint32_t)c & (PAFFY_RING - 1)));
+        if (c >= lo && c + 16 <= hi) {
+            *reinterpret_cast<uint4 *>(out + c) = v;
+        } else {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int b = 0; b < 16; b++)
+                if (c + b >= lo && c + b < hi) out[c + b] = (uint8_t)(w[b >> 2] >> ((b & 3) * 8));
+        }
+    }
+}
+
+/* Progress of one record's output through the ring. */
+struct Emitter {
+    uint8_t *ring;
+    uint8_t *out;
+    uint64_t begin;   /* first byte of the record */
+    uint64_t pos;     /* next byte to produce */
+    uint64_t flushed; /* multiple of 16: everything below is in HBM */
+    __device__ __forceinline__ void start(uint8_t *r, uint8_t *o, uint64_t off) {
+        ring = r;
+        out = o;
+        begin = pos = off;
+        flushed = off & ~15ull;
+    }
+    /* all lanes deposited `bytes` bytes at pos: push the complete 16-byte chunks out */
+    __device__ __forceinline__ void commit(uint64_t bytes) {
+        __syncthreads();
+        uint64_t np = pos + bytes, to = np & ~15ull;
+        if (to > flushed) {
+            ring_flush(ring, out, flushed, to, begin, np);
+            flushed = to;
+        }
+        pos = np;
+        __syncthreads();
+    }
+    __device__ __forceinline__ void finish() {
+        if (pos > flushed) ring_flush(ring, out, flushed, (pos + 15) & ~15ull, begin, pos);
+    }
+};
+
+/* ---------------- terminals ---------------- */
+
+struct ShatterConst {
+    uint32_t lenA, lenB, lenC;
+    uint32_t row_const, row_max;
+};
+
+/* Row of paf_shatter2 + paf_write: A qs \t qe B ts \t te \t L \t L C L "M\n" */
+template <class SINK>
+__device__ __forceinline__ void put_row(SINK &w, const uint32_t *A, const uint32_t *B, const uint32_t *C, const ShatterConst &k,
+                                        int64_t q0, int64_t t0, int64_t len) {
+    put_lds(w, A, k.lenA);
+    put_dec(w, q0);
+    w.put('\t', 1);
+    put_dec(w, q0 + len);
+    put_lds(w, B, k.lenB);
+    put_dec(w, t0);
+    w.put('\t', 1);
+    put_dec(w, t0 + len);
+    w.put('\t', 1);
+    put_dec(w, len);
+    w.put('\t', 1);
+    put_dec(w, len);
+    put_lds(w, C, k.lenC);
+    put_dec(w, len);
+    w.put((uint32_t)'M' | ((uint32_t)'\n' << 8), 2);
+}
+__device__ __forceinline__ uint32_t row_len(const ShatterConst &k, int64_t q0, int64_t t0, int64_t len) {
+    return k.row_const + dec_len(q0) + dec_len(q0 + len) + dec_len(t0) + dec_len(t0 + len) + 3 * dec_len(len);
+}
+
+/*
+ * paf_shatter, impl/paf.c:629-663, sizing: total bytes / rows, or the first failing assert /
+ * child paf_check in op order (key = op index * 32 + code).
+ */
+template <class OPS>
+__device__ int shatter_size(const RecState &s, const View<OPS> &v, const ShatterConst &k, int64_t &bytes, int64_t &rows,
+                            int64_t *scratch) {
+    uint32_t b, e;
+    sweep_bounds(v.n, b, e);
+    int64_t c[2] = {0, 0}, tot[2];
+    for (uint32_t i = b; i < e; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        if (op != OP_D) c[0] += len;
+        if (op != OP_I) c[1] += len;
+    }
+    block_excl_scan<2>(c, tot, scratch);
+    int64_t cq = c[0], ct = c[1], err = INT64_MAX;
+    int64_t acc[2] = {0, 0};
+    for (uint32_t i = b; i < e; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        int code = 0;
+        if (!(len >= 1)) code = PAFFY_ERR_SHATTER_ZERO_LEN;
+        else if (op == OP_M) {
+            int64_t q0, t0 = s.ts + ct;
+            if (s.same) q0 = s.qs + cq;
+            else q0 = s.qe - (cq + len);
+            /* paf_check on the child (impl/paf.c:624) */
+            if (q0 < 0 || q0 >= s.qlen) code = PAFFY_ERR_CHECK_QSTART;
+            else if (q0 + len > s.qlen) code = PAFFY_ERR_CHECK_QEND;
+            else if (t0 < 0 || t0 >= s.tlen) code = PAFFY_ERR_CHECK_TSTART;
+            else if (t0 + len > s.tlen) code = PAFFY_ERR_CHECK_TEND;
+            acc[0] += row_len(k, q0, t0, len);
+            acc[1] += 1;
+        } else if (op != OP_I && op != OP_D) code = PAFFY_ERR_SHATTER_BAD_OP;
+        if (code && err == INT64_MAX) err = (int64_t)i * 32 + code;
+        if (op != OP_D) cq += len;
+        if (op != OP_I) ct += len;
+    }
+    err = block_min_i64(err, scratch);
+    block_sum<2>(acc, scratch);
+    bytes = acc[0];
+    rows = acc[1];
+    if (err != INT64_MAX) return (int)(err & 31);
+    if (tot[1] != s.te - s.ts) return PAFFY_ERR_SHATTER_END;
+    if (tot[0] != s.qe - s.qs) return PAFFY_ERR_SHATTER_END;
+    return 0;
+}
+
+/* Emit the rows of a (validated) record, window by window, through the ring. */
+template <class OPS>
+__device__ void shatter_emit(const RecState &s, const View<OPS> &v, const ShatterConst &k, const uint32_t *A, const uint32_t *B,
+                             const uint32_t *C, Emitter &em, int64_t *scratch) {
+    const uint32_t cap_bytes = PAFFY_RING - 32;
+    const uint32_t rows_cap = cap_bytes / k.row_max; /* >= 1, checked by the caller */
+    uint32_t w_safe = rows_cap < 2 * PAFFY_NT ? rows_cap : 2 * PAFFY_NT;
+    uint32_t w_full = 2 * rows_cap < 2 * PAFFY_NT ? 2 * rows_cap : 2 * PAFFY_NT;
+    int64_t cq = 0, ct = 0;
+    uint32_t i = 0, w_try = w_full;
+    while (i < v.n) {
+        uint32_t w = v.n - i < w_try ? v.n - i : w_try;
+        uint32_t per = (w + PAFFY_NT - 1) / PAFFY_NT;
+        uint32_t b = i + threadIdx.x * per, e = b + per;
+        if (b > i + w) b = i + w;
+        if (e > i + w) e = i + w;
+        int64_t c[2] = {0, 0}, tot[2];
+        for (uint32_t j = b; j < e; j++) {
+            int64_t len;
+            int op;
+            v.get(j, len, op);
+            if (op != OP_D) c[0] += len;
+            if (op != OP_I) c[1] += len;
+        }
+        block_excl_scan<2>(c, tot, scratch);
+        int64_t pq = cq + c[0], pt = ct + c[1];
+        int64_t nb[1] = {0}, nbt[1];
+        {
+            int64_t q = pq, t = pt;
+            for (uint32_t j = b; j < e; j++) {
+                int64_t len;
+                int op;
+                v.get(j, len, op);
+                if (op == OP_M) {
+                    int64_t q0 = s.same ? s.qs + q : s.qe - (q + len);
+                    nb[0] += row_len(k, q0, s.ts + t, len);
+                }
+                if (op != OP_D) q += len;
+                if (op != OP_I) t += len;
+            }
+        }
+        block_excl_scan<1>(nb, nbt, scratch);
+        if (nbt[0] > (int64_t)cap_bytes && w > w_safe) { /* unusually dense window: retry with the safe size */
+            w_try = w_safe;
+            continue;
+        }
+        RingWriter rw;
+        rw.init(em.ring, (uint32_t)(em.pos + (uint64_t)nb[0]));
+        {
+            int64_t q = pq, t = pt;
+            for (uint32_t j = b; j < e; j++) {
+                int64_t len;
+                int op;
+                v.get(j, len, op);
+                if (op == OP_M) {
+                    int64_t q0 = s.same ? s.qs + q : s.qe - (q + len);
+                    put_row(rw, A, B, C, k, q0, s.ts + t, len);
+                }
+                if (op != OP_D) q += len;
+                if (op != OP_I) t += len;
+            }
+        }
+        rw.finish();
+        em.commit((uint64_t)nbt[0]);
+        cq += tot[0];
+        ct += tot[1];
+        i += w;
+        w_try = w_full;
+    }
+}
+
+/* Header of paf_write_to_buffer up to (and including) "\tcg:Z:" -- impl/paf.c:317-368. */
+__device__ void build_header(Piece &w, const RecState &s, const uint8_t *in, bool newline) {
+    w.name(in, s.qn_off, s.qn_len);
+    w.ch('\t'); w.num(s.qlen);
+    w.ch('\t'); w.num(s.qs);
+    w.ch('\t'); w.num(s.qe);
+    w.ch('\t'); w.ch(s.same ? '+' : '-');
+    w.ch('\t'); w.name(in, s.tn_off, s.tn_len);
+    w.ch('\t'); w.num(s.tlen);
+    w.ch('\t'); w.num(s.ts);
+    w.ch('\t'); w.num(s.te);
+    w.ch('\t'); w.num(s.nmatch);
+    w.ch('\t'); w.num(s.nbases);
+    w.ch('\t'); w.num(s.mapq);
+    piece_tags(w, s, s.chain_score);
+    if (s.has_cigar) w.str("\tcg:Z:");
+    if (newline) w.ch('\n');
+}
+__device__ uint32_t header_len(const RecState &s, bool newline) {
+    uint32_t n = s.qn_len + s.tn_len + 12 + dec_len(s.qlen) + dec_len(s.qs) + dec_len(s.qe) + dec_len(s.tlen) + dec_len(s.ts) +
+                 dec_len(s.te) + dec_len(s.nmatch) + dec_len(s.nbases) + dec_len(s.mapq) + tags_len(s, s.chain_score);
+    if (s.has_cigar) n += 6;
+    if (newline) n += 1;
+    return n;
+}
+
+/* Bytes of the cigar text of the view: sum of digits + 1 per op (impl/paf.c:369-380). */
+template <class OPS>
+__device__ int64_t cigar_text_len(const View<OPS> &v, int64_t *scratch) {
+    uint32_t b, e;
+    sweep_bounds(v.n, b, e);
+    int64_t a[1] = {0};
+    for (uint32_t i = b; i < e; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        a[0] += dec_len(len) + 1;
+    }
+    block_sum<1>(a, scratch);
+    return a[0];
+}
+
+/* One whole line (paf_write): header piece from LDS, then the ops, then '\n'. */
+template <class OPS>
+__device__ void write_emit(const View<OPS> &v, bool has_cigar, const uint32_t *H, uint32_t lenH, Emitter &em, int64_t *scratch) {
+    /* header: 16 bytes per lane per window */
+    for (uint32_t base = 0; base < lenH; base += 16 * PAFFY_NT) {
+        uint32_t left = lenH - base;
+        uint32_t wbytes = left < 16 * PAFFY_NT ? left : 16 * PAFFY_NT;
+        uint32_t mine_off = 16 * threadIdx.x;
+        if (mine_off < wbytes) {
+            uint32_t mine = wbytes - mine_off < 16 ? wbytes - mine_off : 16;
+            RingWriter rw;
+            rw.init(em.ring, (uint32_t)(em.pos + mine_off));
+            put_lds(rw, H + ((base + mine_off) >> 2), mine);
+            rw.finish();
+        }
+        em.commit(wbytes);
+    }
+    if (!has_cigar || v.n == 0) return; /* the header piece already ends the line */
+    const uint32_t cap_bytes = PAFFY_RING - 32;
+    const uint32_t w_full = 16 * PAFFY_NT, w_safe = cap_bytes / 21; /* an op prints as at most 20 + 1 bytes */
+    uint32_t i = 0, w_try = w_full;
+    while (i < v.n) {
+        uint32_t w = v.n - i < w_try ? v.n - i : w_try;
+        uint32_t per = (w + PAFFY_NT - 1) / PAFFY_NT;
+        uint32_t b = i + threadIdx.x * per, e = b + per;
+        if (b > i + w) b = i + w;
+        if (e > i + w) e = i + w;
+        const bool last = (i + w == v.n);
+        int64_t nb[1] = {0}, nbt[1];
+        for (uint32_t j = b; j < e; j++) {
+            int64_t len;
+            int op;
+            v.get(j, len, op);
+            nb[0] += dec_len(len) + 1;
+        }
+        if (last && e == v.n && b < e) nb[0] += 1; /* '\n' goes with the last op */
+        block_excl_scan<1>(nb, nbt, scratch);
+        if (nbt[0] > (int64_t)cap_bytes && w > w_safe) {
+            w_try = w_safe;
+            continue;
+        }
+        if (b < e) {
+            RingWriter rw;
+            rw.init(em.ring, (uint32_t)(em.pos + (uint64_t)nb[0]));
+            for (uint32_t j = b; j < e; j++) {
+                int64_t len;
+                int op;
+                v.get(j, len, op);
+                put_dec(rw, len);
+                rw.put(op_char_of(op), 1);
+            }
+            if (last && e == v.n) rw.put('\n', 1);
+            rw.finish();
+        }
+        em.commit((uint64_t)nbt[0]);
+        i += w;
+        w_try = w_full;
+    }
+}
+
+/* ---------------- the record program ---------------- */
+
+struct RecLds {
+    uint8_t *ring;   /* PAFFY_RING bytes, 16-aligned; doubles as the cigar text staging area */
+    uint32_t *pieces; /* 3 * PAFFY_TMPL_MAX bytes */
+    int64_t *scratch; /* 64 words */
+    Shared *sh;
+};
+
+__device__ __forceinline__ void report(const KParams &P, uint32_t rec, int code, int stage, int aux, uint32_t klass) {
+    if (threadIdx.x == 0) {
+        P.status[rec] = (uint32_t)code | ((uint32_t)((stage + 1) & 0xff) << 8) | (klass << 16);
+        P.err_aux[rec] = aux;
+        P.out_len[rec] = 0;
+        P.out_rows[rec] = 0;
+        if (code)
+            atomicMin(&P.info->first_err_key,
+                      ((unsigned long long)rec << 16) | ((unsigned long long)((stage + 1) & 0xff) << 8) | (unsigned long long)code);
+    }
+}
+
+/*
+ * Runs the stage list on record `rec`. `ops`/`cap` is the op store to parse into; with
+ * pre_n != UINT32_MAX the ops are already there (arena class, emit pass).
+ * Returns false when the record does not fit this store (sizing pass, LDS class only).
+ */
+template <class OPS, bool EMIT>
+__device__ bool run_record(const KParams &P, uint32_t rec, const OPS &ops, uint32_t cap, uint32_t pre_n, const RecLds &L, uint32_t klass,
+                           uint32_t *n_ops_out) {
+    const RecMeta m = P.meta[rec];
+    if (m.err) {
+        if (!EMIT) report(P, rec, m.err, -1, m.err_aux, klass);
+        return true;
+    }
+    RecState s;
+    s.qlen = m.qlen; s.qs = m.qs; s.qe = m.qe; s.tlen = m.tlen; s.ts = m.ts; s.te = m.te;
+    s.nmatch = m.nmatch; s.nbases = m.nbases; s.mapq = m.mapq; s.score = m.score;
+    s.tile_level = m.tile_level; s.chain_id = m.chain_id; s.chain_score = m.chain_score;
+    s.qn_off = m.qname_off; s.qn_len = m.qname_len; s.tn_off = m.tname_off; s.tn_len = m.tname_len;
+    s.same = m.same_strand != 0;
+    s.type = m.type;
+    s.has_cigar = m.has_cg && m.cg_len > 0; /* cigar_parse("") == NULL, impl/paf.c:71-73 */
+
+    uint32_t n = 0;
+    if (s.has_cigar) {
+        if (pre_n != 0xffffffffu) {
+            n = pre_n;
+        } else {
+            bool fits;
+            uint32_t err_pos;
+            uint32_t r = parse_cigar(P.in, m.cg_off, m.cg_len, ops, cap, L.ring, L.scratch, L.sh, &fits, &err_pos);
+            if (r & 0x80000000u) r = parse_cigar_serial(P.in, m.cg_off, m.cg_len, ops, cap, L.sh, &fits, &err_pos);
+            n = r;
+            if (err_pos != 0xffffffffu) { /* st_errAbort, impl/paf.c:102 */
+                if (!EMIT) report(P, rec, PAFFY_ERR_CIGAR_CHAR, -1, err_pos < m.cg_off + m.cg_len ? P.in[err_pos] : 0, klass);
+                return true;
+            }
+            if (!fits) return false;
+        }
+    }
+    *n_ops_out = n;
+    View<OPS> v;
+    v.ops = ops; v.lo = 0; v.n = n; v.rev = false; v.swp = false; v.sub_lo = v.sub_hi = 0;
+
+    int32_t last = P.n_stages - 1;
+    for (int32_t si = 0; si < P.n_stages; si++) {
+        const paffy_stage st = P.stages[si];
+        if (si > 0) { /* what `paf_write | paf_parse` between two processes does to the record */
+            if (s.has_cigar && v.n == 0) s.has_cigar = false;
+            if (s.type == 0 && s.tile_level != -1) s.type = s.tile_level > 1 ? 'S' : 'P';
+        }
+        int rc = 0;
+        switch (st.kind) {
+            case PAFFY_INVERT:
+                invert_state(s);
+                invert_view(s, v);
+                rc = check_record(s, v, L.scratch);
+                break;
+            case PAFFY_TRIM_IDENTITY:
+                rc = trim_identity(s, v, st.p0, st.p1, L.scratch, L.sh);
+                if (!rc) rc = check_record(s, v, L.scratch);
+                break;
+            case PAFFY_TRIM_FIXED:
+                rc = trim_fixed(s, v, st.p1, L.scratch, L.sh);
+                if (!rc) rc = check_record(s, v, L.scratch);
+                break;
+            case PAFFY_SHATTER: {
+                /* line pieces shared by every row of this record (paf_shatter2, impl/paf.c:600-627) */
+                ShatterConst k;
+                k.lenA = s.qn_len + 2 + dec_len(s.qlen);
+                k.lenB = s.tn_len + 5 + dec_len(s.tlen);
+                k.lenC = 1 + dec_len(s.mapq) + tags_len(s, 0) + 6; /* children carry s1:i:0 (calloc, impl/paf.c:601) */
+                k.row_const = k.lenA + k.lenB + k.lenC + 6;
+                uint32_t dq = dec_len(s.qlen), dt = dec_len(s.tlen);
+                k.row_max = k.row_const + 2 * dq + 2 * dt + 3 * (dq < dt ? dq : dt);
+                if (k.lenA > PAFFY_TMPL_MAX || k.lenB > PAFFY_TMPL_MAX || k.lenC > PAFFY_TMPL_MAX || k.row_max > PAFFY_RING - 32) {
+                    if (threadIdx.x == 0) atomicOr(&P.info->internal, INTERNAL_TMPL_TOO_LONG);
+                    if (!EMIT) report(P, rec, 0, si, 0, klass);
+                    return true;
+                }
+                if (!EMIT) {
+                    int64_t bytes, rows;
+                    rc = shatter_size(s, v, k, bytes, rows, L.scratch);
+                    if (rc) break;
+                    if (threadIdx.x == 0) {
+                        P.status[rec] = klass << 16;
+                        P.out_len[rec] = bytes;
+                        P.out_rows[rec] = rows;
+                    }
+                    return true;
+                } else {
+                    uint32_t *A = L.pieces, *B = L.pieces + PAFFY_TMPL_MAX / 4, *C = L.pieces + 2 * (PAFFY_TMPL_MAX / 4);
+                    if (threadIdx.x == 0) {
+                        Piece w{(uint8_t *)A, 0, PAFFY_TMPL_MAX, false};
+                        w.name(P.in, s.qn_off, s.qn_len);
+                        w.ch('\t'); w.num(s.qlen); w.ch('\t');
+                    } else if (threadIdx.x == 64) {
+                        Piece w{(uint8_t *)B, 0, PAFFY_TMPL_MAX, false};
+                        w.ch('\t'); w.ch(s.same ? '+' : '-'); w.ch('\t');
+                        w.name(P.in, s.tn_off, s.tn_len);
+                        w.ch('\t'); w.num(s.tlen); w.ch('\t');
+                    } else if (threadIdx.x == 128) {
+                        Piece w{(uint8_t *)C, 0, PAFFY_TMPL_MAX, false};
+                        w.ch('\t'); w.num(s.mapq);
+                        piece_tags(w, s, 0);
+                        w.str("\tcg:Z:");
+                    }
+                    __syncthreads();
+                    Emitter em;
+                    em.start(L.ring, P.out, (uint64_t)P.out_off[rec]);
+                    shatter_emit(s, v, k, A, B, C, em, L.scratch);
+                    em.finish();
+                    return true;
+                }
+            }
+            case PAFFY_PASS:
+                break;
+            default:
+                rc = 0;
+                break;
+        }
+        if (rc) {
+            if (!EMIT) report(P, rec, rc, si, 0, klass);
+            return true;
+        }
+        (void)last;
+    }
+    /* paf_write of the transformed record */
+    const bool nl_in_header = !(s.has_cigar && v.n > 0);
+    const uint32_t lenH = header_len(s, nl_in_header);
+    if (lenH > 3 * PAFFY_TMPL_MAX) {
+        if (threadIdx.x == 0) atomicOr(&P.info->internal, INTERNAL_TMPL_TOO_LONG);
+        if (!EMIT) report(P, rec, 0, P.n_stages, 0, klass);
+        return true;
+    }
+    if (!EMIT) {
+        int64_t bytes = lenH;
+        if (!nl_in_header) bytes += cigar_text_len(v, L.scratch) + 1;
+        if (threadIdx.x == 0) {
+            P.status[rec] = klass << 16;
+            P.out_len[rec] = bytes;
+            P.out_rows[rec] = 1;
+        }
+    } else {
+        if (threadIdx.x == 0) {
+            Piece w{(uint8_t *)L.pieces, 0, 3 * PAFFY_TMPL_MAX, false};
+            build_header(w, s, P.in, nl_in_header);
+        }
+        __syncthreads();
+        Emitter em;
+        em.start(L.ring, P.out, (uint64_t)P.out_off[rec]);
+        write_emit(v, s.has_cigar, L.pieces, lenH, em, L.scratch);
+        em.finish();
+    }
+    return true;
+}
+
+#define PAFFY_LDS_BYTES (PAFFY_RING + PAFFY_OPS_CAP * 4 + 3 * PAFFY_TMPL_MAX + 64 * 8 + 64)
+
+__device__ __forceinline__ RecLds carve_lds(uint8_t *smem, uint32_t **ops_lds) {
+    RecLds L;
+    L.ring = smem;
+    *ops_lds = reinterpret_cast<uint32_t *>(smem + PAFFY_RING);
+    L.pieces = reinterpret_cast<uint32_t *>(smem + PAFFY_RING + PAFFY_OPS_CAP * 4);
+    L.scratch = reinterpret_cast<int64_t *>(smem + PAFFY_RING + PAFFY_OPS_CAP * 4 + 3 * PAFFY_TMPL_MAX);
+    L.sh = reinterpret_cast<Shared *>(smem + PAFFY_RING + PAFFY_OPS_CAP * 4 + 3 * PAFFY_TMPL_MAX + 64 * 8);
+    return L;
+}
+
+/* LDS class: one workgroup per record, ops re-parsed from the text into LDS. */
+template <bool EMIT>
+__global__ __launch_bounds__(PAFFY_NT) void k_record_lds(KParams P) {
+    extern __shared__ uint4 smem4[];
+    uint32_t *ops_lds;
+    RecLds L = carve_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds);
+    const uint32_t rec = blockIdx.x;
+    if (EMIT) {
+        if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return; /* nothing at or after the first failure */
+        if ((P.status[rec] >> 16) != KLASS_LDS) return;
+    }
+    OpsLds ops{ops_lds};
+    uint32_t n_ops = 0;
+    bool ok = run_record<OpsLds, EMIT>(P, rec, ops, PAFFY_OPS_CAP, 0xffffffffu, L, KLASS_LDS, &n_ops);
+    if (!EMIT && !ok && threadIdx.x == 0) { /* route to the arena kernel */
+        P.status[rec] = (uint32_t)KLASS_ARENA << 16;
+        P.out_len[rec] = 0;
+        P.out_rows[rec] = 0;
+        uint32_t slot = atomicAdd(&P.info->w_count, 1u);
+        P.w_list[slot] = rec;
+    }
+}
+
+/* Arena class: records whose ops do not fit LDS; persistent workgroups walk the list. */
+template <bool EMIT>
+__global__ __launch_bounds__(PAFFY_NT) void k_record_arena(KParams P) {
+    extern __shared__ uint4 smem4[];
+    uint32_t *ops_lds;
+    RecLds L = carve_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds);
+    const uint32_t count = P.info->w_count;
+    const uint32_t first_err = (uint32_t)(P.info->first_err_key >> 16);
+    for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
+        const uint32_t rec = P.w_list[li];
+        if (EMIT) {
+            if (rec < first_err) {
+                OpsArena ops{P.arena + P.arena_off[rec]};
+                uint32_t n_ops = 0;
+                run_record<OpsArena, true>(P, rec, ops, 0xffffffffu, P.n_ops[rec], L, KLASS_ARENA, &n_ops);
+            }
+        } else {
+            /* upper bound for the allocation: one op per cigar byte */
+            const uint32_t cg_len = P.meta[rec].cg_len;
+            if (threadIdx.x == 0) L.sh->bcast[3] = (int64_t)atomicAdd(&P.info->arena_used, (unsigned long long)cg_len);
+            __syncthreads();
+            const uint64_t off = (uint64_t)L.sh->bcast[3];
+            __syncthreads();
+            if (off + cg_len <= P.arena_cap) {
+                OpsArena ops{P.arena + off};
+                uint32_t n_ops = 0;
+                run_record<OpsArena, false>(P, rec, ops, cg_len, 0xffffffffu, L, KLASS_ARENA, &n_ops);
+                if (threadIdx.x == 0) {
+                    P.n_ops[rec] = n_ops;
+                    P.arena_off[rec] = off;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+#endif

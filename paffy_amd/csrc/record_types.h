@@ -1,0 +1,71 @@
+/*
+ * record_types.h -- HBM data model shared by the kernels and the host API.
+ *
+ * A batch is the raw PAF text (never copied: names and cigar text are addressed by offset)
+ * plus, per record, one RecMeta (fixed fields parsed by k_header) and a few per-record result
+ * words written by the sizing pass. Cigar ops are never materialised in HBM for records whose
+ * ops fit the LDS store (<= PAFFY_OPS_CAP ops, lengths < 2^29): they are re-parsed from the
+ * text by the workgroup that owns the record. Larger / wider records keep 8-byte ops
+ * (length << 8 | op, the CigarRecord layout of inc/paf.h:61-64) in a global arena.
+ */
+#ifndef PAFFY_RECORD_TYPES_H_
+#define PAFFY_RECORD_TYPES_H_
+
+#include <stdint.h>
+
+#include "../../include/paffy_hip.h"
+
+#define PAFFY_OPS_CAP 8192u /* 4-byte ops held in LDS per workgroup (32 KiB) */
+#define PAFFY_TMPL_MAX 1024u /* bytes per pre-rendered line piece held in LDS */
+#define PAFFY_HALO 32u
+
+enum { OP_M = 0, OP_I = 1, OP_D = 2, OP_EQ = 3, OP_X = 4 }; /* inc/paf.h:52-58 */
+
+struct RecMeta {
+    int64_t qlen, qs, qe, tlen, ts, te, nmatch, nbases, mapq; /* fields 2-4, 7-12 */
+    int64_t score, tile_level, chain_id, chain_score;         /* AS tl cn s1 (defaults 0,-1,-1,-1) */
+    uint32_t qname_off, qname_len, tname_off, tname_len;      /* slices of the input text */
+    uint32_t cg_off, cg_len;                                  /* value of the last cg:Z: tag */
+    uint8_t same_strand, type, has_cg, pad0;
+    int32_t err;     /* PAFFY_ERR_* found while parsing the fixed fields */
+    int32_t err_aux; /* offending character */
+    uint32_t pad1;
+};
+
+/* Record classes decided by the sizing pass. */
+enum { KLASS_LDS = 0, KLASS_ARENA = 1 };
+
+struct DevInfo {
+    unsigned long long first_err_key; /* min over failing records of rec<<16 | (stage+1)<<8 | code */
+    unsigned long long arena_used;    /* bump pointer (in ops) */
+    unsigned long long out_bytes, out_rows;
+    uint32_t n_seps, n_lines;
+    uint32_t w_count;   /* records routed to the arena kernel */
+    uint32_t internal;  /* internal-limit flags (must stay 0) */
+};
+
+struct KParams {
+    const uint8_t *in;
+    uint32_t in_len;
+    uint32_t n_rec;
+    const RecMeta *meta;
+    paffy_stage stages[PAFFY_MAX_STAGES];
+    int32_t n_stages;
+    /* per-record results of the sizing pass */
+    int64_t *out_len;
+    int64_t *out_rows;
+    uint32_t *status;   /* code | (stage+1)<<8 | klass<<16 */
+    int32_t *err_aux;
+    uint32_t *n_ops;
+    uint64_t *arena_off;
+    /* emit pass */
+    const int64_t *out_off;
+    uint8_t *out;
+    /* arena class */
+    uint64_t *arena;
+    uint64_t arena_cap; /* in ops */
+    uint32_t *w_list;
+    DevInfo *info;
+};
+
+#endif

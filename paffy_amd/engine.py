@@ -1,0 +1,225 @@
+"""ctypes binding of libpaffy_hip.so plus helpers named after the reference commands.
+
+Names follow the reference CLI (`paffy invert | trim | shatter`, impl/paf_<cmd>.c): a Stage is
+one command of a pipe; `trim` takes the reference's -r/-t/-f options. torch is used only for
+device buffers and the stream handle.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+_LIB = os.path.join(HERE, "libpaffy_hip.so")
+
+INVERT, TRIM_IDENTITY, TRIM_FIXED, SHATTER, ADD_MISMATCHES, REMOVE_MISMATCHES, PASS = 1, 2, 3, 4, 5, 6, 7
+
+
+class Stage(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("p0", C.c_float), ("p1", C.c_float)]
+
+
+class _Error(C.Structure):
+    _fields_ = [("code", C.c_int32), ("stage", C.c_int32), ("record", C.c_int64), ("aux", C.c_int64)]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("n_records", C.c_int64), ("n_rows", C.c_int64), ("in_bytes", C.c_int64), ("out_bytes", C.c_int64),
+                ("error", _Error)]
+
+
+class PafError(RuntimeError):
+    """A record the reference would abort on; .info holds the plan (records before it are emitted)."""
+
+    def __init__(self, msg, info, exit_status):
+        super().__init__(msg)
+        self.info = info
+        self.exit_status = exit_status
+
+
+def stage(kind, trim_identity=0.05, trim_fraction=1.0):
+    """One command of a pipe. trim_identity = `paffy trim -r`, trim_fraction = `-t` (impl/paf_trim.c:14-16)."""
+    return Stage(kind, trim_identity, trim_fraction)
+
+
+def library_path():
+    return _LIB
+
+
+def build_library(force=False):
+    """Compile the gfx950 shared library in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(HERE), "include", "paffy_hip.h"))
+    stale = not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise RuntimeError(f"{_LIB} is missing: run paffy_amd.build_library() (there is no CPU fallback)")
+        L = C.CDLL(_LIB)
+        vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
+        L.paffy_hip_create.argtypes = [C.POINTER(vp), C.c_int]
+        L.paffy_hip_destroy.argtypes = [vp]
+        L.paffy_hip_set_stream.argtypes = [vp, vp]
+        L.paffy_hip_plan.argtypes = [vp, C.POINTER(Stage), i32, vp, i64, C.POINTER(PlanInfo)]
+        L.paffy_hip_emit.argtypes = [vp, vp, i64]
+        L.paffy_hip_sync.argtypes = [vp]
+        L.paffy_hip_error_exit_status.argtypes = [i32]
+        L.paffy_hip_error_string.restype = C.c_char_p
+        L.paffy_hip_error_string.argtypes = [i32]
+        L.paffy_hip_last_error.restype = C.c_char_p
+        L.paffy_hip_last_error.argtypes = [vp]
+        L.paffy_hip_profile_enable.argtypes = [vp, C.c_int]
+        L.paffy_hip_profile_reset.argtypes = [vp]
+        L.paffy_hip_profile_read.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(i64), C.c_int]
+        L.paffy_hip_synth.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64)]
+        L.paffy_hip_device_count.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _pad16(n):
+    return (n + 15) // 16 * 16 + 16
+
+
+class Engine:
+    """One HIP context (workspace + stream) on the current torch device."""
+
+    def __init__(self, device=None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("paffy_amd needs a GPU: the hot path has no CPU implementation")
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self._ctx = C.c_void_p()
+        rc = lib().paffy_hip_create(C.byref(self._ctx), self.device.index)
+        if rc:
+            raise RuntimeError(f"paffy_hip_create failed ({rc})")
+        self.use_stream(torch.cuda.current_stream(self.device))
+
+    def close(self):
+        if self._ctx:
+            lib().paffy_hip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_stream(self, stream):
+        self.stream = stream
+        lib().paffy_hip_set_stream(self._ctx, C.c_void_p(stream.cuda_stream))
+
+    def _check(self, rc, what):
+        if rc:
+            raise RuntimeError(f"{what} failed ({rc}): {lib().paffy_hip_last_error(self._ctx).decode()}")
+
+    # ---- device-buffer level (what bench.py times) ----
+    def to_device(self, data):
+        """bytes -> padded uint8 device tensor (the library reads up to the next multiple of 16)."""
+        t = self.torch
+        buf = t.zeros(_pad16(len(data)), dtype=t.uint8, device=self.device)
+        if len(data):
+            buf[: len(data)] = t.frombuffer(bytearray(data), dtype=t.uint8).to(self.device)
+        return buf
+
+    def plan(self, stages, d_in, in_len):
+        arr = (Stage * max(1, len(stages)))(*stages)
+        info = PlanInfo()
+        rc = lib().paffy_hip_plan(self._ctx, arr, len(stages), C.c_void_p(d_in.data_ptr()), in_len, C.byref(info))
+        self._check(rc, "paffy_hip_plan")
+        return info
+
+    def emit(self, d_out):
+        rc = lib().paffy_hip_emit(self._ctx, C.c_void_p(d_out.data_ptr()), d_out.numel())
+        self._check(rc, "paffy_hip_emit")
+
+    def sync(self):
+        self._check(lib().paffy_hip_sync(self._ctx), "paffy_hip_sync")
+
+    def alloc_out(self, nbytes):
+        return self.torch.empty(_pad16(nbytes), dtype=self.torch.uint8, device=self.device)
+
+    # ---- bytes level (tests, small inputs) ----
+    def run(self, stages, data, raise_on_error=True):
+        """Apply a pipe of commands to PAF text; returns (output bytes, PlanInfo)."""
+        d_in = self.to_device(data)
+        info = self.plan(stages, d_in, len(data))
+        out = b""
+        if info.out_bytes:
+            d_out = self.alloc_out(info.out_bytes)
+            self.emit(d_out)
+            self.sync()
+            out = bytes(d_out[: info.out_bytes].cpu().numpy().tobytes())
+        if info.error.code and raise_on_error:
+            L = lib()
+            raise PafError(f"record {info.error.record}: {L.paffy_hip_error_string(info.error.code).decode()}", info,
+                           L.paffy_hip_error_exit_status(info.error.code))
+        return out, info
+
+    def run_chain(self, stages, data):
+        """Run the commands one by one over text, as separate `paffy` processes in a shell pipe would."""
+        for st in stages:
+            data, _ = self.run([st], data)
+        return data
+
+    def synth(self, seed, mean_ops, r0, n):
+        """Synthetic PAF records [r0, r0+n) generated on the device; returns (tensor, nbytes)."""
+        nbytes = C.c_int64()
+        self._check(lib().paffy_hip_synth(self._ctx, seed, mean_ops, r0, n, None, 0, C.byref(nbytes)), "paffy_hip_synth(size)")
+        buf = self.torch.zeros(_pad16(nbytes.value), dtype=self.torch.uint8, device=self.device)
+        self._check(lib().paffy_hip_synth(self._ctx, seed, mean_ops, r0, n, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(nbytes)),
+                    "paffy_hip_synth(fill)")
+        return buf, nbytes.value
+
+    # ---- per-kernel HIP-event timing ----
+    def profile(self, on=True):
+        lib().paffy_hip_profile_enable(self._ctx, 1 if on else 0)
+        lib().paffy_hip_profile_reset(self._ctx)
+
+    def profile_read(self):
+        cap = 32
+        names, ms, cnt = (C.c_char_p * cap)(), (C.c_double * cap)(), (C.c_int64 * cap)()
+        n = lib().paffy_hip_profile_read(self._ctx, names, ms, cnt, cap)
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(min(n, cap))}
+
+
+_default = None
+
+
+def _engine():
+    global _default
+    if _default is None:
+        _default = Engine()
+    return _default
+
+
+def pipe(stages, data):
+    """`paffy a | paffy b | ...` over PAF text (bytes in, bytes out)."""
+    return _engine().run(stages, data)[0]
+
+
+def invert(data):
+    """paffy invert (impl/paf_invert.c)."""
+    return pipe([stage(INVERT)], data)
+
+
+def shatter(data):
+    """paffy shatter (impl/paf_shatter.c)."""
+    return pipe([stage(SHATTER)], data)
+
+
+def trim(data, trim_identity=0.05, trim_fraction=1.0, fixed_trim=False):
+    """paffy trim [-r trim_identity] [-t trim_fraction] [-f] (impl/paf_trim.c)."""
+    return pipe([stage(TRIM_FIXED if fixed_trim else TRIM_IDENTITY, trim_identity, trim_fraction)], data)

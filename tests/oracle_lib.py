@@ -65,7 +65,8 @@ def stage(kind, p0=0.05, p1=1.0):
 
 
 def _take(ptr, n):
-    data = C.string_at(ptr, n.value) if ptr.value else b""
+    # string_at takes a C int; shatter outputs pass 2 GiB
+    data = bytes((C.c_char * n.value).from_address(ptr.value)) if ptr.value and n.value else b""
     if ptr.value:
         lib().po_free(ptr)
     return data

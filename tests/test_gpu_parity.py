@@ -1,0 +1,188 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle: bit-exact output bytes."""
+import hashlib
+import json
+import os
+
+import pytest
+
+import oracle_lib as O
+import synth_lib
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+S = O.stage
+PIPES = {
+    "pass": [S(O.PASS)],
+    "invert": [S(O.INVERT)],
+    "invert|invert": [S(O.INVERT), S(O.INVERT)],
+    "trim": [S(O.TRIM_IDENTITY)],
+    "trim -r 0.95": [S(O.TRIM_IDENTITY, 0.95, 1.0)],
+    "trim -r 0 -t 0.3": [S(O.TRIM_IDENTITY, 0.0, 0.3)],
+    "trim -f -t 0.1": [S(O.TRIM_FIXED, 0.05, 0.1)],
+    "trim -f -t 0": [S(O.TRIM_FIXED, 0.05, 0.0)],
+    "trim -f -t 1": [S(O.TRIM_FIXED, 0.05, 1.0)],
+    "shatter": [S(O.SHATTER)],
+    "invert|trim|shatter": [S(O.INVERT), S(O.TRIM_IDENTITY), S(O.SHATTER)],
+    "trim -f|invert|shatter": [S(O.TRIM_FIXED, 0.05, 0.2), S(O.INVERT), S(O.SHATTER)],
+}
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import paffy_amd
+
+    e = paffy_amd.Engine()
+    yield e
+    e.close()
+
+
+def gpu_stages(stages):
+    import paffy_amd
+
+    return [paffy_amd.Stage(s.kind, s.p0, s.p1) for s in stages]
+
+
+def first_diff(a, b):
+    n = min(len(a), len(b))
+    for i in range(n):
+        if a[i] != b[i]:
+            return i, a[max(0, i - 60): i + 40], b[max(0, i - 60): i + 40]
+    return n, a[n - 60: n + 40], b[n - 60: n + 40]
+
+
+def check(eng, stages, data, name=""):
+    want, werr = O.run(stages, data)
+    got, info = eng.run(gpu_stages(stages), data, raise_on_error=False)
+    assert info.error.code == werr.code, (name, info.error.code, werr.code, info.error.record, werr.record)
+    if werr.code:
+        assert (info.error.record, info.error.stage) == (werr.record, werr.stage), name
+    assert len(got) == info.out_bytes
+    assert got == want, (name, len(got), len(want), first_diff(got, want))
+    return got, info
+
+
+def kat_line(q, qlen, qs, qe, strand, t, tlen, ts, te, nm, nb, mq, cigar=None, tags=""):
+    s = f"{q}\t{qlen}\t{qs}\t{qe}\t{strand}\t{t}\t{tlen}\t{ts}\t{te}\t{nm}\t{nb}\t{mq}"
+    if tags:
+        s += "\t" + tags
+    if cigar is not None:
+        s += "\tcg:Z:" + cigar
+    return (s + "\n").encode()
+
+
+KAT_RECORDS = [
+    kat_line("query1", 100, 0, 50, "+", "target1", 200, 10, 60, 50, 50, 255),
+    kat_line("q1", 100, 0, 8, "+", "t1", 200, 0, 7, 8, 10, 60, "5M3I2D"),
+    kat_line("q1", 100, 0, 50, "+", "t1", 200, 0, 50, 50, 50, 60, None, "tp:A:P\tAS:i:42\ttl:i:2\tcn:i:5\ts1:i:100"),
+    kat_line("q1", 100, 0, 50, "-", "t1", 200, 0, 50, 50, 50, 60, None, "s1:i:100\tcn:i:5\ttl:i:2\tAS:i:-42\ttp:A:I"),
+    kat_line("query", 100, 10, 18, "+", "target", 200, 20, 27, 8, 10, 60, "5M3I2D"),
+    kat_line("query", 100, 10, 18, "-", "target", 200, 20, 25, 5, 8, 60, "5M3I"),
+    kat_line("q", 100, 5, 15, "+", "t", 100, 5, 15, 10, 10, 60, "10M"),
+    kat_line("q", 100, 0, 8, "+", "t", 100, 0, 7, 7, 8, 60, "2M1I5M"),
+    kat_line("q", 100, 0, 8, "-", "t", 100, 0, 7, 7, 8, 60, "2M1I5M"),
+    kat_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M"),
+    kat_line("q", 100, 0, 7, "+", "t", 100, 0, 9, 7, 9, 60, "3M2D4M"),
+    kat_line("q", 100, 0, 7, "-", "t", 100, 0, 9, 7, 9, 60, "3M2D4M"),
+    kat_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M", "tl:i:2\ts1:i:99\tcn:i:4\tAS:i:7\tNM:i:3\tde:f:0.01"),
+    b"q\t\t100\t0\t5\t+\tt\t100\t0\t5\t5\t5\t60\t\tcg:Z:\n",
+    kat_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, None, "AS:i:-12\tcg:Z:9M\tcg:Z:5M"),
+    kat_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "0000000000000000000000000000000000000000005M"),
+    kat_line("q", 10 ** 15, 10 ** 14, 10 ** 14 + 5, "+", "t", 10 ** 18, 123456789012345678, 123456789012345683, 5, 5, 60, "5M", "AS:i:-9223372036854775807"),
+]
+KAT_EQX = [  # records with =/X ops: not shatterable (assert), fine for invert / trim
+    kat_line("q", 9, 0, 9, "-", "t", 9, 0, 9, 5, 9, 60, "2X5=2X"),
+    kat_line("q", 9, 0, 9, "+", "t", 9, 0, 9, 5, 9, 60, "2X5=2X"),
+    kat_line("q", 9, 0, 7, "-", "t", 9, 0, 7, 5, 7, 60, "2X5="),
+    kat_line("q", 100, 0, 6, "+", "t", 100, 0, 7, 5, 8, 60, "3=2X1I2D"),
+    kat_line("q", 100, 0, 13, "+", "t", 100, 0, 12, 10, 15, 60, "5M3I2D4=1X"),
+]
+
+
+def test_known_answer_records(eng):
+    """The records of /root/reference/tests/paf_unit_test.c through every fused pipe."""
+    data = b"".join(KAT_RECORDS)
+    for name, stages in PIPES.items():
+        check(eng, stages, data, name)
+        for rec in KAT_RECORDS:
+            check(eng, stages, rec, name)
+    for name in ("pass", "invert", "trim", "trim -r 0 -t 0.3", "trim -f -t 0.1", "trim -f -t 1", "invert|invert"):
+        check(eng, PIPES[name], b"".join(KAT_EQX), name)
+    for thr in (0.0, 1.0):
+        for rec in KAT_EQX:
+            check(eng, [S(O.TRIM_IDENTITY, thr, 1.0)], rec, "kat trim")
+
+
+def test_fixture_digests(eng, human_chimp):
+    """tests/human_chimp.paf: 207 records, 1..20663 ops, both LDS and arena classes."""
+    with open(os.path.join(GOLDEN, "human_chimp_digests.json")) as fh:
+        golden = json.load(fh)
+    for name, stages in PIPES.items():
+        got, info = check(eng, stages, human_chimp, name)
+        assert info.n_records == 207
+        if name in golden:
+            assert hashlib.sha256(got).hexdigest() == golden[name]["sha256"], name
+            assert info.n_rows == golden[name]["lines"]
+
+
+def test_chained_commands_equal_fused(eng, human_chimp):
+    import paffy_amd
+
+    st = gpu_stages(PIPES["invert|trim|shatter"])
+    assert eng.run_chain(st, human_chimp) == eng.run(st, human_chimp)[0]
+    # cfg 1 of BASELINE.json: shatter | invert, run as two commands
+    want = O.run([S(O.SHATTER), S(O.INVERT)], human_chimp)[0]
+    assert eng.run_chain([paffy_amd.stage(paffy_amd.SHATTER), paffy_amd.stage(paffy_amd.INVERT)], human_chimp) == want
+
+
+@pytest.mark.parametrize("seed,mean_ops,n", [(0x5EED0002, 512, 700), (0x5EED0003, 2048, 300), (0x5EED0009, 3, 3000), (0x5EED000A, 9000, 40)])
+def test_synthetic_records(eng, seed, mean_ops, n):
+    data = synth_lib.generate(seed, mean_ops, 0, n)
+    for name in ("invert|trim|shatter", "shatter", "invert", "trim", "trim -f -t 0.1"):
+        check(eng, PIPES[name], data, name)
+
+
+def test_device_generator_matches_host(eng):
+    for seed, mean_ops, r0, n in [(0x5EED0003, 2048, 0, 200), (0x5EED0002, 512, 12345, 500), (7, 1, 0, 1000)]:
+        buf, nbytes = eng.synth(seed, mean_ops, r0, n)
+        assert bytes(buf[:nbytes].cpu().numpy().tobytes()) == synth_lib.generate(seed, mean_ops, r0, n)
+
+
+def test_edges(eng):
+    ok = kat_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M")
+    for stages in (PIPES["pass"], PIPES["shatter"], PIPES["invert|trim|shatter"]):
+        assert eng.run(gpu_stages(stages), b"")[0] == b""
+        check(eng, stages, ok[:-1])           # final line without '\n'
+        check(eng, stages, ok * 3 + ok[:-1])
+    long_name = ("Q" * 700).encode()
+    rec = long_name + b"\t100\t0\t5\t-\t" + b"T" * 333 + b"\t100\t0\t5\t5\t5\t60\tcg:Z:2M1D2M1I\n"
+    rec = rec.replace(b"\t0\t5\t-", b"\t0\t5\t-", 1)
+    for name in ("pass", "invert"):
+        check(eng, PIPES[name], rec + ok, name)
+    # many tiny records: every alignment of a line start modulo 16
+    tiny = b"".join(kat_line("c%d" % i, 1000 + i, i, i + 5, "+-"[i & 1], "d", 2000, 7, 12, 5, 5, i, "2M1I2M1D1M" if i % 3 else "5M") for i in range(500))
+    for name in ("pass", "invert", "shatter", "invert|trim|shatter", "trim -f -t 0.1"):
+        check(eng, PIPES[name], tiny, name)
+
+
+def test_error_paths(eng):
+    ok = kat_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M")
+    cases = [
+        (b"q\t100\t0\t5\t*\tt\t100\t0\t5\t5\t5\t60\n", PIPES["pass"]),
+        (kat_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M", "tp:A:i"), PIPES["pass"]),
+        (kat_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M2S"), PIPES["pass"]),
+        (kat_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M3"), PIPES["pass"]),
+        (kat_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5="), PIPES["shatter"]),
+        (kat_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "0M5M"), PIPES["shatter"]),
+        (kat_line("q", 100, 0, 6, "+", "t", 100, 0, 5, 5, 5, 60, "5M"), PIPES["shatter"]),
+        (kat_line("q", 100, 0, 6, "+", "t", 100, 0, 5, 5, 5, 60, "5M"), PIPES["invert"]),
+        (kat_line("q", 100, 98, 103, "+", "t", 100, 0, 5, 5, 5, 60, "5M"), PIPES["shatter"]),
+        (kat_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60), PIPES["trim"]),
+        (kat_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60), PIPES["trim -f -t 0.1"]),
+        (b"q\t100\t0\t5\t+\tt\t100\t0\n", PIPES["pass"]),
+        (b"\n", PIPES["pass"]),
+    ]
+    for bad, stages in cases:
+        got, info = check(eng, stages, ok + bad + ok)
+        assert info.error.code != 0 and info.error.record == 1
+        assert got == O.run(stages, ok)[0]
