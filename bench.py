@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- PAF records/s of the fused `invert | trim | shatter` pipe on MI355X.
+
+A step is one pass of the hot path (plan + emit through the C-ABI) over one batch of synthetic
+PAF text that is already resident in HBM. Workloads follow BASELINE.json / SURVEY 8d:
+  cfg3 (default): 10M-record stream, mean 2048 cigar ops, `invert | trim | shatter`
+  cfg2          :  1M-record stream, mean  512 cigar ops, `shatter`
+Every step takes the next `--batch` records of the stream (rank r of N takes every N-th batch),
+so K steps process K*batch distinct records per GPU (weak scaling, no data-path collective).
+
+Prints ONE JSON line on rank 0 (see the driver contract): value = records/s over all GPUs;
+`roofline` prices the dominant kernel (k_record_lds<emit>) with algorithmic bytes = input line
+bytes + output line bytes of the batch over its HIP-event duration; `cpu_baseline`
+times the CPU oracle (a port of the reference algorithm; the reference cannot be built here)
+single-threaded on a bounded sample of the same records.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+WORKLOADS = {
+    "cfg3": dict(seed=0x5EED0003, mean_ops=2048, total=10_000_000, pipe="invert|trim|shatter",
+                 desc="10M synthetic PAF records, mean 2k cigar ops, invert | trim | shatter"),
+    "cfg2": dict(seed=0x5EED0002, mean_ops=512, total=1_000_000, pipe="shatter",
+                 desc="1M synthetic PAF records, mean 512 cigar ops, shatter"),
+}
+
+
+def stages_for(pipe, mod):
+    kinds = {"invert": mod.INVERT, "trim": mod.TRIM_IDENTITY, "shatter": mod.SHATTER}
+    return [mod.stage(kinds[k]) for k in pipe.split("|")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=65536, help="records per step per GPU")
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample", type=int, default=8192, help="records of the stream timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    args = ap.parse_args()
+
+    import torch
+
+    import paffy_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    wl = WORKLOADS[args.workload]
+    eng = paffy_amd.Engine()
+    stages = stages_for(wl["pipe"], paffy_amd)
+    n_batches = args.warmup + args.steps
+
+    # ---- synthetic input, generated on the device, resident before the timed region ----
+    batches = []
+    for i in range(n_batches):
+        b_global = i * world + rank  # rank r takes every world-th batch of the stream
+        r0 = (b_global * args.batch) % max(1, wl["total"] - args.batch + 1)
+        buf, nbytes = eng.synth(wl["seed"], wl["mean_ops"], r0, args.batch)
+        batches.append((buf, nbytes, r0))
+    torch.cuda.synchronize()
+
+    # one untimed plan to size the output slab (reused by every step)
+    info0 = eng.plan(stages, batches[0][0], batches[0][1])
+    out_cap = int(info0.out_bytes * 1.25) + (1 << 20)
+    d_out = eng.alloc_out(out_cap)
+
+    def step(i):
+        nonlocal d_out, out_cap
+        buf, nbytes, _ = batches[i]
+        info = eng.plan(stages, buf, nbytes)
+        if info.error.code:
+            raise RuntimeError(f"synthetic record failed: code {info.error.code} record {info.error.record}")
+        if info.out_bytes > out_cap:
+            out_cap = int(info.out_bytes * 1.25)
+            d_out = eng.alloc_out(out_cap)
+        eng.emit(d_out)
+        return info
+
+    for i in range(args.warmup):
+        step(i)
+    eng.sync()
+
+    eng.profile(not args.no_kernel_events)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    infos = [step(args.warmup + i) for i in range(args.steps)]
+    eng.sync()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernels = eng.profile_read()
+    eng.profile(False)
+
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    records = args.batch * args.steps * world
+    in_bytes = sum(i.in_bytes for i in infos)
+    out_bytes = sum(i.out_bytes for i in infos)
+    rows = sum(i.n_rows for i in infos)
+
+    if rank == 0:
+        dom = "k_record_lds<emit>"
+        roofline = None
+        if dom in kernels and kernels[dom][1] > 0:
+            ms, launches = kernels[dom]
+            per_launch_bytes = (in_bytes + out_bytes) / args.steps
+            achieved = per_launch_bytes / (ms / launches * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_kernel_ms": round(ms / launches, 4),
+                        "algorithmic_bytes_per_launch": int(per_launch_bytes)}
+        cpu = None
+        if args.cpu_sample > 0:
+            cpu = cpu_baseline(eng, wl, stages, args.cpu_sample)
+        line = {
+            "metric": "PAF records/sec (shatter+invert+trim pipe); % HBM roofline at 1/2/4/8 GPU",
+            "value": round(records / elapsed, 1),
+            "unit": "records/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8/int64 (float32 identity predicate)",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {wl['desc']}", "pipe": wl["pipe"], "records_per_step_per_gpu": args.batch,
+                       "records_timed": records, "stream_records": wl["total"], "mean_cigar_ops": wl["mean_ops"],
+                       "input_bytes_per_record": round(in_bytes / (args.batch * args.steps), 1),
+                       "output_bytes_per_record": round(out_bytes / (args.batch * args.steps), 1),
+                       "output_rows_per_record": round(rows / (args.batch * args.steps), 2),
+                       "sharding": "contiguous record batches per rank, no collective"},
+            "whole_path_GBps_per_gpu": round((in_bytes + out_bytes) / elapsed / 1e9, 1),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kernels.items()},
+        }
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(eng, wl, stages, n):
+    """CPU leg: the oracle (port of the reference algorithm, single thread) on the first n records of
+    the stream; its output also checks the GPU output for the same records."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+
+    import oracle_lib as O
+
+    buf, nbytes = eng.synth(wl["seed"], wl["mean_ops"], 0, n)
+    data = bytes(buf[:nbytes].cpu().numpy().tobytes())
+    kinds = {1: O.INVERT, 2: O.TRIM_IDENTITY, 4: O.SHATTER}
+    ost = [O.stage(kinds[s.kind], s.p0, s.p1) for s in stages]
+    L = O.lib()
+    arr = (O.Stage * len(ost))(*ost)
+    out, on, err = C.c_void_p(), C.c_int64(), O.Error()
+    t0 = time.perf_counter()
+    L.po_run(arr, len(ost), data, len(data), None, 0, C.byref(out), C.byref(on), C.byref(err))
+    dt = time.perf_counter() - t0
+    want = bytes((C.c_char * on.value).from_address(out.value)) if on.value else b""
+    L.po_free(out)
+    got, _ = eng.run(stages, data)
+    return {"value": round(n / dt, 1), "unit": "records/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} records of the same stream ({len(data)} B in, {len(want)} B out), {dt:.1f} s, single thread",
+            "gpu_output_matches": bool(got == want and err.code == 0)}
+
+
+if __name__ == "__main__":
+    main()

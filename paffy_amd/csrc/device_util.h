@@ -1,10 +1,10 @@
 /*
  * device_util.h -- wave64 / LDS building blocks for the gfx950 PAF kernels.
  *
- *  - block-wide exclusive scans and min/max reductions over int64 tuples (wave shuffles,
- *    one LDS hop between the 4 waves of a 256-thread workgroup)
+ *  - wave64 scans / reductions on DPP row shifts and broadcasts (no LDS traffic), combined across
+ *    the 4 waves of a 256-thread workgroup with one LDS hop and a single barrier
  *  - decimal digit counting and packed ASCII conversion (impl/paf.c:10-34 int64_to_str semantics)
- *  - RingWriter: a per-lane byte stream funnelled into aligned dword stores of an LDS ring whose
+ *  - RingWriter: a per-lane byte stream funnelled into aligned 8-byte stores of an LDS ring whose
  *    address is (global output offset mod RING), so that a workgroup's output leaves LDS as full
  *    16-byte coalesced global stores whatever the byte alignment of the rows inside it.
  */
@@ -18,26 +18,90 @@
 #define PAFFY_NWAVE (PAFFY_NT / 64)
 #define PAFFY_RING 32768u            /* LDS output ring bytes (power of two) */
 
+/* ---------------- wave64 DPP primitives ---------------- */
+
+/*
+ * Cross-lane data movement with DPP modifiers (no LDS round trip, unlike ds_bpermute-based
+ * __shfl): row_shr:n within rows of 16 lanes, then row_bcast:15 / row_bcast:31 to finish a
+ * 64-lane inclusive scan in 7 steps.
+ */
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_BCAST15 0x142
+#define DPP_BCAST31 0x143
+
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int64_t dpp_mov_i64(int64_t x) { /* lanes without a source receive 0 */
+    int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, CTRL, ROW_MASK, BANK_MASK, false);
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)((uint64_t)x >> 32), CTRL, ROW_MASK, BANK_MASK, false);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+/* inclusive prefix sum over the 64 lanes of a wave */
+__device__ __forceinline__ int64_t wave_incl_scan(int64_t v) {
+    int64_t x = v;
+    x += dpp_mov_i64<DPP_ROW_SHR(1), 0xf, 0xf>(v);
+    x += dpp_mov_i64<DPP_ROW_SHR(2), 0xf, 0xf>(v);
+    x += dpp_mov_i64<DPP_ROW_SHR(3), 0xf, 0xf>(v);
+    x += dpp_mov_i64<DPP_ROW_SHR(4), 0xf, 0xe>(x);
+    x += dpp_mov_i64<DPP_ROW_SHR(8), 0xf, 0xc>(x);
+    x += dpp_mov_i64<DPP_BCAST15, 0xa, 0xf>(x);
+    x += dpp_mov_i64<DPP_BCAST31, 0xc, 0xf>(x);
+    return x;
+}
+__device__ __forceinline__ int64_t wave_last(int64_t x) { /* value held by lane 63, wave-uniform */
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 63);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)x >> 32), 63);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+/* min over the wave (same 7-step pattern; lanes without a source keep their own value) */
+__device__ __forceinline__ int64_t wave_min(int64_t v) {
+    int64_t x = v;
+#define PAFFY_MIN_STEP(CTRL, RM, BM, SRC)                                                            \
+    {                                                                                                \
+        int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)x, (int)(uint32_t)(SRC), CTRL, RM, BM, false); \
+        int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)((uint64_t)x >> 32), (int)(uint32_t)((uint64_t)(SRC) >> 32), CTRL, RM, BM, false); \
+        int64_t t = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);                        \
+        x = t < x ? t : x;                                                                           \
+    }
+    PAFFY_MIN_STEP(DPP_ROW_SHR(1), 0xf, 0xf, v)
+    PAFFY_MIN_STEP(DPP_ROW_SHR(2), 0xf, 0xf, v)
+    PAFFY_MIN_STEP(DPP_ROW_SHR(3), 0xf, 0xf, v)
+    PAFFY_MIN_STEP(DPP_ROW_SHR(4), 0xf, 0xe, x)
+    PAFFY_MIN_STEP(DPP_ROW_SHR(8), 0xf, 0xc, x)
+    PAFFY_MIN_STEP(DPP_BCAST15, 0xa, 0xf, x)
+    PAFFY_MIN_STEP(DPP_BCAST31, 0xc, 0xf, x)
+#undef PAFFY_MIN_STEP
+    return wave_last(x);
+}
+
 /* ---------------- block-wide scans / reductions ---------------- */
 
-/* Exclusive scan of K int64 values per thread; tot[] receives the block totals. scratch: NWAVE*K. */
+/*
+ * Scratch protocol: every collective writes one slot set of `scratch` and ends with a single
+ * barrier; consecutive collectives alternate between two slot sets (toggle kept per thread, all
+ * threads call the same sequence), so the slots of collective i are not rewritten before the
+ * barrier of collective i+1 has been passed by every reader of i. scratch: 2 * NWAVE * 4 words.
+ */
+struct BlockComm {
+    int64_t *scratch;
+    uint32_t flip;
+    __device__ __forceinline__ int64_t *slots() {
+        int64_t *p = scratch + flip * (PAFFY_NWAVE * 4);
+        flip ^= 1u;
+        return p;
+    }
+};
+
+/* Exclusive scan of K (<= 4) int64 values per thread; tot[] receives the block totals. */
 template <int K>
-__device__ __forceinline__ void block_excl_scan(int64_t (&v)[K], int64_t (&tot)[K], int64_t *scratch) {
+__device__ __forceinline__ void block_excl_scan(int64_t (&v)[K], int64_t (&tot)[K], BlockComm &bc) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int64_t inc[K];
+    int64_t *sl = bc.slots();
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        int64_t x = v[k];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int64_t t = __shfl_up(x, d, 64);
-            if (lane >= d) x += t;
-        }
-        inc[k] = x;
-    }
-    if (lane == 63) {
-#pragma unroll
-        for (int k = 0; k < K; k++) scratch[wave * K + k] = inc[k];
+        inc[k] = wave_incl_scan(v[k]);
+        if (lane == 63) sl[wave * K + k] = inc[k];
     }
     __syncthreads();
 #pragma unroll
@@ -45,58 +109,47 @@ __device__ __forceinline__ void block_excl_scan(int64_t (&v)[K], int64_t (&tot)[
         int64_t base = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < PAFFY_NWAVE; w++) {
-            int64_t s = scratch[w * K + k];
+            int64_t s = sl[w * K + k];
             if (w < wave) base += s;
             total += s;
         }
         tot[k] = total;
         v[k] = base + inc[k] - v[k];
     }
-    __syncthreads();
 }
 
 /* Block totals only (every thread receives them). */
 template <int K>
-__device__ __forceinline__ void block_sum(int64_t (&v)[K], int64_t *scratch) {
+__device__ __forceinline__ void block_sum(int64_t (&v)[K], BlockComm &bc) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t *sl = bc.slots();
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        int64_t x = v[k];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-        v[k] = x;
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < K; k++) scratch[wave * K + k] = v[k];
+        int64_t t = wave_last(wave_incl_scan(v[k]));
+        if (lane == 0) sl[wave * K + k] = t;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < K; k++) {
         int64_t total = 0;
 #pragma unroll
-        for (int w = 0; w < PAFFY_NWAVE; w++) total += scratch[w * K + k];
+        for (int w = 0; w < PAFFY_NWAVE; w++) total += sl[w * K + k];
         v[k] = total;
     }
-    __syncthreads();
 }
 
-__device__ __forceinline__ int64_t block_min_i64(int64_t x, int64_t *scratch) {
+__device__ __forceinline__ int64_t block_min_i64(int64_t x, BlockComm &bc) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        int64_t t = __shfl_xor(x, d, 64);
-        x = t < x ? t : x;
-    }
-    if (lane == 0) scratch[wave] = x;
+    int64_t *sl = bc.slots();
+    int64_t m = wave_min(x);
+    if (lane == 0) sl[wave] = m;
     __syncthreads();
-    int64_t r = scratch[0];
+    int64_t r = sl[0];
 #pragma unroll
-    for (int w = 1; w < PAFFY_NWAVE; w++) r = scratch[w] < r ? scratch[w] : r;
-    __syncthreads();
+    for (int w = 1; w < PAFFY_NWAVE; w++) r = sl[w] < r ? sl[w] : r;
     return r;
 }
-__device__ __forceinline__ int64_t block_max_i64(int64_t x, int64_t *scratch) { return -block_min_i64(-x, scratch); }
+__device__ __forceinline__ int64_t block_max_i64(int64_t x, BlockComm &bc) { return -block_min_i64(-x, bc); }
 
 /* ---------------- decimal helpers ---------------- */
 
@@ -124,10 +177,16 @@ __device__ __constant__ uint64_t PAFFY_P10[20] = {1ull,
 /* Characters int64_to_str (impl/paf.c:10-34) writes for v: digits plus a leading '-'. */
 __device__ __forceinline__ int dec_len(int64_t v) {
     uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
-    int bits = 64 - __clzll((long long)(u | 1));
-    int t = (bits * 1233) >> 12;
-    int d = t + (u >= PAFFY_P10[t] ? 1 : 0);
-    if (d < 1) d = 1;
+    int d;
+    if ((u >> 32) == 0) { /* common case: immediate compares, no memory access */
+        uint32_t x = (uint32_t)u;
+        d = 1 + (x >= 10u) + (x >= 100u) + (x >= 1000u) + (x >= 10000u) + (x >= 100000u) + (x >= 1000000u) + (x >= 10000000u) +
+            (x >= 100000000u) + (x >= 1000000000u);
+    } else {
+        int bits = 64 - __clzll((long long)u);
+        int t = (bits * 1233) >> 12;
+        d = t + (u >= PAFFY_P10[t] ? 1 : 0);
+    }
     return d + (v < 0 ? 1 : 0);
 }
 
@@ -141,47 +200,61 @@ __device__ __forceinline__ uint32_t bcd4(uint32_t y) {
 /* ---------------- byte sinks ---------------- */
 
 /*
- * RingWriter: one lane's contiguous byte stream [s, e) of the workgroup's output window.
- * Bytes are funnelled through a 64-bit accumulator and leave as aligned dword LDS stores;
- * the (at most 3) bytes that share a dword with a neighbouring lane's stream go out as byte
- * stores. put(w, n): append the low n (0..4) bytes of w; bytes of w above n must be zero.
+ * RingWriter: one lane's contiguous byte stream [s, e) of the workgroup's output window, funnelled
+ * through a 64-bit accumulator into aligned 8-byte LDS stores. Two phases per window:
+ *   phase 1 (put): full 8-byte words only. A lane's first word also covers the (< 8) bytes before
+ *     s in that word; they belong to the tails of earlier lanes and are rewritten in phase 2.
+ *   barrier
+ *   phase 2 (tail): the (< 8) bytes after the last full word, as 4/2/1-byte stores.
+ * A lane whose first word reaches back before the window start preloads the previous window's
+ * pending bytes found there.
+ * put(w, n): append the low n (0..8) bytes of w; bytes of w above n must be zero.
  */
 struct RingWriter {
     uint8_t *ring;
     uint64_t acc;
     uint32_t nacc, wpos, head;
-    bool first;
-    __device__ __forceinline__ void init(uint8_t *r, uint32_t s) {
+    /* stream starts `off` bytes into the window that starts at byte p0 (low 32 bits of the output offset) */
+    __device__ __forceinline__ void init(uint8_t *r, uint32_t p0, uint32_t off) {
         ring = r;
-        head = s & 3u;
+        const uint32_t s = p0 + off;
+        head = s & 7u;
         wpos = s - head;
         nacc = head;
         acc = 0;
-        first = head != 0;
+        if (head > off) /* the first word reaches back before the window: keep the previous window's pending bytes */
+            acc = *reinterpret_cast<const uint64_t *>(ring + (wpos & (PAFFY_RING - 1))) & ((1ull << (8 * (head - off))) - 1ull);
     }
-    __device__ __forceinline__ void word(uint32_t d) {
-        uint32_t a = wpos & (PAFFY_RING - 1);
-        if (first) {
-            for (uint32_t b = head; b < 4; b++) ring[a + b] = (uint8_t)(d >> (8 * b));
-            first = false;
-        } else {
-            *reinterpret_cast<uint32_t *>(ring + a) = d;
-        }
-        wpos += 4;
-    }
-    __device__ __forceinline__ void put(uint32_t w, uint32_t n) {
-        acc |= (uint64_t)w << (nacc * 8);
+    __device__ __forceinline__ void put(uint64_t w, uint32_t n) {
+        const uint32_t sh = nacc * 8;
+        const uint64_t t = acc | (w << sh);
         nacc += n;
-        if (nacc >= 4) {
-            word((uint32_t)acc);
-            acc >>= 32;
-            nacc -= 4;
+        if (nacc >= 8) {
+            *reinterpret_cast<uint64_t *>(ring + (wpos & (PAFFY_RING - 1))) = t;
+            wpos += 8;
+            acc = sh ? (w >> (64 - sh)) : 0ull;
+            nacc -= 8;
+            head = 0;
+        } else {
+            acc = t;
         }
     }
-    __device__ __forceinline__ void finish() {
-        uint32_t a = wpos & (PAFFY_RING - 1);
-        uint32_t lo = first ? head : 0;
-        for (uint32_t b = lo; b < nacc; b++) ring[a + b] = (uint8_t)(acc >> (8 * b));
+    __device__ __forceinline__ void tail() { /* phase 2 */
+        uint8_t *p = ring + (wpos & (PAFFY_RING - 1));
+        if (head == 0) {
+            uint32_t b = 0;
+            if (nacc & 4u) {
+                *reinterpret_cast<uint32_t *>(p) = (uint32_t)acc;
+                b = 4;
+            }
+            if (nacc & 2u) {
+                *reinterpret_cast<uint16_t *>(p + b) = (uint16_t)(acc >> (8 * b));
+                b += 2;
+            }
+            if (nacc & 1u) p[b] = (uint8_t)(acc >> (8 * b));
+        } else { /* no full word was stored: only bytes [head, nacc) are ours */
+            for (uint32_t b = head; b < nacc; b++) p[b] = (uint8_t)(acc >> (8 * b));
+        }
         nacc = 0;
     }
 };
@@ -190,65 +263,107 @@ struct RingWriter {
 struct ByteWriter {
     uint8_t *p;
     uint32_t n;
-    __device__ __forceinline__ void put(uint32_t w, uint32_t k) {
+    __device__ __forceinline__ void put(uint64_t w, uint32_t k) {
         for (uint32_t b = 0; b < k; b++) p[n + b] = (uint8_t)(w >> (8 * b));
         n += k;
     }
 };
 
-template <class SINK>
-__device__ __forceinline__ void put_upto8(SINK &s, uint32_t x) { /* x < 10^8, no leading zeros */
+/* 8 decimal digits of x < 10^8 as ASCII, most significant digit in byte 0 */
+__device__ __forceinline__ uint64_t ascii8(uint32_t x) {
+    uint32_t hi4 = x / 10000u, lo4 = x - hi4 * 10000u;
+    return ((((uint64_t)bcd4(lo4)) << 32) | bcd4(hi4)) + 0x3030303030303030ull;
+}
+/* decimal digits of x < 10^8 without leading zeros, left-aligned; *n = digit count (1..8) */
+__device__ __forceinline__ uint64_t ascii_upto8(uint32_t x, uint32_t *n) {
     uint32_t hi4 = x / 10000u, lo4 = x - hi4 * 10000u;
     uint32_t w0 = bcd4(hi4), w1 = bcd4(lo4);
     uint32_t z = w0 ? ((uint32_t)__ffs((int)w0) - 1) >> 3 : (w1 ? 4 + (((uint32_t)__ffs((int)w1) - 1) >> 3) : 7);
-    uint64_t c = (((uint64_t)w1 << 32) | w0) + 0x3030303030303030ull;
-    c >>= 8 * z;
-    uint32_t n = 8 - z;
-    s.put((uint32_t)c, n < 4 ? n : 4);
-    s.put((uint32_t)(c >> 32), n > 4 ? n - 4 : 0);
+    *n = 8 - z;
+    return ((((uint64_t)w1 << 32) | w0) + 0x3030303030303030ull) >> (8 * z);
 }
-template <class SINK>
-__device__ __forceinline__ void put_exact8(SINK &s, uint32_t x) { /* 8 digits with leading zeros */
-    uint32_t hi4 = x / 10000u, lo4 = x - hi4 * 10000u;
-    s.put(bcd4(hi4) + 0x30303030u, 4);
-    s.put(bcd4(lo4) + 0x30303030u, 4);
-}
-/* int64_to_str, impl/paf.c:10-34. */
-template <class SINK>
-__device__ __forceinline__ void put_dec(SINK &s, int64_t v) {
+
+/* A number pre-rendered as up to three 8-byte groups (int64_to_str, impl/paf.c:10-34). */
+struct DecText {
+    uint64_t top;  /* sign and leading group, left-aligned */
+    uint32_t ntop; /* bytes in top (1..8); a '-' that does not fit goes out on its own */
+    uint32_t g1, g0; /* following full 8-digit groups */
+    uint32_t groups; /* 0..2 */
+    bool neg_separate;
+};
+__device__ __forceinline__ void dec_text(int64_t v, DecText &d) {
     uint64_t u = (uint64_t)v;
-    if (v < 0) {
-        s.put('-', 1);
-        u = (uint64_t)0 - u;
-    }
+    const bool neg = v < 0;
+    if (neg) u = (uint64_t)0 - u;
+    uint32_t top;
+    d.g1 = d.g0 = 0;
+    d.groups = 0;
     if ((u >> 32) == 0) {
         uint32_t x = (uint32_t)u;
         if (x < 100000000u) {
-            put_upto8(s, x);
+            top = x;
         } else {
-            uint32_t q = x / 100000000u;
-            put_upto8(s, q);
-            put_exact8(s, x - q * 100000000u);
+            top = x / 100000000u;
+            d.g0 = x - top * 100000000u;
+            d.groups = 1;
         }
     } else if (u < 10000000000000000ull) {
         uint64_t q = u / 100000000ull;
-        put_upto8(s, (uint32_t)q);
-        put_exact8(s, (uint32_t)(u - q * 100000000ull));
+        top = (uint32_t)q;
+        d.g0 = (uint32_t)(u - q * 100000000ull);
+        d.groups = 1;
     } else {
         uint64_t q = u / 10000000000000000ull, r = u - q * 10000000000000000ull;
         uint64_t r1 = r / 100000000ull;
-        put_upto8(s, (uint32_t)q);
-        put_exact8(s, (uint32_t)r1);
-        put_exact8(s, (uint32_t)(r - r1 * 100000000ull));
+        top = (uint32_t)q;
+        d.g1 = (uint32_t)r1;
+        d.g0 = (uint32_t)(r - r1 * 100000000ull);
+        d.groups = 2;
+    }
+    d.top = ascii_upto8(top, &d.ntop);
+    d.neg_separate = false;
+    if (neg) {
+        if (d.ntop < 8) {
+            d.top = (d.top << 8) | (uint64_t)'-';
+            d.ntop += 1;
+        } else {
+            d.neg_separate = true;
+        }
     }
 }
-/* Append len bytes of a dword-aligned LDS string. */
+/* lead: one extra character in front (0 = none), folded into the first group when it fits */
 template <class SINK>
-__device__ __forceinline__ void put_lds(SINK &s, const uint32_t *src, uint32_t len) {
-    uint32_t full = len >> 2;
-    for (uint32_t k = 0; k < full; k++) s.put(src[k], 4);
-    uint32_t rem = len & 3u;
-    if (rem) s.put(src[full] & ((1u << (8 * rem)) - 1u), rem);
+__device__ __forceinline__ void put_text(SINK &s, const DecText &d, uint32_t lead) {
+    uint64_t t = d.top;
+    uint32_t n = d.ntop;
+    if (d.neg_separate) {
+        s.put(lead ? ((uint64_t)'-' << 8) | lead : (uint64_t)'-', lead ? 2 : 1);
+    } else if (lead) {
+        if (n < 8) {
+            t = (t << 8) | lead;
+            n += 1;
+        } else {
+            s.put(lead, 1);
+        }
+    }
+    s.put(t, n);
+#pragma unroll 1
+    for (uint32_t g = d.groups; g > 0; g--) s.put(ascii8(g == 2 ? d.g1 : d.g0), 8);
+}
+template <class SINK>
+__device__ __forceinline__ void put_dec(SINK &s, int64_t v) {
+    DecText d;
+    dec_text(v, d);
+    put_text(s, d, 0);
+}
+/* Append len bytes of an 8-byte-aligned LDS string. */
+template <class SINK>
+__device__ __forceinline__ void put_lds(SINK &s, const uint64_t *src, uint32_t len) {
+    const uint32_t full = len >> 3;
+#pragma unroll 1
+    for (uint32_t k = 0; k < full; k++) s.put(src[k], 8);
+    const uint32_t rem = len & 7u;
+    if (rem) s.put(src[full] & ((1ull << (8 * rem)) - 1ull), rem);
 }
 
 #endif

@@ -49,7 +49,8 @@ __device__ __forceinline__ void sep_masks(const uint8_t *in, uint32_t in_len, ui
 }
 
 __global__ __launch_bounds__(PAFFY_NT) void k_sep_count(const uint8_t *in, uint32_t in_len, uint2 *tile_counts) {
-    __shared__ int64_t scratch[16];
+    __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
+    BlockComm scratch{scratch_mem, 0};
     const uint32_t tile0 = blockIdx.x * SEP_TILE;
     int64_t acc[2] = {0, 0};
     for (uint32_t off = threadIdx.x * 16; off < SEP_TILE; off += PAFFY_NT * 16) {
@@ -71,7 +72,8 @@ __global__ __launch_bounds__(PAFFY_NT) void k_sep_count(const uint8_t *in, uint3
 
 /* single workgroup: exclusive scan of the per-tile counts */
 __global__ __launch_bounds__(PAFFY_NT) void k_scan_tiles(uint2 *tile_counts, uint32_t n_tiles, DevInfo *info) {
-    __shared__ int64_t scratch[16];
+    __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
+    BlockComm scratch{scratch_mem, 0};
     int64_t carry0 = 0, carry1 = 0;
     for (uint32_t base = 0; base < n_tiles; base += PAFFY_NT) {
         uint32_t i = base + threadIdx.x;
@@ -90,7 +92,8 @@ __global__ __launch_bounds__(PAFFY_NT) void k_scan_tiles(uint2 *tile_counts, uin
 
 __global__ __launch_bounds__(PAFFY_NT) void k_sep_write(const uint8_t *in, uint32_t in_len, const uint2 *tile_off, uint32_t *sep_pos,
                                                          uint32_t *nl_idx) {
-    __shared__ int64_t scratch[16];
+    __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
+    BlockComm scratch{scratch_mem, 0};
     const uint32_t tile0 = blockIdx.x * SEP_TILE;
     uint2 base = tile_off[blockIdx.x];
     uint32_t sbase = base.x, lbase = base.y;
@@ -220,7 +223,8 @@ __global__ __launch_bounds__(PAFFY_NT) void k_header(const uint8_t *in, const ui
 /* single workgroup; records at or after the first failing one contribute nothing */
 __global__ __launch_bounds__(PAFFY_NT) void k_scan_records(const int64_t *out_len, const int64_t *out_rows, uint32_t n, int64_t *out_off,
                                                             DevInfo *info) {
-    __shared__ int64_t scratch[16];
+    __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
+    BlockComm scratch{scratch_mem, 0};
     const uint32_t first_err = (uint32_t)(info->first_err_key >> 16);
     int64_t cb = 0, cr = 0;
     for (uint32_t base = 0; base < n; base += PAFFY_NT) {
@@ -251,7 +255,8 @@ __global__ __launch_bounds__(PAFFY_NT) void k_synth_fill(psynth_cfg cfg, uint64_
     if (i < n) psynth_emit_record(&cfg, r0 + i, reinterpret_cast<char *>(out) + off[i]);
 }
 __global__ __launch_bounds__(PAFFY_NT) void k_scan_i64(const int64_t *in, uint32_t n, int64_t *out_excl, int64_t *total) {
-    __shared__ int64_t scratch[16];
+    __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
+    BlockComm scratch{scratch_mem, 0};
     int64_t carry = 0;
     for (uint32_t base = 0; base < n; base += PAFFY_NT) {
         uint32_t i = base + threadIdx.x;
@@ -281,7 +286,7 @@ struct ProfEntry {
 struct paffy_hip_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
-    DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, arena, info, synth_sizes;
+    DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, arena, info, synth_sizes, rec_plan;
     DevInfo *h_info = nullptr; /* pinned */
     /* plan state */
     bool planned = false;
@@ -379,7 +384,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     if (!c) return;
     prof_collect(c);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
-                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->arena, &c->info, &c->synth_sizes};
+                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_info) (void)hipHostFree(c->h_info);
@@ -451,6 +456,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     if (ensure(c, c->n_ops, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->arena_off, sizeof(uint64_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->w_list, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->rec_plan, sizeof(RecPlan) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (c->arena.cap == 0 && ensure(c, c->arena, (size_t)8 << 20)) return PAFFY_E_HIP;
 
     LAUNCH(c, "k_sep_write", k_sep_write, dim3(n_tiles), dim3(PAFFY_NT), 0, in, len, static_cast<const uint2 *>(c->tile_counts.p),
@@ -472,6 +478,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     kp.err_aux = static_cast<int32_t *>(c->err_aux.p);
     kp.n_ops = static_cast<uint32_t *>(c->n_ops.p);
     kp.arena_off = static_cast<uint64_t *>(c->arena_off.p);
+    kp.rec_plan = c->rec_plan.p;
     kp.out_off = static_cast<const int64_t *>(c->out_off.p);
     kp.w_list = static_cast<uint32_t *>(c->w_list.p);
     kp.info = static_cast<DevInfo *>(c->info.p);

@@ -85,6 +85,14 @@ struct RecState {
     bool has_cigar;
 };
 
+/* What the stage list left of a record; written by the sizing pass, read by the emit pass. */
+struct RecPlan {
+    int64_t qs, qe, ts, te, sub_lo, sub_hi;
+    uint32_t lo, n;
+    uint32_t flags; /* bit0 rev, bit1 swp, bit2 query/target swapped, bit3 has_cigar, bits 8-15 type */
+    uint32_t pad;
+};
+
 struct Shared { /* small workgroup-shared words */
     uint32_t err_pos;
     uint32_t flags;
@@ -117,7 +125,7 @@ __device__ __forceinline__ void sweep_bounds(uint32_t n, uint32_t &b, uint32_t &
  */
 template <class OPS>
 __device__ uint32_t parse_cigar(const uint8_t *in, uint32_t cg_off, uint32_t cg_len, const OPS &ops, uint32_t cap, uint8_t *txt,
-                                int64_t *scratch, Shared *sh, bool *fits, uint32_t *err_pos) {
+                                BlockComm &bc, Shared *sh, bool *fits, uint32_t *err_pos) {
     const uint32_t tid = threadIdx.x;
     const uint32_t end = cg_off + cg_len;
     const uint32_t a0 = cg_off & ~15u;
@@ -148,7 +156,7 @@ __device__ uint32_t parse_cigar(const uint8_t *in, uint32_t cg_off, uint32_t cg_
             if (inr && dig && pos == end - 1) atomicMin(&sh->err_pos, end); /* trailing digits: switch sees NUL */
         }
         int64_t cnt[1] = {(int64_t)__popc(opmask)}, tot[1];
-        block_excl_scan<1>(cnt, tot, scratch);
+        block_excl_scan<1>(cnt, tot, bc);
         uint32_t idx = n + (uint32_t)cnt[0];
         while (opmask) {
             int j = __ffs((int)opmask) - 1;
@@ -241,7 +249,7 @@ __device__ __forceinline__ void invert_view(const RecState &s, View<OPS> &v) { /
 
 /* paf_check, impl/paf.c:427-461. Returns 0 or the PAFFY_ERR_CHECK_* code. */
 template <class OPS>
-__device__ int check_record(const RecState &s, const View<OPS> &v, int64_t *scratch) {
+__device__ int check_record(const RecState &s, const View<OPS> &v, BlockComm &bc) {
     if (s.qs < 0 || s.qs >= s.qlen) return PAFFY_ERR_CHECK_QSTART;
     if (s.qs > s.qe || s.qe > s.qlen) return PAFFY_ERR_CHECK_QEND;
     if (s.ts < 0 || s.ts >= s.tlen) return PAFFY_ERR_CHECK_TSTART;
@@ -257,7 +265,7 @@ __device__ int check_record(const RecState &s, const View<OPS> &v, int64_t *scra
             if (op != OP_D) acc[0] += len;
             if (op != OP_I) acc[1] += len;
         }
-        block_sum<2>(acc, scratch);
+        block_sum<2>(acc, bc);
         if (acc[0] != s.qe - s.qs) return PAFFY_ERR_CHECK_CIGAR_Q;
         if (acc[1] != s.te - s.ts) return PAFFY_ERR_CHECK_CIGAR_T;
     }
@@ -271,7 +279,7 @@ __device__ __forceinline__ double ratio_f32(int64_t num, int64_t den) {
 
 /* matches / mismatches of the whole view: paf_trim_unreliable_ends2(.., 0, 1, -1), impl/paf.c:811-840 */
 template <class OPS>
-__device__ void match_stats(const View<OPS> &v, int64_t &m, int64_t &x, int64_t *scratch) {
+__device__ void match_stats(const View<OPS> &v, int64_t &m, int64_t &x, BlockComm &bc) {
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
     int64_t acc[2] = {0, 0};
@@ -282,14 +290,14 @@ __device__ void match_stats(const View<OPS> &v, int64_t &m, int64_t &x, int64_t 
         if (op == OP_EQ || op == OP_M) acc[0] += len;
         else acc[1] += len; /* X, I and D all count as mismatches */
     }
-    block_sum<2>(acc, scratch);
+    block_sum<2>(acc, bc);
     m = acc[0];
     x = acc[1];
 }
 
 /* paf_trim_unreliable_prefix + paf_trim_upto, impl/paf.c:842-904 (thresholds arrive as float32). */
 template <class OPS>
-__device__ void trim_prefix(RecState &s, View<OPS> &v, float thr_f, float id_f, int64_t max_trim, int64_t *scratch, Shared *sh) {
+__device__ void trim_prefix(RecState &s, View<OPS> &v, float thr_f, float id_f, int64_t max_trim, BlockComm &bc, Shared *sh) {
     const double thr = (double)thr_f, idd = (double)id_f;
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
@@ -302,7 +310,7 @@ __device__ void trim_prefix(RecState &s, View<OPS> &v, float thr_f, float id_f, 
         if (op == OP_EQ || op == OP_M) c[0] += len;
         else c[1] += len;
     }
-    block_excl_scan<2>(c, tot, scratch);
+    block_excl_scan<2>(c, tot, bc);
     /* sweep B: last index (while cumulative <= max_trim) whose prefix identity < threshold */
     int64_t cm = c[0], cx = c[1], found = -1;
     for (uint32_t i = b; i < e; i++) {
@@ -314,7 +322,7 @@ __device__ void trim_prefix(RecState &s, View<OPS> &v, float thr_f, float id_f, 
         if (max_trim >= 0 && cm + cx > max_trim) break;
         if (ratio_f32(cm, cm + cx) < thr) found = i;
     }
-    int64_t trim_idx = block_max_i64(found, scratch);
+    int64_t trim_idx = block_max_i64(found, bc);
     if (trim_idx < 0) return;
     /* inclusive cumulative at trim_idx, broadcast by its owner */
     if (trim_idx >= (int64_t)b && trim_idx < (int64_t)e) {
@@ -343,7 +351,7 @@ __device__ void trim_prefix(RecState &s, View<OPS> &v, float thr_f, float id_f, 
         if (op == OP_EQ || op == OP_M) em += len;
         else ex += len;
     }
-    best = block_min_i64(best, scratch);
+    best = block_min_i64(best, bc);
     int64_t count = best != INT64_MAX ? best : trim_idx + 1;
     if (count <= 0) return;
     /* paf_trim_upto: advance coordinates over the dropped ops */
@@ -355,7 +363,7 @@ __device__ void trim_prefix(RecState &s, View<OPS> &v, float thr_f, float id_f, 
         if (op != OP_I) d[0] += len;
         if (op != OP_D) d[1] += len;
     }
-    block_sum<2>(d, scratch);
+    block_sum<2>(d, bc);
     s.ts += d[0];
     if (s.same) s.qs += d[1];
     else s.qe -= d[1];
@@ -364,21 +372,21 @@ __device__ void trim_prefix(RecState &s, View<OPS> &v, float thr_f, float id_f, 
 
 /* paf_trim_unreliable_tails, impl/paf.c:906-953. Returns 0 or PAFFY_ERR_TRIM_IDENTITY_ASSERT. */
 template <class OPS>
-__device__ int trim_identity(RecState &s, View<OPS> &v, float score_fraction, float max_fraction, int64_t *scratch, Shared *sh) {
+__device__ int trim_identity(RecState &s, View<OPS> &v, float score_fraction, float max_fraction, BlockComm &bc, Shared *sh) {
     int64_t m, x;
-    match_stats(v, m, x, scratch);
+    match_stats(v, m, x, bc);
     const double identity = ratio_f32(m, m + x);
     const double thr = __dsub_rn(identity, __dmul_rn(identity, (double)score_fraction));
     const int64_t max_trim = __float2ll_rz(__fmul_rn(__ll2float_rn(m + x), max_fraction));
     const float thr_f = __double2float_rn(thr), id_f = __double2float_rn(identity);
-    trim_prefix(s, v, thr_f, id_f, max_trim, scratch, sh);
+    trim_prefix(s, v, thr_f, id_f, max_trim, bc, sh);
     invert_state(s);
     invert_view(s, v);
-    trim_prefix(s, v, thr_f, id_f, max_trim, scratch, sh);
+    trim_prefix(s, v, thr_f, id_f, max_trim, bc, sh);
     invert_state(s);
     invert_view(s, v);
     int64_t m2, x2;
-    match_stats(v, m2, x2, scratch);
+    match_stats(v, m2, x2, bc);
     const double final_identity = ratio_f32(m2, m2 + x2);
     return final_identity >= identity ? 0 : PAFFY_ERR_TRIM_IDENTITY_ASSERT;
 }
@@ -391,7 +399,7 @@ __device__ __forceinline__ bool is_aligned_op(int op) { return op == OP_M || op 
  * `end` aligned bases are gone; the op that crosses `end` is shortened. dq/dt: bases consumed.
  */
 template <class OPS>
-__device__ void trim_front_fixed(View<OPS> &v, int64_t end, int64_t &dq, int64_t &dt, int64_t *scratch, Shared *sh) {
+__device__ void trim_front_fixed(View<OPS> &v, int64_t end, int64_t &dq, int64_t &dt, BlockComm &bc, Shared *sh) {
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
     int64_t c[1] = {0}, tot[1];
@@ -401,7 +409,7 @@ __device__ void trim_front_fixed(View<OPS> &v, int64_t end, int64_t &dq, int64_t
         v.get(i, len, op);
         if (is_aligned_op(op)) c[0] += len;
     }
-    block_excl_scan<1>(c, tot, scratch);
+    block_excl_scan<1>(c, tot, bc);
     int64_t tb = c[0], stop = INT64_MAX, stop_tb = 0;
     for (uint32_t i = b; i < e; i++) {
         int64_t len;
@@ -416,7 +424,7 @@ __device__ void trim_front_fixed(View<OPS> &v, int64_t end, int64_t &dq, int64_t
             tb += len;
         }
     }
-    int64_t s_idx = block_min_i64(stop, scratch);
+    int64_t s_idx = block_min_i64(stop, bc);
     if (s_idx != INT64_MAX && s_idx >= (int64_t)b && s_idx < (int64_t)e) sh->bcast[0] = stop_tb;
     __syncthreads();
     int64_t tb_s = s_idx != INT64_MAX ? sh->bcast[0] : 0;
@@ -430,7 +438,7 @@ __device__ void trim_front_fixed(View<OPS> &v, int64_t end, int64_t &dq, int64_t
         if (op != OP_D) d[0] += len;
         if (op != OP_I) d[1] += len;
     }
-    block_sum<2>(d, scratch);
+    block_sum<2>(d, bc);
     dq = d[0];
     dt = d[1];
     v.drop_front(drop);
@@ -444,7 +452,7 @@ __device__ void trim_front_fixed(View<OPS> &v, int64_t end, int64_t &dq, int64_t
 
 /* paf_trim_end_fraction + paf_trim_ends, impl/paf.c:578-598. */
 template <class OPS>
-__device__ int trim_fixed(RecState &s, View<OPS> &v, float pct, int64_t *scratch, Shared *sh) {
+__device__ int trim_fixed(RecState &s, View<OPS> &v, float pct, BlockComm &bc, Shared *sh) {
     if (!(pct >= 0.0f && pct <= 1.0f)) return PAFFY_ERR_TRIM_FIXED_ASSERT;
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
@@ -455,16 +463,16 @@ __device__ int trim_fixed(RecState &s, View<OPS> &v, float pct, int64_t *scratch
         v.get(i, len, op);
         if (is_aligned_op(op)) a[0] += len;
     }
-    block_sum<1>(a, scratch);
+    block_sum<1>(a, bc);
     const int64_t end = __double2ll_rz((double)__fmul_rn(__ll2float_rn(a[0]), pct) / 2.0);
     if (!s.has_cigar) return PAFFY_ERR_NULL_CIGAR;
     int64_t dq, dt;
-    trim_front_fixed(v, end, dq, dt, scratch, sh);
+    trim_front_fixed(v, end, dq, dt, bc, sh);
     if (s.same) s.qs += dq;
     else s.qe -= dq;
     s.ts += dt;
     v.rev = !v.rev;
-    trim_front_fixed(v, end, dq, dt, scratch, sh);
+    trim_front_fixed(v, end, dq, dt, bc, sh);
     v.rev = !v.rev;
     if (s.same) s.qe -= dq;
     else s.qs += dq;
@@ -561,7 +569,13 @@ struct Emitter {
         begin = pos = off;
         flushed = off & ~15ull;
     }
-    /* all lanes deposited `bytes` bytes at pos: push the complete 16-byte chunks out */
+    /*
+     * A window: every lane put() its full words (phase 1); then
+     *   __syncthreads(); rw.tail(); em.commit(bytes);
+     * commit waits for the tails and pushes the complete 16-byte chunks out. The ring bytes
+     * flushed here are only overwritten by a later window's deposits, which come after that
+     * window's scan barriers, so no trailing barrier is needed.
+     */
     __device__ __forceinline__ void commit(uint64_t bytes) {
         __syncthreads();
         uint64_t np = pos + bytes, to = np & ~15ull;
@@ -570,7 +584,6 @@ struct Emitter {
             flushed = to;
         }
         pos = np;
-        __syncthreads();
     }
     __device__ __forceinline__ void finish() {
         if (pos > flushed) ring_flush(ring, out, flushed, (pos + 15) & ~15ull, begin, pos);
@@ -586,23 +599,27 @@ struct ShatterConst {
 
 /* Row of paf_shatter2 + paf_write: A qs \t qe B ts \t te \t L \t L C L "M\n" */
 template <class SINK>
-__device__ __forceinline__ void put_row(SINK &w, const uint32_t *A, const uint32_t *B, const uint32_t *C, const ShatterConst &k,
+__device__ __forceinline__ void put_row(SINK &w, const uint64_t *A, const uint64_t *B, const uint64_t *C, const ShatterConst &k,
                                         int64_t q0, int64_t t0, int64_t len) {
-    put_lds(w, A, k.lenA);
-    put_dec(w, q0);
-    w.put('\t', 1);
-    put_dec(w, q0 + len);
-    put_lds(w, B, k.lenB);
-    put_dec(w, t0);
-    w.put('\t', 1);
-    put_dec(w, t0 + len);
-    w.put('\t', 1);
-    put_dec(w, len);
-    w.put('\t', 1);
-    put_dec(w, len);
+    DecText dl;
+    dec_text(len, dl); /* written three times */
+#pragma unroll 1
+    for (int f = 0; f < 4; f++) { /* A qs | \t qe | B ts | \t te */
+        if (f == 0) put_lds(w, A, k.lenA);
+        else if (f == 2) put_lds(w, B, k.lenB);
+        DecText d;
+        dec_text(f == 0 ? q0 : f == 1 ? q0 + len : f == 2 ? t0 : t0 + len, d);
+        put_text(w, d, (f & 1) ? '\t' : 0);
+    }
+    put_text(w, dl, '\t');
+    put_text(w, dl, '\t');
     put_lds(w, C, k.lenC);
-    put_dec(w, len);
-    w.put((uint32_t)'M' | ((uint32_t)'\n' << 8), 2);
+    if (dl.groups == 0 && !dl.neg_separate && dl.ntop <= 6) { /* digits + "M\n" in one word */
+        w.put(dl.top | ((uint64_t)'M' << (8 * dl.ntop)) | ((uint64_t)'\n' << (8 * dl.ntop + 8)), dl.ntop + 2);
+    } else {
+        put_text(w, dl, 0);
+        w.put((uint64_t)'M' | ((uint64_t)'\n' << 8), 2);
+    }
 }
 __device__ __forceinline__ uint32_t row_len(const ShatterConst &k, int64_t q0, int64_t t0, int64_t len) {
     return k.row_const + dec_len(q0) + dec_len(q0 + len) + dec_len(t0) + dec_len(t0 + len) + 3 * dec_len(len);
@@ -614,7 +631,7 @@ __device__ __forceinline__ uint32_t row_len(const ShatterConst &k, int64_t q0, i
  */
 template <class OPS>
 __device__ int shatter_size(const RecState &s, const View<OPS> &v, const ShatterConst &k, int64_t &bytes, int64_t &rows,
-                            int64_t *scratch) {
+                            BlockComm &bc) {
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
     int64_t c[2] = {0, 0}, tot[2];
@@ -625,7 +642,7 @@ __device__ int shatter_size(const RecState &s, const View<OPS> &v, const Shatter
         if (op != OP_D) c[0] += len;
         if (op != OP_I) c[1] += len;
     }
-    block_excl_scan<2>(c, tot, scratch);
+    block_excl_scan<2>(c, tot, bc);
     int64_t cq = c[0], ct = c[1], err = INT64_MAX;
     int64_t acc[2] = {0, 0};
     for (uint32_t i = b; i < e; i++) {
@@ -650,8 +667,8 @@ __device__ int shatter_size(const RecState &s, const View<OPS> &v, const Shatter
         if (op != OP_D) cq += len;
         if (op != OP_I) ct += len;
     }
-    err = block_min_i64(err, scratch);
-    block_sum<2>(acc, scratch);
+    err = block_min_i64(err, bc);
+    block_sum<2>(acc, bc);
     bytes = acc[0];
     rows = acc[1];
     if (err != INT64_MAX) return (int)(err & 31);
@@ -662,8 +679,8 @@ __device__ int shatter_size(const RecState &s, const View<OPS> &v, const Shatter
 
 /* Emit the rows of a (validated) record, window by window, through the ring. */
 template <class OPS>
-__device__ void shatter_emit(const RecState &s, const View<OPS> &v, const ShatterConst &k, const uint32_t *A, const uint32_t *B,
-                             const uint32_t *C, Emitter &em, int64_t *scratch) {
+__device__ void shatter_emit(const RecState &s, const View<OPS> &v, const ShatterConst &k, const uint64_t *A, const uint64_t *B,
+                             const uint64_t *C, Emitter &em, BlockComm &bc) {
     const uint32_t cap_bytes = PAFFY_RING - 32;
     const uint32_t rows_cap = cap_bytes / k.row_max; /* >= 1, checked by the caller */
     uint32_t w_safe = rows_cap < 2 * PAFFY_NT ? rows_cap : 2 * PAFFY_NT;
@@ -684,7 +701,7 @@ __device__ void shatter_emit(const RecState &s, const View<OPS> &v, const Shatte
             if (op != OP_D) c[0] += len;
             if (op != OP_I) c[1] += len;
         }
-        block_excl_scan<2>(c, tot, scratch);
+        block_excl_scan<2>(c, tot, bc);
         int64_t pq = cq + c[0], pt = ct + c[1];
         int64_t nb[1] = {0}, nbt[1];
         {
@@ -701,13 +718,13 @@ __device__ void shatter_emit(const RecState &s, const View<OPS> &v, const Shatte
                 if (op != OP_I) t += len;
             }
         }
-        block_excl_scan<1>(nb, nbt, scratch);
+        block_excl_scan<1>(nb, nbt, bc);
         if (nbt[0] > (int64_t)cap_bytes && w > w_safe) { /* unusually dense window: retry with the safe size */
             w_try = w_safe;
             continue;
         }
         RingWriter rw;
-        rw.init(em.ring, (uint32_t)(em.pos + (uint64_t)nb[0]));
+        rw.init(em.ring, (uint32_t)em.pos, (uint32_t)nb[0]);
         {
             int64_t q = pq, t = pt;
             for (uint32_t j = b; j < e; j++) {
@@ -722,7 +739,8 @@ __device__ void shatter_emit(const RecState &s, const View<OPS> &v, const Shatte
                 if (op != OP_I) t += len;
             }
         }
-        rw.finish();
+        __syncthreads();
+        rw.tail();
         em.commit((uint64_t)nbt[0]);
         cq += tot[0];
         ct += tot[1];
@@ -759,7 +777,7 @@ __device__ uint32_t header_len(const RecState &s, bool newline) {
 
 /* Bytes of the cigar text of the view: sum of digits + 1 per op (impl/paf.c:369-380). */
 template <class OPS>
-__device__ int64_t cigar_text_len(const View<OPS> &v, int64_t *scratch) {
+__device__ int64_t cigar_text_len(const View<OPS> &v, BlockComm &bc) {
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
     int64_t a[1] = {0};
@@ -769,25 +787,28 @@ __device__ int64_t cigar_text_len(const View<OPS> &v, int64_t *scratch) {
         v.get(i, len, op);
         a[0] += dec_len(len) + 1;
     }
-    block_sum<1>(a, scratch);
+    block_sum<1>(a, bc);
     return a[0];
 }
 
 /* One whole line (paf_write): header piece from LDS, then the ops, then '\n'. */
 template <class OPS>
-__device__ void write_emit(const View<OPS> &v, bool has_cigar, const uint32_t *H, uint32_t lenH, Emitter &em, int64_t *scratch) {
+__device__ void write_emit(const View<OPS> &v, bool has_cigar, const uint64_t *H, uint32_t lenH, Emitter &em, BlockComm &bc) {
     /* header: 16 bytes per lane per window */
     for (uint32_t base = 0; base < lenH; base += 16 * PAFFY_NT) {
         uint32_t left = lenH - base;
         uint32_t wbytes = left < 16 * PAFFY_NT ? left : 16 * PAFFY_NT;
         uint32_t mine_off = 16 * threadIdx.x;
+        RingWriter rw;
+        rw.init(em.ring, (uint32_t)em.pos, mine_off);
         if (mine_off < wbytes) {
             uint32_t mine = wbytes - mine_off < 16 ? wbytes - mine_off : 16;
-            RingWriter rw;
-            rw.init(em.ring, (uint32_t)(em.pos + mine_off));
-            put_lds(rw, H + ((base + mine_off) >> 2), mine);
-            rw.finish();
+            put_lds(rw, H + ((base + mine_off) >> 3), mine);
+        } else {
+            rw.nacc = rw.head = 0; /* nothing to write */
         }
+        __syncthreads();
+        rw.tail();
         em.commit(wbytes);
     }
     if (!has_cigar || v.n == 0) return; /* the header piece already ends the line */
@@ -809,24 +830,29 @@ __device__ void write_emit(const View<OPS> &v, bool has_cigar, const uint32_t *H
             nb[0] += dec_len(len) + 1;
         }
         if (last && e == v.n && b < e) nb[0] += 1; /* '\n' goes with the last op */
-        block_excl_scan<1>(nb, nbt, scratch);
+        block_excl_scan<1>(nb, nbt, bc);
         if (nbt[0] > (int64_t)cap_bytes && w > w_safe) {
             w_try = w_safe;
             continue;
         }
-        if (b < e) {
-            RingWriter rw;
-            rw.init(em.ring, (uint32_t)(em.pos + (uint64_t)nb[0]));
-            for (uint32_t j = b; j < e; j++) {
-                int64_t len;
-                int op;
-                v.get(j, len, op);
-                put_dec(rw, len);
+        RingWriter rw;
+        rw.init(em.ring, (uint32_t)em.pos, (uint32_t)nb[0]);
+        for (uint32_t j = b; j < e; j++) {
+            int64_t len;
+            int op;
+            v.get(j, len, op);
+            DecText d;
+            dec_text(len, d);
+            if (d.groups == 0 && !d.neg_separate && d.ntop <= 7) { /* digits + op letter in one word */
+                rw.put(d.top | ((uint64_t)op_char_of(op) << (8 * d.ntop)), d.ntop + 1);
+            } else {
+                put_text(rw, d, 0);
                 rw.put(op_char_of(op), 1);
             }
-            if (last && e == v.n) rw.put('\n', 1);
-            rw.finish();
         }
+        if (last && e == v.n && b < e) rw.put('\n', 1);
+        __syncthreads();
+        rw.tail();
         em.commit((uint64_t)nbt[0]);
         i += w;
         w_try = w_full;
@@ -836,9 +862,9 @@ __device__ void write_emit(const View<OPS> &v, bool has_cigar, const uint32_t *H
 /* ---------------- the record program ---------------- */
 
 struct RecLds {
-    uint8_t *ring;   /* PAFFY_RING bytes, 16-aligned; doubles as the cigar text staging area */
-    uint32_t *pieces; /* 3 * PAFFY_TMPL_MAX bytes */
-    int64_t *scratch; /* 64 words */
+    uint8_t *ring;    /* PAFFY_RING bytes, 16-aligned; doubles as the cigar text staging area */
+    uint64_t *pieces; /* 3 * PAFFY_TMPL_MAX bytes */
+    mutable BlockComm bc; /* 64 words of LDS */
     Shared *sh;
 };
 
@@ -854,20 +880,20 @@ __device__ __forceinline__ void report(const KParams &P, uint32_t rec, int code,
     }
 }
 
-/*
- * Runs the stage list on record `rec`. `ops`/`cap` is the op store to parse into; with
- * pre_n != UINT32_MAX the ops are already there (arena class, emit pass).
- * Returns false when the record does not fit this store (sizing pass, LDS class only).
- */
-template <class OPS, bool EMIT>
-__device__ bool run_record(const KParams &P, uint32_t rec, const OPS &ops, uint32_t cap, uint32_t pre_n, const RecLds &L, uint32_t klass,
-                           uint32_t *n_ops_out) {
-    const RecMeta m = P.meta[rec];
-    if (m.err) {
-        if (!EMIT) report(P, rec, m.err, -1, m.err_aux, klass);
-        return true;
-    }
-    RecState s;
+__device__ __forceinline__ void shatter_consts(const RecState &s, ShatterConst &k) {
+    /* line pieces shared by every row of a record (paf_shatter2, impl/paf.c:600-627) */
+    k.lenA = s.qn_len + 2 + dec_len(s.qlen);
+    k.lenB = s.tn_len + 5 + dec_len(s.tlen);
+    k.lenC = 1 + dec_len(s.mapq) + tags_len(s, 0) + 6; /* children carry s1:i:0 (calloc, impl/paf.c:601) */
+    k.row_const = k.lenA + k.lenB + k.lenC + 6;
+    uint32_t dq = dec_len(s.qlen), dt = dec_len(s.tlen);
+    k.row_max = k.row_const + 2 * dq + 2 * dt + 3 * (dq < dt ? dq : dt);
+}
+__device__ __forceinline__ bool shatter_fits(const ShatterConst &k) {
+    return k.lenA <= PAFFY_TMPL_MAX && k.lenB <= PAFFY_TMPL_MAX && k.lenC <= PAFFY_TMPL_MAX && k.row_max <= PAFFY_RING - 32;
+}
+
+__device__ __forceinline__ void load_state(const RecMeta &m, RecState &s) {
     s.qlen = m.qlen; s.qs = m.qs; s.qe = m.qe; s.tlen = m.tlen; s.ts = m.ts; s.te = m.te;
     s.nmatch = m.nmatch; s.nbases = m.nbases; s.mapq = m.mapq; s.score = m.score;
     s.tile_level = m.tile_level; s.chain_id = m.chain_id; s.chain_score = m.chain_score;
@@ -875,139 +901,166 @@ __device__ bool run_record(const KParams &P, uint32_t rec, const OPS &ops, uint3
     s.same = m.same_strand != 0;
     s.type = m.type;
     s.has_cigar = m.has_cg && m.cg_len > 0; /* cigar_parse("") == NULL, impl/paf.c:71-73 */
+}
 
+/*
+ * Sizing pass for record `rec`: parse the cigar into `ops` (capacity `cap`), run the stage list,
+ * record the exact output size, the first failing check and the RecPlan the emit pass resumes
+ * from. Returns false when the record does not fit this op store (LDS class only).
+ */
+template <class OPS>
+__device__ bool size_record(const KParams &P, uint32_t rec, const OPS &ops, uint32_t cap, const RecLds &L, uint32_t klass,
+                            uint32_t *n_ops_out) {
+    const RecMeta m = P.meta[rec];
+    if (m.err) {
+        report(P, rec, m.err, -1, m.err_aux, klass);
+        return true;
+    }
+    RecState s;
+    load_state(m, s);
     uint32_t n = 0;
     if (s.has_cigar) {
-        if (pre_n != 0xffffffffu) {
-            n = pre_n;
-        } else {
-            bool fits;
-            uint32_t err_pos;
-            uint32_t r = parse_cigar(P.in, m.cg_off, m.cg_len, ops, cap, L.ring, L.scratch, L.sh, &fits, &err_pos);
-            if (r & 0x80000000u) r = parse_cigar_serial(P.in, m.cg_off, m.cg_len, ops, cap, L.sh, &fits, &err_pos);
-            n = r;
-            if (err_pos != 0xffffffffu) { /* st_errAbort, impl/paf.c:102 */
-                if (!EMIT) report(P, rec, PAFFY_ERR_CIGAR_CHAR, -1, err_pos < m.cg_off + m.cg_len ? P.in[err_pos] : 0, klass);
-                return true;
-            }
-            if (!fits) return false;
+        bool fits;
+        uint32_t err_pos;
+        uint32_t r = parse_cigar(P.in, m.cg_off, m.cg_len, ops, cap, L.ring, L.bc, L.sh, &fits, &err_pos);
+        if (r & 0x80000000u) r = parse_cigar_serial(P.in, m.cg_off, m.cg_len, ops, cap, L.sh, &fits, &err_pos);
+        n = r;
+        if (err_pos != 0xffffffffu) { /* st_errAbort, impl/paf.c:102 */
+            report(P, rec, PAFFY_ERR_CIGAR_CHAR, -1, err_pos < m.cg_off + m.cg_len ? P.in[err_pos] : 0, klass);
+            return true;
         }
+        if (!fits) return false;
     }
     *n_ops_out = n;
     View<OPS> v;
     v.ops = ops; v.lo = 0; v.n = n; v.rev = false; v.swp = false; v.sub_lo = v.sub_hi = 0;
-
-    int32_t last = P.n_stages - 1;
-    for (int32_t si = 0; si < P.n_stages; si++) {
+    bool swapped = false, shatter = false;
+    int32_t si = 0;
+    for (; si < P.n_stages; si++) {
         const paffy_stage st = P.stages[si];
         if (si > 0) { /* what `paf_write | paf_parse` between two processes does to the record */
             if (s.has_cigar && v.n == 0) s.has_cigar = false;
             if (s.type == 0 && s.tile_level != -1) s.type = s.tile_level > 1 ? 'S' : 'P';
         }
         int rc = 0;
-        switch (st.kind) {
-            case PAFFY_INVERT:
-                invert_state(s);
-                invert_view(s, v);
-                rc = check_record(s, v, L.scratch);
-                break;
-            case PAFFY_TRIM_IDENTITY:
-                rc = trim_identity(s, v, st.p0, st.p1, L.scratch, L.sh);
-                if (!rc) rc = check_record(s, v, L.scratch);
-                break;
-            case PAFFY_TRIM_FIXED:
-                rc = trim_fixed(s, v, st.p1, L.scratch, L.sh);
-                if (!rc) rc = check_record(s, v, L.scratch);
-                break;
-            case PAFFY_SHATTER: {
-                /* line pieces shared by every row of this record (paf_shatter2, impl/paf.c:600-627) */
-                ShatterConst k;
-                k.lenA = s.qn_len + 2 + dec_len(s.qlen);
-                k.lenB = s.tn_len + 5 + dec_len(s.tlen);
-                k.lenC = 1 + dec_len(s.mapq) + tags_len(s, 0) + 6; /* children carry s1:i:0 (calloc, impl/paf.c:601) */
-                k.row_const = k.lenA + k.lenB + k.lenC + 6;
-                uint32_t dq = dec_len(s.qlen), dt = dec_len(s.tlen);
-                k.row_max = k.row_const + 2 * dq + 2 * dt + 3 * (dq < dt ? dq : dt);
-                if (k.lenA > PAFFY_TMPL_MAX || k.lenB > PAFFY_TMPL_MAX || k.lenC > PAFFY_TMPL_MAX || k.row_max > PAFFY_RING - 32) {
-                    if (threadIdx.x == 0) atomicOr(&P.info->internal, INTERNAL_TMPL_TOO_LONG);
-                    if (!EMIT) report(P, rec, 0, si, 0, klass);
-                    return true;
-                }
-                if (!EMIT) {
-                    int64_t bytes, rows;
-                    rc = shatter_size(s, v, k, bytes, rows, L.scratch);
-                    if (rc) break;
-                    if (threadIdx.x == 0) {
-                        P.status[rec] = klass << 16;
-                        P.out_len[rec] = bytes;
-                        P.out_rows[rec] = rows;
-                    }
-                    return true;
-                } else {
-                    uint32_t *A = L.pieces, *B = L.pieces + PAFFY_TMPL_MAX / 4, *C = L.pieces + 2 * (PAFFY_TMPL_MAX / 4);
-                    if (threadIdx.x == 0) {
-                        Piece w{(uint8_t *)A, 0, PAFFY_TMPL_MAX, false};
-                        w.name(P.in, s.qn_off, s.qn_len);
-                        w.ch('\t'); w.num(s.qlen); w.ch('\t');
-                    } else if (threadIdx.x == 64) {
-                        Piece w{(uint8_t *)B, 0, PAFFY_TMPL_MAX, false};
-                        w.ch('\t'); w.ch(s.same ? '+' : '-'); w.ch('\t');
-                        w.name(P.in, s.tn_off, s.tn_len);
-                        w.ch('\t'); w.num(s.tlen); w.ch('\t');
-                    } else if (threadIdx.x == 128) {
-                        Piece w{(uint8_t *)C, 0, PAFFY_TMPL_MAX, false};
-                        w.ch('\t'); w.num(s.mapq);
-                        piece_tags(w, s, 0);
-                        w.str("\tcg:Z:");
-                    }
-                    __syncthreads();
-                    Emitter em;
-                    em.start(L.ring, P.out, (uint64_t)P.out_off[rec]);
-                    shatter_emit(s, v, k, A, B, C, em, L.scratch);
-                    em.finish();
-                    return true;
-                }
-            }
-            case PAFFY_PASS:
-                break;
-            default:
-                rc = 0;
-                break;
+        if (st.kind == PAFFY_INVERT) {
+            invert_state(s);
+            invert_view(s, v);
+            swapped = !swapped;
+            rc = check_record(s, v, L.bc);
+        } else if (st.kind == PAFFY_TRIM_IDENTITY) {
+            rc = trim_identity(s, v, st.p0, st.p1, L.bc, L.sh);
+            if (!rc) rc = check_record(s, v, L.bc);
+        } else if (st.kind == PAFFY_TRIM_FIXED) {
+            rc = trim_fixed(s, v, st.p1, L.bc, L.sh);
+            if (!rc) rc = check_record(s, v, L.bc);
+        } else if (st.kind == PAFFY_SHATTER) {
+            shatter = true;
+            break;
         }
         if (rc) {
-            if (!EMIT) report(P, rec, rc, si, 0, klass);
+            report(P, rec, rc, si, 0, klass);
             return true;
         }
-        (void)last;
     }
-    /* paf_write of the transformed record */
-    const bool nl_in_header = !(s.has_cigar && v.n > 0);
-    const uint32_t lenH = header_len(s, nl_in_header);
-    if (lenH > 3 * PAFFY_TMPL_MAX) {
-        if (threadIdx.x == 0) atomicOr(&P.info->internal, INTERNAL_TMPL_TOO_LONG);
-        if (!EMIT) report(P, rec, 0, P.n_stages, 0, klass);
-        return true;
-    }
-    if (!EMIT) {
-        int64_t bytes = lenH;
-        if (!nl_in_header) bytes += cigar_text_len(v, L.scratch) + 1;
-        if (threadIdx.x == 0) {
-            P.status[rec] = klass << 16;
-            P.out_len[rec] = bytes;
-            P.out_rows[rec] = 1;
+    int64_t bytes, rows;
+    if (shatter) {
+        ShatterConst k;
+        shatter_consts(s, k);
+        if (!shatter_fits(k)) {
+            if (threadIdx.x == 0) atomicOr(&P.info->internal, INTERNAL_TMPL_TOO_LONG);
+            report(P, rec, 0, si, 0, klass);
+            return true;
+        }
+        int rc = shatter_size(s, v, k, bytes, rows, L.bc);
+        if (rc) {
+            report(P, rec, rc, si, 0, klass);
+            return true;
         }
     } else {
+        const bool nl_in_header = !(s.has_cigar && v.n > 0);
+        const uint32_t lenH = header_len(s, nl_in_header);
+        if (lenH > 3 * PAFFY_TMPL_MAX) {
+            if (threadIdx.x == 0) atomicOr(&P.info->internal, INTERNAL_TMPL_TOO_LONG);
+            report(P, rec, 0, P.n_stages, 0, klass);
+            return true;
+        }
+        bytes = lenH;
+        if (!nl_in_header) bytes += cigar_text_len(v, L.bc) + 1;
+        rows = 1;
+    }
+    if (threadIdx.x == 0) {
+        P.status[rec] = klass << 16;
+        P.out_len[rec] = bytes;
+        P.out_rows[rec] = rows;
+        RecPlan pl;
+        pl.qs = s.qs; pl.qe = s.qe; pl.ts = s.ts; pl.te = s.te; pl.sub_lo = v.sub_lo; pl.sub_hi = v.sub_hi;
+        pl.lo = v.lo; pl.n = v.n;
+        pl.flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | (s.has_cigar ? 8u : 0u) | ((uint32_t)s.type << 8) |
+                   (shatter ? 16u : 0u);
+        pl.pad = 0;
+        static_cast<RecPlan *>(P.rec_plan)[rec] = pl;
+    }
+    return true;
+}
+
+/*
+ * Emit pass: the record is known to be valid; resume from its RecPlan. `pre_parsed`: the ops are
+ * already in `ops` (arena class), otherwise they are re-parsed from the text into LDS.
+ */
+template <class OPS>
+__device__ void emit_record(const KParams &P, uint32_t rec, const OPS &ops, uint32_t cap, bool pre_parsed, const RecLds &L) {
+    const RecMeta m = P.meta[rec];
+    const RecPlan pl = static_cast<const RecPlan *>(P.rec_plan)[rec];
+    RecState s;
+    load_state(m, s);
+    if (s.has_cigar && !pre_parsed) {
+        bool fits;
+        uint32_t err_pos;
+        uint32_t r = parse_cigar(P.in, m.cg_off, m.cg_len, ops, cap, L.ring, L.bc, L.sh, &fits, &err_pos);
+        if (r & 0x80000000u) parse_cigar_serial(P.in, m.cg_off, m.cg_len, ops, cap, L.sh, &fits, &err_pos);
+    }
+    if (pl.flags & 4u) invert_state(s);
+    s.qs = pl.qs; s.qe = pl.qe; s.ts = pl.ts; s.te = pl.te;
+    s.has_cigar = (pl.flags & 8u) != 0;
+    s.type = (uint8_t)(pl.flags >> 8);
+    View<OPS> v;
+    v.ops = ops; v.lo = pl.lo; v.n = pl.n; v.rev = pl.flags & 1u; v.swp = (pl.flags & 2u) != 0;
+    v.sub_lo = pl.sub_lo; v.sub_hi = pl.sub_hi;
+    Emitter em;
+    em.start(L.ring, P.out, (uint64_t)P.out_off[rec]);
+    if (pl.flags & 16u) {
+        ShatterConst k;
+        shatter_consts(s, k);
+        uint64_t *A = L.pieces, *B = L.pieces + PAFFY_TMPL_MAX / 8, *C = L.pieces + 2 * (PAFFY_TMPL_MAX / 8);
+        if (threadIdx.x == 0) {
+            Piece w{(uint8_t *)A, 0, PAFFY_TMPL_MAX, false};
+            w.name(P.in, s.qn_off, s.qn_len);
+            w.ch('\t'); w.num(s.qlen); w.ch('\t');
+        } else if (threadIdx.x == 64) {
+            Piece w{(uint8_t *)B, 0, PAFFY_TMPL_MAX, false};
+            w.ch('\t'); w.ch(s.same ? '+' : '-'); w.ch('\t');
+            w.name(P.in, s.tn_off, s.tn_len);
+            w.ch('\t'); w.num(s.tlen); w.ch('\t');
+        } else if (threadIdx.x == 128) {
+            Piece w{(uint8_t *)C, 0, PAFFY_TMPL_MAX, false};
+            w.ch('\t'); w.num(s.mapq);
+            piece_tags(w, s, 0);
+            w.str("\tcg:Z:");
+        }
+        __syncthreads();
+        shatter_emit(s, v, k, A, B, C, em, L.bc);
+    } else {
+        const bool nl_in_header = !(s.has_cigar && v.n > 0);
+        const uint32_t lenH = header_len(s, nl_in_header);
         if (threadIdx.x == 0) {
             Piece w{(uint8_t *)L.pieces, 0, 3 * PAFFY_TMPL_MAX, false};
             build_header(w, s, P.in, nl_in_header);
         }
         __syncthreads();
-        Emitter em;
-        em.start(L.ring, P.out, (uint64_t)P.out_off[rec]);
-        write_emit(v, s.has_cigar, L.pieces, lenH, em, L.scratch);
-        em.finish();
+        write_emit(v, s.has_cigar, L.pieces, lenH, em, L.bc);
     }
-    return true;
+    em.finish();
 }
 
 #define PAFFY_LDS_BYTES (PAFFY_RING + PAFFY_OPS_CAP * 4 + 3 * PAFFY_TMPL_MAX + 64 * 8 + 64)
@@ -1016,8 +1069,9 @@ __device__ __forceinline__ RecLds carve_lds(uint8_t *smem, uint32_t **ops_lds) {
     RecLds L;
     L.ring = smem;
     *ops_lds = reinterpret_cast<uint32_t *>(smem + PAFFY_RING);
-    L.pieces = reinterpret_cast<uint32_t *>(smem + PAFFY_RING + PAFFY_OPS_CAP * 4);
-    L.scratch = reinterpret_cast<int64_t *>(smem + PAFFY_RING + PAFFY_OPS_CAP * 4 + 3 * PAFFY_TMPL_MAX);
+    L.pieces = reinterpret_cast<uint64_t *>(smem + PAFFY_RING + PAFFY_OPS_CAP * 4);
+    L.bc.scratch = reinterpret_cast<int64_t *>(smem + PAFFY_RING + PAFFY_OPS_CAP * 4 + 3 * PAFFY_TMPL_MAX);
+    L.bc.flip = 0;
     L.sh = reinterpret_cast<Shared *>(smem + PAFFY_RING + PAFFY_OPS_CAP * 4 + 3 * PAFFY_TMPL_MAX + 64 * 8);
     return L;
 }
@@ -1035,7 +1089,9 @@ __global__ __launch_bounds__(PAFFY_NT) void k_record_lds(KParams P) {
     }
     OpsLds ops{ops_lds};
     uint32_t n_ops = 0;
-    bool ok = run_record<OpsLds, EMIT>(P, rec, ops, PAFFY_OPS_CAP, 0xffffffffu, L, KLASS_LDS, &n_ops);
+    bool ok = true;
+    if (EMIT) emit_record<OpsLds>(P, rec, ops, PAFFY_OPS_CAP, false, L);
+    else ok = size_record<OpsLds>(P, rec, ops, PAFFY_OPS_CAP, L, KLASS_LDS, &n_ops);
     if (!EMIT && !ok && threadIdx.x == 0) { /* route to the arena kernel */
         P.status[rec] = (uint32_t)KLASS_ARENA << 16;
         P.out_len[rec] = 0;
@@ -1058,8 +1114,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_record_arena(KParams P) {
         if (EMIT) {
             if (rec < first_err) {
                 OpsArena ops{P.arena + P.arena_off[rec]};
-                uint32_t n_ops = 0;
-                run_record<OpsArena, true>(P, rec, ops, 0xffffffffu, P.n_ops[rec], L, KLASS_ARENA, &n_ops);
+                emit_record<OpsArena>(P, rec, ops, 0xffffffffu, true, L);
             }
         } else {
             /* upper bound for the allocation: one op per cigar byte */
@@ -1071,7 +1126,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_record_arena(KParams P) {
             if (off + cg_len <= P.arena_cap) {
                 OpsArena ops{P.arena + off};
                 uint32_t n_ops = 0;
-                run_record<OpsArena, false>(P, rec, ops, cg_len, 0xffffffffu, L, KLASS_ARENA, &n_ops);
+                size_record<OpsArena>(P, rec, ops, cg_len, L, KLASS_ARENA, &n_ops);
                 if (threadIdx.x == 0) {
                     P.n_ops[rec] = n_ops;
                     P.arena_off[rec] = off;

@@ -58,6 +58,7 @@ struct KParams {
     int32_t *err_aux;
     uint32_t *n_ops;
     uint64_t *arena_off;
+    void *rec_plan; /* RecPlan[n_rec] */
     /* emit pass */
     const int64_t *out_off;
     uint8_t *out;
