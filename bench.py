@@ -9,7 +9,7 @@ Every step takes the next `--batch` records of the stream (rank r of N takes eve
 so K steps process K*batch distinct records per GPU (weak scaling, no data-path collective).
 
 Prints ONE JSON line on rank 0 (see the driver contract): value = records/s over all GPUs;
-`roofline` prices the dominant kernel (k_record_lds<emit>) with algorithmic bytes = input line
+`roofline` prices the dominant kernel (k_emit_lds) with algorithmic bytes = input line
 bytes + output line bytes of the batch over its HIP-event duration; `cpu_baseline`
 times the CPU oracle (a port of the reference algorithm; the reference cannot be built here)
 single-threaded on a bounded sample of the same records.
@@ -126,7 +126,7 @@ def main():
     rows = sum(i.n_rows for i in infos)
 
     if rank == 0:
-        dom = "k_record_lds<emit>"
+        dom = "k_emit_lds"
         roofline = None
         if dom in kernels and kernels[dom][1] > 0:
             ms, launches = kernels[dom]

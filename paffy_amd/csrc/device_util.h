@@ -74,6 +74,17 @@ __device__ __forceinline__ int64_t wave_min(int64_t v) {
     return wave_last(x);
 }
 
+/* exclusive scan inside one wave; tot[] = wave totals (wave-uniform). No LDS, no barrier. */
+template <int K>
+__device__ __forceinline__ void wave_excl_scan(int64_t (&v)[K], int64_t (&tot)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        int64_t inc = wave_incl_scan(v[k]);
+        tot[k] = wave_last(inc);
+        v[k] = inc - v[k];
+    }
+}
+
 /* ---------------- block-wide scans / reductions ---------------- */
 
 /*
@@ -201,7 +212,8 @@ __device__ __forceinline__ uint32_t bcd4(uint32_t y) {
 
 /*
  * RingWriter: one lane's contiguous byte stream [s, e) of the workgroup's output window, funnelled
- * through a 64-bit accumulator into aligned 8-byte LDS stores. Two phases per window:
+ * through a 64-bit accumulator into aligned 8-byte LDS stores of a ring indexed by
+ * (output offset mod ring size). Two phases per window:
  *   phase 1 (put): full 8-byte words only. A lane's first word also covers the (< 8) bytes before
  *     s in that word; they belong to the tails of earlier lanes and are rewritten in phase 2.
  *   barrier
@@ -213,34 +225,49 @@ __device__ __forceinline__ uint32_t bcd4(uint32_t y) {
 struct RingWriter {
     uint8_t *ring;
     uint64_t acc;
-    uint32_t nacc, wpos, head;
-    /* stream starts `off` bytes into the window that starts at byte p0 (low 32 bits of the output offset) */
-    __device__ __forceinline__ void init(uint8_t *r, uint32_t p0, uint32_t off) {
+    uint32_t nacc, head;
+    uint32_t rpos, rsize; /* ring cursor (multiple of 8, < rsize); the ring size need not be a power of two */
+    /*
+     * The window starts at ring index p0r (< ring_bytes, congruent to the output offset mod 16);
+     * this lane's stream starts `off` (< ring_bytes) bytes into the window.
+     */
+    __device__ __forceinline__ void init(uint8_t *r, uint32_t ring_bytes, uint32_t p0r, uint32_t off) {
         ring = r;
-        const uint32_t s = p0 + off;
+        rsize = ring_bytes;
+        uint32_t s = p0r + off;
+        if (s >= ring_bytes) s -= ring_bytes;
         head = s & 7u;
-        wpos = s - head;
+        rpos = s - head;
         nacc = head;
         acc = 0;
         if (head > off) /* the first word reaches back before the window: keep the previous window's pending bytes */
-            acc = *reinterpret_cast<const uint64_t *>(ring + (wpos & (PAFFY_RING - 1))) & ((1ull << (8 * (head - off))) - 1ull);
+            acc = *reinterpret_cast<const uint64_t *>(ring + rpos) & ((1ull << (8 * (head - off))) - 1ull);
+    }
+    __device__ __forceinline__ void store(uint64_t t) {
+        *reinterpret_cast<uint64_t *>(ring + rpos) = t;
+        rpos += 8;
+        if (rpos == rsize) rpos = 0;
+        head = 0;
     }
     __device__ __forceinline__ void put(uint64_t w, uint32_t n) {
         const uint32_t sh = nacc * 8;
         const uint64_t t = acc | (w << sh);
         nacc += n;
         if (nacc >= 8) {
-            *reinterpret_cast<uint64_t *>(ring + (wpos & (PAFFY_RING - 1))) = t;
-            wpos += 8;
-            acc = sh ? (w >> (64 - sh)) : 0ull;
+            store(t);
+            acc = (w >> 1) >> (63 - sh); /* = w >> (64 - sh), and 0 for sh == 0 */
             nacc -= 8;
-            head = 0;
         } else {
             acc = t;
         }
     }
+    __device__ __forceinline__ void put8(uint64_t w) { /* exactly 8 bytes: always one full word out */
+        const uint32_t sh = nacc * 8;
+        store(acc | (w << sh));
+        acc = (w >> 1) >> (63 - sh);
+    }
     __device__ __forceinline__ void tail() { /* phase 2 */
-        uint8_t *p = ring + (wpos & (PAFFY_RING - 1));
+        uint8_t *p = ring + rpos;
         if (head == 0) {
             uint32_t b = 0;
             if (nacc & 4u) {
@@ -267,6 +294,7 @@ struct ByteWriter {
         for (uint32_t b = 0; b < k; b++) p[n + b] = (uint8_t)(w >> (8 * b));
         n += k;
     }
+    __device__ __forceinline__ void put8(uint64_t w) { put(w, 8); }
 };
 
 /* 8 decimal digits of x < 10^8 as ASCII, most significant digit in byte 0 */
@@ -331,6 +359,7 @@ __device__ __forceinline__ void dec_text(int64_t v, DecText &d) {
         }
     }
 }
+__device__ __forceinline__ uint32_t text_len(const DecText &d) { return d.ntop + 8 * d.groups + (d.neg_separate ? 1u : 0u); }
 /* lead: one extra character in front (0 = none), folded into the first group when it fits */
 template <class SINK>
 __device__ __forceinline__ void put_text(SINK &s, const DecText &d, uint32_t lead) {
@@ -348,7 +377,7 @@ __device__ __forceinline__ void put_text(SINK &s, const DecText &d, uint32_t lea
     }
     s.put(t, n);
 #pragma unroll 1
-    for (uint32_t g = d.groups; g > 0; g--) s.put(ascii8(g == 2 ? d.g1 : d.g0), 8);
+    for (uint32_t g = d.groups; g > 0; g--) s.put8(ascii8(g == 2 ? d.g1 : d.g0));
 }
 template <class SINK>
 __device__ __forceinline__ void put_dec(SINK &s, int64_t v) {
@@ -361,7 +390,7 @@ template <class SINK>
 __device__ __forceinline__ void put_lds(SINK &s, const uint64_t *src, uint32_t len) {
     const uint32_t full = len >> 3;
 #pragma unroll 1
-    for (uint32_t k = 0; k < full; k++) s.put(src[k], 8);
+    for (uint32_t k = 0; k < full; k++) s.put8(src[k]);
     const uint32_t rem = len & 7u;
     if (rem) s.put(src[full] & ((1ull << (8 * rem)) - 1ull), rem);
 }

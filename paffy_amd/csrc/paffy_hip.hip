@@ -6,10 +6,11 @@
  *                              '\n' positions are compacted into sep_pos[], newline ranks into
  *                              nl_idx[] (replaces stFile_getLine + strtok_r, impl/paf.c:144-212)
  *   k_header                   one lane per record: fixed fields and tags (paf_parse, impl/paf.c:137-209)
- *   k_record_lds<false>        one workgroup per record: cigar -> LDS ops -> transforms -> exact size
+ *   k_size_lds                 one workgroup per record: cigar -> LDS ops (mirrored to HBM) -> transforms -> exact size + plan
  *   k_record_arena<false>      same for records whose ops do not fit LDS (ops in an HBM arena)
  *   k_scan_records             exclusive prefix sum of the sizes up to the first failing record
- *   k_record_lds<true> / k_record_arena<true>   the lines, through the LDS ring, 16 B coalesced stores
+ *   k_emit_lds / k_record_arena<true>   the lines: each wave formats its share of the record through its own
+ *                              LDS ring and flushes 16-byte coalesced stores
  */
 #include <hip/hip_runtime.h>
 
@@ -286,7 +287,7 @@ struct ProfEntry {
 struct paffy_hip_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
-    DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, arena, info, synth_sizes, rec_plan;
+    DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, arena, info, synth_sizes, rec_plan, ops_mirror;
     DevInfo *h_info = nullptr; /* pinned */
     /* plan state */
     bool planned = false;
@@ -372,10 +373,10 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
         return PAFFY_E_HIP;
     }
     /* the record kernels use more than the default 64 KiB of LDS */
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_record_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_record_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_record_arena<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_record_arena<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emit_lds), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_EMIT_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_record_arena<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_record_arena<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_EMIT_LDS_BYTES);
     *out = c;
     return 0;
 }
@@ -384,7 +385,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     if (!c) return;
     prof_collect(c);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
-                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan};
+                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_info) (void)hipHostFree(c->h_info);
@@ -457,6 +458,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     if (ensure(c, c->arena_off, sizeof(uint64_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->w_list, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->rec_plan, sizeof(RecPlan) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->ops_mirror, sizeof(uint32_t) * ((size_t)len / 2 + 64))) return PAFFY_E_HIP;
     if (c->arena.cap == 0 && ensure(c, c->arena, (size_t)8 << 20)) return PAFFY_E_HIP;
 
     LAUNCH(c, "k_sep_write", k_sep_write, dim3(n_tiles), dim3(PAFFY_NT), 0, in, len, static_cast<const uint2 *>(c->tile_counts.p),
@@ -479,16 +481,17 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     kp.n_ops = static_cast<uint32_t *>(c->n_ops.p);
     kp.arena_off = static_cast<uint64_t *>(c->arena_off.p);
     kp.rec_plan = c->rec_plan.p;
+    kp.ops_mirror = static_cast<uint32_t *>(c->ops_mirror.p);
     kp.out_off = static_cast<const int64_t *>(c->out_off.p);
     kp.w_list = static_cast<uint32_t *>(c->w_list.p);
     kp.info = static_cast<DevInfo *>(c->info.p);
 
     if (n_lines > 0) {
-        LAUNCH(c, "k_record_lds<size>", k_record_lds<false>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_LDS_BYTES, kp);
+        LAUNCH(c, "k_size_lds", k_size_lds, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
         for (int attempt = 0; attempt < 2; attempt++) {
             kp.arena = static_cast<uint64_t *>(c->arena.p);
             kp.arena_cap = c->arena.cap / 8;
-            LAUNCH(c, "k_record_arena<size>", k_record_arena<false>, dim3(512), dim3(PAFFY_NT), PAFFY_LDS_BYTES, kp);
+            LAUNCH(c, "k_record_arena<size>", k_record_arena<false>, dim3(512), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             if (fetch_info(c)) return PAFFY_E_HIP;
             if (c->h_info->arena_used <= kp.arena_cap) break;
             /* arena too small: grow to the exact demand and redo the arena records */
@@ -534,9 +537,9 @@ int paffy_hip_emit(paffy_hip_ctx *c, void *d_out, int64_t out_cap) {
     if (out_cap < c->plan.out_bytes) return PAFFY_E_CAPACITY;
     KParams kp = c->kp;
     kp.out = static_cast<uint8_t *>(d_out);
-    LAUNCH(c, "k_record_lds<emit>", k_record_lds<true>, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_LDS_BYTES, kp);
+    LAUNCH(c, "k_emit_lds", k_emit_lds, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
     if (c->h_info->w_count > 0)
-        LAUNCH(c, "k_record_arena<emit>", k_record_arena<true>, dim3(512), dim3(PAFFY_NT), PAFFY_LDS_BYTES, kp);
+        LAUNCH(c, "k_record_arena<emit>", k_record_arena<true>, dim3(512), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
     return 0;
 }
 

@@ -26,15 +26,30 @@
 
 /* ---------------- op stores ---------------- */
 
-struct OpsLds { /* 4-byte ops in LDS: len << 3 | op, len < 2^29 */
+struct OpsLds { /* 4-byte ops in LDS (len << 3 | op, len < 2^29), mirrored to HBM for the emit pass */
     uint32_t *p;
+    uint32_t *g;     /* HBM mirror of this record's ops */
+    uint32_t g_cap;  /* entries of the mirror that belong to this record */
     static constexpr bool kNarrow = true;
     __device__ __forceinline__ void get(uint32_t i, int64_t &len, int &op) const {
         uint32_t w = p[i];
         op = (int)(w & 7u);
         len = (int64_t)(w >> 3);
     }
-    __device__ __forceinline__ void set(uint32_t i, int64_t len, int op) const { p[i] = ((uint32_t)len << 3) | (uint32_t)op; }
+    __device__ __forceinline__ void set(uint32_t i, int64_t len, int op) const {
+        uint32_t w = ((uint32_t)len << 3) | (uint32_t)op;
+        p[i] = w;
+        if (i < g_cap) g[i] = w;
+    }
+};
+struct OpsGlobal { /* the HBM mirror, read by the emit pass */
+    const uint32_t *p;
+    static constexpr bool kNarrow = true;
+    __device__ __forceinline__ void get(uint32_t i, int64_t &len, int &op) const {
+        uint32_t w = p[i];
+        op = (int)(w & 7u);
+        len = (int64_t)(w >> 3);
+    }
 };
 struct OpsArena { /* 8-byte ops in HBM: the CigarRecord layout, inc/paf.h:61-64 */
     uint64_t *p;
@@ -89,8 +104,10 @@ struct RecState {
 struct RecPlan {
     int64_t qs, qe, ts, te, sub_lo, sub_hi;
     uint32_t lo, n;
-    uint32_t flags; /* bit0 rev, bit1 swp, bit2 query/target swapped, bit3 has_cigar, bits 8-15 type */
-    uint32_t pad;
+    uint32_t flags; /* bit0 rev, bit1 swp, bit2 query/target swapped, bit3 has_cigar, bit4 shatter, bits 8-15 type */
+    uint32_t chunk; /* ops per lane in the sizing sweep: wave w owns view ops [64*w*chunk, 64*(w+1)*chunk) */
+    /* shatter: query / target bases consumed and output bytes produced before each wave's range */
+    int64_t wq[PAFFY_NWAVE], wt[PAFFY_NWAVE], wo[PAFFY_NWAVE];
 };
 
 struct Shared { /* small workgroup-shared words */
@@ -541,52 +558,70 @@ __device__ uint32_t tags_len(const RecState &s, int64_t s1) {
 
 /* ---------------- ring -> HBM ---------------- */
 
-/* Store ring bytes [from, to) (from, to multiples of 16) to out; bytes outside [lo, hi) are not ours. */
-__device__ __forceinline__ void ring_flush(const uint8_t *ring, uint8_t *out, uint64_t from, uint64_t to, uint64_t lo, uint64_t hi) {
-    for (uint64_t c = from + 16ull * threadIdx.x; c < to; c += 16ull * PAFFY_NT) {
-        uint4 v = *reinterpret_cast<const uint4 *>(ring + ((uint32_t)c & (PAFFY_RING - 1)));
-        if (c >= lo && c + 16 <= hi) {
-            *reinterpret_cast<uint4 *>(out + c) = v;
-        } else {
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int b = 0; b < 16; b++)
-                if (c + b >= lo && c + b < hi) out[c + b] = (uint8_t)(w[b >> 2] >> ((b & 3) * 8));
-        }
-    }
-}
-
-/* Progress of one record's output through the ring. */
+/*
+ * Progress of one contiguous output range through an LDS ring of R bytes (multiple of 16), ring
+ * index = output offset mod R. The range is produced by a group of lanes: the whole workgroup
+ * (GROUP = PAFFY_NT, barriers between the phases) or a single wave (GROUP = 64: the LDS operations
+ * of one wave execute in order, so the phases need no barrier).
+ */
+template <int GROUP, uint32_t R>
 struct Emitter {
     uint8_t *ring;
     uint8_t *out;
-    uint64_t begin;   /* first byte of the record */
+    uint64_t begin;   /* first byte of the range */
     uint64_t pos;     /* next byte to produce */
     uint64_t flushed; /* multiple of 16: everything below is in HBM */
+    uint32_t pos_r, flushed_r; /* ring indices of pos and flushed */
     __device__ __forceinline__ void start(uint8_t *r, uint8_t *o, uint64_t off) {
         ring = r;
         out = o;
         begin = pos = off;
         flushed = off & ~15ull;
+        pos_r = (uint32_t)(off % R);
+        flushed_r = pos_r - (pos_r & 15u);
+    }
+    __device__ __forceinline__ void sync() {
+        if (GROUP == 64) __builtin_amdgcn_wave_barrier();
+        else __syncthreads();
+    }
+    /* store ring chunks [flushed, to) to HBM; bytes outside [begin, hi) are not ours */
+    __device__ __forceinline__ void flush_to(uint64_t to, uint64_t hi) {
+        const uint32_t li = threadIdx.x & (GROUP - 1);
+        const uint32_t nch = (uint32_t)((to - flushed) >> 4);
+        for (uint32_t ch = li; ch < nch; ch += GROUP) {
+            uint32_t ri = flushed_r + 16 * ch;
+            if (ri >= R) ri -= R;
+            const uint64_t c = flushed + 16ull * ch;
+            uint4 v = *reinterpret_cast<const uint4 *>(ring + ri);
+            if (c >= begin && c + 16 <= hi) {
+                *reinterpret_cast<uint4 *>(out + c) = v;
+            } else {
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int b = 0; b < 16; b++)
+                    if (c + b >= begin && c + b < hi) out[c + b] = (uint8_t)(w[b >> 2] >> ((b & 3) * 8));
+            }
+        }
+        uint32_t adv = flushed_r + 16 * nch;
+        flushed_r = adv >= R ? adv - R : adv;
+        flushed = to;
     }
     /*
-     * A window: every lane put() its full words (phase 1); then
-     *   __syncthreads(); rw.tail(); em.commit(bytes);
-     * commit waits for the tails and pushes the complete 16-byte chunks out. The ring bytes
-     * flushed here are only overwritten by a later window's deposits, which come after that
-     * window's scan barriers, so no trailing barrier is needed.
+     * A window: every lane put() its full words (phase 1); then em.sync(); rw.tail(); em.commit(bytes).
+     * commit waits for the tails and pushes the complete 16-byte chunks out. The ring bytes flushed
+     * here are only overwritten by a later window's deposits (bytes < R - 32 per window).
      */
-    __device__ __forceinline__ void commit(uint64_t bytes) {
-        __syncthreads();
-        uint64_t np = pos + bytes, to = np & ~15ull;
-        if (to > flushed) {
-            ring_flush(ring, out, flushed, to, begin, np);
-            flushed = to;
-        }
+    __device__ __forceinline__ void commit(uint32_t bytes) {
+        sync();
+        const uint64_t np = pos + bytes, to = np & ~15ull;
+        if (to > flushed) flush_to(to, np);
         pos = np;
+        uint32_t pr = pos_r + bytes;
+        pos_r = pr >= R ? pr - R : pr;
+        if (GROUP == 64) __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ void finish() {
-        if (pos > flushed) ring_flush(ring, out, flushed, (pos + 15) & ~15ull, begin, pos);
+        if (pos > flushed) flush_to((pos + 15) & ~15ull, pos);
     }
 };
 
@@ -597,41 +632,87 @@ struct ShatterConst {
     uint32_t row_const, row_max;
 };
 
-/* Row of paf_shatter2 + paf_write: A qs \t qe B ts \t te \t L \t L C L "M\n" */
-template <class SINK>
-__device__ __forceinline__ void put_row(SINK &w, const uint64_t *A, const uint64_t *B, const uint64_t *C, const ShatterConst &k,
-                                        int64_t q0, int64_t t0, int64_t len) {
-    DecText dl;
-    dec_text(len, dl); /* written three times */
-#pragma unroll 1
-    for (int f = 0; f < 4; f++) { /* A qs | \t qe | B ts | \t te */
-        if (f == 0) put_lds(w, A, k.lenA);
-        else if (f == 2) put_lds(w, B, k.lenB);
-        DecText d;
-        dec_text(f == 0 ? q0 : f == 1 ? q0 + len : f == 2 ? t0 : t0 + len, d);
-        put_text(w, d, (f & 1) ? '\t' : 0);
-    }
-    put_text(w, dl, '\t');
-    put_text(w, dl, '\t');
-    put_lds(w, C, k.lenC);
-    if (dl.groups == 0 && !dl.neg_separate && dl.ntop <= 6) { /* digits + "M\n" in one word */
-        w.put(dl.top | ((uint64_t)'M' << (8 * dl.ntop)) | ((uint64_t)'\n' << (8 * dl.ntop + 8)), dl.ntop + 2);
-    } else {
-        put_text(w, dl, 0);
-        w.put((uint64_t)'M' | ((uint64_t)'\n' << 8), 2);
-    }
+/* The five numbers of a row as text, and the row's byte count. */
+struct RowText {
+    DecText q0, q1, t0, t1, l;
+    uint32_t bytes;
+};
+__device__ __forceinline__ void row_text(const ShatterConst &k, int64_t q0, int64_t t0, int64_t len, RowText &r) {
+    dec_text(q0, r.q0);
+    dec_text(q0 + len, r.q1);
+    dec_text(t0, r.t0);
+    dec_text(t0 + len, r.t1);
+    dec_text(len, r.l);
+    r.bytes = k.row_const + text_len(r.q0) + text_len(r.q1) + text_len(r.t0) + text_len(r.t1) + 3 * text_len(r.l);
 }
 __device__ __forceinline__ uint32_t row_len(const ShatterConst &k, int64_t q0, int64_t t0, int64_t len) {
     return k.row_const + dec_len(q0) + dec_len(q0 + len) + dec_len(t0) + dec_len(t0 + len) + 3 * dec_len(len);
 }
 
+/* Line pieces A, B, C of a record held in (wave-uniform) registers when they are short enough. */
+struct RowPieces {
+    uint64_t a[4], b[4], c[6];
+    const uint64_t *A, *B, *C; /* LDS copies, any length */
+    bool in_regs;
+};
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t x) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ void load_pieces(RowPieces &t, const ShatterConst &k, const uint64_t *A, const uint64_t *B, const uint64_t *C) {
+    t.A = A; t.B = B; t.C = C;
+    t.in_regs = k.lenA <= 32 && k.lenB <= 32 && k.lenC <= 48;
+    if (t.in_regs) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) t.a[i] = uniform_u64(A[i]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) t.b[i] = uniform_u64(B[i]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) t.c[i] = uniform_u64(C[i]);
+    }
+}
+template <int N, class SINK>
+__device__ __forceinline__ void put_regs(SINK &w, const uint64_t (&t)[N], uint32_t len) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if (len >= 8u * (i + 1)) w.put8(t[i]);
+        else if (len > 8u * i) w.put(t[i] & ((1ull << (8 * (len - 8u * i))) - 1ull), len - 8u * i);
+    }
+}
+
+/* Row of paf_shatter2 + paf_write: A qs \t qe B ts \t te \t L \t L C L "M\n" */
+template <class SINK>
+__device__ __forceinline__ void put_row(SINK &w, const RowPieces &t, const ShatterConst &k, const RowText &r) {
+    if (t.in_regs) put_regs<4>(w, t.a, k.lenA);
+    else put_lds(w, t.A, k.lenA);
+    put_text(w, r.q0, 0);
+    put_text(w, r.q1, '\t');
+    if (t.in_regs) put_regs<4>(w, t.b, k.lenB);
+    else put_lds(w, t.B, k.lenB);
+    put_text(w, r.t0, 0);
+    put_text(w, r.t1, '\t');
+    put_text(w, r.l, '\t');
+    put_text(w, r.l, '\t');
+    if (t.in_regs) put_regs<6>(w, t.c, k.lenC);
+    else put_lds(w, t.C, k.lenC);
+    if (r.l.groups == 0 && !r.l.neg_separate && r.l.ntop <= 6) { /* digits + "M\n" in one word */
+        w.put(r.l.top | ((uint64_t)'M' << (8 * r.l.ntop)) | ((uint64_t)'\n' << (8 * r.l.ntop + 8)), r.l.ntop + 2);
+    } else {
+        put_text(w, r.l, 0);
+        w.put((uint64_t)'M' | ((uint64_t)'\n' << 8), 2);
+    }
+}
+
 /*
  * paf_shatter, impl/paf.c:629-663, sizing: total bytes / rows, or the first failing assert /
- * child paf_check in op order (key = op index * 32 + code).
+ * child paf_check in op order (key = op index * 32 + code). Also records, for the emit pass,
+ * the bases consumed and bytes produced before each wave's share of the ops (lane chunks of
+ * `chunk` ops, so wave w owns [64*w*chunk, 64*(w+1)*chunk)).
  */
 template <class OPS>
 __device__ int shatter_size(const RecState &s, const View<OPS> &v, const ShatterConst &k, int64_t &bytes, int64_t &rows,
-                            BlockComm &bc) {
+                            RecPlan *plan_out, BlockComm &bc) {
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
     int64_t c[2] = {0, 0}, tot[2];
@@ -644,7 +725,7 @@ __device__ int shatter_size(const RecState &s, const View<OPS> &v, const Shatter
     }
     block_excl_scan<2>(c, tot, bc);
     int64_t cq = c[0], ct = c[1], err = INT64_MAX;
-    int64_t acc[2] = {0, 0};
+    int64_t acc[2] = {0, 0}, acct[2];
     for (uint32_t i = b; i < e; i++) {
         int64_t len;
         int op;
@@ -668,85 +749,110 @@ __device__ int shatter_size(const RecState &s, const View<OPS> &v, const Shatter
         if (op != OP_I) ct += len;
     }
     err = block_min_i64(err, bc);
-    block_sum<2>(acc, bc);
-    bytes = acc[0];
-    rows = acc[1];
+    block_excl_scan<2>(acc, acct, bc);
+    bytes = acct[0];
+    rows = acct[1];
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t w = threadIdx.x >> 6;
+        plan_out->wq[w] = c[0];
+        plan_out->wt[w] = c[1];
+        plan_out->wo[w] = acc[0];
+    }
     if (err != INT64_MAX) return (int)(err & 31);
     if (tot[1] != s.te - s.ts) return PAFFY_ERR_SHATTER_END;
     if (tot[0] != s.qe - s.qs) return PAFFY_ERR_SHATTER_END;
     return 0;
 }
 
-/* Emit the rows of a (validated) record, window by window, through the ring. */
+/*
+ * Emit the rows of a (validated) record. Every wave owns a contiguous share of the ops whose
+ * starting coordinates and output byte come from the sizing pass; it runs its own windows of up
+ * to 128 ops (two per lane, loaded from HBM, DPP scans, its own LDS ring, coalesced 16-byte
+ * flushes). No workgroup barrier anywhere.
+ */
+#define PAFFY_WAVE_RING 9216u /* bytes of LDS ring per wave: 64 rows of the usual ~130-byte lines */
 template <class OPS>
-__device__ void shatter_emit(const RecState &s, const View<OPS> &v, const ShatterConst &k, const uint64_t *A, const uint64_t *B,
-                             const uint64_t *C, Emitter &em, BlockComm &bc) {
-    const uint32_t cap_bytes = PAFFY_RING - 32;
-    const uint32_t rows_cap = cap_bytes / k.row_max; /* >= 1, checked by the caller */
-    uint32_t w_safe = rows_cap < 2 * PAFFY_NT ? rows_cap : 2 * PAFFY_NT;
-    uint32_t w_full = 2 * rows_cap < 2 * PAFFY_NT ? 2 * rows_cap : 2 * PAFFY_NT;
-    int64_t cq = 0, ct = 0;
-    uint32_t i = 0, w_try = w_full;
-    while (i < v.n) {
-        uint32_t w = v.n - i < w_try ? v.n - i : w_try;
-        uint32_t per = (w + PAFFY_NT - 1) / PAFFY_NT;
-        uint32_t b = i + threadIdx.x * per, e = b + per;
-        if (b > i + w) b = i + w;
-        if (e > i + w) e = i + w;
-        int64_t c[2] = {0, 0}, tot[2];
-        for (uint32_t j = b; j < e; j++) {
-            int64_t len;
-            int op;
-            v.get(j, len, op);
-            if (op != OP_D) c[0] += len;
-            if (op != OP_I) c[1] += len;
-        }
-        block_excl_scan<2>(c, tot, bc);
-        int64_t pq = cq + c[0], pt = ct + c[1];
+__device__ void shatter_emit(const RecState &s, const View<OPS> &v, const ShatterConst &k, const RowPieces &pieces, const RecPlan &pl,
+                             uint8_t *ring, uint8_t *out, uint64_t rec_off) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t span = 64ull * pl.chunk;
+    const uint32_t wb = span * wave < v.n ? (uint32_t)(span * wave) : v.n;
+    const uint32_t we = span * (wave + 1) < v.n ? (uint32_t)(span * (wave + 1)) : v.n;
+    int64_t cq = pl.wq[wave], ct = pl.wt[wave];
+    Emitter<64, PAFFY_WAVE_RING> em;
+    em.start(ring + wave * PAFFY_WAVE_RING, out, rec_off + (uint64_t)pl.wo[wave]);
+    const uint32_t cap_bytes = PAFFY_WAVE_RING - 32;
+    const uint32_t rows_cap = cap_bytes / k.row_max; /* >= 1, checked by the sizing pass */
+    const uint32_t w_safe = rows_cap < 128 ? rows_cap : 128;
+    const uint32_t w_full = 2 * rows_cap < 128 ? 2 * rows_cap : 128;
+    uint32_t i = wb, w_try = w_full;
+    while (i < we) {
+        const uint32_t w = we - i < w_try ? we - i : w_try;
+        /* this lane's two ops of the window */
+        const uint32_t j0 = i + 2 * lane;
+        int64_t len0 = 0, len1 = 0;
+        int op0 = -1, op1 = -1;
+        if (j0 < i + w) v.get(j0, len0, op0);
+        if (j0 + 1 < i + w) v.get(j0 + 1, len1, op1);
+        int64_t c[2], tot[2];
+        c[0] = (op0 >= 0 && op0 != OP_D ? len0 : 0) + (op1 >= 0 && op1 != OP_D ? len1 : 0);
+        c[1] = (op0 >= 0 && op0 != OP_I ? len0 : 0) + (op1 >= 0 && op1 != OP_I ? len1 : 0);
+        wave_excl_scan<2>(c, tot);
+        const int64_t pq = cq + c[0], pt = ct + c[1];
+        /* row text of the first M op is kept; a second M op in the pair is rare and recomputed */
+        RowText rt;
+        int cached = -1;
         int64_t nb[1] = {0}, nbt[1];
         {
             int64_t q = pq, t = pt;
-            for (uint32_t j = b; j < e; j++) {
-                int64_t len;
-                int op;
-                v.get(j, len, op);
+#pragma unroll 1
+            for (int sl = 0; sl < 2; sl++) {
+                const int64_t len = sl ? len1 : len0;
+                const int op = sl ? op1 : op0;
                 if (op == OP_M) {
-                    int64_t q0 = s.same ? s.qs + q : s.qe - (q + len);
-                    nb[0] += row_len(k, q0, s.ts + t, len);
+                    const int64_t q0 = s.same ? s.qs + q : s.qe - (q + len);
+                    if (cached < 0) {
+                        row_text(k, q0, s.ts + t, len, rt);
+                        nb[0] += rt.bytes;
+                        cached = sl;
+                    } else {
+                        nb[0] += row_len(k, q0, s.ts + t, len);
+                    }
                 }
-                if (op != OP_D) q += len;
-                if (op != OP_I) t += len;
+                if (op >= 0 && op != OP_D) q += len;
+                if (op >= 0 && op != OP_I) t += len;
             }
         }
-        block_excl_scan<1>(nb, nbt, bc);
+        wave_excl_scan<1>(nb, nbt);
         if (nbt[0] > (int64_t)cap_bytes && w > w_safe) { /* unusually dense window: retry with the safe size */
             w_try = w_safe;
             continue;
         }
         RingWriter rw;
-        rw.init(em.ring, (uint32_t)em.pos, (uint32_t)nb[0]);
+        rw.init(em.ring, PAFFY_WAVE_RING, em.pos_r, (uint32_t)nb[0]);
         {
             int64_t q = pq, t = pt;
-            for (uint32_t j = b; j < e; j++) {
-                int64_t len;
-                int op;
-                v.get(j, len, op);
+#pragma unroll 1
+            for (int sl = 0; sl < 2; sl++) {
+                const int64_t len = sl ? len1 : len0;
+                const int op = sl ? op1 : op0;
                 if (op == OP_M) {
-                    int64_t q0 = s.same ? s.qs + q : s.qe - (q + len);
-                    put_row(rw, A, B, C, k, q0, s.ts + t, len);
+                    if (sl != cached) row_text(k, s.same ? s.qs + q : s.qe - (q + len), s.ts + t, len, rt);
+                    put_row(rw, pieces, k, rt);
                 }
-                if (op != OP_D) q += len;
-                if (op != OP_I) t += len;
+                if (op >= 0 && op != OP_D) q += len;
+                if (op >= 0 && op != OP_I) t += len;
             }
         }
-        __syncthreads();
+        em.sync();
         rw.tail();
-        em.commit((uint64_t)nbt[0]);
+        em.commit((uint32_t)nbt[0]);
         cq += tot[0];
         ct += tot[1];
         i += w;
         w_try = w_full;
     }
+    em.finish();
 }
 
 /* Header of paf_write_to_buffer up to (and including) "\tcg:Z:" -- impl/paf.c:317-368. */
@@ -791,28 +897,31 @@ __device__ int64_t cigar_text_len(const View<OPS> &v, BlockComm &bc) {
     return a[0];
 }
 
-/* One whole line (paf_write): header piece from LDS, then the ops, then '\n'. */
+/* One whole line (paf_write): header piece from LDS, then the ops, then '\n' (workgroup-level windows). */
+#define PAFFY_BLOCK_RING 32768u
+typedef Emitter<PAFFY_NT, PAFFY_BLOCK_RING> BlockEmitter;
 template <class OPS>
-__device__ void write_emit(const View<OPS> &v, bool has_cigar, const uint64_t *H, uint32_t lenH, Emitter &em, BlockComm &bc) {
+__device__ void write_emit(const View<OPS> &v, bool has_cigar, const uint64_t *H, uint32_t lenH, BlockEmitter &em, BlockComm &bc) {
     /* header: 16 bytes per lane per window */
     for (uint32_t base = 0; base < lenH; base += 16 * PAFFY_NT) {
         uint32_t left = lenH - base;
         uint32_t wbytes = left < 16 * PAFFY_NT ? left : 16 * PAFFY_NT;
         uint32_t mine_off = 16 * threadIdx.x;
         RingWriter rw;
-        rw.init(em.ring, (uint32_t)em.pos, mine_off);
         if (mine_off < wbytes) {
             uint32_t mine = wbytes - mine_off < 16 ? wbytes - mine_off : 16;
+            rw.init(em.ring, PAFFY_BLOCK_RING, em.pos_r, mine_off);
             put_lds(rw, H + ((base + mine_off) >> 3), mine);
         } else {
+            rw.init(em.ring, PAFFY_BLOCK_RING, em.pos_r, 0);
             rw.nacc = rw.head = 0; /* nothing to write */
         }
-        __syncthreads();
+        em.sync();
         rw.tail();
         em.commit(wbytes);
     }
     if (!has_cigar || v.n == 0) return; /* the header piece already ends the line */
-    const uint32_t cap_bytes = PAFFY_RING - 32;
+    const uint32_t cap_bytes = PAFFY_BLOCK_RING - 32;
     const uint32_t w_full = 16 * PAFFY_NT, w_safe = cap_bytes / 21; /* an op prints as at most 20 + 1 bytes */
     uint32_t i = 0, w_try = w_full;
     while (i < v.n) {
@@ -836,7 +945,7 @@ __device__ void write_emit(const View<OPS> &v, bool has_cigar, const uint64_t *H
             continue;
         }
         RingWriter rw;
-        rw.init(em.ring, (uint32_t)em.pos, (uint32_t)nb[0]);
+        rw.init(em.ring, PAFFY_BLOCK_RING, em.pos_r, (uint32_t)nb[0]);
         for (uint32_t j = b; j < e; j++) {
             int64_t len;
             int op;
@@ -851,9 +960,9 @@ __device__ void write_emit(const View<OPS> &v, bool has_cigar, const uint64_t *H
             }
         }
         if (last && e == v.n && b < e) rw.put('\n', 1);
-        __syncthreads();
+        em.sync();
         rw.tail();
-        em.commit((uint64_t)nbt[0]);
+        em.commit((uint32_t)nbt[0]);
         i += w;
         w_try = w_full;
     }
@@ -862,7 +971,7 @@ __device__ void write_emit(const View<OPS> &v, bool has_cigar, const uint64_t *H
 /* ---------------- the record program ---------------- */
 
 struct RecLds {
-    uint8_t *ring;    /* PAFFY_RING bytes, 16-aligned; doubles as the cigar text staging area */
+    uint8_t *ring;    /* output ring(s); in the sizing kernel the cigar text staging area */
     uint64_t *pieces; /* 3 * PAFFY_TMPL_MAX bytes */
     mutable BlockComm bc; /* 64 words of LDS */
     Shared *sh;
@@ -890,7 +999,7 @@ __device__ __forceinline__ void shatter_consts(const RecState &s, ShatterConst &
     k.row_max = k.row_const + 2 * dq + 2 * dt + 3 * (dq < dt ? dq : dt);
 }
 __device__ __forceinline__ bool shatter_fits(const ShatterConst &k) {
-    return k.lenA <= PAFFY_TMPL_MAX && k.lenB <= PAFFY_TMPL_MAX && k.lenC <= PAFFY_TMPL_MAX && k.row_max <= PAFFY_RING - 32;
+    return k.lenA <= PAFFY_TMPL_MAX && k.lenB <= PAFFY_TMPL_MAX && k.lenC <= PAFFY_TMPL_MAX && k.row_max <= PAFFY_WAVE_RING - 32;
 }
 
 __device__ __forceinline__ void load_state(const RecMeta &m, RecState &s) {
@@ -963,6 +1072,7 @@ __device__ bool size_record(const KParams &P, uint32_t rec, const OPS &ops, uint
             return true;
         }
     }
+    RecPlan *plan = static_cast<RecPlan *>(P.rec_plan) + rec;
     int64_t bytes, rows;
     if (shatter) {
         ShatterConst k;
@@ -972,7 +1082,7 @@ __device__ bool size_record(const KParams &P, uint32_t rec, const OPS &ops, uint
             report(P, rec, 0, si, 0, klass);
             return true;
         }
-        int rc = shatter_size(s, v, k, bytes, rows, L.bc);
+        int rc = shatter_size(s, v, k, bytes, rows, plan, L.bc);
         if (rc) {
             report(P, rec, rc, si, 0, klass);
             return true;
@@ -993,33 +1103,22 @@ __device__ bool size_record(const KParams &P, uint32_t rec, const OPS &ops, uint
         P.status[rec] = klass << 16;
         P.out_len[rec] = bytes;
         P.out_rows[rec] = rows;
-        RecPlan pl;
-        pl.qs = s.qs; pl.qe = s.qe; pl.ts = s.ts; pl.te = s.te; pl.sub_lo = v.sub_lo; pl.sub_hi = v.sub_hi;
-        pl.lo = v.lo; pl.n = v.n;
-        pl.flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | (s.has_cigar ? 8u : 0u) | ((uint32_t)s.type << 8) |
-                   (shatter ? 16u : 0u);
-        pl.pad = 0;
-        static_cast<RecPlan *>(P.rec_plan)[rec] = pl;
+        plan->qs = s.qs; plan->qe = s.qe; plan->ts = s.ts; plan->te = s.te; plan->sub_lo = v.sub_lo; plan->sub_hi = v.sub_hi;
+        plan->lo = v.lo; plan->n = v.n;
+        plan->flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | (s.has_cigar ? 8u : 0u) | ((uint32_t)s.type << 8) |
+                      (shatter ? 16u : 0u);
+        plan->chunk = ((v.n + PAFFY_NT - 1) / PAFFY_NT) | 1u; /* = sweep_bounds() */
     }
     return true;
 }
 
-/*
- * Emit pass: the record is known to be valid; resume from its RecPlan. `pre_parsed`: the ops are
- * already in `ops` (arena class), otherwise they are re-parsed from the text into LDS.
- */
+/* Emit pass: the record is known to be valid; resume from its RecPlan with the ops in HBM. */
 template <class OPS>
-__device__ void emit_record(const KParams &P, uint32_t rec, const OPS &ops, uint32_t cap, bool pre_parsed, const RecLds &L) {
+__device__ void emit_record(const KParams &P, uint32_t rec, const OPS &ops, const RecLds &L) {
     const RecMeta m = P.meta[rec];
     const RecPlan pl = static_cast<const RecPlan *>(P.rec_plan)[rec];
     RecState s;
     load_state(m, s);
-    if (s.has_cigar && !pre_parsed) {
-        bool fits;
-        uint32_t err_pos;
-        uint32_t r = parse_cigar(P.in, m.cg_off, m.cg_len, ops, cap, L.ring, L.bc, L.sh, &fits, &err_pos);
-        if (r & 0x80000000u) parse_cigar_serial(P.in, m.cg_off, m.cg_len, ops, cap, L.sh, &fits, &err_pos);
-    }
     if (pl.flags & 4u) invert_state(s);
     s.qs = pl.qs; s.qe = pl.qe; s.ts = pl.ts; s.te = pl.te;
     s.has_cigar = (pl.flags & 8u) != 0;
@@ -1027,8 +1126,6 @@ __device__ void emit_record(const KParams &P, uint32_t rec, const OPS &ops, uint
     View<OPS> v;
     v.ops = ops; v.lo = pl.lo; v.n = pl.n; v.rev = pl.flags & 1u; v.swp = (pl.flags & 2u) != 0;
     v.sub_lo = pl.sub_lo; v.sub_hi = pl.sub_hi;
-    Emitter em;
-    em.start(L.ring, P.out, (uint64_t)P.out_off[rec]);
     if (pl.flags & 16u) {
         ShatterConst k;
         shatter_consts(s, k);
@@ -1037,19 +1134,24 @@ __device__ void emit_record(const KParams &P, uint32_t rec, const OPS &ops, uint
             Piece w{(uint8_t *)A, 0, PAFFY_TMPL_MAX, false};
             w.name(P.in, s.qn_off, s.qn_len);
             w.ch('\t'); w.num(s.qlen); w.ch('\t');
+            while (w.n < 32) w.ch(0);
         } else if (threadIdx.x == 64) {
             Piece w{(uint8_t *)B, 0, PAFFY_TMPL_MAX, false};
             w.ch('\t'); w.ch(s.same ? '+' : '-'); w.ch('\t');
             w.name(P.in, s.tn_off, s.tn_len);
             w.ch('\t'); w.num(s.tlen); w.ch('\t');
+            while (w.n < 32) w.ch(0);
         } else if (threadIdx.x == 128) {
             Piece w{(uint8_t *)C, 0, PAFFY_TMPL_MAX, false};
             w.ch('\t'); w.num(s.mapq);
             piece_tags(w, s, 0);
             w.str("\tcg:Z:");
+            while (w.n < 48) w.ch(0);
         }
         __syncthreads();
-        shatter_emit(s, v, k, A, B, C, em, L.bc);
+        RowPieces pieces;
+        load_pieces(pieces, k, A, B, C);
+        shatter_emit(s, v, k, pieces, pl, L.ring, P.out, (uint64_t)P.out_off[rec]);
     } else {
         const bool nl_in_header = !(s.has_cigar && v.n > 0);
         const uint32_t lenH = header_len(s, nl_in_header);
@@ -1058,41 +1160,53 @@ __device__ void emit_record(const KParams &P, uint32_t rec, const OPS &ops, uint
             build_header(w, s, P.in, nl_in_header);
         }
         __syncthreads();
+        BlockEmitter em;
+        em.start(L.ring, P.out, (uint64_t)P.out_off[rec]);
         write_emit(v, s.has_cigar, L.pieces, lenH, em, L.bc);
+        em.finish();
     }
-    em.finish();
 }
 
-#define PAFFY_LDS_BYTES (PAFFY_RING + PAFFY_OPS_CAP * 4 + 3 * PAFFY_TMPL_MAX + 64 * 8 + 64)
+/* LDS budgets: both kernels fit four workgroups per CU (160 KiB). */
+#define PAFFY_SIZE_LDS_BYTES (PAFFY_OPS_CAP * 4 + (PAFFY_HALO + PAFFY_NT * 16) + 64 * 8 + 64)
+#define PAFFY_EMIT_LDS_BYTES (PAFFY_NWAVE * PAFFY_WAVE_RING + 3 * PAFFY_TMPL_MAX + 64 * 8 + 64)
 
-__device__ __forceinline__ RecLds carve_lds(uint8_t *smem, uint32_t **ops_lds) {
+__device__ __forceinline__ RecLds carve_size_lds(uint8_t *smem, uint32_t **ops_lds) {
+    RecLds L;
+    *ops_lds = reinterpret_cast<uint32_t *>(smem);
+    L.ring = smem + PAFFY_OPS_CAP * 4; /* text staging */
+    L.pieces = nullptr;
+    L.bc.scratch = reinterpret_cast<int64_t *>(smem + PAFFY_OPS_CAP * 4 + PAFFY_HALO + PAFFY_NT * 16);
+    L.bc.flip = 0;
+    L.sh = reinterpret_cast<Shared *>(smem + PAFFY_OPS_CAP * 4 + PAFFY_HALO + PAFFY_NT * 16 + 64 * 8);
+    return L;
+}
+__device__ __forceinline__ RecLds carve_emit_lds(uint8_t *smem) {
     RecLds L;
     L.ring = smem;
-    *ops_lds = reinterpret_cast<uint32_t *>(smem + PAFFY_RING);
-    L.pieces = reinterpret_cast<uint64_t *>(smem + PAFFY_RING + PAFFY_OPS_CAP * 4);
-    L.bc.scratch = reinterpret_cast<int64_t *>(smem + PAFFY_RING + PAFFY_OPS_CAP * 4 + 3 * PAFFY_TMPL_MAX);
+    L.pieces = reinterpret_cast<uint64_t *>(smem + PAFFY_NWAVE * PAFFY_WAVE_RING);
+    L.bc.scratch = reinterpret_cast<int64_t *>(smem + PAFFY_NWAVE * PAFFY_WAVE_RING + 3 * PAFFY_TMPL_MAX);
     L.bc.flip = 0;
-    L.sh = reinterpret_cast<Shared *>(smem + PAFFY_RING + PAFFY_OPS_CAP * 4 + 3 * PAFFY_TMPL_MAX + 64 * 8);
+    L.sh = reinterpret_cast<Shared *>(smem + PAFFY_NWAVE * PAFFY_WAVE_RING + 3 * PAFFY_TMPL_MAX + 64 * 8);
     return L;
 }
 
-/* LDS class: one workgroup per record, ops re-parsed from the text into LDS. */
-template <bool EMIT>
-__global__ __launch_bounds__(PAFFY_NT) void k_record_lds(KParams P) {
+/* Where the HBM mirror of a record's 4-byte ops lives: cigars do not overlap and an op takes at
+ * least two text bytes (digits + letter), so index cg_off / 2 is private to the record. */
+__device__ __forceinline__ uint32_t mirror_index(const RecMeta &m) { return m.cg_off >> 1; }
+
+/* Sizing, LDS class: one workgroup per record, ops parsed from the text into LDS (and mirrored). */
+__global__ __launch_bounds__(PAFFY_NT, 4) void k_size_lds(KParams P) {
     extern __shared__ uint4 smem4[];
     uint32_t *ops_lds;
-    RecLds L = carve_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds);
+    RecLds L = carve_size_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds);
     const uint32_t rec = blockIdx.x;
-    if (EMIT) {
-        if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return; /* nothing at or after the first failure */
-        if ((P.status[rec] >> 16) != KLASS_LDS) return;
-    }
-    OpsLds ops{ops_lds};
+    const RecMeta &m = P.meta[rec];
+    OpsLds ops{ops_lds, P.ops_mirror + mirror_index(m), (m.cg_len + 1) >> 1};
     uint32_t n_ops = 0;
-    bool ok = true;
-    if (EMIT) emit_record<OpsLds>(P, rec, ops, PAFFY_OPS_CAP, false, L);
-    else ok = size_record<OpsLds>(P, rec, ops, PAFFY_OPS_CAP, L, KLASS_LDS, &n_ops);
-    if (!EMIT && !ok && threadIdx.x == 0) { /* route to the arena kernel */
+    bool ok = size_record<OpsLds>(P, rec, ops, PAFFY_OPS_CAP, L, KLASS_LDS, &n_ops);
+    if (ok && n_ops > ((m.cg_len + 1) >> 1)) ok = false; /* digit-less ops overran the mirror: arena class */
+    if (!ok && threadIdx.x == 0) { /* route to the arena kernel */
         P.status[rec] = (uint32_t)KLASS_ARENA << 16;
         P.out_len[rec] = 0;
         P.out_rows[rec] = 0;
@@ -1101,20 +1215,31 @@ __global__ __launch_bounds__(PAFFY_NT) void k_record_lds(KParams P) {
     }
 }
 
+/* Emit, LDS class. */
+__global__ __launch_bounds__(PAFFY_NT, 4) void k_emit_lds(KParams P) {
+    extern __shared__ uint4 smem4[];
+    RecLds L = carve_emit_lds(reinterpret_cast<uint8_t *>(smem4));
+    const uint32_t rec = blockIdx.x;
+    if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return; /* nothing at or after the first failure */
+    if ((P.status[rec] >> 16) != KLASS_LDS) return;
+    OpsGlobal ops{P.ops_mirror + mirror_index(P.meta[rec])};
+    emit_record<OpsGlobal>(P, rec, ops, L);
+}
+
 /* Arena class: records whose ops do not fit LDS; persistent workgroups walk the list. */
 template <bool EMIT>
 __global__ __launch_bounds__(PAFFY_NT) void k_record_arena(KParams P) {
     extern __shared__ uint4 smem4[];
     uint32_t *ops_lds;
-    RecLds L = carve_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds);
+    RecLds L = EMIT ? carve_emit_lds(reinterpret_cast<uint8_t *>(smem4)) : carve_size_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds);
     const uint32_t count = P.info->w_count;
     const uint32_t first_err = (uint32_t)(P.info->first_err_key >> 16);
     for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
         const uint32_t rec = P.w_list[li];
         if (EMIT) {
-            if (rec < first_err) {
+            if (rec < first_err && (P.status[rec] & 0xff) == 0) {
                 OpsArena ops{P.arena + P.arena_off[rec]};
-                emit_record<OpsArena>(P, rec, ops, 0xffffffffu, true, L);
+                emit_record<OpsArena>(P, rec, ops, L);
             }
         } else {
             /* upper bound for the allocation: one op per cigar byte */

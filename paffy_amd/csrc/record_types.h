@@ -16,7 +16,7 @@
 #include "../../include/paffy_hip.h"
 
 #define PAFFY_OPS_CAP 8192u /* 4-byte ops held in LDS per workgroup (32 KiB) */
-#define PAFFY_TMPL_MAX 1024u /* bytes per pre-rendered line piece held in LDS */
+#define PAFFY_TMPL_MAX 768u /* bytes per pre-rendered line piece held in LDS */
 #define PAFFY_HALO 32u
 
 enum { OP_M = 0, OP_I = 1, OP_D = 2, OP_EQ = 3, OP_X = 4 }; /* inc/paf.h:52-58 */
@@ -59,6 +59,7 @@ struct KParams {
     uint32_t *n_ops;
     uint64_t *arena_off;
     void *rec_plan; /* RecPlan[n_rec] */
+    uint32_t *ops_mirror; /* 4-byte ops of LDS-class records, indexed from cg_off / 2 */
     /* emit pass */
     const int64_t *out_off;
     uint8_t *out;
