@@ -201,10 +201,15 @@ __device__ __forceinline__ int dec_len(int64_t v) {
     return d + (v < 0 ? 1 : 0);
 }
 
-/* 4 decimal digits of y < 10000 as bytes, most significant digit in byte 0. */
+/* 4 decimal digits of y < 10000 as bytes, most significant digit in byte 0. All products fit
+ * 24 x 24 -> 32 bits, so they use the full-rate v_mul_u32_u24 (32-bit mul_hi/mul_lo are slower). */
 __device__ __forceinline__ uint32_t bcd4(uint32_t y) {
-    uint32_t a = y / 100u, b = y - a * 100u;
-    uint32_t d0 = a / 10u, d1 = a - d0 * 10u, d2 = b / 10u, d3 = b - d2 * 10u;
+    uint32_t a = __umul24(y, 5243u) >> 19; /* y / 100 for y < 43699 */
+    uint32_t b = y - __umul24(a, 100u);
+    uint32_t d0 = __umul24(a, 103u) >> 10; /* a / 10 for a < 100 */
+    uint32_t d1 = a - __umul24(d0, 10u);
+    uint32_t d2 = __umul24(b, 103u) >> 10;
+    uint32_t d3 = b - __umul24(d2, 10u);
     return d0 | (d1 << 8) | (d2 << 16) | (d3 << 24);
 }
 
@@ -299,13 +304,19 @@ struct ByteWriter {
 
 /* 8 decimal digits of x < 10^8 as ASCII, most significant digit in byte 0 */
 __device__ __forceinline__ uint64_t ascii8(uint32_t x) {
-    uint32_t hi4 = x / 10000u, lo4 = x - hi4 * 10000u;
+    uint32_t hi4 = x / 10000u, lo4 = x - __umul24(hi4, 10000u);
     return ((((uint64_t)bcd4(lo4)) << 32) | bcd4(hi4)) + 0x3030303030303030ull;
 }
 /* decimal digits of x < 10^8 without leading zeros, left-aligned; *n = digit count (1..8) */
 __device__ __forceinline__ uint64_t ascii_upto8(uint32_t x, uint32_t *n) {
-    uint32_t hi4 = x / 10000u, lo4 = x - hi4 * 10000u;
-    uint32_t w0 = bcd4(hi4), w1 = bcd4(lo4);
+    uint32_t w0 = 0, w1;
+    if (x < 10000u) { /* one group of four: no 32-bit division at all */
+        w1 = bcd4(x);
+    } else {
+        uint32_t hi4 = x / 10000u, lo4 = x - __umul24(hi4, 10000u);
+        w0 = bcd4(hi4);
+        w1 = bcd4(lo4);
+    }
     uint32_t z = w0 ? ((uint32_t)__ffs((int)w0) - 1) >> 3 : (w1 ? 4 + (((uint32_t)__ffs((int)w1) - 1) >> 3) : 7);
     *n = 8 - z;
     return ((((uint64_t)w1 << 32) | w0) + 0x3030303030303030ull) >> (8 * z);

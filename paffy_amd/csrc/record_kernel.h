@@ -45,6 +45,12 @@ struct OpsLds { /* 4-byte ops in LDS (len << 3 | op, len < 2^29), mirrored to HB
 struct OpsGlobal { /* the HBM mirror, read by the emit pass */
     const uint32_t *p;
     static constexpr bool kNarrow = true;
+    typedef uint32_t raw_t;
+    __device__ __forceinline__ raw_t raw(uint32_t i) const { return p[i]; }
+    static __device__ __forceinline__ void decode(raw_t w, int64_t &len, int &op) {
+        op = (int)(w & 7u);
+        len = (int64_t)(w >> 3);
+    }
     __device__ __forceinline__ void get(uint32_t i, int64_t &len, int &op) const {
         uint32_t w = p[i];
         op = (int)(w & 7u);
@@ -54,6 +60,12 @@ struct OpsGlobal { /* the HBM mirror, read by the emit pass */
 struct OpsArena { /* 8-byte ops in HBM: the CigarRecord layout, inc/paf.h:61-64 */
     uint64_t *p;
     static constexpr bool kNarrow = false;
+    typedef uint64_t raw_t;
+    __device__ __forceinline__ raw_t raw(uint32_t i) const { return p[i]; }
+    static __device__ __forceinline__ void decode(raw_t w, int64_t &len, int &op) {
+        op = (int)(w & 0xffu);
+        len = (int64_t)w >> 8;
+    }
     __device__ __forceinline__ void get(uint32_t i, int64_t &len, int &op) const {
         uint64_t w = p[i];
         op = (int)(w & 0xffu);
@@ -71,6 +83,15 @@ struct View {
     __device__ __forceinline__ void get(uint32_t i, int64_t &len, int &op) const {
         uint32_t raw = rev ? lo + n - 1 - i : lo + i;
         ops.get(raw, len, op);
+        if (swp && (op == OP_I || op == OP_D)) op ^= 3;
+        if (raw == lo) len -= sub_lo;
+        if (raw == lo + n - 1) len -= sub_hi;
+    }
+    /* split form of get(): issue the load early, decode when the value is needed */
+    __device__ __forceinline__ uint32_t raw_index(uint32_t i) const { return rev ? lo + n - 1 - i : lo + i; }
+    template <class RAW>
+    __device__ __forceinline__ void decode(RAW w, uint32_t raw, int64_t &len, int &op) const {
+        OPS::decode(w, len, op);
         if (swp && (op == OP_I || op == OP_D)) op ^= 3;
         if (raw == lo) len -= sub_lo;
         if (raw == lo + n - 1) len -= sub_hi;
@@ -594,7 +615,11 @@ struct Emitter {
             const uint64_t c = flushed + 16ull * ch;
             uint4 v = *reinterpret_cast<const uint4 *>(ring + ri);
             if (c >= begin && c + 16 <= hi) {
+#if !defined(PAFFY_ABL) || PAFFY_ABL != 1
                 *reinterpret_cast<uint4 *>(out + c) = v;
+#else
+                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#endif
             } else {
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -786,14 +811,35 @@ __device__ void shatter_emit(const RecState &s, const View<OPS> &v, const Shatte
     const uint32_t w_safe = rows_cap < 128 ? rows_cap : 128;
     const uint32_t w_full = 2 * rows_cap < 128 ? 2 * rows_cap : 128;
     uint32_t i = wb, w_try = w_full;
+    /* raw op words are loaded one window ahead so that the HBM latency hides behind the formatting */
+    typename OPS::raw_t nraw0 = 0, nraw1 = 0;
+    uint32_t n_i = 0xffffffffu, n_w = 0; /* window the prefetched pair belongs to */
     while (i < we) {
         const uint32_t w = we - i < w_try ? we - i : w_try;
         /* this lane's two ops of the window */
         const uint32_t j0 = i + 2 * lane;
+        const bool has0 = j0 < i + w, has1 = j0 + 1 < i + w;
+        const uint32_t r0 = v.raw_index(j0), r1 = v.raw_index(j0 + 1);
+        typename OPS::raw_t raw0 = 0, raw1 = 0;
+        if (n_i == i && n_w == w) {
+            raw0 = nraw0;
+            raw1 = nraw1;
+        } else {
+            if (has0) raw0 = v.ops.raw(r0);
+            if (has1) raw1 = v.ops.raw(r1);
+        }
+        { /* issue the loads of the following window now; they are decoded next iteration */
+            n_i = i + w;
+            n_w = we - n_i < w_full ? we - n_i : w_full;
+            const uint32_t k0 = n_i + 2 * lane;
+            nraw0 = nraw1 = 0;
+            if (k0 < n_i + n_w) nraw0 = v.ops.raw(v.raw_index(k0));
+            if (k0 + 1 < n_i + n_w) nraw1 = v.ops.raw(v.raw_index(k0 + 1));
+        }
         int64_t len0 = 0, len1 = 0;
         int op0 = -1, op1 = -1;
-        if (j0 < i + w) v.get(j0, len0, op0);
-        if (j0 + 1 < i + w) v.get(j0 + 1, len1, op1);
+        if (has0) v.decode(raw0, r0, len0, op0);
+        if (has1) v.decode(raw1, r1, len1, op1);
         int64_t c[2], tot[2];
         c[0] = (op0 >= 0 && op0 != OP_D ? len0 : 0) + (op1 >= 0 && op1 != OP_D ? len1 : 0);
         c[1] = (op0 >= 0 && op0 != OP_I ? len0 : 0) + (op1 >= 0 && op1 != OP_I ? len1 : 0);
@@ -838,7 +884,11 @@ __device__ void shatter_emit(const RecState &s, const View<OPS> &v, const Shatte
                 const int op = sl ? op1 : op0;
                 if (op == OP_M) {
                     if (sl != cached) row_text(k, s.same ? s.qs + q : s.qe - (q + len), s.ts + t, len, rt);
+#if !defined(PAFFY_ABL) || PAFFY_ABL != 2
                     put_row(rw, pieces, k, rt);
+#else
+                    rw.put(rt.q0.top ^ rt.q1.top ^ rt.t0.top ^ rt.t1.top ^ rt.l.top, 8);
+#endif
                 }
                 if (op >= 0 && op != OP_D) q += len;
                 if (op >= 0 && op != OP_I) t += len;
@@ -846,7 +896,11 @@ __device__ void shatter_emit(const RecState &s, const View<OPS> &v, const Shatte
         }
         em.sync();
         rw.tail();
+#if !defined(PAFFY_ABL) || PAFFY_ABL != 3
         em.commit((uint32_t)nbt[0]);
+#else
+        em.pos += (uint32_t)nbt[0]; { uint32_t pr = em.pos_r + (uint32_t)nbt[0]; em.pos_r = pr >= PAFFY_WAVE_RING ? pr - PAFFY_WAVE_RING : pr; }
+#endif
         cq += tot[0];
         ct += tot[1];
         i += w;
@@ -1216,7 +1270,10 @@ __global__ __launch_bounds__(PAFFY_NT, 4) void k_size_lds(KParams P) {
 }
 
 /* Emit, LDS class. */
-__global__ __launch_bounds__(PAFFY_NT, 4) void k_emit_lds(KParams P) {
+#ifndef PAFFY_EMIT_OCC
+#define PAFFY_EMIT_OCC 3
+#endif
+__global__ __launch_bounds__(PAFFY_NT, PAFFY_EMIT_OCC) void k_emit_lds(KParams P) {
     extern __shared__ uint4 smem4[];
     RecLds L = carve_emit_lds(reinterpret_cast<uint8_t *>(smem4));
     const uint32_t rec = blockIdx.x;

@@ -10,7 +10,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-_LIB = os.path.join(HERE, "libpaffy_hip.so")
+_LIB = os.environ.get("PAFFY_HIP_LIB", os.path.join(HERE, "libpaffy_hip.so"))  # override for A/B experiments only
 
 INVERT, TRIM_IDENTITY, TRIM_FIXED, SHATTER, ADD_MISMATCHES, REMOVE_MISMATCHES, PASS = 1, 2, 3, 4, 5, 6, 7
 
