@@ -1,0 +1,132 @@
+/*
+ * paffy_cmds.c -- option tables and entry points of the hot-path subcommands.
+ * Flags follow the reference drivers: common -i/--inputFile -o/--outputFile -l/--logLevel
+ * -h/--help; trim adds -t/--trimFraction -r/--trimIdentity -f/--fixedTrim
+ * (impl/paf_trim.c:53-63); -h prints usage and returns 0, an unknown option returns 1.
+ */
+#include <getopt.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "paffy_host.h"
+
+typedef struct {
+    const char *in_path, *out_path, *log_level;
+    float trim_fraction, trim_identity; /* floats, as the reference's statics (impl/paf_trim.c:14-16) */
+    int fixed_trim;
+} cmd_opts;
+
+static void usage_common(const char *cmd, const char *what) {
+    fprintf(stderr, "paffy %s [options], MI355X build\n%s\n", cmd, what);
+    fprintf(stderr, "-i --inputFile : PAF file to read (default: stdin)\n");
+    fprintf(stderr, "-o --outputFile : PAF file to write (default: stdout)\n");
+}
+static void usage_tail(void) {
+    fprintf(stderr, "-l --logLevel : log level (INFO, DEBUG)\n");
+    fprintf(stderr, "-h --help : print this message\n");
+}
+
+/* returns -1 to continue, otherwise the exit code */
+static int parse_opts(int argc, char *argv[], const char *cmd, const char *what, int is_trim, cmd_opts *o) {
+    static struct option common[] = {{"logLevel", required_argument, 0, 'l'}, {"inputFile", required_argument, 0, 'i'},
+                                     {"outputFile", required_argument, 0, 'o'}, {"help", no_argument, 0, 'h'},
+                                     {"trimFraction", required_argument, 0, 't'}, {"trimIdentity", required_argument, 0, 'r'},
+                                     {"fixedTrim", no_argument, 0, 'f'}, {0, 0, 0, 0}};
+    struct option opts[8];
+    memcpy(opts, common, sizeof(common));
+    if (!is_trim) memset(&opts[4], 0, sizeof(struct option)); /* terminate after the common four */
+    memset(o, 0, sizeof(*o));
+    o->trim_fraction = 1.0f;
+    o->trim_identity = 0.05f;
+    optind = 1;
+    for (;;) {
+        int idx = 0;
+        int key = getopt_long(argc, argv, is_trim ? "l:i:o:ht:r:f" : "l:i:o:h", opts, &idx);
+        if (key == -1) break;
+        switch (key) {
+            case 'l': o->log_level = optarg; break;
+            case 'i': o->in_path = optarg; break;
+            case 'o': o->out_path = optarg; break;
+            case 't': o->trim_fraction = (float)atof(optarg); break;
+            case 'r': o->trim_identity = (float)atof(optarg); break;
+            case 'f': o->fixed_trim = 1; break;
+            case 'h':
+            default:
+                usage_common(cmd, what);
+                if (is_trim) {
+                    fprintf(stderr, "-r --trimIdentity : trim tails whose identity is below x - x*r of the alignment identity x "
+                                    "(0..1, default %f)\n", 0.05);
+                    fprintf(stderr, "-t --trimFraction : fraction of aligned bases to trim per end; with identity trimming the "
+                                    "largest tail (0..1, default %f)\n", 1.0);
+                    fprintf(stderr, "-f --fixedTrim : trim a constant --trimFraction instead of trimming by identity\n");
+                }
+                usage_tail();
+                return key == 'h' ? 0 : 1;
+        }
+    }
+    return -1;
+}
+
+static int run_stream_cmd(const cmd_opts *o, const paffy_stage *stages, int n_stages, const char *name) {
+    time_t t0 = time(NULL);
+    host_set_log_level(o->log_level);
+    host_log_info("Input file string : %s\n", o->in_path ? o->in_path : "(stdin)");
+    host_log_info("Output file string : %s\n", o->out_path ? o->out_path : "(stdout)");
+    FILE *in = o->in_path ? fopen(o->in_path, "r") : stdin;
+    if (!in) {
+        fprintf(stderr, "paffy %s: cannot open %s\n", name, o->in_path);
+        return 1;
+    }
+    FILE *out = o->out_path ? fopen(o->out_path, "w") : stdout;
+    if (!out) {
+        fprintf(stderr, "paffy %s: cannot open %s\n", name, o->out_path);
+        return 1;
+    }
+    int rc = host_stream(stages, n_stages, in, out);
+    if (o->in_path) fclose(in);
+    if (o->out_path) fclose(out);
+    host_log_info("Paffy %s is done!, %lld seconds have elapsed\n", name, (long long)(time(NULL) - t0));
+    return rc;
+}
+
+int paffy_shatter_main(int argc, char *argv[]) {
+    cmd_opts o;
+    int rc = parse_opts(argc, argv, "shatter", "Break up paf alignments into their gapless match blocks", 0, &o);
+    if (rc >= 0) return rc;
+    paffy_stage st = {PAFFY_SHATTER, 0.05f, 1.0f};
+    return run_stream_cmd(&o, &st, 1, "shatter");
+}
+
+int paffy_invert_main(int argc, char *argv[]) {
+    cmd_opts o;
+    int rc = parse_opts(argc, argv, "invert", "Swap query and target of every alignment", 0, &o);
+    if (rc >= 0) return rc;
+    paffy_stage st = {PAFFY_INVERT, 0.05f, 1.0f};
+    return run_stream_cmd(&o, &st, 1, "invert");
+}
+
+int paffy_trim_main(int argc, char *argv[]) {
+    cmd_opts o;
+    int rc = parse_opts(argc, argv, "trim", "Trim the ends of every alignment", 1, &o);
+    if (rc >= 0) return rc;
+    host_set_log_level(o.log_level);
+    host_log_info("Trim fraction using : %f\n", o.trim_fraction);
+    host_log_info("Trim by identity fraction : %f\n", o.trim_identity);
+    paffy_stage st = {o.fixed_trim ? PAFFY_TRIM_FIXED : PAFFY_TRIM_IDENTITY, o.trim_identity, o.trim_fraction};
+    return run_stream_cmd(&o, &st, 1, "trim");
+}
+
+int paffy_add_mismatches_main(int argc, char *argv[]) {
+    (void)argc;
+    (void)argv;
+    fprintf(stderr, "paffy add_mismatches: not available in this build yet\n");
+    return 1;
+}
+
+int paffy_tile_main(int argc, char *argv[]) {
+    (void)argc;
+    (void)argv;
+    fprintf(stderr, "paffy tile: not available in this build yet\n");
+    return 1;
+}

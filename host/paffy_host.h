@@ -1,0 +1,34 @@
+/*
+ * paffy_host.h -- host drivers of the `paffy <command>` CLI over the gfx950 C-ABI.
+ *
+ * Same subcommand names, option letters / long names and exit codes as the reference CLI
+ * (paffy_main.c:46-84, impl/paf_<cmd>.c getopt tables); each paffy_<cmd>_main replaces the
+ * reference's per-record loop with whole-batch calls into include/paffy_hip.h.
+ */
+#ifndef PAFFY_HOST_H_
+#define PAFFY_HOST_H_
+
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../include/paffy_hip.h"
+
+int paffy_shatter_main(int argc, char *argv[]);
+int paffy_invert_main(int argc, char *argv[]);
+int paffy_trim_main(int argc, char *argv[]);
+int paffy_add_mismatches_main(int argc, char *argv[]);
+int paffy_tile_main(int argc, char *argv[]);
+
+/* Log level shared by the drivers: 0 off, 1 info, 2 debug (set from -l/--logLevel). */
+void host_set_log_level(const char *s);
+void host_log_info(const char *fmt, ...);
+
+/*
+ * Stream `in` through a stage list: the input is cut into chunks that end on a line boundary,
+ * every chunk is one plan/emit round trip, outputs are written in order. On a failing record
+ * everything before it is written, the reference's message is printed and the process ends
+ * the way the reference does (exit 1, SIGABRT or SIGSEGV). Returns 0 on success.
+ */
+int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out);
+
+#endif

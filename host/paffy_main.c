@@ -1,0 +1,58 @@
+/*
+ * paffy_main.c -- `paffy <command> [options]` dispatcher of the MI355X build.
+ * Contract of the reference dispatcher (paffy_main.c:46-84): no arguments -> usage, status 0;
+ * unknown command -> message + usage, status 1; otherwise the command's own status. The hot-path
+ * commands (shatter, invert, trim, add_mismatches, tile) run on the GPU; the others are outside
+ * this build's scope and say so with status 1.
+ */
+#include <stdio.h>
+#include <string.h>
+
+#include "paffy_host.h"
+
+typedef int (*cmd_fn)(int, char **);
+static const struct {
+    const char *name;
+    cmd_fn fn;
+    const char *help;
+} COMMANDS[] = {
+    {"add_mismatches", paffy_add_mismatches_main, "Replace Ms with =/Xs in the cigar (or -a: the reverse)"},
+    {"chain", NULL, "Chain alignments (not in this build)"},
+    {"dechunk", NULL, "Map chunk coordinates back (not in this build)"},
+    {"dedupe", NULL, "Drop duplicate alignments (not in this build)"},
+    {"filter", NULL, "Filter alignments on their stats (not in this build)"},
+    {"invert", paffy_invert_main, "Switch query and target coordinates"},
+    {"shatter", paffy_shatter_main, "Break alignments into gapless blocks"},
+    {"tile", paffy_tile_main, "Give alignments tile levels along the query"},
+    {"to_bed", NULL, "Coverage map in BED format (not in this build)"},
+    {"trim", paffy_trim_main, "Slice off lower identity tails"},
+    {"upconvert", NULL, "Convert coordinates to extracted subsequences (not in this build)"},
+    {"split_file", NULL, "Split a PAF file per contig (not in this build)"},
+    {"view", NULL, "Pretty print alignments (not in this build)"},
+};
+
+static void usage(void) {
+    fprintf(stderr, "paffy: toolkit for working with PAF files (MI355X hot-path build)\n\n");
+    fprintf(stderr, "usage: paffy <command> [options]\n\navailable commands:\n");
+    for (size_t i = 0; i < sizeof(COMMANDS) / sizeof(COMMANDS[0]); i++) fprintf(stderr, "    %-24s %s\n", COMMANDS[i].name, COMMANDS[i].help);
+    fprintf(stderr, "\n");
+}
+
+int main(int argc, char *argv[]) {
+    if (argc < 2) {
+        usage();
+        return 0;
+    }
+    for (size_t i = 0; i < sizeof(COMMANDS) / sizeof(COMMANDS[0]); i++) {
+        if (strcmp(argv[1], COMMANDS[i].name) == 0) {
+            if (!COMMANDS[i].fn) {
+                fprintf(stderr, "paffy %s is outside the scope of this build (hot path only)\n", argv[1]);
+                return 1;
+            }
+            return COMMANDS[i].fn(argc - 1, argv + 1);
+        }
+    }
+    fprintf(stderr, "%s is not a valid paffy command\n", argv[1]);
+    usage();
+    return 1;
+}

@@ -1,0 +1,102 @@
+/*
+ * paffy_stream.c -- chunked streaming of PAF text through the C-ABI (host side of the
+ * shatter / invert / trim drivers; replaces the read-transform-write loop of
+ * impl/paf_invert.c:84-89 and friends).
+ */
+#include <signal.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "paffy_host.h"
+
+static int g_log_level = 0;
+
+void host_set_log_level(const char *s) {
+    g_log_level = 0;
+    if (!s) return;
+    if (!strcasecmp(s, "INFO")) g_log_level = 1;
+    else if (!strcasecmp(s, "DEBUG")) g_log_level = 2;
+}
+
+void host_log_info(const char *fmt, ...) {
+    if (g_log_level < 1) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+}
+
+static size_t chunk_bytes(void) {
+    const char *e = getenv("PAFFY_CHUNK_MB");
+    long mb = e ? atol(e) : 256;
+    if (mb < 1) mb = 1;
+    if (mb > 1900) mb = 1900; /* one batch stays below 2 GiB */
+    return (size_t)mb << 20;
+}
+
+/* Ends the process the way the reference would for this record error. */
+static void die_like_reference(const paffy_error *e, int64_t record_base) {
+    int status = paffy_hip_error_exit_status(e->code);
+    fflush(stdout);
+    if (e->code == PAFFY_ERR_STRAND)
+        fprintf(stderr, "Got an unexpected strand character (%c) in a paf string\n", (int)e->aux);
+    else if (e->code == PAFFY_ERR_CIGAR_CHAR)
+        fprintf(stderr, "Got an unexpected character paf cigar string: %c\n", (int)e->aux);
+    else
+        fprintf(stderr, "%s (record %lld)\n", paffy_hip_error_string(e->code), (long long)(record_base + e->record));
+    if (status == 134) raise(SIGABRT);
+    if (status == 139) raise(SIGSEGV);
+    exit(status ? status : 1);
+}
+
+int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out) {
+    paffy_hip_ctx *ctx = NULL;
+    if (paffy_hip_create(&ctx, -1) != 0) {
+        fprintf(stderr, "paffy: no usable GPU (this build has no CPU path)\n");
+        return 1;
+    }
+    const size_t cap = chunk_bytes();
+    size_t buf_cap = cap + (1 << 20), have = 0;
+    char *buf = (char *)malloc(buf_cap);
+    int64_t records_done = 0;
+    int eof = 0, rc = 0;
+    while (!eof || have > 0) {
+        if (!eof) {
+            if (have == buf_cap) { /* a single line longer than the chunk: grow */
+                buf_cap *= 2;
+                buf = (char *)realloc(buf, buf_cap);
+            }
+            size_t want = (have < cap ? cap : buf_cap) - have;
+            size_t got = fread(buf + have, 1, want, in);
+            have += got;
+            if (got < want) eof = 1;
+        }
+        size_t use = have;
+        if (!eof) { /* keep the partial last line for the next chunk */
+            while (use > 0 && buf[use - 1] != '\n') use--;
+            if (use == 0) continue; /* no complete line yet: read more */
+        }
+        if (use == 0) break;
+        char *h_out = NULL;
+        int64_t out_len = 0;
+        paffy_plan_info info;
+        int r = paffy_hip_run_host(ctx, stages, n_stages, buf, (int64_t)use, &h_out, &out_len, &info);
+        if (r != 0) {
+            fprintf(stderr, "paffy: GPU call failed (%d): %s\n", r, paffy_hip_last_error(ctx));
+            rc = 1;
+            free(h_out);
+            break;
+        }
+        if (out_len > 0) fwrite(h_out, 1, (size_t)out_len, out);
+        free(h_out);
+        if (info.error.code) die_like_reference(&info.error, records_done);
+        records_done += info.n_records;
+        memmove(buf, buf + use, have - use);
+        have -= use;
+    }
+    free(buf);
+    paffy_hip_destroy(ctx);
+    fflush(out);
+    return rc;
+}

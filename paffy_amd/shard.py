@@ -1,0 +1,55 @@
+"""Sharding of the stream commands across GPUs.
+
+Records of shatter / invert / trim / add_mismatches are independent (each iteration of the
+reference loop touches one Paf, impl/paf_invert.c:84-89), so the N-GPU path is a partition of
+the record stream with no data-path collective: rank r owns batches r, r+N, r+2N, ... of
+`batch` records each. Output order is restored by concatenating per-batch outputs in batch
+order; the only exchange is an all-gather of per-batch output byte counts (8 bytes per batch) so
+that every rank knows where its bytes go in the ordered output (pwrite / gather-to-writer).
+`tile` shards by query contig instead (its state is keyed by query name, impl/paf.c:675-688).
+"""
+
+
+def batches_of_rank(rank, world, total_records, batch):
+    """[(batch_index, first_record, n_records)] owned by `rank`: round-robin over the stream's batches."""
+    out = []
+    n_batches = (total_records + batch - 1) // batch
+    for b in range(rank, n_batches, world):
+        r0 = b * batch
+        out.append((b, r0, min(batch, total_records - r0)))
+    return out
+
+
+def output_offsets(sizes_by_batch):
+    """Exclusive prefix sum of the per-batch output sizes (index = batch index) -> byte offset of every batch."""
+    offs, acc = [], 0
+    for s in sizes_by_batch:
+        offs.append(acc)
+        acc += s
+    return offs, acc
+
+
+def gather_batch_sizes(dist, local, n_batches, device="cpu"):
+    """All-gather of {batch_index: out_bytes}: every rank ends with the full size table.
+
+    `local` maps the batch indices this rank processed to their output byte counts. Works with
+    any torch.distributed backend (nccl = RCCL on the GPU box, gloo in the CPU tests).
+    """
+    import torch
+
+    t = torch.zeros(n_batches, dtype=torch.int64, device=device)
+    for b, s in local.items():
+        t[b] = s
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)  # disjoint ownership: a sum is a gather
+    return [int(x) for x in t.tolist()]
+
+
+def contig_partition(weights, world):
+    """`tile`: assign query contigs to ranks, heaviest first onto the lightest rank (weights: name -> work)."""
+    loads = [0] * world
+    owner = {}
+    for name, w in sorted(weights.items(), key=lambda kv: (-kv[1], kv[0])):
+        r = min(range(world), key=lambda i: (loads[i], i))
+        owner[name] = r
+        loads[r] += w
+    return owner

@@ -1,0 +1,80 @@
+"""`bin/paffy` CLI: dispatcher contract on CPU, byte parity with the oracle on the GPU."""
+import os
+import subprocess
+
+import pytest
+
+import oracle_lib as O
+from conftest import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PAFFY = os.path.join(ROOT, "bin", "paffy")
+S = O.stage
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    import paffy_amd
+
+    paffy_amd.build_library()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+
+
+def run(args, data=b"", env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([PAFFY] + args, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    return p.returncode, p.stdout, p.stderr
+
+
+def test_dispatcher_contract():
+    """paffy_main.c:46-84: no args -> usage rc 0; unknown command -> rc 1; -h -> rc 0; bad flag -> rc 1."""
+    rc, out, err = run([])
+    assert rc == 0 and out == b"" and b"usage: paffy <command>" in err
+    for name in (b"add_mismatches", b"invert", b"shatter", b"tile", b"trim", b"chain", b"view", b"split_file"):
+        assert name in err
+    rc, _, err = run(["frobnicate"])
+    assert rc == 1 and b"frobnicate is not a valid paffy command" in err
+    for cmd in ("shatter", "invert", "trim"):
+        rc, out, err = run([cmd, "-h"])
+        assert rc == 0 and out == b"" and b"--inputFile" in err and b"--logLevel" in err
+        assert run([cmd, "--help"])[0] == 0
+        assert run([cmd, "-Z"])[0] == 1
+    assert b"--trimIdentity" in run(["trim", "-h"])[2] and b"--fixedTrim" in run(["trim", "-h"])[2]
+    assert run(["dedupe"])[0] == 1  # outside the hot path
+
+
+@pytest.mark.gpu
+def test_cli_matches_oracle(human_chimp, tmp_path):
+    cases = [(["shatter"], [S(O.SHATTER)]), (["invert"], [S(O.INVERT)]), (["trim"], [S(O.TRIM_IDENTITY)]),
+             (["trim", "-r", "0.2", "-t", "0.5"], [S(O.TRIM_IDENTITY, 0.2, 0.5)]),
+             (["trim", "--fixedTrim", "--trimFraction", "0.1"], [S(O.TRIM_FIXED, 0.05, 0.1)])]
+    for args, stages in cases:
+        rc, out, err = run(args, human_chimp)
+        assert rc == 0, err
+        assert out == O.run(stages, human_chimp)[0], args
+    # -i / -o files and small chunks (lines straddling chunk boundaries)
+    src, dst = tmp_path / "in.paf", tmp_path / "out.paf"
+    src.write_bytes(human_chimp)
+    rc, out, err = run(["invert", "-i", str(src), "-o", str(dst), "-l", "INFO"], env={"PAFFY_CHUNK_MB": "1"})
+    assert rc == 0 and out == b"" and b"Input file string" in err
+    assert dst.read_bytes() == O.run([S(O.INVERT)], human_chimp)[0]
+
+
+@pytest.mark.gpu
+def test_cli_shell_pipe(human_chimp):
+    """cfg 1 of BASELINE.json and the cfg-3 shape as real shell pipes of three processes."""
+    p = subprocess.run(f"{PAFFY} shatter | {PAFFY} invert", shell=True, input=human_chimp, stdout=subprocess.PIPE)
+    assert p.returncode == 0 and p.stdout == O.run([S(O.SHATTER), S(O.INVERT)], human_chimp)[0]
+    p = subprocess.run(f"{PAFFY} invert | {PAFFY} trim | {PAFFY} shatter", shell=True, input=human_chimp, stdout=subprocess.PIPE)
+    assert p.returncode == 0 and p.stdout == O.run([S(O.INVERT), S(O.TRIM_IDENTITY), S(O.SHATTER)], human_chimp)[0]
+
+
+@pytest.mark.gpu
+def test_cli_error_status():
+    ok = b"q\t100\t0\t5\t+\tt\t100\t0\t5\t5\t5\t60\tcg:Z:5M\n"
+    bad_strand = b"q\t100\t0\t5\t*\tt\t100\t0\t5\t5\t5\t60\tcg:Z:5M\n"
+    rc, out, err = run(["invert"], ok + bad_strand + ok)
+    assert rc == 1 and out == O.run([S(O.INVERT)], ok)[0] and b"unexpected strand character (*)" in err
+    rc, out, err = run(["shatter"], ok + ok.replace(b"5M", b"5=") + ok)
+    assert rc == -6 and out == O.run([S(O.SHATTER)], ok)[0]  # assert -> SIGABRT, as the reference
