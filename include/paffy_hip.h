@@ -120,6 +120,13 @@ int paffy_hip_sync(paffy_hip_ctx *ctx);
 int paffy_hip_run_host(paffy_hip_ctx *ctx, const paffy_stage *stages, int32_t n_stages, const char *h_in, int64_t in_len,
                        char **h_out, int64_t *out_len, paffy_plan_info *info);
 
+/*
+ * Sequences for PAFFY_ADD_MISMATCHES: what the reference loads with fastaReadToFunction into a
+ * name -> sequence hash (impl/paf_add_mismatches.c:89-97). names[i] is the NUL-terminated FASTA
+ * header used as key, seqs[i] / lens[i] the bases (host memory; copied to HBM here).
+ */
+int paffy_hip_set_sequences(paffy_hip_ctx *ctx, int64_t n, const char *const *names, const char *const *seqs, const int64_t *lens);
+
 /* Exit status the reference process ends with for a record error (1, 134 or 139). */
 int paffy_hip_error_exit_status(int32_t code);
 const char *paffy_hip_error_string(int32_t code);

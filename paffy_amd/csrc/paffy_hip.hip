@@ -16,6 +16,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -218,6 +219,43 @@ __global__ __launch_bounds__(PAFFY_NT) void k_header(const uint8_t *in, const ui
 }
 
 /* ------------------------------------------------------------------ */
+/* sequence lookup (add_mismatches)                                     */
+/* ------------------------------------------------------------------ */
+
+/* names sorted bytewise (memcmp, shorter first on a tie): binary search per record name; replaces the
+ * stHash_search by name of impl/paf_add_mismatches.c:116,123 */
+__device__ int32_t find_seq(const uint8_t *in, uint32_t off, uint32_t len, const uint8_t *names, const uint32_t *name_off, int32_t n) {
+    int32_t lo = 0, hi = n - 1;
+    while (lo <= hi) {
+        int32_t mid = (lo + hi) >> 1;
+        const uint8_t *nm = names + name_off[mid];
+        uint32_t nl = name_off[mid + 1] - name_off[mid];
+        uint32_t k = 0, m = len < nl ? len : nl;
+        int cmp = 0;
+        for (; k < m; k++) {
+            int d = (int)in[off + k] - (int)nm[k];
+            if (d) {
+                cmp = d;
+                break;
+            }
+        }
+        if (cmp == 0) cmp = len < nl ? -1 : (len > nl ? 1 : 0);
+        if (cmp == 0) return mid;
+        if (cmp < 0) hi = mid - 1;
+        else lo = mid + 1;
+    }
+    return -1;
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_seq_lookup(const uint8_t *in, const RecMeta *meta, uint32_t n_rec, const uint8_t *names,
+                                                          const uint32_t *name_off, int32_t n_seqs, int32_t *rec_qseq, int32_t *rec_tseq) {
+    uint32_t r = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (r >= n_rec) return;
+    const RecMeta &m = meta[r];
+    rec_qseq[r] = m.err ? -1 : find_seq(in, m.qname_off, m.qname_len, names, name_off, n_seqs);
+    rec_tseq[r] = m.err ? -1 : find_seq(in, m.tname_off, m.tname_len, names, name_off, n_seqs);
+}
+
+/* ------------------------------------------------------------------ */
 /* record sizes -> offsets                                              */
 /* ------------------------------------------------------------------ */
 
@@ -287,7 +325,8 @@ struct ProfEntry {
 struct paffy_hip_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
-    DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, arena, info, synth_sizes, rec_plan, ops_mirror;
+    DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, arena, info, synth_sizes, rec_plan, ops_mirror, seq_blob, seq_table, seq_names, seq_name_off, rec_qseq, rec_tseq;
+    int32_t n_seqs = 0;
     DevInfo *h_info = nullptr; /* pinned */
     /* plan state */
     bool planned = false;
@@ -385,7 +424,8 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     if (!c) return;
     prof_collect(c);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
-                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror};
+                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off,
+                      &c->rec_qseq, &c->rec_tseq};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_info) (void)hipHostFree(c->h_info);
@@ -410,10 +450,13 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
                    paffy_plan_info *info) {
     if (!c || !info || (n_stages > 0 && !stages) || n_stages < 0 || n_stages > PAFFY_MAX_STAGES) return PAFFY_E_ARG;
     if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
+    bool need_seqs = false;
     for (int32_t i = 0; i < n_stages; i++) {
         int k = stages[i].kind;
         bool ok = k == PAFFY_INVERT || k == PAFFY_TRIM_IDENTITY || k == PAFFY_TRIM_FIXED || k == PAFFY_PASS ||
+                  k == PAFFY_REMOVE_MISMATCHES || (k == PAFFY_ADD_MISMATCHES && c->n_seqs > 0) ||
                   (k == PAFFY_SHATTER && i == n_stages - 1);
+        if (k == PAFFY_ADD_MISMATCHES) need_seqs = true;
         if (!ok) {
             c->last_error = "stage list not fusable in this build";
             return PAFFY_E_UNSUPPORTED;
@@ -482,23 +525,43 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     kp.arena_off = static_cast<uint64_t *>(c->arena_off.p);
     kp.rec_plan = c->rec_plan.p;
     kp.ops_mirror = static_cast<uint32_t *>(c->ops_mirror.p);
+    if (need_seqs && n_lines > 0) {
+        if (ensure(c, c->rec_qseq, sizeof(int32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+        if (ensure(c, c->rec_tseq, sizeof(int32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+        LAUNCH(c, "k_seq_lookup", k_seq_lookup, dim3((n_lines + PAFFY_NT - 1) / PAFFY_NT), dim3(PAFFY_NT), 0, in,
+               static_cast<const RecMeta *>(c->meta.p), n_lines, static_cast<const uint8_t *>(c->seq_names.p),
+               static_cast<const uint32_t *>(c->seq_name_off.p), c->n_seqs, static_cast<int32_t *>(c->rec_qseq.p),
+               static_cast<int32_t *>(c->rec_tseq.p));
+        kp.seq_base = static_cast<const uint8_t *>(c->seq_blob.p);
+        kp.seqs = static_cast<const SeqEntry *>(c->seq_table.p);
+        kp.rec_qseq = static_cast<const int32_t *>(c->rec_qseq.p);
+        kp.rec_tseq = static_cast<const int32_t *>(c->rec_tseq.p);
+    }
     kp.out_off = static_cast<const int64_t *>(c->out_off.p);
     kp.w_list = static_cast<uint32_t *>(c->w_list.p);
     kp.info = static_cast<DevInfo *>(c->info.p);
 
     if (n_lines > 0) {
-        LAUNCH(c, "k_size_lds", k_size_lds, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
-        for (int attempt = 0; attempt < 2; attempt++) {
+        for (int attempt = 0; attempt < 3; attempt++) {
             kp.arena = static_cast<uint64_t *>(c->arena.p);
             kp.arena_cap = c->arena.cap / 8;
+            LAUNCH(c, "k_size_lds", k_size_lds, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             LAUNCH(c, "k_record_arena<size>", k_record_arena<false>, dim3(512), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             if (fetch_info(c)) return PAFFY_E_HIP;
             if (c->h_info->arena_used <= kp.arena_cap) break;
-            /* arena too small: grow to the exact demand and redo the arena records */
-            size_t need = (size_t)c->h_info->arena_used * 8;
+            /* arena too small: grow to the demand seen so far and redo the sizing pass */
+            size_t need = (size_t)c->h_info->arena_used * 8 * 2;
             if (ensure(c, c->arena, need)) return PAFFY_E_HIP;
-            unsigned long long z = 0;
-            HIPCHK(c, hipMemcpyAsync(&static_cast<DevInfo *>(c->info.p)->arena_used, &z, sizeof(z), hipMemcpyHostToDevice, c->stream));
+            DevInfo z = *c->h_info;
+            z.arena_used = 0;
+            z.w_count = 0;
+            z.first_err_key = ~0ull;
+            HIPCHK(c, hipMemcpyAsync(c->info.p, &z, sizeof(z), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (attempt == 2) {
+                c->last_error = "arena demand kept growing";
+                return PAFFY_E_HIP;
+            }
         }
         LAUNCH(c, "k_scan_records", k_scan_records, dim3(1), dim3(PAFFY_NT), 0, kp.out_len, kp.out_rows, n_lines,
                static_cast<int64_t *>(c->out_off.p), kp.info);
@@ -575,6 +638,49 @@ int paffy_hip_run_host(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_st
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
     return rc;
+}
+
+int paffy_hip_set_sequences(paffy_hip_ctx *c, int64_t n, const char *const *names, const char *const *seqs, const int64_t *lens) {
+    if (!c || n < 0 || (n > 0 && (!names || !seqs || !lens))) return PAFFY_E_ARG;
+    c->n_seqs = 0;
+    if (n == 0) return 0;
+    std::vector<int64_t> order((size_t)n);
+    for (int64_t i = 0; i < n; i++) order[(size_t)i] = i;
+    std::vector<size_t> nlen((size_t)n);
+    for (int64_t i = 0; i < n; i++) nlen[(size_t)i] = strlen(names[i]);
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        size_t m = nlen[(size_t)a] < nlen[(size_t)b] ? nlen[(size_t)a] : nlen[(size_t)b];
+        int d = memcmp(names[a], names[b], m);
+        if (d) return d < 0;
+        return nlen[(size_t)a] < nlen[(size_t)b];
+    });
+    std::vector<uint32_t> name_off((size_t)n + 1);
+    std::string blob;
+    std::vector<SeqEntry> table((size_t)n);
+    uint64_t total = 0;
+    for (int64_t k = 0; k < n; k++) {
+        int64_t i = order[(size_t)k];
+        name_off[(size_t)k] = (uint32_t)blob.size();
+        blob.append(names[i], nlen[(size_t)i]);
+        table[(size_t)k].off = total;
+        table[(size_t)k].len = lens[i];
+        total += (uint64_t)lens[i];
+    }
+    name_off[(size_t)n] = (uint32_t)blob.size();
+    if (ensure(c, c->seq_blob, total + 64)) return PAFFY_E_HIP;
+    if (ensure(c, c->seq_table, sizeof(SeqEntry) * (size_t)n)) return PAFFY_E_HIP;
+    if (ensure(c, c->seq_names, blob.size() + 16)) return PAFFY_E_HIP;
+    if (ensure(c, c->seq_name_off, sizeof(uint32_t) * ((size_t)n + 1))) return PAFFY_E_HIP;
+    for (int64_t k = 0; k < n; k++) {
+        int64_t i = order[(size_t)k];
+        if (lens[i] > 0)
+            HIPCHK(c, hipMemcpy(static_cast<uint8_t *>(c->seq_blob.p) + table[(size_t)k].off, seqs[i], (size_t)lens[i], hipMemcpyHostToDevice));
+    }
+    HIPCHK(c, hipMemcpy(c->seq_table.p, table.data(), sizeof(SeqEntry) * (size_t)n, hipMemcpyHostToDevice));
+    if (!blob.empty()) HIPCHK(c, hipMemcpy(c->seq_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->seq_name_off.p, name_off.data(), sizeof(uint32_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
+    c->n_seqs = (int32_t)n;
+    return 0;
 }
 
 int paffy_hip_error_exit_status(int32_t code) {

@@ -518,6 +518,192 @@ __device__ int trim_fixed(RecState &s, View<OPS> &v, float pct, BlockComm &bc, S
     return 0;
 }
 
+/* ---------------- stages that rebuild the op array ---------------- */
+
+struct MirrorDst { /* 4-byte ops into the HBM mirror of an LDS-class record */
+    uint32_t *g;
+    uint32_t cap;
+    static constexpr bool kNarrow = true;
+    __device__ __forceinline__ void set(uint32_t i, int64_t len, int op) const {
+        if (i < cap) g[i] = ((uint32_t)len << 3) | (uint32_t)op;
+    }
+};
+
+/*
+ * paf_remove_mismatches, impl/paf.c:786-809: every maximal run of M / = / X ops becomes one M
+ * (lengths summed in the 56-bit field), I and D ops are copied. Workgroup-parallel: an op is
+ * a head unless it and its predecessor are both match-type; heads are numbered by a scan and
+ * each match-type head walks its run. Writes the new array to `dst`; returns its length.
+ * *narrow_ok is cleared when a merged length does not fit a 4-byte op.
+ */
+template <class OPS, class DST>
+__device__ uint32_t merge_match_runs(const View<OPS> &v, const DST &dst, BlockComm &bc, Shared *sh, bool *narrow_ok) {
+    if (threadIdx.x == 0) sh->flags = 0;
+    uint32_t b, e;
+    sweep_bounds(v.n, b, e);
+    bool prev_mt = false;
+    if (b > 0 && b < v.n) {
+        int64_t len;
+        int op;
+        v.get(b - 1, len, op);
+        prev_mt = is_aligned_op(op);
+    }
+    int64_t cnt[1] = {0}, tot[1];
+    {
+        bool pm = prev_mt;
+        for (uint32_t i = b; i < e; i++) {
+            int64_t len;
+            int op;
+            v.get(i, len, op);
+            bool mt = is_aligned_op(op);
+            if (!(mt && pm)) cnt[0]++;
+            pm = mt;
+        }
+    }
+    block_excl_scan<1>(cnt, tot, bc);
+    uint32_t o = (uint32_t)cnt[0];
+    bool pm = prev_mt, wide = false;
+    for (uint32_t i = b; i < e; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        bool mt = is_aligned_op(op);
+        if (!(mt && pm)) {
+            if (mt) {
+                int64_t sum = len;
+                for (uint32_t j = i + 1; j < v.n; j++) {
+                    int64_t l2;
+                    int o2;
+                    v.get(j, l2, o2);
+                    if (!is_aligned_op(o2)) break;
+                    sum += l2;
+                }
+                sum = (int64_t)((uint64_t)sum << 8) >> 8;
+                if (DST::kNarrow && (sum < 0 || sum >= (1ll << 29))) wide = true;
+                dst.set(o, sum, OP_M);
+            } else {
+                dst.set(o, len, op);
+            }
+            o++;
+        }
+        pm = mt;
+    }
+    if (wide) atomicOr(&sh->flags, 0x100u);
+    __syncthreads();
+    *narrow_ok = !(sh->flags & 0x100u);
+    __syncthreads();
+    return (uint32_t)tot[0];
+}
+
+/* stString_reverseComplementChar [sonLib, absent]: A<->T, C<->G in both cases, identity otherwise
+ * (parity unpinned for other letters). */
+__device__ __forceinline__ uint32_t rc_base(uint32_t c) {
+    switch (c) {
+        case 'A': return 'T'; case 'T': return 'A'; case 'C': return 'G'; case 'G': return 'C';
+        case 'a': return 't'; case 't': return 'a'; case 'c': return 'g'; case 'g': return 'c';
+        default: return c;
+    }
+}
+__device__ __forceinline__ uint32_t up_base(uint32_t c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; } /* toupper, C locale */
+
+/*
+ * paf_encode_mismatches, impl/paf.c:739-784: each M op becomes its maximal runs of matching (=)
+ * and mismatching (X) columns against the two sequences; other ops are copied. Two walks over the
+ * bases (count, then fill) with one lane per op chunk. The new array goes to a fresh arena block.
+ * Returns 0 or PAFFY_ERR_SEQ_RANGE; *n_out = new op count; *blk = arena offset (UINT64_MAX: no room).
+ */
+template <class OPS>
+__device__ int encode_mismatch_runs(const KParams &P, const RecState &s, const View<OPS> &v, const uint8_t *Q, int64_t qseq_len,
+                                    const uint8_t *T, int64_t tseq_len, BlockComm &bc, Shared *sh, uint32_t *n_out, uint64_t *blk) {
+    uint32_t b, e;
+    sweep_bounds(v.n, b, e);
+    int64_t c[2] = {0, 0}, tot[2];
+    for (uint32_t i = b; i < e; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        if (op != OP_D) c[0] += len;
+        if (op != OP_I) c[1] += len;
+    }
+    block_excl_scan<2>(c, tot, bc);
+    /* walk 1: count */
+    int64_t cnt[1] = {0}, ctot[1], bad = INT64_MAX;
+    {
+        int64_t qi = c[0], tj = s.ts + c[1];
+        for (uint32_t i = b; i < e; i++) {
+            int64_t len;
+            int op;
+            v.get(i, len, op);
+            if (op == OP_M) {
+                const int64_t qoff = s.same ? s.qs + qi : s.qe - (qi + 1);
+                const bool in_range = len <= 0 || (tj >= 0 && tj + len <= tseq_len &&
+                                                   (s.same ? (qoff >= 0 && qoff + len <= qseq_len) : (qoff < qseq_len && qoff - (len - 1) >= 0)));
+                if (!in_range) {
+                    if (bad == INT64_MAX) bad = i;
+                } else {
+                    bool prev = false;
+                    for (int64_t k = 0; k < len; k++) {
+                        uint32_t qc = s.same ? Q[qoff + k] : rc_base(Q[qoff - k]);
+                        bool m = up_base(T[tj + k]) == up_base(qc);
+                        if (k == 0 || m != prev) cnt[0]++;
+                        prev = m;
+                    }
+                }
+            } else {
+                cnt[0]++;
+            }
+            if (op != OP_D) qi += len;
+            if (op != OP_I) tj += len;
+        }
+    }
+    bad = block_min_i64(bad, bc);
+    block_excl_scan<1>(cnt, ctot, bc);
+    *n_out = (uint32_t)ctot[0];
+    if (bad != INT64_MAX) return PAFFY_ERR_SEQ_RANGE;
+    if (threadIdx.x == 0) sh->bcast[3] = (int64_t)atomicAdd(&P.info->arena_used, (unsigned long long)ctot[0]);
+    __syncthreads();
+    const uint64_t off = (uint64_t)sh->bcast[3];
+    __syncthreads();
+    if (off + (uint64_t)ctot[0] > P.arena_cap) { /* no room: the host grows the arena and repeats the pass */
+        *blk = ~0ull;
+        return 0;
+    }
+    *blk = off;
+    OpsArena dst{P.arena + off};
+    /* walk 2: fill */
+    {
+        uint32_t o = (uint32_t)cnt[0];
+        int64_t qi = c[0], tj = s.ts + c[1];
+        for (uint32_t i = b; i < e; i++) {
+            int64_t len;
+            int op;
+            v.get(i, len, op);
+            if (op == OP_M) {
+                const int64_t qoff = s.same ? s.qs + qi : s.qe - (qi + 1);
+                bool prev = false;
+                int64_t run = 0;
+                for (int64_t k = 0; k < len; k++) {
+                    uint32_t qc = s.same ? Q[qoff + k] : rc_base(Q[qoff - k]);
+                    bool m = up_base(T[tj + k]) == up_base(qc);
+                    if (k > 0 && m != prev) {
+                        dst.set(o++, run, prev ? OP_EQ : OP_X);
+                        run = 0;
+                    }
+                    run++;
+                    prev = m;
+                }
+                if (len > 0) dst.set(o++, run, prev ? OP_EQ : OP_X);
+            } else {
+                dst.set(o++, len, op);
+            }
+            if (op != OP_D) qi += len;
+            if (op != OP_I) tj += len;
+        }
+    }
+    __syncthreads();
+    return 0;
+}
+
 /* ---------------- line pieces ---------------- */
 
 /* Serial LDS byte builder used by one lane per piece. */
@@ -1072,7 +1258,7 @@ __device__ __forceinline__ void load_state(const RecMeta &m, RecState &s) {
  * from. Returns false when the record does not fit this op store (LDS class only).
  */
 template <class OPS>
-__device__ bool size_record(const KParams &P, uint32_t rec, const OPS &ops, uint32_t cap, const RecLds &L, uint32_t klass,
+__device__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t cap, const RecLds &L, uint32_t klass,
                             uint32_t *n_ops_out) {
     const RecMeta m = P.meta[rec];
     if (m.err) {
@@ -1117,6 +1303,49 @@ __device__ bool size_record(const KParams &P, uint32_t rec, const OPS &ops, uint
         } else if (st.kind == PAFFY_TRIM_FIXED) {
             rc = trim_fixed(s, v, st.p1, L.bc, L.sh);
             if (!rc) rc = check_record(s, v, L.bc);
+        } else if (st.kind == PAFFY_REMOVE_MISMATCHES) {
+            if (s.has_cigar) {
+                bool narrow_ok = true;
+                uint32_t n2;
+                if constexpr (OPS::kNarrow) { /* LDS class: new array via the HBM mirror, then back into LDS */
+                    MirrorDst dst{ops.g, ops.g_cap};
+                    n2 = merge_match_runs(v, dst, L.bc, L.sh, &narrow_ok);
+                    if (!narrow_ok || v.n > ops.g_cap) return false; /* needs 8-byte ops: arena class */
+                    for (uint32_t i = threadIdx.x; i < n2; i += PAFFY_NT) ops.p[i] = ops.g[i];
+                    __syncthreads();
+                } else { /* arena class: new array in a fresh arena block */
+                    if (threadIdx.x == 0) L.sh->bcast[3] = (int64_t)atomicAdd(&P.info->arena_used, (unsigned long long)v.n);
+                    __syncthreads();
+                    const uint64_t off = (uint64_t)L.sh->bcast[3];
+                    __syncthreads();
+                    if (off + v.n > P.arena_cap) return true; /* no room: the host grows the arena and repeats the pass */
+                    OpsArena dst{P.arena + off};
+                    n2 = merge_match_runs(v, dst, L.bc, L.sh, &narrow_ok);
+                    ops.p = dst.p;
+                }
+                v.ops = ops; v.lo = 0; v.n = n2; v.rev = false; v.swp = false; v.sub_lo = v.sub_hi = 0;
+            }
+            rc = check_record(s, v, L.bc);
+        } else if (st.kind == PAFFY_ADD_MISMATCHES) {
+            if constexpr (OPS::kNarrow) {
+                return false; /* the new op array lives in the arena: arena class */
+            } else {
+                const int32_t qi = swapped ? P.rec_tseq[rec] : P.rec_qseq[rec], ti = swapped ? P.rec_qseq[rec] : P.rec_tseq[rec];
+                if (qi < 0) rc = PAFFY_ERR_MISSING_QUERY_SEQ;   /* impl/paf_add_mismatches.c:117-120 */
+                else if (ti < 0) rc = PAFFY_ERR_MISSING_TARGET_SEQ; /* :123-127 */
+                else if (s.has_cigar) {
+                    uint32_t n2 = 0;
+                    uint64_t blk = 0;
+                    rc = encode_mismatch_runs(P, s, v, P.seq_base + P.seqs[qi].off, P.seqs[qi].len, P.seq_base + P.seqs[ti].off,
+                                              P.seqs[ti].len, L.bc, L.sh, &n2, &blk);
+                    if (!rc) {
+                        if (blk == ~0ull) return true; /* arena full: repeated by the host */
+                        ops.p = P.arena + blk;
+                        v.ops = ops; v.lo = 0; v.n = n2; v.rev = false; v.swp = false; v.sub_lo = v.sub_hi = 0;
+                    }
+                }
+                if (!rc) rc = check_record(s, v, L.bc);
+            }
         } else if (st.kind == PAFFY_SHATTER) {
             shatter = true;
             break;
@@ -1311,7 +1540,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_record_arena(KParams P) {
                 size_record<OpsArena>(P, rec, ops, cg_len, L, KLASS_ARENA, &n_ops);
                 if (threadIdx.x == 0) {
                     P.n_ops[rec] = n_ops;
-                    P.arena_off[rec] = off;
+                    P.arena_off[rec] = (uint64_t)(ops.p - P.arena); /* a stage may have moved the ops to a new block */
                 }
             }
         }

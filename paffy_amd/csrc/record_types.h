@@ -35,6 +35,12 @@ struct RecMeta {
 /* Record classes decided by the sizing pass. */
 enum { KLASS_LDS = 0, KLASS_ARENA = 1 };
 
+/* One FASTA sequence resident in HBM (add_mismatches). */
+struct SeqEntry {
+    uint64_t off; /* into seq_base */
+    int64_t len;
+};
+
 struct DevInfo {
     unsigned long long first_err_key; /* min over failing records of rec<<16 | (stage+1)<<8 | code */
     unsigned long long arena_used;    /* bump pointer (in ops) */
@@ -60,6 +66,11 @@ struct KParams {
     uint64_t *arena_off;
     void *rec_plan; /* RecPlan[n_rec] */
     uint32_t *ops_mirror; /* 4-byte ops of LDS-class records, indexed from cg_off / 2 */
+    /* add_mismatches: sequences in HBM and, per record, the index of its query / target sequence (-1: absent) */
+    const uint8_t *seq_base;
+    const SeqEntry *seqs;
+    const int32_t *rec_qseq;
+    const int32_t *rec_tseq;
     /* emit pass */
     const int64_t *out_off;
     uint8_t *out;

@@ -72,6 +72,7 @@ def lib():
         L.paffy_hip_plan.argtypes = [vp, C.POINTER(Stage), i32, vp, i64, C.POINTER(PlanInfo)]
         L.paffy_hip_emit.argtypes = [vp, vp, i64]
         L.paffy_hip_sync.argtypes = [vp]
+        L.paffy_hip_set_sequences.argtypes = [vp, i64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(i64)]
         L.paffy_hip_error_exit_status.argtypes = [i32]
         L.paffy_hip_error_string.restype = C.c_char_p
         L.paffy_hip_error_string.argtypes = [i32]
@@ -144,6 +145,16 @@ class Engine:
     def emit(self, d_out):
         rc = lib().paffy_hip_emit(self._ctx, C.c_void_p(d_out.data_ptr()), d_out.numel())
         self._check(rc, "paffy_hip_emit")
+
+    def set_sequences(self, seqs):
+        """FASTA sequences for add_mismatches: {header: bases}, as `paffy add_mismatches a.fa b.fa` would load them."""
+        names = [k if isinstance(k, bytes) else k.encode() for k in seqs]
+        vals = [v if isinstance(v, bytes) else v.encode() for v in seqs.values()]
+        n = len(names)
+        a = (C.c_char_p * max(1, n))(*names)
+        b = (C.c_char_p * max(1, n))(*vals)
+        ln = (C.c_int64 * max(1, n))(*[len(v) for v in vals])
+        self._check(lib().paffy_hip_set_sequences(self._ctx, n, a, b, ln), "paffy_hip_set_sequences")
 
     def sync(self):
         self._check(lib().paffy_hip_sync(self._ctx), "paffy_hip_sync")
@@ -218,6 +229,15 @@ def invert(data):
 def shatter(data):
     """paffy shatter (impl/paf_shatter.c)."""
     return pipe([stage(SHATTER)], data)
+
+
+def add_mismatches(data, seqs=None, remove=False):
+    """paffy add_mismatches [fasta...] / paffy add_mismatches -a (impl/paf_add_mismatches.c)."""
+    if remove:
+        return pipe([stage(REMOVE_MISMATCHES)], data)
+    e = _engine()
+    e.set_sequences(seqs)
+    return e.run([stage(ADD_MISMATCHES)], data)[0]
 
 
 def trim(data, trim_identity=0.05, trim_fraction=1.0, fixed_trim=False):

@@ -1,0 +1,116 @@
+"""add_mismatches (M -> =/X against FASTA) and add_mismatches -a (=/X -> M) on the GPU vs the oracle."""
+import random
+
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+S = O.stage
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import paffy_amd
+
+    e = paffy_amd.Engine()
+    yield e
+    e.close()
+
+
+def gs(stages):
+    import paffy_amd
+
+    return [paffy_amd.Stage(s.kind, s.p0, s.p1) for s in stages]
+
+
+def make_genomes(rng, n_contigs=3, length=6000):
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    seqs = {}
+    for c in range(n_contigs):
+        t = [rng.choice("ACGT") for _ in range(length)]
+        for _ in range(length // 200):
+            t[rng.randrange(length)] = "N"
+        q = list(t)
+        for i in range(length):
+            r = rng.random()
+            if r < 0.03:
+                q[i] = rng.choice("ACGT")
+            elif r < 0.06:
+                q[i] = q[i].lower()
+        seqs[f"pt.chr{c + 1}"] = "".join(x.lower() if rng.random() < 0.02 else x for x in t)
+        seqs[f"hs.chr{c + 1}"] = "".join(q)
+        # a reverse-complement relative of the target, for '-' records on the diagonal
+        seqs[f"rc.chr{c + 1}"] = "".join(comp.get(x.upper(), x) for x in reversed(q))
+    return seqs
+
+
+def make_records(rng, seqs, n, length=6000):
+    out = []
+    for r in range(n):
+        c = rng.randrange(1, 4)
+        ops, qspan, tspan = [], 0, 0
+        for k in range(rng.choice([1, 2, 5, 20, 60])):
+            L = rng.choice([1, 2, 7, 40, 150])
+            ops.append(f"{L}M"); qspan += L; tspan += L
+            if rng.random() < 0.7:
+                g = rng.choice([1, 2, 5])
+                if rng.random() < 0.5:
+                    ops.append(f"{g}I"); qspan += g
+                else:
+                    ops.append(f"{g}D"); tspan += g
+        ops.append("3M"); qspan += 3; tspan += 3
+        mode = rng.randrange(3)
+        ts = rng.randrange(0, length - tspan)
+        if mode == 0:      # '+' on the diagonal: long '=' runs
+            q, strand, qs = f"hs.chr{c}", "+", min(ts, length - qspan)
+        elif mode == 1:    # '-' against the reverse-complement relative
+            q, strand = f"rc.chr{c}", "-"
+            qs = max(0, min(length - qspan, length - ts - qspan))
+        else:              # anywhere: short runs
+            q, strand, qs = f"hs.chr{rng.randrange(1, 4)}", rng.choice("+-"), rng.randrange(0, length - qspan)
+        out.append(f"{q}\t{length}\t{qs}\t{qs + qspan}\t{strand}\tpt.chr{c}\t{length}\t{ts}\t{ts + tspan}\t{tspan}\t{tspan}\t60\ttp:A:P\tcg:Z:{''.join(ops)}\n")
+    return "".join(out).encode()
+
+
+def test_add_and_remove_mismatches(eng):
+    rng = random.Random(7)
+    seqs = make_genomes(rng)
+    data = make_records(rng, seqs, 400)
+    want, werr = O.run([S(O.ADD_MISMATCHES)], data, seqs)
+    assert werr.code == 0 and b"=" in want and b"X" in want
+    eng.set_sequences(seqs)
+    got, info = eng.run(gs([S(O.ADD_MISMATCHES)]), data)
+    assert got == want
+    # =/X -> M again: both the LDS class and the original text
+    back, _ = eng.run(gs([S(O.REMOVE_MISMATCHES)]), got)
+    assert back == O.run([S(O.REMOVE_MISMATCHES)], want)[0]
+    assert back == O.run([S(O.REMOVE_MISMATCHES)], data)[0]  # adjacent M ops of the input merge too
+    # fused with other stages
+    for stages in ([S(O.ADD_MISMATCHES), S(O.TRIM_IDENTITY)], [S(O.INVERT), S(O.ADD_MISMATCHES)],
+                   [S(O.ADD_MISMATCHES), S(O.REMOVE_MISMATCHES), S(O.SHATTER)], [S(O.REMOVE_MISMATCHES), S(O.INVERT)]):
+        src = got if stages[0].kind == O.REMOVE_MISMATCHES else data
+        w, e = O.run(stages, src, seqs)
+        g, i = eng.run(gs(stages), src, raise_on_error=False)
+        assert i.error.code == e.code and g == w, [s.kind for s in stages]
+
+
+def test_remove_mismatches_fixture(eng, human_chimp):
+    assert eng.run(gs([S(O.REMOVE_MISMATCHES)]), human_chimp)[0] == O.run([S(O.REMOVE_MISMATCHES)], human_chimp)[0]
+    kat = b"q\t100\t0\t6\t+\tt\t100\t0\t5\t5\t6\t60\tcg:Z:3=2X1I\n"
+    assert eng.run(gs([S(O.REMOVE_MISMATCHES)]), kat)[0] == b"q\t100\t0\t6\t+\tt\t100\t0\t5\t5\t6\t60\tAS:i:0\tcg:Z:5M1I\n"
+
+
+def test_known_answers_and_errors(eng):
+    """paf_unit_test.c:525-559 and the missing-sequence exits of impl/paf_add_mismatches.c:117-127."""
+    def enc(q, t, L):
+        eng.set_sequences({"q": q, "t": t})
+        rec = f"q\t{L}\t0\t{L}\t+\tt\t{L}\t0\t{L}\t{L}\t{L}\t60\tcg:Z:{L}M\n".encode()
+        return eng.run(gs([S(O.ADD_MISMATCHES)]), rec)[0].split(b"cg:Z:")[1].strip()
+    assert enc("AAAAA", "AAAAA", 5) == b"5=" and enc("AAAAA", "CCCCC", 5) == b"5X" and enc("AATT", "AACC", 4) == b"2=2X"
+    ok = b"q\t5\t0\t5\t+\tt\t5\t0\t5\t5\t5\t60\tcg:Z:5M\n"
+    eng.set_sequences({"q": "AAAAA", "t": "AAAAA"})
+    for bad, code in ((ok.replace(b"q\t5", b"zz\t5"), 17), (ok.replace(b"\tt\t", b"\tzz\t"), 18)):
+        got, info = eng.run(gs([S(O.ADD_MISMATCHES)]), ok + bad + ok, raise_on_error=False)
+        w, e = O.run([S(O.ADD_MISMATCHES)], ok + bad + ok, {"q": "AAAAA", "t": "AAAAA"})
+        assert (info.error.code, info.error.record) == (code, 1) == (e.code, e.record) and got == w
