@@ -4,6 +4,7 @@
  * -h/--help; trim adds -t/--trimFraction -r/--trimIdentity -f/--fixedTrim
  * (impl/paf_trim.c:53-63); -h prints usage and returns 0, an unknown option returns 1.
  */
+#define _GNU_SOURCE
 #include <getopt.h>
 #include <stdlib.h>
 #include <string.h>
@@ -117,16 +118,117 @@ int paffy_trim_main(int argc, char *argv[]) {
     return run_stream_cmd(&o, &st, 1, "trim");
 }
 
-int paffy_add_mismatches_main(int argc, char *argv[]) {
-    (void)argc;
-    (void)argv;
-    fprintf(stderr, "paffy add_mismatches: not available in this build yet\n");
-    return 1;
+/* FASTA -> (header, sequence) pairs. Key = the whole header line after '>', sequence = all
+ * non-whitespace characters up to the next header (the fastaReadToFunction /
+ * fastaRead_readToMapFunction behaviour assumed in SURVEY Appendix C; parity unpinned). */
+typedef struct {
+    char **names, **seqs;
+    int64_t *lens;
+    int64_t n, cap;
+} fasta_set;
+
+static void fasta_push(fasta_set *f, char *name, char *seq, int64_t len) {
+    if (f->n == f->cap) {
+        f->cap = f->cap ? f->cap * 2 : 64;
+        f->names = (char **)realloc(f->names, sizeof(char *) * (size_t)f->cap);
+        f->seqs = (char **)realloc(f->seqs, sizeof(char *) * (size_t)f->cap);
+        f->lens = (int64_t *)realloc(f->lens, sizeof(int64_t) * (size_t)f->cap);
+    }
+    f->names[f->n] = name;
+    f->seqs[f->n] = seq;
+    f->lens[f->n] = len;
+    f->n++;
 }
 
+static int fasta_read(const char *path, fasta_set *f) {
+    FILE *fh = fopen(path, "r");
+    if (!fh) return -1;
+    char *line = NULL, *name = NULL, *seq = NULL;
+    size_t lcap = 0;
+    int64_t slen = 0, scap = 0;
+    ssize_t got;
+    while ((got = getline(&line, &lcap, fh)) >= 0) {
+        while (got > 0 && (line[got - 1] == '\n' || line[got - 1] == '\r')) line[--got] = '\0';
+        if (line[0] == '>') {
+            if (name) fasta_push(f, name, seq, slen);
+            name = strdup(line + 1);
+            seq = NULL;
+            slen = scap = 0;
+        } else if (name) {
+            if (slen + got + 1 > scap) {
+                scap = (slen + got + 1) * 2;
+                seq = (char *)realloc(seq, (size_t)scap);
+            }
+            for (ssize_t i = 0; i < got; i++)
+                if (line[i] != ' ' && line[i] != '\t') seq[slen++] = line[i];
+        }
+    }
+    if (name) fasta_push(f, name, seq ? seq : strdup(""), slen);
+    free(line);
+    fclose(fh);
+    return 0;
+}
+
+/* impl/paf_add_mismatches.c: options l:i:o:h plus -a / --removeMismatches; FASTA files are positional */
+int paffy_add_mismatches_main(int argc, char *argv[]) {
+    static struct option opts[] = {{"logLevel", required_argument, 0, 'l'}, {"inputFile", required_argument, 0, 'i'},
+                                   {"outputFile", required_argument, 0, 'o'}, {"removeMismatches", no_argument, 0, 'a'},
+                                   {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+    cmd_opts o;
+    memset(&o, 0, sizeof(o));
+    int remove = 0;
+    optind = 1;
+    for (;;) {
+        int idx = 0;
+        int key = getopt_long(argc, argv, "l:i:o:ha", opts, &idx);
+        if (key == -1) break;
+        switch (key) {
+            case 'l': o.log_level = optarg; break;
+            case 'i': o.in_path = optarg; break;
+            case 'o': o.out_path = optarg; break;
+            case 'a': remove = 1; break;
+            case 'h':
+            default:
+                fprintf(stderr, "paffy add_mismatches [fasta_files]xN [options], MI355X build\n"
+                                "Replace each M op by runs of = (match) and X (mismatch) against the sequences\n");
+                fprintf(stderr, "-i --inputFile : PAF file to read (default: stdin)\n-o --outputFile : PAF file to write (default: stdout)\n");
+                fprintf(stderr, "-a --removeMismatches : the reverse: merge = and X (and M) runs into M\n");
+                usage_tail();
+                return key == 'h' ? 0 : 1;
+        }
+    }
+    host_set_log_level(o.log_level);
+    paffy_stage st = {remove ? PAFFY_REMOVE_MISMATCHES : PAFFY_ADD_MISMATCHES, 0.05f, 1.0f};
+    if (!remove) {
+        fasta_set f;
+        memset(&f, 0, sizeof(f));
+        for (int i = optind; i < argc; i++) {
+            host_log_info("Parsing sequence file : %s\n", argv[i]);
+            if (fasta_read(argv[i], &f) != 0) {
+                fprintf(stderr, "paffy add_mismatches: cannot open %s\n", argv[i]);
+                return 1;
+            }
+        }
+        host_log_info("Read %i sequences from sequence files\n", (int)f.n);
+        host_set_sequences((const char *const *)f.names, (const char *const *)f.seqs, f.lens, f.n);
+    }
+    return run_stream_cmd(&o, &st, 1, "add_mismatches");
+}
+
+/* impl/paf_tile.c: whole-file command; the batch is the file */
 int paffy_tile_main(int argc, char *argv[]) {
-    (void)argc;
-    (void)argv;
-    fprintf(stderr, "paffy tile: not available in this build yet\n");
-    return 1;
+    cmd_opts o;
+    int rc = parse_opts(argc, argv, "tile", "Give every alignment a tile level along its query sequence", 0, &o);
+    if (rc >= 0) return rc;
+    host_set_log_level(o.log_level);
+    FILE *in = o.in_path ? fopen(o.in_path, "r") : stdin;
+    FILE *out = o.out_path ? fopen(o.out_path, "w") : stdout;
+    if (!in || !out) {
+        fprintf(stderr, "paffy tile: cannot open %s\n", !in ? o.in_path : o.out_path);
+        return 1;
+    }
+    rc = host_tile(in, out);
+    if (o.in_path) fclose(in);
+    if (o.out_path) fclose(out);
+    return rc;
 }

@@ -31,4 +31,10 @@ void host_log_info(const char *fmt, ...);
  */
 int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out);
 
+/* `paffy tile`: reads all of `in`, one tile_plan + emit, writes `out`. */
+int host_tile(FILE *in, FILE *out);
+
+/* Sequences handed to the context that host_stream creates (add_mismatches); pointers must stay valid. */
+void host_set_sequences(const char *const *names, const char *const *seqs, const int64_t *lens, int64_t n);
+
 #endif

@@ -3,6 +3,7 @@
  * shatter / invert / trim drivers; replaces the read-transform-write loop of
  * impl/paf_invert.c:84-89 and friends).
  */
+#define _GNU_SOURCE
 #include <signal.h>
 #include <stdarg.h>
 #include <stdlib.h>
@@ -11,6 +12,16 @@
 #include "paffy_host.h"
 
 static int g_log_level = 0;
+static const char *const *g_seq_names, *const *g_seq_data;
+static const int64_t *g_seq_lens;
+static int64_t g_seq_n = 0;
+
+void host_set_sequences(const char *const *names, const char *const *seqs, const int64_t *lens, int64_t n) {
+    g_seq_names = names;
+    g_seq_data = seqs;
+    g_seq_lens = lens;
+    g_seq_n = n;
+}
 
 void host_set_log_level(const char *s) {
     g_log_level = 0;
@@ -43,6 +54,10 @@ static void die_like_reference(const paffy_error *e, int64_t record_base) {
         fprintf(stderr, "Got an unexpected strand character (%c) in a paf string\n", (int)e->aux);
     else if (e->code == PAFFY_ERR_CIGAR_CHAR)
         fprintf(stderr, "Got an unexpected character paf cigar string: %c\n", (int)e->aux);
+    else if (e->code == PAFFY_ERR_MISSING_QUERY_SEQ)
+        fprintf(stderr, "No query sequence found for record %lld\n", (long long)(record_base + e->record));
+    else if (e->code == PAFFY_ERR_MISSING_TARGET_SEQ)
+        fprintf(stderr, "No target sequence found for record %lld\n", (long long)(record_base + e->record));
     else
         fprintf(stderr, "%s (record %lld)\n", paffy_hip_error_string(e->code), (long long)(record_base + e->record));
     if (status == 134) raise(SIGABRT);
@@ -54,6 +69,10 @@ int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out) {
     paffy_hip_ctx *ctx = NULL;
     if (paffy_hip_create(&ctx, -1) != 0) {
         fprintf(stderr, "paffy: no usable GPU (this build has no CPU path)\n");
+        return 1;
+    }
+    if (g_seq_n > 0 && paffy_hip_set_sequences(ctx, g_seq_n, g_seq_names, g_seq_data, g_seq_lens) != 0) {
+        fprintf(stderr, "paffy: could not load the sequences onto the GPU: %s\n", paffy_hip_last_error(ctx));
         return 1;
     }
     const size_t cap = chunk_bytes();
@@ -97,6 +116,50 @@ int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out) {
     }
     free(buf);
     paffy_hip_destroy(ctx);
+    fflush(out);
+    return rc;
+}
+
+int host_tile(FILE *in, FILE *out) {
+    size_t cap = 1 << 20, have = 0;
+    char *buf = (char *)malloc(cap);
+    for (;;) {
+        if (have == cap) {
+            cap *= 2;
+            buf = (char *)realloc(buf, cap);
+        }
+        size_t got = fread(buf + have, 1, cap - have, in);
+        if (got == 0) break;
+        have += got;
+    }
+    paffy_hip_ctx *ctx = NULL;
+    if (paffy_hip_create(&ctx, -1) != 0) {
+        fprintf(stderr, "paffy: no usable GPU (this build has no CPU path)\n");
+        return 1;
+    }
+    void *d_in = NULL, *d_out = NULL;
+    paffy_plan_info info;
+    int rc = 1;
+    if (paffy_hip_malloc(&d_in, (int64_t)have + 64) == 0 && paffy_hip_memcpy_h2d(d_in, buf, (int64_t)have) == 0 &&
+        paffy_hip_tile_plan(ctx, d_in, (int64_t)have, &info) == 0) {
+        if (info.error.code) die_like_reference(&info.error, 0);
+        rc = 0;
+        if (info.out_bytes > 0) {
+            char *h = (char *)malloc((size_t)info.out_bytes);
+            if (paffy_hip_malloc(&d_out, info.out_bytes + 64) == 0 && paffy_hip_emit(ctx, d_out, info.out_bytes + 64) == 0 &&
+                paffy_hip_sync(ctx) == 0 && paffy_hip_memcpy_d2h(h, d_out, info.out_bytes) == 0)
+                fwrite(h, 1, (size_t)info.out_bytes, out);
+            else
+                rc = 1;
+            free(h);
+        }
+    } else {
+        fprintf(stderr, "paffy tile: GPU call failed: %s\n", paffy_hip_last_error(ctx));
+    }
+    if (d_in) paffy_hip_free(d_in);
+    if (d_out) paffy_hip_free(d_out);
+    paffy_hip_destroy(ctx);
+    free(buf);
     fflush(out);
     return rc;
 }

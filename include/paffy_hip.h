@@ -110,6 +110,14 @@ int paffy_hip_plan(paffy_hip_ctx *ctx, const paffy_stage *stages, int32_t n_stag
                    paffy_plan_info *info);
 
 /*
+ * tile_plan: `paffy tile` (impl/paf_tile.c:156-178) over the whole batch: every record gets its
+ * tile level (tl) from per-base coverage counters of its QUERY sequence, visiting records by
+ * (s1 desc, AS desc, input order); the output lists all records in that order with the cigar text
+ * unchanged. A failing record means no output at all. Followed by paffy_hip_emit().
+ */
+int paffy_hip_tile_plan(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len, paffy_plan_info *info);
+
+/*
  * emit: write the planned output to d_out (16-byte aligned, out_cap >= info.out_bytes). Returns
  * after enqueueing; paffy_hip_sync() or any synchronisation of the stream completes it.
  */

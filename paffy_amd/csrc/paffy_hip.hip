@@ -24,6 +24,7 @@
 #include "../../include/paffy_hip.h"
 #include "paf_synth_core.h"
 #include "record_kernel.h"
+#include "tile_kernel.h"
 
 #define SEP_TILE 65536u /* bytes per workgroup in the separator passes */
 
@@ -282,6 +283,72 @@ __global__ __launch_bounds__(PAFFY_NT) void k_scan_records(const int64_t *out_le
 }
 
 /* ------------------------------------------------------------------ */
+/* tile: keys for the host ordering, sizes and the verbatim writer       */
+/* ------------------------------------------------------------------ */
+
+struct TileKey {
+    int64_t chain_score, score, qlen;
+    uint64_t name_hash;
+    uint32_t name_len;
+    int32_t err;
+};
+
+__global__ __launch_bounds__(PAFFY_NT) void k_tile_keys(const uint8_t *in, const RecMeta *meta, uint32_t n, TileKey *keys) {
+    uint32_t r = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (r >= n) return;
+    const RecMeta &m = meta[r];
+    TileKey k;
+    k.chain_score = m.chain_score;
+    k.score = m.score;
+    k.qlen = m.qlen;
+    k.name_len = m.qname_len;
+    k.err = m.err;
+    uint64_t h = 0xcbf29ce484222325ull; /* FNV-1a over the query name */
+    for (uint32_t i = 0; i < m.qname_len; i++) h = (h ^ in[m.qname_off + i]) * 0x100000001b3ull;
+    k.name_hash = h;
+    keys[r] = k;
+}
+
+__device__ __forceinline__ void tile_state(const RecMeta &m, int64_t level, RecState &s) {
+    load_state(m, s);
+    s.has_cigar = false; /* the cigar is written verbatim from the text, impl/paf.c:381-385 */
+    s.tile_level = level;
+}
+
+/* out_len[k] for the record at visiting position k */
+__global__ __launch_bounds__(PAFFY_NT) void k_tile_size(const RecMeta *meta, const uint32_t *order, const int64_t *level, uint32_t n,
+                                                         int64_t *out_len) {
+    uint32_t k = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (k >= n) return;
+    const RecMeta &m = meta[order[k]];
+    RecState s;
+    tile_state(m, level[order[k]], s);
+    out_len[k] = header_len(s, false) + (m.has_cg ? 6 + (int64_t)m.cg_len : 0) + 1;
+}
+
+/* one workgroup per output line: header from LDS, then "\tcg:Z:" + the cigar text as it was read */
+__global__ __launch_bounds__(PAFFY_NT) void k_tile_emit(const uint8_t *in, const RecMeta *meta, const uint32_t *order, const int64_t *level,
+                                                         const int64_t *out_off, uint8_t *out) {
+    __shared__ uint8_t hdr[3 * PAFFY_TMPL_MAX + 8];
+    __shared__ uint32_t hlen;
+    const RecMeta m = meta[order[blockIdx.x]];
+    if (threadIdx.x == 0) {
+        RecState s;
+        tile_state(m, level[order[blockIdx.x]], s);
+        Piece w{hdr, 0, 3 * PAFFY_TMPL_MAX, false};
+        build_header(w, s, in, false);
+        if (m.has_cg) w.str("\tcg:Z:");
+        hlen = w.n;
+    }
+    __syncthreads();
+    uint8_t *o = out + out_off[blockIdx.x];
+    const uint32_t hl = hlen, cl = m.has_cg ? m.cg_len : 0;
+    for (uint32_t i = threadIdx.x; i < hl; i += PAFFY_NT) o[i] = hdr[i];
+    for (uint32_t i = threadIdx.x; i < cl; i += PAFFY_NT) o[hl + i] = in[m.cg_off + i];
+    if (threadIdx.x == 0) o[hl + cl] = '\n';
+}
+
+/* ------------------------------------------------------------------ */
 /* synthetic workload, one lane per record                   */
 /* ------------------------------------------------------------------ */
 
@@ -327,6 +394,10 @@ struct paffy_hip_ctx {
     std::string last_error;
     DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, arena, info, synth_sizes, rec_plan, ops_mirror, seq_blob, seq_table, seq_names, seq_name_off, rec_qseq, rec_tseq;
     int32_t n_seqs = 0;
+    DevBuf tile_keys, tile_order, tile_rank, tile_coff, tile_cbase, tile_cov, tile_level, tile_len;
+    bool plan_is_tile = false;
+    uint32_t tile_n = 0;
+    const uint8_t *tile_in = nullptr;
     DevInfo *h_info = nullptr; /* pinned */
     /* plan state */
     bool planned = false;
@@ -412,6 +483,7 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
         return PAFFY_E_HIP;
     }
     /* the record kernels use more than the default 64 KiB of LDS */
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile), hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emit_lds), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_EMIT_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_record_arena<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
@@ -425,7 +497,8 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     prof_collect(c);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
                       &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off,
-                      &c->rec_qseq, &c->rec_tseq};
+                      &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
+                      &c->tile_cov, &c->tile_level, &c->tile_len};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_info) (void)hipHostFree(c->h_info);
@@ -446,36 +519,8 @@ static int fetch_info(paffy_hip_ctx *c) {
     return 0;
 }
 
-int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages, const void *d_in, int64_t in_len,
-                   paffy_plan_info *info) {
-    if (!c || !info || (n_stages > 0 && !stages) || n_stages < 0 || n_stages > PAFFY_MAX_STAGES) return PAFFY_E_ARG;
-    if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
-    bool need_seqs = false;
-    for (int32_t i = 0; i < n_stages; i++) {
-        int k = stages[i].kind;
-        bool ok = k == PAFFY_INVERT || k == PAFFY_TRIM_IDENTITY || k == PAFFY_TRIM_FIXED || k == PAFFY_PASS ||
-                  k == PAFFY_REMOVE_MISMATCHES || (k == PAFFY_ADD_MISMATCHES && c->n_seqs > 0) ||
-                  (k == PAFFY_SHATTER && i == n_stages - 1);
-        if (k == PAFFY_ADD_MISMATCHES) need_seqs = true;
-        if (!ok) {
-            c->last_error = "stage list not fusable in this build";
-            return PAFFY_E_UNSUPPORTED;
-        }
-    }
-    c->planned = false;
-    memset(info, 0, sizeof(*info));
-    info->in_bytes = in_len;
-    memset(&c->plan, 0, sizeof(c->plan));
-    c->plan.in_bytes = in_len;
-    KParams &kp = c->kp;
-    memset(&kp, 0, sizeof(kp));
-    if (in_len == 0) {
-        c->planned = true;
-        kp.n_rec = 0;
-        return 0;
-    }
-    const uint8_t *in = static_cast<const uint8_t *>(d_in);
-    const uint32_t len = (uint32_t)in_len;
+/* Separator index + header parse shared by plan and tile_plan. */
+static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, uint32_t *n_lines_out) {
     const uint32_t n_tiles = (len + SEP_TILE - 1) / SEP_TILE;
 
     DevInfo zero;
@@ -488,6 +533,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
            static_cast<DevInfo *>(c->info.p));
     if (fetch_info(c)) return PAFFY_E_HIP;
     const uint32_t n_seps = c->h_info->n_seps, n_lines = c->h_info->n_lines;
+    *n_lines_out = n_lines;
 
     if (ensure(c, c->sep_pos, sizeof(uint32_t) * (size_t)(n_seps + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->nl_idx, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
@@ -510,6 +556,46 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
         LAUNCH(c, "k_header", k_header, dim3((n_lines + PAFFY_NT - 1) / PAFFY_NT), dim3(PAFFY_NT), 0, in,
                static_cast<const uint32_t *>(c->sep_pos.p), static_cast<const uint32_t *>(c->nl_idx.p), n_lines,
                static_cast<RecMeta *>(c->meta.p));
+
+    return 0;
+}
+
+int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages, const void *d_in, int64_t in_len,
+                   paffy_plan_info *info) {
+    if (!c || !info || (n_stages > 0 && !stages) || n_stages < 0 || n_stages > PAFFY_MAX_STAGES) return PAFFY_E_ARG;
+    if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
+    bool need_seqs = false;
+    for (int32_t i = 0; i < n_stages; i++) {
+        int k = stages[i].kind;
+        bool ok = k == PAFFY_INVERT || k == PAFFY_TRIM_IDENTITY || k == PAFFY_TRIM_FIXED || k == PAFFY_PASS ||
+                  k == PAFFY_REMOVE_MISMATCHES || (k == PAFFY_ADD_MISMATCHES && c->n_seqs > 0) ||
+                  (k == PAFFY_SHATTER && i == n_stages - 1);
+        if (k == PAFFY_ADD_MISMATCHES) need_seqs = true;
+        if (!ok) {
+            c->last_error = "stage list not fusable in this build";
+            return PAFFY_E_UNSUPPORTED;
+        }
+    }
+    c->planned = false;
+    c->plan_is_tile = false;
+    memset(info, 0, sizeof(*info));
+    info->in_bytes = in_len;
+    memset(&c->plan, 0, sizeof(c->plan));
+    c->plan.in_bytes = in_len;
+    KParams &kp = c->kp;
+    memset(&kp, 0, sizeof(kp));
+    if (in_len == 0) {
+        c->planned = true;
+        kp.n_rec = 0;
+        return 0;
+    }
+    const uint8_t *in = static_cast<const uint8_t *>(d_in);
+    const uint32_t len = (uint32_t)in_len;
+    uint32_t n_lines = 0;
+    {
+        int rc = index_and_parse(c, in, len, &n_lines);
+        if (rc) return rc;
+    }
 
     kp.in = in;
     kp.in_len = len;
@@ -592,12 +678,180 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     return 0;
 }
 
+
+/*
+ * `paffy tile` over a whole batch (impl/paf_tile.c:156-178). The visiting order (stable sort by
+ * chain_score desc, score desc) and the grouping by query name are computed on the host from 40
+ * bytes per record; the per-base coverage walk runs on the GPU, one workgroup per query sequence.
+ * Any failing record means nothing is written (the reference writes only after the last record).
+ */
+int paffy_hip_tile_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, paffy_plan_info *info) {
+    if (!c || !info) return PAFFY_E_ARG;
+    if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
+    c->planned = false;
+    c->plan_is_tile = true;
+    memset(info, 0, sizeof(*info));
+    memset(&c->plan, 0, sizeof(c->plan));
+    info->in_bytes = c->plan.in_bytes = in_len;
+    memset(&c->kp, 0, sizeof(c->kp));
+    c->tile_n = 0;
+    if (in_len == 0) {
+        c->planned = true;
+        return 0;
+    }
+    const uint8_t *in = static_cast<const uint8_t *>(d_in);
+    uint32_t n = 0;
+    {
+        int rc = index_and_parse(c, in, (uint32_t)in_len, &n);
+        if (rc) return rc;
+    }
+    c->plan.n_records = n;
+    if (n == 0) {
+        *info = c->plan;
+        c->planned = true;
+        return 0;
+    }
+    const uint32_t grid = (n + PAFFY_NT - 1) / PAFFY_NT;
+    if (ensure(c, c->tile_keys, sizeof(TileKey) * (size_t)n)) return PAFFY_E_HIP;
+    LAUNCH(c, "k_tile_keys", k_tile_keys, dim3(grid), dim3(PAFFY_NT), 0, in, static_cast<const RecMeta *>(c->meta.p), n,
+           static_cast<TileKey *>(c->tile_keys.p));
+    std::vector<TileKey> keys(n);
+    HIPCHK(c, hipMemcpyAsync(keys.data(), c->tile_keys.p, sizeof(TileKey) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    /* read_pafs parses every line before anything else happens: the first bad line in input order wins */
+    for (uint32_t i = 0; i < n; i++)
+        if (keys[i].err) {
+            c->plan.error.code = keys[i].err;
+            c->plan.error.stage = -1;
+            c->plan.error.record = i;
+            int32_t aux = 0;
+            RecMeta m;
+            HIPCHK(c, hipMemcpy(&m, static_cast<RecMeta *>(c->meta.p) + i, sizeof(m), hipMemcpyDeviceToHost));
+            aux = m.err_aux;
+            c->plan.error.aux = aux;
+            *info = c->plan;
+            c->planned = true;
+            return 0;
+        }
+    /* visiting order: paf_cmp_by_descending_score, impl/paf_tile.c:28-34, ties in input order (stable) */
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        if (keys[a].chain_score != keys[b].chain_score) return keys[a].chain_score > keys[b].chain_score;
+        return keys[a].score > keys[b].score;
+    });
+    std::vector<uint32_t> rank_of(n);
+    for (uint32_t k = 0; k < n; k++) rank_of[order[k]] = k;
+    /* query sequences: keyed by (hash, length) of the name; counters are allocated on first sight (impl/paf.c:675-688) */
+    struct Contig { uint64_t hash; uint32_t name_len; int64_t qlen; std::vector<uint32_t> recs; };
+    std::vector<Contig> contigs;
+    std::vector<std::pair<std::pair<uint64_t, uint32_t>, uint32_t>> index; /* sorted lookup */
+    {
+        std::vector<uint32_t> by_name(order);
+        std::stable_sort(by_name.begin(), by_name.end(), [&](uint32_t a, uint32_t b) {
+            if (keys[a].name_hash != keys[b].name_hash) return keys[a].name_hash < keys[b].name_hash;
+            return keys[a].name_len < keys[b].name_len;
+        });
+        for (uint32_t k = 0; k < n; k++) { /* by_name keeps visiting order inside a group (stable) */
+            uint32_t r = by_name[k];
+            if (contigs.empty() || contigs.back().hash != keys[r].name_hash || contigs.back().name_len != keys[r].name_len)
+                contigs.push_back(Contig{keys[r].name_hash, keys[r].name_len, keys[r].qlen, {}});
+            contigs.back().recs.push_back(r);
+        }
+    }
+    /* assert(seq_count_array->length == paf->query_length), impl/paf.c:685: first offender in visiting order */
+    uint32_t bad_rank = 0xffffffffu;
+    for (auto &cg : contigs) {
+        cg.qlen = keys[cg.recs[0]].qlen; /* length seen first, in visiting order */
+        for (uint32_t r : cg.recs)
+            if (keys[r].qlen != cg.qlen && rank_of[r] < bad_rank) bad_rank = rank_of[r];
+    }
+    std::vector<uint32_t> flat;
+    std::vector<uint32_t> coff(contigs.size() + 1);
+    std::vector<uint64_t> cbase(contigs.size());
+    uint64_t cov_total = 0;
+    flat.reserve(n);
+    for (size_t ci = 0; ci < contigs.size(); ci++) {
+        coff[ci] = (uint32_t)flat.size();
+        cbase[ci] = cov_total;
+        cov_total += (uint64_t)(contigs[ci].qlen > 0 ? contigs[ci].qlen : 0) + 64;
+        for (uint32_t r : contigs[ci].recs) flat.push_back(r);
+    }
+    coff[contigs.size()] = (uint32_t)flat.size();
+    if (ensure(c, c->tile_order, sizeof(uint32_t) * (size_t)n)) return PAFFY_E_HIP;
+    if (ensure(c, c->tile_rank, sizeof(uint32_t) * (size_t)n)) return PAFFY_E_HIP;
+    if (ensure(c, c->tile_coff, sizeof(uint32_t) * coff.size())) return PAFFY_E_HIP;
+    if (ensure(c, c->tile_cbase, sizeof(uint64_t) * cbase.size())) return PAFFY_E_HIP;
+    if (ensure(c, c->tile_cov, sizeof(uint16_t) * (size_t)cov_total)) return PAFFY_E_HIP;
+    if (ensure(c, c->tile_level, sizeof(int64_t) * (size_t)n)) return PAFFY_E_HIP;
+    if (ensure(c, c->tile_len, sizeof(int64_t) * (size_t)(n + 2))) return PAFFY_E_HIP;
+    HIPCHK(c, hipMemcpyAsync(c->tile_order.p, flat.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->tile_rank.p, rank_of.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->tile_coff.p, coff.data(), sizeof(uint32_t) * coff.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->tile_cbase.p, cbase.data(), sizeof(uint64_t) * cbase.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->tile_cov.p, 0, sizeof(uint16_t) * (size_t)cov_total, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->tile_level.p, 0xff, sizeof(int64_t) * (size_t)n, c->stream));
+    if (bad_rank != 0xffffffffu) { /* seed the first-error key with the length assert */
+        unsigned long long key = ((unsigned long long)bad_rank << 16) | (1ull << 8) | (unsigned long long)PAFFY_ERR_TILE_ASSERT;
+        HIPCHK(c, hipMemcpyAsync(&static_cast<DevInfo *>(c->info.p)->first_err_key, &key, sizeof(key), hipMemcpyHostToDevice, c->stream));
+    }
+    TileParams tp;
+    tp.in = in;
+    tp.meta = static_cast<const RecMeta *>(c->meta.p);
+    tp.order = static_cast<const uint32_t *>(c->tile_order.p);
+    tp.contig_off = static_cast<const uint32_t *>(c->tile_coff.p);
+    tp.contig_base = static_cast<const uint64_t *>(c->tile_cbase.p);
+    tp.rank_of = static_cast<const uint32_t *>(c->tile_rank.p);
+    tp.counts = static_cast<uint16_t *>(c->tile_cov.p);
+    tp.n_contigs = (uint32_t)contigs.size();
+    tp.tile_level = static_cast<int64_t *>(c->tile_level.p);
+    tp.info = static_cast<DevInfo *>(c->info.p);
+    tp.err_aux = static_cast<int32_t *>(c->err_aux.p);
+    const uint32_t tgrid = tp.n_contigs < 2048 ? tp.n_contigs : 2048;
+    LAUNCH(c, "k_tile", k_tile, dim3(tgrid), dim3(PAFFY_NT), TILE_LDS_BYTES, tp);
+    /* sizes and offsets in visiting order (= the order array sorted by rank) */
+    HIPCHK(c, hipMemcpyAsync(c->tile_order.p, order.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    int64_t *lens = static_cast<int64_t *>(c->tile_len.p);
+    LAUNCH(c, "k_tile_size", k_tile_size, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const RecMeta *>(c->meta.p),
+           static_cast<const uint32_t *>(c->tile_order.p), static_cast<const int64_t *>(c->tile_level.p), n, lens);
+    LAUNCH(c, "k_scan_i64", k_scan_i64, dim3(1), dim3(PAFFY_NT), 0, lens, n, static_cast<int64_t *>(c->out_off.p), lens + n);
+    int64_t total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, lens + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (fetch_info(c)) return PAFFY_E_HIP;
+    if (c->profile) prof_collect(c);
+    if (c->h_info->first_err_key != ~0ull) {
+        unsigned long long k = c->h_info->first_err_key;
+        uint32_t rk = (uint32_t)(k >> 16);
+        c->plan.error.code = (int32_t)(k & 0xff);
+        c->plan.error.stage = 0;
+        c->plan.error.record = order[rk];
+        int32_t aux = 0;
+        HIPCHK(c, hipMemcpy(&aux, static_cast<int32_t *>(c->err_aux.p) + order[rk], sizeof(aux), hipMemcpyDeviceToHost));
+        c->plan.error.aux = c->plan.error.code == PAFFY_ERR_CIGAR_CHAR ? aux : 0;
+        c->plan.out_bytes = 0; /* write_pafs never runs */
+    } else {
+        c->plan.out_bytes = total;
+        c->plan.n_rows = n;
+    }
+    c->tile_n = c->plan.out_bytes ? n : 0;
+    c->tile_in = in;
+    *info = c->plan;
+    c->planned = true;
+    return 0;
+}
+
 int paffy_hip_emit(paffy_hip_ctx *c, void *d_out, int64_t out_cap) {
     if (!c) return PAFFY_E_ARG;
     if (!c->planned) return PAFFY_E_STATE;
-    if (c->plan.out_bytes == 0 || c->kp.n_rec == 0) return 0;
+    if (c->plan.out_bytes == 0 || (!c->plan_is_tile && c->kp.n_rec == 0)) return 0;
     if (!d_out || (reinterpret_cast<uintptr_t>(d_out) & 15)) return PAFFY_E_ARG;
     if (out_cap < c->plan.out_bytes) return PAFFY_E_CAPACITY;
+    if (c->plan_is_tile) {
+        LAUNCH(c, "k_tile_emit", k_tile_emit, dim3(c->tile_n), dim3(PAFFY_NT), 0, c->tile_in, static_cast<const RecMeta *>(c->meta.p),
+               static_cast<const uint32_t *>(c->tile_order.p), static_cast<const int64_t *>(c->tile_level.p),
+               static_cast<const int64_t *>(c->out_off.p), static_cast<uint8_t *>(d_out));
+        return 0;
+    }
     KParams kp = c->kp;
     kp.out = static_cast<uint8_t *>(d_out);
     LAUNCH(c, "k_emit_lds", k_emit_lds, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);

@@ -71,6 +71,7 @@ def lib():
         L.paffy_hip_set_stream.argtypes = [vp, vp]
         L.paffy_hip_plan.argtypes = [vp, C.POINTER(Stage), i32, vp, i64, C.POINTER(PlanInfo)]
         L.paffy_hip_emit.argtypes = [vp, vp, i64]
+        L.paffy_hip_tile_plan.argtypes = [vp, vp, i64, C.POINTER(PlanInfo)]
         L.paffy_hip_sync.argtypes = [vp]
         L.paffy_hip_set_sequences.argtypes = [vp, i64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(i64)]
         L.paffy_hip_error_exit_status.argtypes = [i32]
@@ -141,6 +142,27 @@ class Engine:
         rc = lib().paffy_hip_plan(self._ctx, arr, len(stages), C.c_void_p(d_in.data_ptr()), in_len, C.byref(info))
         self._check(rc, "paffy_hip_plan")
         return info
+
+    def tile_plan(self, d_in, in_len):
+        info = PlanInfo()
+        self._check(lib().paffy_hip_tile_plan(self._ctx, C.c_void_p(d_in.data_ptr()), in_len, C.byref(info)), "paffy_hip_tile_plan")
+        return info
+
+    def tile(self, data, raise_on_error=True):
+        """paffy tile (impl/paf_tile.c) over PAF text; returns (output bytes, PlanInfo)."""
+        d_in = self.to_device(data)
+        info = self.tile_plan(d_in, len(data))
+        out = b""
+        if info.out_bytes:
+            d_out = self.alloc_out(info.out_bytes)
+            self.emit(d_out)
+            self.sync()
+            out = bytes(d_out[: info.out_bytes].cpu().numpy().tobytes())
+        if info.error.code and raise_on_error:
+            L = lib()
+            raise PafError(f"record {info.error.record}: {L.paffy_hip_error_string(info.error.code).decode()}", info,
+                           L.paffy_hip_error_exit_status(info.error.code))
+        return out, info
 
     def emit(self, d_out):
         rc = lib().paffy_hip_emit(self._ctx, C.c_void_p(d_out.data_ptr()), d_out.numel())
@@ -238,6 +260,11 @@ def add_mismatches(data, seqs=None, remove=False):
     e = _engine()
     e.set_sequences(seqs)
     return e.run([stage(ADD_MISMATCHES)], data)[0]
+
+
+def tile(data):
+    """paffy tile (impl/paf_tile.c)."""
+    return _engine().tile(data)[0]
 
 
 def trim(data, trim_identity=0.05, trim_fraction=1.0, fixed_trim=False):

@@ -35,7 +35,7 @@ def test_dispatcher_contract():
         assert name in err
     rc, _, err = run(["frobnicate"])
     assert rc == 1 and b"frobnicate is not a valid paffy command" in err
-    for cmd in ("shatter", "invert", "trim"):
+    for cmd in ("shatter", "invert", "trim", "tile", "add_mismatches"):
         rc, out, err = run([cmd, "-h"])
         assert rc == 0 and out == b"" and b"--inputFile" in err and b"--logLevel" in err
         assert run([cmd, "--help"])[0] == 0
@@ -78,3 +78,20 @@ def test_cli_error_status():
     assert rc == 1 and out == O.run([S(O.INVERT)], ok)[0] and b"unexpected strand character (*)" in err
     rc, out, err = run(["shatter"], ok + ok.replace(b"5M", b"5=") + ok)
     assert rc == -6 and out == O.run([S(O.SHATTER)], ok)[0]  # assert -> SIGABRT, as the reference
+
+
+@pytest.mark.gpu
+def test_cli_tile_and_mismatches(human_chimp, tmp_path):
+    rc, out, err = run(["tile"], human_chimp)
+    assert rc == 0 and out == O.tile(human_chimp)[0]
+    rc, out, err = run(["add_mismatches", "-a"], human_chimp)
+    assert rc == 0 and out == O.run([S(O.REMOVE_MISMATCHES)], human_chimp)[0]
+    # FASTA files on the command line, as `paffy add_mismatches q.fa t.fa`
+    seqs = {"q": "ACGTACGTAC" * 3, "t": "ACGTACGAAC" * 3}
+    (tmp_path / "q.fa").write_text(">q\n" + seqs["q"][:17] + "\n" + seqs["q"][17:] + "\n")
+    (tmp_path / "t.fa").write_text(">t\n" + seqs["t"] + "\n")
+    rec = b"q\t30\t2\t27\t+\tt\t30\t2\t27\t25\t25\t60\tcg:Z:25M\n"
+    rc, out, err = run(["add_mismatches", str(tmp_path / "q.fa"), str(tmp_path / "t.fa")], rec)
+    assert rc == 0 and out == O.run([S(O.ADD_MISMATCHES)], rec, seqs)[0] and b"X" in out
+    rc, out, err = run(["add_mismatches", str(tmp_path / "q.fa")], rec)  # target sequence missing: exit(1)
+    assert rc == 1 and out == b"" and b"No target sequence" in err
