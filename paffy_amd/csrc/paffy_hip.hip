@@ -332,13 +332,13 @@ __global__ __launch_bounds__(PAFFY_NT) void k_tile_emit(const uint8_t *in, const
     __shared__ uint8_t hdr[3 * PAFFY_TMPL_MAX + 8];
     __shared__ uint32_t hlen;
     const RecMeta m = meta[order[blockIdx.x]];
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {
         RecState s;
         tile_state(m, level[order[blockIdx.x]], s);
         Piece w{hdr, 0, 3 * PAFFY_TMPL_MAX, false};
         build_header(w, s, in, false);
-        if (m.has_cg) w.str("\tcg:Z:");
-        hlen = w.n;
+        if (m.has_cg) w.str("\tcg:Z:", 6);
+        if (threadIdx.x == 0) hlen = w.n;
     }
     __syncthreads();
     uint8_t *o = out + out_off[blockIdx.x];
@@ -392,7 +392,7 @@ struct ProfEntry {
 struct paffy_hip_ctx {
     hipStream_t stream = nullptr;
     std::string last_error;
-    DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, arena, info, synth_sizes, rec_plan, ops_mirror, seq_blob, seq_table, seq_names, seq_name_off, rec_qseq, rec_tseq;
+    DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, b_list, arena, info, synth_sizes, rec_plan, ops_mirror, seq_blob, seq_table, seq_names, seq_name_off, rec_qseq, rec_tseq;
     int32_t n_seqs = 0;
     DevBuf tile_keys, tile_order, tile_rank, tile_coff, tile_cbase, tile_cov, tile_level, tile_len;
     bool plan_is_tile = false;
@@ -484,7 +484,7 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
     }
     /* the record kernels use more than the default 64 KiB of LDS */
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile), hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emit_lds), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_EMIT_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_record_arena<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_record_arena<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_EMIT_LDS_BYTES);
@@ -496,7 +496,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     if (!c) return;
     prof_collect(c);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
-                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off,
+                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
                       &c->tile_cov, &c->tile_level, &c->tile_len};
     for (DevBuf *b : bufs)
@@ -546,6 +546,7 @@ static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, ui
     if (ensure(c, c->n_ops, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->arena_off, sizeof(uint64_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->w_list, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->b_list, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->rec_plan, sizeof(RecPlan) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->ops_mirror, sizeof(uint32_t) * ((size_t)len / 2 + 64))) return PAFFY_E_HIP;
     if (c->arena.cap == 0 && ensure(c, c->arena, (size_t)8 << 20)) return PAFFY_E_HIP;
@@ -625,13 +626,19 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     }
     kp.out_off = static_cast<const int64_t *>(c->out_off.p);
     kp.w_list = static_cast<uint32_t *>(c->w_list.p);
+    kp.b_list = static_cast<uint32_t *>(c->b_list.p);
     kp.info = static_cast<DevInfo *>(c->info.p);
 
     if (n_lines > 0) {
         for (int attempt = 0; attempt < 3; attempt++) {
             kp.arena = static_cast<uint64_t *>(c->arena.p);
             kp.arena_cap = c->arena.cap / 8;
+            kp.ops_cap = PAFFY_OPS_CAP;
+            kp.from_list = 0;
             LAUNCH(c, "k_size_lds", k_size_lds, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
+            kp.ops_cap = PAFFY_OPS_CAP_BIG;
+            kp.from_list = 1;
+            LAUNCH(c, "k_size_lds<big>", k_size_lds, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), kp);
             LAUNCH(c, "k_record_arena<size>", k_record_arena<false>, dim3(512), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             if (fetch_info(c)) return PAFFY_E_HIP;
             if (c->h_info->arena_used <= kp.arena_cap) break;
@@ -641,6 +648,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             DevInfo z = *c->h_info;
             z.arena_used = 0;
             z.w_count = 0;
+            z.b_count = 0;
             z.first_err_key = ~0ull;
             HIPCHK(c, hipMemcpyAsync(c->info.p, &z, sizeof(z), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -706,54 +706,77 @@ __device__ int encode_mismatch_runs(const KParams &P, const RecState &s, const V
 
 /* ---------------- line pieces ---------------- */
 
-/* Serial LDS byte builder used by one lane per piece. */
+/*
+ * Wave-cooperative LDS byte builder for the per-record line pieces: all 64 lanes of one wave call
+ * every method with the same arguments and lane k writes byte k of what is appended (no serial
+ * digit loops, no per-lane arrays).
+ */
 struct Piece {
     uint8_t *p;
     uint32_t n, cap;
     bool over;
-    __device__ __forceinline__ void ch(uint32_t c) {
-        if (n < cap) p[n] = (uint8_t)c;
+    __device__ __forceinline__ uint32_t lane() const { return threadIdx.x & 63u; }
+    __device__ __forceinline__ void put_at(uint32_t k, uint32_t c) {
+        if (n + k < cap) p[n + k] = (uint8_t)c;
         else over = true;
+    }
+    __device__ __forceinline__ void ch(uint32_t c) {
+        if (lane() == 0) put_at(0, c);
         n++;
     }
-    __device__ __forceinline__ void str(const char *s) {
-        while (*s) ch((uint8_t)*s++);
+    __device__ __forceinline__ void str(const char *s, uint32_t len) { /* len <= 64 */
+        if (lane() < len) put_at(lane(), (uint8_t)s[lane()]);
+        n += len;
     }
-    __device__ void num(int64_t v) {
-        char tmp[24];
-        int k = 0;
-        uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
-        if (u == 0) tmp[k++] = '0';
-        while (u) {
-            uint64_t q = u / 10;
-            tmp[k++] = (char)('0' + (int)(u - q * 10));
-            u = q;
+    __device__ __forceinline__ void num(int64_t v) { /* int64_to_str, impl/paf.c:10-34 */
+        DecText d;
+        dec_text(v, d);
+        const uint32_t total = text_len(d);
+        uint32_t k = lane();
+        if (k < total) {
+            uint32_t c;
+            uint32_t kk = k;
+            if (d.neg_separate) kk = k - 1;
+            if (d.neg_separate && k == 0) {
+                c = '-';
+            } else if (kk < d.ntop) {
+                c = (uint32_t)(d.top >> (8 * kk)) & 0xffu;
+            } else {
+                const uint32_t k2 = kk - d.ntop, g = k2 >> 3, b = k2 & 7u;
+                const uint32_t grp = (d.groups == 2 && g == 0) ? d.g1 : d.g0;
+                c = (uint32_t)(ascii8(grp) >> (8 * b)) & 0xffu;
+            }
+            put_at(k, c);
         }
-        if (v < 0) ch('-');
-        while (k) ch((uint8_t)tmp[--k]);
+        n += total;
     }
-    __device__ void name(const uint8_t *in, uint32_t off, uint32_t len) {
-        for (uint32_t i = 0; i < len; i++) ch(in[off + i]);
+    __device__ __forceinline__ void name(const uint8_t *in, uint32_t off, uint32_t len) {
+        for (uint32_t i = lane(); i < len; i += 64) put_at(i, in[off + i]);
+        n += len;
+    }
+    __device__ __forceinline__ void pad_to(uint32_t m) { /* zero fill so that whole words can be read back */
+        for (uint32_t i = n + lane(); i < m; i += 64)
+            if (i < cap) p[i] = 0;
     }
 };
 
 /* Optional tags in the fixed order of impl/paf.c:343-365; `s1` is the chain_score to print. */
-__device__ void piece_tags(Piece &w, const RecState &s, int64_t s1) {
+__device__ __forceinline__ void piece_tags(Piece &w, const RecState &s, int64_t s1) {
     if (s.type != 0 || s.tile_level != -1) {
         uint32_t t = s.type;
         if (t == 0) t = s.tile_level > 1 ? 'S' : 'P';
-        w.str("\ttp:A:");
+        w.str("\ttp:A:", 6);
         w.ch(t);
     }
     if (s.score != 2147483647ll) { /* INT_MAX guard, impl/paf.c:349 */
-        w.str("\tAS:i:");
+        w.str("\tAS:i:", 6);
         w.num(s.score);
     }
-    if (s.tile_level != -1) { w.str("\ttl:i:"); w.num(s.tile_level); }
-    if (s.chain_id != -1) { w.str("\tcn:i:"); w.num(s.chain_id); }
-    if (s1 != -1) { w.str("\ts1:i:"); w.num(s1); }
+    if (s.tile_level != -1) { w.str("\ttl:i:", 6); w.num(s.tile_level); }
+    if (s.chain_id != -1) { w.str("\tcn:i:", 6); w.num(s.chain_id); }
+    if (s1 != -1) { w.str("\ts1:i:", 6); w.num(s1); }
 }
-__device__ uint32_t tags_len(const RecState &s, int64_t s1) {
+__device__ __forceinline__ uint32_t tags_len(const RecState &s, int64_t s1) {
     uint32_t n = 0;
     if (s.type != 0 || s.tile_level != -1) n += 7;
     if (s.score != 2147483647ll) n += 6 + dec_len(s.score);
@@ -1110,7 +1133,7 @@ __device__ void build_header(Piece &w, const RecState &s, const uint8_t *in, boo
     w.ch('\t'); w.num(s.nbases);
     w.ch('\t'); w.num(s.mapq);
     piece_tags(w, s, s.chain_score);
-    if (s.has_cigar) w.str("\tcg:Z:");
+    if (s.has_cigar) w.str("\tcg:Z:", 6);
     if (newline) w.ch('\n');
 }
 __device__ uint32_t header_len(const RecState &s, bool newline) {
@@ -1274,6 +1297,7 @@ __device__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t c
         uint32_t r = parse_cigar(P.in, m.cg_off, m.cg_len, ops, cap, L.ring, L.bc, L.sh, &fits, &err_pos);
         if (r & 0x80000000u) r = parse_cigar_serial(P.in, m.cg_off, m.cg_len, ops, cap, L.sh, &fits, &err_pos);
         n = r;
+        *n_ops_out = n;
         if (err_pos != 0xffffffffu) { /* st_errAbort, impl/paf.c:102 */
             report(P, rec, PAFFY_ERR_CIGAR_CHAR, -1, err_pos < m.cg_off + m.cg_len ? P.in[err_pos] : 0, klass);
             return true;
@@ -1413,23 +1437,24 @@ __device__ void emit_record(const KParams &P, uint32_t rec, const OPS &ops, cons
         ShatterConst k;
         shatter_consts(s, k);
         uint64_t *A = L.pieces, *B = L.pieces + PAFFY_TMPL_MAX / 8, *C = L.pieces + 2 * (PAFFY_TMPL_MAX / 8);
-        if (threadIdx.x == 0) {
+        const uint32_t wave = threadIdx.x >> 6;
+        if (wave == 0) {
             Piece w{(uint8_t *)A, 0, PAFFY_TMPL_MAX, false};
             w.name(P.in, s.qn_off, s.qn_len);
             w.ch('\t'); w.num(s.qlen); w.ch('\t');
-            while (w.n < 32) w.ch(0);
-        } else if (threadIdx.x == 64) {
+            w.pad_to(32);
+        } else if (wave == 1) {
             Piece w{(uint8_t *)B, 0, PAFFY_TMPL_MAX, false};
             w.ch('\t'); w.ch(s.same ? '+' : '-'); w.ch('\t');
             w.name(P.in, s.tn_off, s.tn_len);
             w.ch('\t'); w.num(s.tlen); w.ch('\t');
-            while (w.n < 32) w.ch(0);
-        } else if (threadIdx.x == 128) {
+            w.pad_to(32);
+        } else if (wave == 2) {
             Piece w{(uint8_t *)C, 0, PAFFY_TMPL_MAX, false};
             w.ch('\t'); w.num(s.mapq);
             piece_tags(w, s, 0);
-            w.str("\tcg:Z:");
-            while (w.n < 48) w.ch(0);
+            w.str("\tcg:Z:", 6);
+            w.pad_to(48);
         }
         __syncthreads();
         RowPieces pieces;
@@ -1438,7 +1463,7 @@ __device__ void emit_record(const KParams &P, uint32_t rec, const OPS &ops, cons
     } else {
         const bool nl_in_header = !(s.has_cigar && v.n > 0);
         const uint32_t lenH = header_len(s, nl_in_header);
-        if (threadIdx.x == 0) {
+        if (threadIdx.x < 64) {
             Piece w{(uint8_t *)L.pieces, 0, 3 * PAFFY_TMPL_MAX, false};
             build_header(w, s, P.in, nl_in_header);
         }
@@ -1451,17 +1476,19 @@ __device__ void emit_record(const KParams &P, uint32_t rec, const OPS &ops, cons
 }
 
 /* LDS budgets: both kernels fit four workgroups per CU (160 KiB). */
-#define PAFFY_SIZE_LDS_BYTES (PAFFY_OPS_CAP * 4 + (PAFFY_HALO + PAFFY_NT * 16) + 64 * 8 + 64)
+#define PAFFY_SIZE_LDS_BYTES_FOR(cap) ((cap) * 4 + (PAFFY_HALO + PAFFY_NT * 16) + 64 * 8 + 64)
+#define PAFFY_SIZE_LDS_BYTES PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP)
+#define PAFFY_OPS_CAP_BIG 36864u /* big-LDS sizing class: 144 KiB of ops, one workgroup per CU */
 #define PAFFY_EMIT_LDS_BYTES (PAFFY_NWAVE * PAFFY_WAVE_RING + 3 * PAFFY_TMPL_MAX + 64 * 8 + 64)
 
-__device__ __forceinline__ RecLds carve_size_lds(uint8_t *smem, uint32_t **ops_lds) {
+__device__ __forceinline__ RecLds carve_size_lds(uint8_t *smem, uint32_t **ops_lds, uint32_t cap = PAFFY_OPS_CAP) {
     RecLds L;
     *ops_lds = reinterpret_cast<uint32_t *>(smem);
-    L.ring = smem + PAFFY_OPS_CAP * 4; /* text staging */
+    L.ring = smem + cap * 4; /* text staging */
     L.pieces = nullptr;
-    L.bc.scratch = reinterpret_cast<int64_t *>(smem + PAFFY_OPS_CAP * 4 + PAFFY_HALO + PAFFY_NT * 16);
+    L.bc.scratch = reinterpret_cast<int64_t *>(smem + cap * 4 + PAFFY_HALO + PAFFY_NT * 16);
     L.bc.flip = 0;
-    L.sh = reinterpret_cast<Shared *>(smem + PAFFY_OPS_CAP * 4 + PAFFY_HALO + PAFFY_NT * 16 + 64 * 8);
+    L.sh = reinterpret_cast<Shared *>(smem + cap * 4 + PAFFY_HALO + PAFFY_NT * 16 + 64 * 8);
     return L;
 }
 __device__ __forceinline__ RecLds carve_emit_lds(uint8_t *smem) {
@@ -1478,23 +1505,43 @@ __device__ __forceinline__ RecLds carve_emit_lds(uint8_t *smem) {
  * least two text bytes (digits + letter), so index cg_off / 2 is private to the record. */
 __device__ __forceinline__ uint32_t mirror_index(const RecMeta &m) { return m.cg_off >> 1; }
 
-/* Sizing, LDS class: one workgroup per record, ops parsed from the text into LDS (and mirrored). */
-__global__ __launch_bounds__(PAFFY_NT, 4) void k_size_lds(KParams P) {
-    extern __shared__ uint4 smem4[];
-    uint32_t *ops_lds;
-    RecLds L = carve_size_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds);
-    const uint32_t rec = blockIdx.x;
+/*
+ * Sizing, LDS class: one workgroup per record, ops parsed from the text into LDS (and mirrored).
+ * Launched twice: over the whole batch with the standard store (4 workgroups per CU), then over
+ * the records that did not fit with the big store (P.from_list, one workgroup per CU). What
+ * still does not fit (lengths >= 2^29, rebuilt op arrays) goes to the arena kernel.
+ */
+__device__ __forceinline__ void size_lds_one(const KParams &P, uint32_t rec, uint32_t *ops_lds, const RecLds &L) {
     const RecMeta &m = P.meta[rec];
     OpsLds ops{ops_lds, P.ops_mirror + mirror_index(m), (m.cg_len + 1) >> 1};
     uint32_t n_ops = 0;
-    bool ok = size_record<OpsLds>(P, rec, ops, PAFFY_OPS_CAP, L, KLASS_LDS, &n_ops);
+    bool ok = size_record<OpsLds>(P, rec, ops, P.ops_cap, L, KLASS_LDS, &n_ops);
     if (ok && n_ops > ((m.cg_len + 1) >> 1)) ok = false; /* digit-less ops overran the mirror: arena class */
-    if (!ok && threadIdx.x == 0) { /* route to the arena kernel */
-        P.status[rec] = (uint32_t)KLASS_ARENA << 16;
+    if (!ok && threadIdx.x == 0) {
         P.out_len[rec] = 0;
         P.out_rows[rec] = 0;
-        uint32_t slot = atomicAdd(&P.info->w_count, 1u);
-        P.w_list[slot] = rec;
+        /* too many ops for the standard store only: try the big store; anything else needs the arena */
+        const bool try_big = !P.from_list && n_ops > P.ops_cap && n_ops <= PAFFY_OPS_CAP_BIG && n_ops <= ((m.cg_len + 1) >> 1);
+        if (try_big) {
+            P.b_list[atomicAdd(&P.info->b_count, 1u)] = rec;
+        } else {
+            P.status[rec] = (uint32_t)KLASS_ARENA << 16;
+            P.w_list[atomicAdd(&P.info->w_count, 1u)] = rec;
+        }
+    }
+}
+__global__ __launch_bounds__(PAFFY_NT, 4) void k_size_lds(KParams P) {
+    extern __shared__ uint4 smem4[];
+    uint32_t *ops_lds;
+    RecLds L = carve_size_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds, P.ops_cap);
+    if (!P.from_list) {
+        size_lds_one(P, blockIdx.x, ops_lds, L);
+    } else {
+        const uint32_t count = P.info->b_count;
+        for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
+            size_lds_one(P, P.b_list[li], ops_lds, L);
+            __syncthreads();
+        }
     }
 }
 

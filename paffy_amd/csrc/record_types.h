@@ -47,6 +47,7 @@ struct DevInfo {
     unsigned long long out_bytes, out_rows;
     uint32_t n_seps, n_lines;
     uint32_t w_count;   /* records routed to the arena kernel */
+    uint32_t b_count;   /* records routed to the big-LDS sizing launch */
     uint32_t internal;  /* internal-limit flags (must stay 0) */
 };
 
@@ -78,6 +79,9 @@ struct KParams {
     uint64_t *arena;
     uint64_t arena_cap; /* in ops */
     uint32_t *w_list;
+    uint32_t *b_list;   /* records that did not fit the standard LDS op store */
+    uint32_t ops_cap;   /* 4-byte ops the sizing workgroup's LDS store holds */
+    uint32_t from_list; /* sizing launch walks b_list instead of the whole batch */
     DevInfo *info;
 };
 
