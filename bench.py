@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=65536, help="records per step per GPU")
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--pipe", default=None, help="override the workload's command pipe, e.g. 'shatter' (experiments only)")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="records of the stream timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     args = ap.parse_args()
@@ -66,7 +67,9 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.pipe:
+        wl["pipe"] = args.pipe
     eng = paffy_amd.Engine()
     stages = stages_for(wl["pipe"], paffy_amd)
     n_batches = args.warmup + args.steps

@@ -80,21 +80,32 @@ struct View {
     uint32_t lo, n;
     bool rev, swp;
     int64_t sub_lo, sub_hi; /* bases cut from the raw first / last op of the window (fixed trim) */
+    /*
+     * Running sums over the window, kept current by the transforms so that paf_check and the
+     * identity statistics need no sweep: tm = bases of M and = ops, tx = bases of X, I and D ops
+     * (the matches / mismatches of impl/paf.c:823-828), tq = bases of ops other than D, tt = other than I.
+     */
+    int64_t tm, tx, tq, tt;
+    bool totals_ok;
     __device__ __forceinline__ void get(uint32_t i, int64_t &len, int &op) const {
         uint32_t raw = rev ? lo + n - 1 - i : lo + i;
         ops.get(raw, len, op);
-        if (swp && (op == OP_I || op == OP_D)) op ^= 3;
-        if (raw == lo) len -= sub_lo;
-        if (raw == lo + n - 1) len -= sub_hi;
+        if (swp) op ^= (int)((0x6u >> op) & 1u) * 3; /* I <-> D */
+        if ((sub_lo | sub_hi) != 0) {
+            if (raw == lo) len -= sub_lo;
+            if (raw == lo + n - 1) len -= sub_hi;
+        }
     }
     /* split form of get(): issue the load early, decode when the value is needed */
     __device__ __forceinline__ uint32_t raw_index(uint32_t i) const { return rev ? lo + n - 1 - i : lo + i; }
     template <class RAW>
     __device__ __forceinline__ void decode(RAW w, uint32_t raw, int64_t &len, int &op) const {
         OPS::decode(w, len, op);
-        if (swp && (op == OP_I || op == OP_D)) op ^= 3;
-        if (raw == lo) len -= sub_lo;
-        if (raw == lo + n - 1) len -= sub_hi;
+        if (swp) op ^= (int)((0x6u >> op) & 1u) * 3;
+        if ((sub_lo | sub_hi) != 0) {
+            if (raw == lo) len -= sub_lo;
+            if (raw == lo + n - 1) len -= sub_hi;
+        }
     }
     __device__ __forceinline__ void drop_front(uint32_t k) {
         if (k == 0) return;
@@ -110,6 +121,11 @@ struct View {
     __device__ __forceinline__ void shorten_front(int64_t amt) {
         if (!rev) sub_lo += amt;
         else sub_hi += amt;
+    }
+    __device__ __forceinline__ void reset(const OPS &o, uint32_t count) {
+        ops = o; lo = 0; n = count; rev = false; swp = false; sub_lo = sub_hi = 0;
+        tm = tx = tq = tt = 0;
+        totals_ok = false;
     }
 };
 
@@ -283,54 +299,61 @@ template <class OPS>
 __device__ __forceinline__ void invert_view(const RecState &s, View<OPS> &v) { /* impl/paf.c:476-489 */
     v.swp = !v.swp;
     if (!s.same) v.rev = !v.rev;
+    int64_t t = v.tq; /* I and D trade places */
+    v.tq = v.tt;
+    v.tt = t;
+}
+
+/* one sweep that (re)establishes the running sums of the view */
+template <class OPS>
+__device__ void ensure_totals(View<OPS> &v, BlockComm &bc) {
+    if (v.totals_ok) return;
+    uint32_t b, e;
+    sweep_bounds(v.n, b, e);
+    int64_t a[4] = {0, 0, 0, 0};
+    for (uint32_t i = b; i < e; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        if (op == OP_EQ || op == OP_M) a[0] += len;
+        else a[1] += len;
+        if (op != OP_D) a[2] += len;
+        if (op != OP_I) a[3] += len;
+    }
+    block_sum<4>(a, bc);
+    v.tm = a[0]; v.tx = a[1]; v.tq = a[2]; v.tt = a[3];
+    v.totals_ok = true;
 }
 
 /* paf_check, impl/paf.c:427-461. Returns 0 or the PAFFY_ERR_CHECK_* code. */
 template <class OPS>
-__device__ int check_record(const RecState &s, const View<OPS> &v, BlockComm &bc) {
+__device__ int check_record(const RecState &s, View<OPS> &v, BlockComm &bc) {
     if (s.qs < 0 || s.qs >= s.qlen) return PAFFY_ERR_CHECK_QSTART;
     if (s.qs > s.qe || s.qe > s.qlen) return PAFFY_ERR_CHECK_QEND;
     if (s.ts < 0 || s.ts >= s.tlen) return PAFFY_ERR_CHECK_TSTART;
     if (s.ts > s.te || s.te > s.tlen) return PAFFY_ERR_CHECK_TEND;
     if (s.has_cigar) {
-        uint32_t b, e;
-        sweep_bounds(v.n, b, e);
-        int64_t acc[2] = {0, 0};
-        for (uint32_t i = b; i < e; i++) {
-            int64_t len;
-            int op;
-            v.get(i, len, op);
-            if (op != OP_D) acc[0] += len;
-            if (op != OP_I) acc[1] += len;
-        }
-        block_sum<2>(acc, bc);
-        if (acc[0] != s.qe - s.qs) return PAFFY_ERR_CHECK_CIGAR_Q;
-        if (acc[1] != s.te - s.ts) return PAFFY_ERR_CHECK_CIGAR_T;
+        ensure_totals(v, bc);
+        if (v.tq != s.qe - s.qs) return PAFFY_ERR_CHECK_CIGAR_Q;
+        if (v.tt != s.te - s.ts) return PAFFY_ERR_CHECK_CIGAR_T;
     }
     return 0;
 }
 
 /* float32 quotient widened to double: `((float)a)/(a + b)` of impl/paf.c:832,886,923,937 */
 __device__ __forceinline__ double ratio_f32(int64_t num, int64_t den) {
+    /* both conversions round to nearest even; below 2^32 one v_cvt_f32_u32 each does the same job */
+    if ((((uint64_t)num | (uint64_t)den) >> 32) == 0)
+        return (double)__fdiv_rn(__uint2float_rn((uint32_t)num), __uint2float_rn((uint32_t)den));
     return (double)__fdiv_rn(__ll2float_rn(num), __ll2float_rn(den));
 }
 
 /* matches / mismatches of the whole view: paf_trim_unreliable_ends2(.., 0, 1, -1), impl/paf.c:811-840 */
 template <class OPS>
-__device__ void match_stats(const View<OPS> &v, int64_t &m, int64_t &x, BlockComm &bc) {
-    uint32_t b, e;
-    sweep_bounds(v.n, b, e);
-    int64_t acc[2] = {0, 0};
-    for (uint32_t i = b; i < e; i++) {
-        int64_t len;
-        int op;
-        v.get(i, len, op);
-        if (op == OP_EQ || op == OP_M) acc[0] += len;
-        else acc[1] += len; /* X, I and D all count as mismatches */
-    }
-    block_sum<2>(acc, bc);
-    m = acc[0];
-    x = acc[1];
+__device__ void match_stats(View<OPS> &v, int64_t &m, int64_t &x, BlockComm &bc) {
+    ensure_totals(v, bc);
+    m = v.tm;
+    x = v.tx;
 }
 
 /* paf_trim_unreliable_prefix + paf_trim_upto, impl/paf.c:842-904 (thresholds arrive as float32). */
@@ -392,19 +415,22 @@ __device__ void trim_prefix(RecState &s, View<OPS> &v, float thr_f, float id_f, 
     best = block_min_i64(best, bc);
     int64_t count = best != INT64_MAX ? best : trim_idx + 1;
     if (count <= 0) return;
-    /* paf_trim_upto: advance coordinates over the dropped ops */
-    int64_t d[2] = {0, 0};
+    /* paf_trim_upto: advance coordinates over the dropped ops (and keep the running sums current) */
+    int64_t d[4] = {0, 0, 0, 0};
     for (uint32_t i = b; i < e && (int64_t)i < count; i++) {
         int64_t len;
         int op;
         v.get(i, len, op);
         if (op != OP_I) d[0] += len;
         if (op != OP_D) d[1] += len;
+        if (op == OP_EQ || op == OP_M) d[2] += len;
+        else d[3] += len;
     }
-    block_sum<2>(d, bc);
+    block_sum<4>(d, bc);
     s.ts += d[0];
     if (s.same) s.qs += d[1];
     else s.qe -= d[1];
+    v.tt -= d[0]; v.tq -= d[1]; v.tm -= d[2]; v.tx -= d[3];
     v.drop_front((uint32_t)count);
 }
 
@@ -515,6 +541,7 @@ __device__ int trim_fixed(RecState &s, View<OPS> &v, float pct, BlockComm &bc, S
     if (s.same) s.qe -= dq;
     else s.qs += dq;
     s.te -= dt;
+    v.totals_ok = false;
     return 0;
 }
 
@@ -960,6 +987,11 @@ __device__ int shatter_size(const RecState &s, const View<OPS> &v, const Shatter
     block_excl_scan<2>(c, tot, bc);
     int64_t cq = c[0], ct = c[1], err = INT64_MAX;
     int64_t acc[2] = {0, 0}, acct[2];
+    /* rows of a valid record have coordinates inside [start, end]: when both ends print with the same
+       number of digits every row does, and only the digits of L vary */
+    const uint32_t dqs = dec_len(s.qs), dts = dec_len(s.ts);
+    const bool uniform_digits = s.qs >= 0 && s.ts >= 0 && dqs == (uint32_t)dec_len(s.qe) && dts == (uint32_t)dec_len(s.te);
+    const uint32_t fixed_len = k.row_const + 2 * dqs + 2 * dts;
     for (uint32_t i = b; i < e; i++) {
         int64_t len;
         int op;
@@ -975,7 +1007,7 @@ __device__ int shatter_size(const RecState &s, const View<OPS> &v, const Shatter
             else if (q0 + len > s.qlen) code = PAFFY_ERR_CHECK_QEND;
             else if (t0 < 0 || t0 >= s.tlen) code = PAFFY_ERR_CHECK_TSTART;
             else if (t0 + len > s.tlen) code = PAFFY_ERR_CHECK_TEND;
-            acc[0] += row_len(k, q0, t0, len);
+            acc[0] += (uniform_digits && !code) ? fixed_len + 3 * dec_len(len) : row_len(k, q0, t0, len);
             acc[1] += 1;
         } else if (op != OP_I && op != OP_D) code = PAFFY_ERR_SHATTER_BAD_OP;
         if (code && err == INT64_MAX) err = (int64_t)i * 32 + code;
@@ -1306,7 +1338,7 @@ __device__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t c
     }
     *n_ops_out = n;
     View<OPS> v;
-    v.ops = ops; v.lo = 0; v.n = n; v.rev = false; v.swp = false; v.sub_lo = v.sub_hi = 0;
+    v.reset(ops, n);
     bool swapped = false, shatter = false;
     int32_t si = 0;
     for (; si < P.n_stages; si++) {
@@ -1347,7 +1379,7 @@ __device__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t c
                     n2 = merge_match_runs(v, dst, L.bc, L.sh, &narrow_ok);
                     ops.p = dst.p;
                 }
-                v.ops = ops; v.lo = 0; v.n = n2; v.rev = false; v.swp = false; v.sub_lo = v.sub_hi = 0;
+                v.reset(ops, n2);
             }
             rc = check_record(s, v, L.bc);
         } else if (st.kind == PAFFY_ADD_MISMATCHES) {
@@ -1365,7 +1397,7 @@ __device__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t c
                     if (!rc) {
                         if (blk == ~0ull) return true; /* arena full: repeated by the host */
                         ops.p = P.arena + blk;
-                        v.ops = ops; v.lo = 0; v.n = n2; v.rev = false; v.swp = false; v.sub_lo = v.sub_hi = 0;
+                        v.reset(ops, n2);
                     }
                 }
                 if (!rc) rc = check_record(s, v, L.bc);
@@ -1431,7 +1463,8 @@ __device__ void emit_record(const KParams &P, uint32_t rec, const OPS &ops, cons
     s.has_cigar = (pl.flags & 8u) != 0;
     s.type = (uint8_t)(pl.flags >> 8);
     View<OPS> v;
-    v.ops = ops; v.lo = pl.lo; v.n = pl.n; v.rev = pl.flags & 1u; v.swp = (pl.flags & 2u) != 0;
+    v.reset(ops, pl.n);
+    v.lo = pl.lo; v.rev = pl.flags & 1u; v.swp = (pl.flags & 2u) != 0;
     v.sub_lo = pl.sub_lo; v.sub_hi = pl.sub_hi;
     if (pl.flags & 16u) {
         ShatterConst k;
