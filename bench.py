@@ -41,12 +41,12 @@ def stages_for(pipe, mod):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=150, help="timed batches per GPU (150 x 65536 = the 10M-record stream of cfg3)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=65536, help="records per step per GPU")
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--pipe", default=None, help="override the workload's command pipe, e.g. 'shatter' (experiments only)")
-    ap.add_argument("--cpu-sample", type=int, default=8192, help="records of the stream timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=65536, help="records of the stream timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     args = ap.parse_args()
 
@@ -75,11 +75,13 @@ def main():
     n_batches = args.warmup + args.steps
 
     # ---- synthetic input, generated on the device, resident before the timed region ----
+    from paffy_amd import shard
+
     batches = []
-    for i in range(n_batches):
-        b_global = i * world + rank  # rank r takes every world-th batch of the stream
-        r0 = (b_global * args.batch) % max(1, wl["total"] - args.batch + 1)
-        buf, nbytes = eng.synth(wl["seed"], wl["mean_ops"], r0, args.batch)
+    mine = shard.batches_of_rank(rank, world, n_batches * world * args.batch, args.batch)  # rank r: batches r, r+N, ...
+    for _, first, n in mine:
+        r0 = first % max(1, wl["total"] - args.batch + 1)  # weak scaling: past the end the stream repeats
+        buf, nbytes = eng.synth(wl["seed"], wl["mean_ops"], r0, n)
         batches.append((buf, nbytes, r0))
     torch.cuda.synchronize()
 
@@ -136,7 +138,7 @@ def main():
             per_launch_bytes = (in_bytes + out_bytes) / args.steps
             achieved = per_launch_bytes / (ms / launches * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args, dom),
                         "avg_kernel_ms": round(ms / launches, 4),
                         "algorithmic_bytes_per_launch": int(per_launch_bytes)}
         cpu = None
@@ -169,6 +171,20 @@ def main():
         print(json.dumps(line), flush=True)
     if dist:
         dist.destroy_process_group()
+
+
+def measured_traffic(args, kernel):
+    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (rocprofv3 cannot run
+    inside this process); only reported when they were taken on this workload and batch size."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+        if t.get("workload") == args.workload and t.get("batch") == args.batch and not args.pipe:
+            return t["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(eng, wl, stages, n):

@@ -7,9 +7,9 @@
  *                              nl_idx[] (replaces stFile_getLine + strtok_r, impl/paf.c:144-212)
  *   k_header                   one lane per record: fixed fields and tags (paf_parse, impl/paf.c:137-209)
  *   k_size_lds                 one workgroup per record: cigar -> LDS ops (mirrored to HBM) -> transforms -> exact size + plan
- *   k_record_arena<false>      same for records whose ops do not fit LDS (ops in an HBM arena)
+ *   k_arena_size               same for records whose ops do not fit LDS (ops in an HBM arena)
  *   k_scan_records             exclusive prefix sum of the sizes up to the first failing record
- *   k_emit_lds / k_record_arena<true>   the lines: each wave formats its share of the record through its own
+ *   k_emit_lds<rows|line> / k_arena_emit   the lines: each wave formats its share of the record through its own
  *                              LDS ring and flushes 16-byte coalesced stores
  */
 #include <hip/hip_runtime.h>
@@ -485,9 +485,11 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
     /* the record kernels use more than the default 64 KiB of LDS */
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile), hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emit_lds), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_EMIT_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_record_arena<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_record_arena<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_EMIT_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emit_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_EMIT_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emit_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_EMIT_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_arena_size), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_arena_emit<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_EMIT_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_arena_emit<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_EMIT_LDS_BYTES);
     *out = c;
     return 0;
 }
@@ -639,7 +641,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             kp.ops_cap = PAFFY_OPS_CAP_BIG;
             kp.from_list = 1;
             LAUNCH(c, "k_size_lds<big>", k_size_lds, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), kp);
-            LAUNCH(c, "k_record_arena<size>", k_record_arena<false>, dim3(512), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
+            LAUNCH(c, "k_arena_size", k_arena_size, dim3(512), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             if (fetch_info(c)) return PAFFY_E_HIP;
             if (c->h_info->arena_used <= kp.arena_cap) break;
             /* arena too small: grow to the demand seen so far and redo the sizing pass */
@@ -862,9 +864,14 @@ int paffy_hip_emit(paffy_hip_ctx *c, void *d_out, int64_t out_cap) {
     }
     KParams kp = c->kp;
     kp.out = static_cast<uint8_t *>(d_out);
-    LAUNCH(c, "k_emit_lds", k_emit_lds, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
-    if (c->h_info->w_count > 0)
-        LAUNCH(c, "k_record_arena<emit>", k_record_arena<true>, dim3(512), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
+    const bool shatter = kp.n_stages > 0 && kp.stages[kp.n_stages - 1].kind == PAFFY_SHATTER;
+    if (shatter) {
+        LAUNCH(c, "k_emit_lds", k_emit_lds<true>, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
+        if (c->h_info->w_count > 0) LAUNCH(c, "k_arena_emit", k_arena_emit<true>, dim3(512), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
+    } else {
+        LAUNCH(c, "k_emit_lds<line>", k_emit_lds<false>, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
+        if (c->h_info->w_count > 0) LAUNCH(c, "k_arena_emit<line>", k_arena_emit<false>, dim3(512), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
+    }
     return 0;
 }
 

@@ -1451,11 +1451,16 @@ __device__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t c
     return true;
 }
 
-/* Emit pass: the record is known to be valid; resume from its RecPlan with the ops in HBM. */
-template <class OPS>
+/*
+ * Emit pass: the record is known to be valid; resume from its RecPlan with the ops in HBM.
+ * SHATTER selects the terminal at compile time (the host knows the pipe), so the row kernel
+ * carries none of the whole-line writer and vice versa.
+ */
+template <class OPS, bool SHATTER>
 __device__ void emit_record(const KParams &P, uint32_t rec, const OPS &ops, const RecLds &L) {
-    const RecMeta m = P.meta[rec];
-    const RecPlan pl = static_cast<const RecPlan *>(P.rec_plan)[rec];
+    /* by reference: a by-value copy of these structs (indexed per wave below) would live in scratch memory */
+    const RecMeta &m = P.meta[rec];
+    const RecPlan &pl = static_cast<const RecPlan *>(P.rec_plan)[rec];
     RecState s;
     load_state(m, s);
     if (pl.flags & 4u) invert_state(s);
@@ -1466,7 +1471,7 @@ __device__ void emit_record(const KParams &P, uint32_t rec, const OPS &ops, cons
     v.reset(ops, pl.n);
     v.lo = pl.lo; v.rev = pl.flags & 1u; v.swp = (pl.flags & 2u) != 0;
     v.sub_lo = pl.sub_lo; v.sub_hi = pl.sub_hi;
-    if (pl.flags & 16u) {
+    if constexpr (SHATTER) {
         ShatterConst k;
         shatter_consts(s, k);
         uint64_t *A = L.pieces, *B = L.pieces + PAFFY_TMPL_MAX / 8, *C = L.pieces + 2 * (PAFFY_TMPL_MAX / 8);
@@ -1582,6 +1587,7 @@ __global__ __launch_bounds__(PAFFY_NT, 4) void k_size_lds(KParams P) {
 #ifndef PAFFY_EMIT_OCC
 #define PAFFY_EMIT_OCC 3
 #endif
+template <bool SHATTER>
 __global__ __launch_bounds__(PAFFY_NT, PAFFY_EMIT_OCC) void k_emit_lds(KParams P) {
     extern __shared__ uint4 smem4[];
     RecLds L = carve_emit_lds(reinterpret_cast<uint8_t *>(smem4));
@@ -1589,40 +1595,46 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_EMIT_OCC) void k_emit_lds(KParams P
     if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return; /* nothing at or after the first failure */
     if ((P.status[rec] >> 16) != KLASS_LDS) return;
     OpsGlobal ops{P.ops_mirror + mirror_index(P.meta[rec])};
-    emit_record<OpsGlobal>(P, rec, ops, L);
+    emit_record<OpsGlobal, SHATTER>(P, rec, ops, L);
 }
 
 /* Arena class: records whose ops do not fit LDS; persistent workgroups walk the list. */
-template <bool EMIT>
-__global__ __launch_bounds__(PAFFY_NT) void k_record_arena(KParams P) {
+__global__ __launch_bounds__(PAFFY_NT) void k_arena_size(KParams P) {
     extern __shared__ uint4 smem4[];
     uint32_t *ops_lds;
-    RecLds L = EMIT ? carve_emit_lds(reinterpret_cast<uint8_t *>(smem4)) : carve_size_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds);
+    RecLds L = carve_size_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds);
+    const uint32_t count = P.info->w_count;
+    for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
+        const uint32_t rec = P.w_list[li];
+        /* upper bound for the allocation: one op per cigar byte */
+        const uint32_t cg_len = P.meta[rec].cg_len;
+        if (threadIdx.x == 0) L.sh->bcast[3] = (int64_t)atomicAdd(&P.info->arena_used, (unsigned long long)cg_len);
+        __syncthreads();
+        const uint64_t off = (uint64_t)L.sh->bcast[3];
+        __syncthreads();
+        if (off + cg_len <= P.arena_cap) {
+            OpsArena ops{P.arena + off};
+            uint32_t n_ops = 0;
+            size_record<OpsArena>(P, rec, ops, cg_len, L, KLASS_ARENA, &n_ops);
+            if (threadIdx.x == 0) {
+                P.n_ops[rec] = n_ops;
+                P.arena_off[rec] = (uint64_t)(ops.p - P.arena); /* a stage may have moved the ops to a new block */
+            }
+        }
+        __syncthreads();
+    }
+}
+template <bool SHATTER>
+__global__ __launch_bounds__(PAFFY_NT) void k_arena_emit(KParams P) {
+    extern __shared__ uint4 smem4[];
+    RecLds L = carve_emit_lds(reinterpret_cast<uint8_t *>(smem4));
     const uint32_t count = P.info->w_count;
     const uint32_t first_err = (uint32_t)(P.info->first_err_key >> 16);
     for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
         const uint32_t rec = P.w_list[li];
-        if (EMIT) {
-            if (rec < first_err && (P.status[rec] & 0xff) == 0) {
-                OpsArena ops{P.arena + P.arena_off[rec]};
-                emit_record<OpsArena>(P, rec, ops, L);
-            }
-        } else {
-            /* upper bound for the allocation: one op per cigar byte */
-            const uint32_t cg_len = P.meta[rec].cg_len;
-            if (threadIdx.x == 0) L.sh->bcast[3] = (int64_t)atomicAdd(&P.info->arena_used, (unsigned long long)cg_len);
-            __syncthreads();
-            const uint64_t off = (uint64_t)L.sh->bcast[3];
-            __syncthreads();
-            if (off + cg_len <= P.arena_cap) {
-                OpsArena ops{P.arena + off};
-                uint32_t n_ops = 0;
-                size_record<OpsArena>(P, rec, ops, cg_len, L, KLASS_ARENA, &n_ops);
-                if (threadIdx.x == 0) {
-                    P.n_ops[rec] = n_ops;
-                    P.arena_off[rec] = (uint64_t)(ops.p - P.arena); /* a stage may have moved the ops to a new block */
-                }
-            }
+        if (rec < first_err && (P.status[rec] & 0xff) == 0) {
+            OpsArena ops{P.arena + P.arena_off[rec]};
+            emit_record<OpsArena, SHATTER>(P, rec, ops, L);
         }
         __syncthreads();
     }
