@@ -841,27 +841,31 @@ struct Emitter {
         if (GROUP == 64) __builtin_amdgcn_wave_barrier();
         else __syncthreads();
     }
+    __device__ __forceinline__ void store_chunk(uint64_t c, const uint4 &v, uint64_t hi) {
+        if (c >= begin && c + 16 <= hi) {
+            *reinterpret_cast<uint4 *>(out + c) = v;
+        } else {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int b = 0; b < 16; b++)
+                if (c + b >= begin && c + b < hi) out[c + b] = (uint8_t)(w[b >> 2] >> ((b & 3) * 8));
+        }
+    }
     /* store ring chunks [flushed, to) to HBM; bytes outside [begin, hi) are not ours */
     __device__ __forceinline__ void flush_to(uint64_t to, uint64_t hi) {
         const uint32_t li = threadIdx.x & (GROUP - 1);
         const uint32_t nch = (uint32_t)((to - flushed) >> 4);
-        for (uint32_t ch = li; ch < nch; ch += GROUP) {
-            uint32_t ri = flushed_r + 16 * ch;
+        for (uint32_t ch = li; ch < nch; ch += 2 * GROUP) { /* two chunks per step: both LDS reads fly before the stores */
+            const uint32_t ch2 = ch + GROUP;
+            uint32_t ri = flushed_r + 16 * ch, ri2 = flushed_r + 16 * ch2;
             if (ri >= R) ri -= R;
-            const uint64_t c = flushed + 16ull * ch;
+            if (ri2 >= R) ri2 -= R;
+            const bool two = ch2 < nch;
             uint4 v = *reinterpret_cast<const uint4 *>(ring + ri);
-            if (c >= begin && c + 16 <= hi) {
-#if !defined(PAFFY_ABL) || PAFFY_ABL != 1
-                *reinterpret_cast<uint4 *>(out + c) = v;
-#else
-                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-#endif
-            } else {
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int b = 0; b < 16; b++)
-                    if (c + b >= begin && c + b < hi) out[c + b] = (uint8_t)(w[b >> 2] >> ((b & 3) * 8));
-            }
+            uint4 v2 = make_uint4(0, 0, 0, 0);
+            if (two) v2 = *reinterpret_cast<const uint4 *>(ring + ri2);
+            store_chunk(flushed + 16ull * ch, v, hi);
+            if (two) store_chunk(flushed + 16ull * ch2, v2, hi);
         }
         uint32_t adv = flushed_r + 16 * nch;
         flushed_r = adv >= R ? adv - R : adv;
@@ -1585,7 +1589,7 @@ __global__ __launch_bounds__(PAFFY_NT, 4) void k_size_lds(KParams P) {
 
 /* Emit, LDS class. */
 #ifndef PAFFY_EMIT_OCC
-#define PAFFY_EMIT_OCC 3
+#define PAFFY_EMIT_OCC 4
 #endif
 template <bool SHATTER>
 __global__ __launch_bounds__(PAFFY_NT, PAFFY_EMIT_OCC) void k_emit_lds(KParams P) {
