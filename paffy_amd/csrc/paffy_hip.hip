@@ -150,7 +150,7 @@ __device__ int64_t parse_i64_dev(const uint8_t *in, uint32_t p, uint32_t e) {
  * recognised (documented deviation: the reference reads past the token there).
  */
 __global__ __launch_bounds__(PAFFY_NT) void k_header(const uint8_t *in, const uint32_t *sep_pos, const uint32_t *nl_idx, uint32_t n_lines,
-                                                      RecMeta *meta) {
+                                                      RecMeta *meta, uint32_t *big_list, DevInfo *info) {
     const uint32_t r = blockIdx.x * PAFFY_NT + threadIdx.x;
     if (r >= n_lines) return;
     const uint32_t s_end = nl_idx[r];
@@ -217,6 +217,8 @@ __global__ __launch_bounds__(PAFFY_NT) void k_header(const uint8_t *in, const ui
     }
     if (m.err == 0 && field < 12) m.err = PAFFY_ERR_FEW_FIELDS;
     meta[r] = m;
+    /* long cigars go straight to the sizing launch with the bigger LDS store (runs beside the main one) */
+    if (m.err == 0 && (m.cg_len >> 1) > PAFFY_OPS_CAP) big_list[atomicAdd(&info->b_count[0], 1u)] = r;
 }
 
 /* ------------------------------------------------------------------ */
@@ -391,8 +393,10 @@ struct ProfEntry {
 
 struct paffy_hip_ctx {
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr; /* sizing launches of the long-cigar records run here, beside the main launch */
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string last_error;
-    DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, b_list, arena, info, synth_sizes, rec_plan, ops_mirror, seq_blob, seq_table, seq_names, seq_name_off, rec_qseq, rec_tseq;
+    DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, b_list, b_list1, arena, info, synth_sizes, rec_plan, ops_mirror, seq_blob, seq_table, seq_names, seq_name_off, rec_qseq, rec_tseq;
     int32_t n_seqs = 0;
     DevBuf tile_keys, tile_order, tile_rank, tile_coff, tile_cbase, tile_cov, tile_level, tile_len;
     bool plan_is_tile = false;
@@ -482,6 +486,9 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
         delete c;
         return PAFFY_E_HIP;
     }
+    (void)hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     /* the record kernels use more than the default 64 KiB of LDS */
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile), hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
@@ -498,12 +505,15 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     if (!c) return;
     prof_collect(c);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
-                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off,
+                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
                       &c->tile_cov, &c->tile_level, &c->tile_len};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_info) (void)hipHostFree(c->h_info);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     delete c;
 }
 
@@ -540,6 +550,7 @@ static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, ui
     if (ensure(c, c->sep_pos, sizeof(uint32_t) * (size_t)(n_seps + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->nl_idx, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->meta, sizeof(RecMeta) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->b_list, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->out_len, sizeof(int64_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->out_rows, sizeof(int64_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->out_off, sizeof(int64_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
@@ -549,6 +560,7 @@ static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, ui
     if (ensure(c, c->arena_off, sizeof(uint64_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->w_list, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->b_list, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->b_list1, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->rec_plan, sizeof(RecPlan) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->ops_mirror, sizeof(uint32_t) * ((size_t)len / 2 + 64))) return PAFFY_E_HIP;
     if (c->arena.cap == 0 && ensure(c, c->arena, (size_t)8 << 20)) return PAFFY_E_HIP;
@@ -558,7 +570,7 @@ static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, ui
     if (n_lines > 0)
         LAUNCH(c, "k_header", k_header, dim3((n_lines + PAFFY_NT - 1) / PAFFY_NT), dim3(PAFFY_NT), 0, in,
                static_cast<const uint32_t *>(c->sep_pos.p), static_cast<const uint32_t *>(c->nl_idx.p), n_lines,
-               static_cast<RecMeta *>(c->meta.p));
+               static_cast<RecMeta *>(c->meta.p), static_cast<uint32_t *>(c->b_list.p), static_cast<DevInfo *>(c->info.p));
 
     return 0;
 }
@@ -628,19 +640,35 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     }
     kp.out_off = static_cast<const int64_t *>(c->out_off.p);
     kp.w_list = static_cast<uint32_t *>(c->w_list.p);
-    kp.b_list = static_cast<uint32_t *>(c->b_list.p);
+    kp.b_list[0] = static_cast<uint32_t *>(c->b_list.p);
+    kp.b_list[1] = static_cast<uint32_t *>(c->b_list1.p);
     kp.info = static_cast<DevInfo *>(c->info.p);
 
     if (n_lines > 0) {
         for (int attempt = 0; attempt < 3; attempt++) {
             kp.arena = static_cast<uint64_t *>(c->arena.p);
             kp.arena_cap = c->arena.cap / 8;
+            /* fork: levels 1 and 2 (long cigars, queued by k_header) on the side stream, level 0 on the main one */
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+            {
+                KParams k1 = kp;
+                k1.ops_cap = PAFFY_OPS_CAP_MID;
+                k1.next_cap = PAFFY_OPS_CAP_BIG;
+                k1.level = 1;
+                hipLaunchKernelGGL(k_size_lds, dim3(768), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_MID), c->side, k1);
+                k1.ops_cap = PAFFY_OPS_CAP_BIG;
+                k1.next_cap = 0;
+                k1.level = 2;
+                hipLaunchKernelGGL(k_size_lds, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), c->side, k1);
+                HIPCHK(c, hipGetLastError());
+                HIPCHK(c, hipEventRecord(c->ev_join, c->side));
+            }
             kp.ops_cap = PAFFY_OPS_CAP;
-            kp.from_list = 0;
+            kp.next_cap = 0;
+            kp.level = 0;
             LAUNCH(c, "k_size_lds", k_size_lds, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
-            kp.ops_cap = PAFFY_OPS_CAP_BIG;
-            kp.from_list = 1;
-            LAUNCH(c, "k_size_lds<big>", k_size_lds, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), kp);
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); /* join */
             LAUNCH(c, "k_arena_size", k_arena_size, dim3(512), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             if (fetch_info(c)) return PAFFY_E_HIP;
             if (c->h_info->arena_used <= kp.arena_cap) break;
@@ -650,7 +678,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             DevInfo z = *c->h_info;
             z.arena_used = 0;
             z.w_count = 0;
-            z.b_count = 0;
+            z.b_count[1] = 0; /* b_count[0] was filled by k_header and stays */
             z.first_err_key = ~0ull;
             HIPCHK(c, hipMemcpyAsync(c->info.p, &z, sizeof(z), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));

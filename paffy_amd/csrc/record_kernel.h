@@ -1520,7 +1520,8 @@ __device__ void emit_record(const KParams &P, uint32_t rec, const OPS &ops, cons
 /* LDS budgets: both kernels fit four workgroups per CU (160 KiB). */
 #define PAFFY_SIZE_LDS_BYTES_FOR(cap) ((cap) * 4 + (PAFFY_HALO + PAFFY_NT * 16) + 64 * 8 + 64)
 #define PAFFY_SIZE_LDS_BYTES PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP)
-#define PAFFY_OPS_CAP_BIG 36864u /* big-LDS sizing class: 144 KiB of ops, one workgroup per CU */
+#define PAFFY_OPS_CAP_MID 12288u /* second sizing level: 48 KiB of ops, three workgroups per CU */
+#define PAFFY_OPS_CAP_BIG 36864u /* third sizing level: 144 KiB of ops, one workgroup per CU */
 #define PAFFY_EMIT_LDS_BYTES (PAFFY_NWAVE * PAFFY_WAVE_RING + 3 * PAFFY_TMPL_MAX + 64 * 8 + 64)
 
 __device__ __forceinline__ RecLds carve_size_lds(uint8_t *smem, uint32_t **ops_lds, uint32_t cap = PAFFY_OPS_CAP) {
@@ -1549,9 +1550,9 @@ __device__ __forceinline__ uint32_t mirror_index(const RecMeta &m) { return m.cg
 
 /*
  * Sizing, LDS class: one workgroup per record, ops parsed from the text into LDS (and mirrored).
- * Launched twice: over the whole batch with the standard store (4 workgroups per CU), then over
- * the records that did not fit with the big store (P.from_list, one workgroup per CU). What
- * still does not fit (lengths >= 2^29, rebuilt op arrays) goes to the arena kernel.
+ * Launched three times with growing LDS stores: the whole batch with 8192 ops (4 workgroups per
+ * CU), what did not fit with 12288 ops (3 per CU), then with 36864 ops (1 per CU). What still does
+ * not fit (lengths >= 2^29, rebuilt op arrays) goes to the arena kernel.
  */
 __device__ __forceinline__ void size_lds_one(const KParams &P, uint32_t rec, uint32_t *ops_lds, const RecLds &L) {
     const RecMeta &m = P.meta[rec];
@@ -1562,10 +1563,10 @@ __device__ __forceinline__ void size_lds_one(const KParams &P, uint32_t rec, uin
     if (!ok && threadIdx.x == 0) {
         P.out_len[rec] = 0;
         P.out_rows[rec] = 0;
-        /* too many ops for the standard store only: try the big store; anything else needs the arena */
-        const bool try_big = !P.from_list && n_ops > P.ops_cap && n_ops <= PAFFY_OPS_CAP_BIG && n_ops <= ((m.cg_len + 1) >> 1);
-        if (try_big) {
-            P.b_list[atomicAdd(&P.info->b_count, 1u)] = rec;
+        /* too many ops for this level's store only: try the next, bigger store; anything else needs the arena */
+        const bool try_next = P.next_cap != 0 && n_ops > P.ops_cap && n_ops <= PAFFY_OPS_CAP_BIG && n_ops <= ((m.cg_len + 1) >> 1);
+        if (try_next) {
+            P.b_list[P.level][atomicAdd(&P.info->b_count[P.level], 1u)] = rec;
         } else {
             P.status[rec] = (uint32_t)KLASS_ARENA << 16;
             P.w_list[atomicAdd(&P.info->w_count, 1u)] = rec;
@@ -1576,12 +1577,14 @@ __global__ __launch_bounds__(PAFFY_NT, 4) void k_size_lds(KParams P) {
     extern __shared__ uint4 smem4[];
     uint32_t *ops_lds;
     RecLds L = carve_size_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds, P.ops_cap);
-    if (!P.from_list) {
+    if (P.level == 0) {
+        /* records whose cigar text promises more ops than this store holds were queued for level 1 by k_header */
+        if ((P.meta[blockIdx.x].cg_len >> 1) > PAFFY_OPS_CAP && P.meta[blockIdx.x].err == 0) return;
         size_lds_one(P, blockIdx.x, ops_lds, L);
     } else {
-        const uint32_t count = P.info->b_count;
+        const uint32_t count = P.info->b_count[P.level - 1];
         for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
-            size_lds_one(P, P.b_list[li], ops_lds, L);
+            size_lds_one(P, P.b_list[P.level - 1][li], ops_lds, L);
             __syncthreads();
         }
     }

@@ -47,7 +47,7 @@ struct DevInfo {
     unsigned long long out_bytes, out_rows;
     uint32_t n_seps, n_lines;
     uint32_t w_count;   /* records routed to the arena kernel */
-    uint32_t b_count;   /* records routed to the big-LDS sizing launch */
+    uint32_t b_count[2]; /* records routed to the next (bigger LDS store) sizing launch, per level */
     uint32_t internal;  /* internal-limit flags (must stay 0) */
 };
 
@@ -79,9 +79,10 @@ struct KParams {
     uint64_t *arena;
     uint64_t arena_cap; /* in ops */
     uint32_t *w_list;
-    uint32_t *b_list;   /* records that did not fit the standard LDS op store */
-    uint32_t ops_cap;   /* 4-byte ops the sizing workgroup's LDS store holds */
-    uint32_t from_list; /* sizing launch walks b_list instead of the whole batch */
+    uint32_t *b_list[2]; /* records that did not fit the LDS op store of level 0 / level 1 */
+    uint32_t ops_cap;    /* 4-byte ops the sizing workgroup's LDS store holds */
+    uint32_t next_cap;   /* store of the next level (0: none, overflow goes to the arena) */
+    uint32_t level;      /* 0: whole batch; 1, 2: walk b_list[level - 1] */
     DevInfo *info;
 };
 
