@@ -178,8 +178,8 @@ __device__ __forceinline__ void sweep_bounds(uint32_t n, uint32_t &b, uint32_t &
  * holding a character outside MID=X, or cg_off+cg_len for a trailing digit run.
  */
 template <class OPS>
-__device__ uint32_t parse_cigar(const uint8_t *in, uint32_t cg_off, uint32_t cg_len, const OPS &ops, uint32_t cap, uint8_t *txt,
-                                BlockComm &bc, Shared *sh, bool *fits, uint32_t *err_pos) {
+__device__ __forceinline__ uint32_t parse_cigar(const uint8_t *in, uint32_t cg_off, uint32_t cg_len, const OPS &ops, uint32_t cap, uint8_t *txt,
+                                BlockComm &bc, Shared *sh, bool *fits, uint32_t *err_pos, int64_t (&sums)[4]) {
     const uint32_t tid = threadIdx.x;
     const uint32_t end = cg_off + cg_len;
     const uint32_t a0 = cg_off & ~15u;
@@ -188,6 +188,7 @@ __device__ uint32_t parse_cigar(const uint8_t *in, uint32_t cg_off, uint32_t cg_
         sh->flags = 0;
     }
     uint32_t n = 0;
+    int64_t acc_m = 0, acc_x = 0, acc_q = 0, acc_t = 0; /* this lane's share of the view totals (tm, tx, tq, tt) */
     for (uint32_t tb = a0; tb < end; tb += PAFFY_NT * 16) {
         uint4 h = make_uint4(0, 0, 0, 0);
         if (tb != a0 && tid < 2) h = reinterpret_cast<uint4 *>(txt + PAFFY_HALO + PAFFY_NT * 16 - 32)[tid];
@@ -228,20 +229,39 @@ __device__ uint32_t parse_cigar(const uint8_t *in, uint32_t cg_off, uint32_t cg_
             uint32_t lim = avail < reach ? avail : reach;
             uint64_t len = 0, pw = 1;
             uint32_t k = 0;
-            for (; k < lim; k++) {
+            bool ended = false; /* a non-digit (the previous op letter) closed the run */
+            if (lim >= 4) { /* usual case: the four bytes before the letter in one go (independent LDS reads) */
+                uint32_t d0 = (uint32_t)txt[p] - '0', d1 = (uint32_t)txt[p - 1] - '0', d2 = (uint32_t)txt[p - 2] - '0',
+                         d3 = (uint32_t)txt[p - 3] - '0';
+                if (d0 > 9u) { ended = true; }
+                else if (d1 > 9u) { len = d0; k = 1; ended = true; }
+                else if (d2 > 9u) { len = d0 + 10 * d1; k = 2; ended = true; }
+                else if (d3 > 9u) { len = d0 + 10 * d1 + 100 * d2; k = 3; ended = true; }
+                else { len = d0 + 10 * d1 + 100 * d2 + 1000 * d3; k = 4; pw = 10000; }
+            }
+            for (; !ended && k < lim; k++) {
                 uint32_t d = (uint32_t)txt[p - (int)k] - '0';
-                if (d > 9u) break;
+                if (d > 9u) {
+                    ended = true;
+                    break;
+                }
                 len += d * pw;
                 pw *= 10;
             }
-            if (k == lim && lim < avail) atomicOr(&sh->flags, INTERNAL_DIGIT_RUN); /* run longer than the halo */
+            if (!ended && lim < avail) atomicOr(&sh->flags, INTERNAL_DIGIT_RUN); /* run longer than the halo */
             int64_t l56 = (int64_t)(len << 8) >> 8;
             if (OPS::kNarrow && (l56 < 0 || l56 >= (1ll << 29))) atomicOr(&sh->flags, 0x100u);
             if (idx < cap) ops.set(idx, l56, code);
             idx++;
+            if (code == OP_M || code == OP_EQ) acc_m += l56;
+            else acc_x += l56;
+            if (code != OP_D) acc_q += l56;
+            if (code != OP_I) acc_t += l56;
         }
         n += (uint32_t)tot[0];
     }
+    sums[0] = acc_m; sums[1] = acc_x; sums[2] = acc_q; sums[3] = acc_t;
+    block_sum<4>(sums, bc);
     __syncthreads();
     *err_pos = sh->err_pos;
     uint32_t fl = sh->flags;
@@ -252,7 +272,7 @@ __device__ uint32_t parse_cigar(const uint8_t *in, uint32_t cg_off, uint32_t cg_
 
 /* Sequential fallback for digit runs longer than the LDS halo (leading zeros etc.). */
 template <class OPS>
-__device__ uint32_t parse_cigar_serial(const uint8_t *in, uint32_t cg_off, uint32_t cg_len, const OPS &ops, uint32_t cap, Shared *sh,
+__device__ __forceinline__ uint32_t parse_cigar_serial(const uint8_t *in, uint32_t cg_off, uint32_t cg_len, const OPS &ops, uint32_t cap, Shared *sh,
                                        bool *fits, uint32_t *err_pos) {
     if (threadIdx.x == 0) {
         uint32_t n = 0, ep = 0xffffffffu, wide = 0;
@@ -306,7 +326,7 @@ __device__ __forceinline__ void invert_view(const RecState &s, View<OPS> &v) { /
 
 /* one sweep that (re)establishes the running sums of the view */
 template <class OPS>
-__device__ void ensure_totals(View<OPS> &v, BlockComm &bc) {
+__device__ __forceinline__ void ensure_totals(View<OPS> &v, BlockComm &bc) {
     if (v.totals_ok) return;
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
@@ -327,7 +347,7 @@ __device__ void ensure_totals(View<OPS> &v, BlockComm &bc) {
 
 /* paf_check, impl/paf.c:427-461. Returns 0 or the PAFFY_ERR_CHECK_* code. */
 template <class OPS>
-__device__ int check_record(const RecState &s, View<OPS> &v, BlockComm &bc) {
+__device__ __forceinline__ int check_record(const RecState &s, View<OPS> &v, BlockComm &bc) {
     if (s.qs < 0 || s.qs >= s.qlen) return PAFFY_ERR_CHECK_QSTART;
     if (s.qs > s.qe || s.qe > s.qlen) return PAFFY_ERR_CHECK_QEND;
     if (s.ts < 0 || s.ts >= s.tlen) return PAFFY_ERR_CHECK_TSTART;
@@ -350,7 +370,7 @@ __device__ __forceinline__ double ratio_f32(int64_t num, int64_t den) {
 
 /* matches / mismatches of the whole view: paf_trim_unreliable_ends2(.., 0, 1, -1), impl/paf.c:811-840 */
 template <class OPS>
-__device__ void match_stats(View<OPS> &v, int64_t &m, int64_t &x, BlockComm &bc) {
+__device__ __forceinline__ void match_stats(View<OPS> &v, int64_t &m, int64_t &x, BlockComm &bc) {
     ensure_totals(v, bc);
     m = v.tm;
     x = v.tx;
@@ -358,7 +378,7 @@ __device__ void match_stats(View<OPS> &v, int64_t &m, int64_t &x, BlockComm &bc)
 
 /* paf_trim_unreliable_prefix + paf_trim_upto, impl/paf.c:842-904 (thresholds arrive as float32). */
 template <class OPS>
-__device__ void trim_prefix(RecState &s, View<OPS> &v, float thr_f, float id_f, int64_t max_trim, BlockComm &bc, Shared *sh) {
+__device__ __forceinline__ void trim_prefix(RecState &s, View<OPS> &v, float thr_f, float id_f, int64_t max_trim, BlockComm &bc, Shared *sh) {
     const double thr = (double)thr_f, idd = (double)id_f;
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
@@ -436,19 +456,30 @@ __device__ void trim_prefix(RecState &s, View<OPS> &v, float thr_f, float id_f, 
 
 /* paf_trim_unreliable_tails, impl/paf.c:906-953. Returns 0 or PAFFY_ERR_TRIM_IDENTITY_ASSERT. */
 template <class OPS>
-__device__ int trim_identity(RecState &s, View<OPS> &v, float score_fraction, float max_fraction, BlockComm &bc, Shared *sh) {
+__device__ __forceinline__ int trim_identity(RecState &s, View<OPS> &v, float score_fraction, float max_fraction, BlockComm &bc, Shared *sh) {
     int64_t m, x;
     match_stats(v, m, x, bc);
     const double identity = ratio_f32(m, m + x);
     const double thr = __dsub_rn(identity, __dmul_rn(identity, (double)score_fraction));
     const int64_t max_trim = __float2ll_rz(__fmul_rn(__ll2float_rn(m + x), max_fraction));
     const float thr_f = __double2float_rn(thr), id_f = __double2float_rn(identity);
-    trim_prefix(s, v, thr_f, id_f, max_trim, bc, sh);
-    invert_state(s);
-    invert_view(s, v);
-    trim_prefix(s, v, thr_f, id_f, max_trim, bc, sh);
-    invert_state(s);
-    invert_view(s, v);
+    /* paf_invert only reverses the cigar of '-' records (impl/paf.c:487): for a '+' record the second
+       pass scans the very same op sequence with the same thresholds, so when the first pass removed
+       nothing the second one cannot either */
+    const uint32_t n_before = v.n;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) {
+            if (s.same && v.n == n_before) break;
+            invert_state(s);
+            invert_view(s, v);
+        }
+        trim_prefix(s, v, thr_f, id_f, max_trim, bc, sh);
+        if (pass == 1) {
+            invert_state(s);
+            invert_view(s, v);
+        }
+    }
     int64_t m2, x2;
     match_stats(v, m2, x2, bc);
     const double final_identity = ratio_f32(m2, m2 + x2);
@@ -463,7 +494,7 @@ __device__ __forceinline__ bool is_aligned_op(int op) { return op == OP_M || op 
  * `end` aligned bases are gone; the op that crosses `end` is shortened. dq/dt: bases consumed.
  */
 template <class OPS>
-__device__ void trim_front_fixed(View<OPS> &v, int64_t end, int64_t &dq, int64_t &dt, BlockComm &bc, Shared *sh) {
+__device__ __forceinline__ void trim_front_fixed(View<OPS> &v, int64_t end, int64_t &dq, int64_t &dt, BlockComm &bc, Shared *sh) {
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
     int64_t c[1] = {0}, tot[1];
@@ -516,7 +547,7 @@ __device__ void trim_front_fixed(View<OPS> &v, int64_t end, int64_t &dq, int64_t
 
 /* paf_trim_end_fraction + paf_trim_ends, impl/paf.c:578-598. */
 template <class OPS>
-__device__ int trim_fixed(RecState &s, View<OPS> &v, float pct, BlockComm &bc, Shared *sh) {
+__device__ __forceinline__ int trim_fixed(RecState &s, View<OPS> &v, float pct, BlockComm &bc, Shared *sh) {
     if (!(pct >= 0.0f && pct <= 1.0f)) return PAFFY_ERR_TRIM_FIXED_ASSERT;
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
@@ -564,7 +595,7 @@ struct MirrorDst { /* 4-byte ops into the HBM mirror of an LDS-class record */
  * *narrow_ok is cleared when a merged length does not fit a 4-byte op.
  */
 template <class OPS, class DST>
-__device__ uint32_t merge_match_runs(const View<OPS> &v, const DST &dst, BlockComm &bc, Shared *sh, bool *narrow_ok) {
+__device__ __forceinline__ uint32_t merge_match_runs(const View<OPS> &v, const DST &dst, BlockComm &bc, Shared *sh, bool *narrow_ok) {
     if (threadIdx.x == 0) sh->flags = 0;
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
@@ -640,7 +671,7 @@ __device__ __forceinline__ uint32_t up_base(uint32_t c) { return (c >= 'a' && c 
  * Returns 0 or PAFFY_ERR_SEQ_RANGE; *n_out = new op count; *blk = arena offset (UINT64_MAX: no room).
  */
 template <class OPS>
-__device__ int encode_mismatch_runs(const KParams &P, const RecState &s, const View<OPS> &v, const uint8_t *Q, int64_t qseq_len,
+__device__ __forceinline__ int encode_mismatch_runs(const KParams &P, const RecState &s, const View<OPS> &v, const uint8_t *Q, int64_t qseq_len,
                                     const uint8_t *T, int64_t tseq_len, BlockComm &bc, Shared *sh, uint32_t *n_out, uint64_t *blk) {
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
@@ -976,10 +1007,48 @@ __device__ __forceinline__ void put_row(SINK &w, const RowPieces &t, const Shatt
  * `chunk` ops, so wave w owns [64*w*chunk, 64*(w+1)*chunk)).
  */
 template <class OPS>
-__device__ int shatter_size(const RecState &s, const View<OPS> &v, const ShatterConst &k, int64_t &bytes, int64_t &rows,
-                            RecPlan *plan_out, BlockComm &bc) {
+__device__ __forceinline__ int shatter_size(const RecState &s, const View<OPS> &v, const ShatterConst &k, int64_t &bytes, int64_t &rows,
+                            RecPlan *plan_out, bool checked, BlockComm &bc) {
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
+    {
+        /*
+         * One-sweep path. After a passed paf_check (coordinates inside the sequences, cigar sums equal
+         * to the spans) every child block of a cigar with lengths >= 1 and ops in {M, I, D} lies inside
+         * [start, end], so the child checks and the final asserts of paf_shatter cannot fail; and when
+         * start and end print with the same number of digits a row's size depends on L only.
+         */
+        const uint32_t dq0 = dec_len(s.qs), dt0 = dec_len(s.ts);
+        if (checked && dq0 == (uint32_t)dec_len(s.qe) && dt0 == (uint32_t)dec_len(s.te)) {
+            const uint32_t fixed = k.row_const + 2 * dq0 + 2 * dt0;
+            int64_t a[4] = {0, 0, 0, 0}, at[4], err = INT64_MAX;
+            for (uint32_t i = b; i < e; i++) {
+                int64_t len;
+                int op;
+                v.get(i, len, op);
+                int code = 0;
+                if (!(len >= 1)) code = PAFFY_ERR_SHATTER_ZERO_LEN;
+                else if (op == OP_M) {
+                    a[2] += fixed + 3 * dec_len(len);
+                    a[3] += 1;
+                } else if (op != OP_I && op != OP_D) code = PAFFY_ERR_SHATTER_BAD_OP;
+                if (code && err == INT64_MAX) err = (int64_t)i * 32 + code;
+                if (op != OP_D) a[0] += len;
+                if (op != OP_I) a[1] += len;
+            }
+            err = block_min_i64(err, bc);
+            block_excl_scan<4>(a, at, bc);
+            bytes = at[2];
+            rows = at[3];
+            if ((threadIdx.x & 63) == 0) {
+                const uint32_t w = threadIdx.x >> 6;
+                plan_out->wq[w] = a[0];
+                plan_out->wt[w] = a[1];
+                plan_out->wo[w] = a[2];
+            }
+            return err != INT64_MAX ? (int)(err & 31) : 0;
+        }
+    }
     int64_t c[2] = {0, 0}, tot[2];
     for (uint32_t i = b; i < e; i++) {
         int64_t len;
@@ -1042,7 +1111,7 @@ __device__ int shatter_size(const RecState &s, const View<OPS> &v, const Shatter
  */
 #define PAFFY_WAVE_RING 9216u /* bytes of LDS ring per wave: 64 rows of the usual ~130-byte lines */
 template <class OPS>
-__device__ void shatter_emit(const RecState &s, const View<OPS> &v, const ShatterConst &k, const RowPieces &pieces, const RecPlan &pl,
+__device__ __forceinline__ void shatter_emit(const RecState &s, const View<OPS> &v, const ShatterConst &k, const RowPieces &pieces, const RecPlan &pl,
                              uint8_t *ring, uint8_t *out, uint64_t rec_off) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t span = 64ull * pl.chunk;
@@ -1155,7 +1224,7 @@ __device__ void shatter_emit(const RecState &s, const View<OPS> &v, const Shatte
 }
 
 /* Header of paf_write_to_buffer up to (and including) "\tcg:Z:" -- impl/paf.c:317-368. */
-__device__ void build_header(Piece &w, const RecState &s, const uint8_t *in, bool newline) {
+__device__ __forceinline__ void build_header(Piece &w, const RecState &s, const uint8_t *in, bool newline) {
     w.name(in, s.qn_off, s.qn_len);
     w.ch('\t'); w.num(s.qlen);
     w.ch('\t'); w.num(s.qs);
@@ -1182,7 +1251,7 @@ __device__ uint32_t header_len(const RecState &s, bool newline) {
 
 /* Bytes of the cigar text of the view: sum of digits + 1 per op (impl/paf.c:369-380). */
 template <class OPS>
-__device__ int64_t cigar_text_len(const View<OPS> &v, BlockComm &bc) {
+__device__ __forceinline__ int64_t cigar_text_len(const View<OPS> &v, BlockComm &bc) {
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
     int64_t a[1] = {0};
@@ -1200,7 +1269,7 @@ __device__ int64_t cigar_text_len(const View<OPS> &v, BlockComm &bc) {
 #define PAFFY_BLOCK_RING 32768u
 typedef Emitter<PAFFY_NT, PAFFY_BLOCK_RING> BlockEmitter;
 template <class OPS>
-__device__ void write_emit(const View<OPS> &v, bool has_cigar, const uint64_t *H, uint32_t lenH, BlockEmitter &em, BlockComm &bc) {
+__device__ __forceinline__ void write_emit(const View<OPS> &v, bool has_cigar, const uint64_t *H, uint32_t lenH, BlockEmitter &em, BlockComm &bc) {
     /* header: 16 bytes per lane per window */
     for (uint32_t base = 0; base < lenH; base += 16 * PAFFY_NT) {
         uint32_t left = lenH - base;
@@ -1317,7 +1386,7 @@ __device__ __forceinline__ void load_state(const RecMeta &m, RecState &s) {
  * from. Returns false when the record does not fit this op store (LDS class only).
  */
 template <class OPS>
-__device__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t cap, const RecLds &L, uint32_t klass,
+__device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t cap, const RecLds &L, uint32_t klass,
                             uint32_t *n_ops_out) {
     const RecMeta m = P.meta[rec];
     if (m.err) {
@@ -1327,11 +1396,18 @@ __device__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t c
     RecState s;
     load_state(m, s);
     uint32_t n = 0;
+    int64_t parse_sums[4] = {0, 0, 0, 0};
+    bool have_sums = false;
     if (s.has_cigar) {
         bool fits;
         uint32_t err_pos;
-        uint32_t r = parse_cigar(P.in, m.cg_off, m.cg_len, ops, cap, L.ring, L.bc, L.sh, &fits, &err_pos);
-        if (r & 0x80000000u) r = parse_cigar_serial(P.in, m.cg_off, m.cg_len, ops, cap, L.sh, &fits, &err_pos);
+        uint32_t r;
+        r = parse_cigar(P.in, m.cg_off, m.cg_len, ops, cap, L.ring, L.bc, L.sh, &fits, &err_pos, parse_sums);
+        have_sums = true;
+        if (r & 0x80000000u) {
+            r = parse_cigar_serial(P.in, m.cg_off, m.cg_len, ops, cap, L.sh, &fits, &err_pos);
+            have_sums = false;
+        }
         n = r;
         *n_ops_out = n;
         if (err_pos != 0xffffffffu) { /* st_errAbort, impl/paf.c:102 */
@@ -1343,7 +1419,12 @@ __device__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t c
     *n_ops_out = n;
     View<OPS> v;
     v.reset(ops, n);
+    if (have_sums) { /* the parse already summed every op */
+        v.tm = parse_sums[0]; v.tx = parse_sums[1]; v.tq = parse_sums[2]; v.tt = parse_sums[3];
+        v.totals_ok = true;
+    }
     bool swapped = false, shatter = false;
+    bool checked = false; /* a paf_check has passed since the record last changed */
     int32_t si = 0;
     for (; si < P.n_stages; si++) {
         const paffy_stage st = P.stages[si];
@@ -1414,6 +1495,7 @@ __device__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t c
             report(P, rec, rc, si, 0, klass);
             return true;
         }
+        checked = st.kind != PAFFY_PASS; /* every other stage ends with a passed paf_check */
     }
     RecPlan *plan = static_cast<RecPlan *>(P.rec_plan) + rec;
     int64_t bytes, rows;
@@ -1425,7 +1507,7 @@ __device__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t c
             report(P, rec, 0, si, 0, klass);
             return true;
         }
-        int rc = shatter_size(s, v, k, bytes, rows, plan, L.bc);
+        int rc = shatter_size(s, v, k, bytes, rows, plan, checked, L.bc);
         if (rc) {
             report(P, rec, rc, si, 0, klass);
             return true;
@@ -1461,7 +1543,7 @@ __device__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t c
  * carries none of the whole-line writer and vice versa.
  */
 template <class OPS, bool SHATTER>
-__device__ void emit_record(const KParams &P, uint32_t rec, const OPS &ops, const RecLds &L) {
+__device__ __forceinline__ void emit_record(const KParams &P, uint32_t rec, const OPS &ops, const RecLds &L) {
     /* by reference: a by-value copy of these structs (indexed per wave below) would live in scratch memory */
     const RecMeta &m = P.meta[rec];
     const RecPlan &pl = static_cast<const RecPlan *>(P.rec_plan)[rec];
@@ -1573,7 +1655,10 @@ __device__ __forceinline__ void size_lds_one(const KParams &P, uint32_t rec, uin
         }
     }
 }
-__global__ __launch_bounds__(PAFFY_NT, 4) void k_size_lds(KParams P) {
+#ifndef PAFFY_SIZE_OCC
+#define PAFFY_SIZE_OCC 4
+#endif
+__global__ __launch_bounds__(PAFFY_NT, PAFFY_SIZE_OCC) void k_size_lds(KParams P) {
     extern __shared__ uint4 smem4[];
     uint32_t *ops_lds;
     RecLds L = carve_size_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds, P.ops_cap);
