@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=65536, help="records per step per GPU")
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a one-GPU rehearsal)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--pipe", default=None, help="override the workload's command pipe, e.g. 'shatter' (experiments only)")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="records of the stream timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
@@ -61,8 +63,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(0 if args.one_device else local_rank)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(args.dist_backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -121,14 +126,22 @@ def main():
     eng.profile(False)
 
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        red_dev = dev if args.dist_backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # whole-job byte and row counts (every rank holds only its own batches)
+        c = torch.tensor([float(sum(i.in_bytes for i in infos)), float(sum(i.out_bytes for i in infos)),
+                          float(sum(i.n_rows for i in infos))], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        job_in, job_out, job_rows = (float(x) for x in c.tolist())
 
     records = args.batch * args.steps * world
-    in_bytes = sum(i.in_bytes for i in infos)
+    in_bytes = sum(i.in_bytes for i in infos)    # rank 0's own batches: what one k_emit_lds launch moves
     out_bytes = sum(i.out_bytes for i in infos)
     rows = sum(i.n_rows for i in infos)
+    if not dist:
+        job_in, job_out, job_rows = float(in_bytes), float(out_bytes), float(rows)
 
     if rank == 0:
         dom = "k_emit_lds"
@@ -163,7 +176,7 @@ def main():
                        "output_bytes_per_record": round(out_bytes / (args.batch * args.steps), 1),
                        "output_rows_per_record": round(rows / (args.batch * args.steps), 2),
                        "sharding": "contiguous record batches per rank, no collective"},
-            "whole_path_GBps_per_gpu": round((in_bytes + out_bytes) / elapsed / 1e9, 1),
+            "whole_path_GBps_per_gpu": round((job_in + job_out) / world / elapsed / 1e9, 1),
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kernels.items()},

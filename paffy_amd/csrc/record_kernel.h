@@ -1249,53 +1249,70 @@ __device__ uint32_t header_len(const RecState &s, bool newline) {
     return n;
 }
 
-/* Bytes of the cigar text of the view: sum of digits + 1 per op (impl/paf.c:369-380). */
+/*
+ * Bytes of the cigar text of the view: sum of digits + 1 per op (impl/paf.c:369-380). Also leaves,
+ * for the emit pass, the text bytes in front of each wave's share of the ops (wave w owns lane
+ * chunks [64*w*chunk, 64*(w+1)*chunk), as in sweep_bounds()).
+ */
 template <class OPS>
-__device__ __forceinline__ int64_t cigar_text_len(const View<OPS> &v, BlockComm &bc) {
+__device__ __forceinline__ int64_t cigar_text_len(const View<OPS> &v, RecPlan *plan_out, BlockComm &bc) {
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
-    int64_t a[1] = {0};
+    int64_t a[1] = {0}, at[1];
     for (uint32_t i = b; i < e; i++) {
         int64_t len;
         int op;
         v.get(i, len, op);
         a[0] += dec_len(len) + 1;
     }
-    block_sum<1>(a, bc);
-    return a[0];
+    block_excl_scan<1>(a, at, bc);
+    if ((threadIdx.x & 63) == 0) plan_out->wo[threadIdx.x >> 6] = a[0];
+    return at[0];
 }
 
-/* One whole line (paf_write): header piece from LDS, then the ops, then '\n' (workgroup-level windows). */
-#define PAFFY_BLOCK_RING 32768u
-typedef Emitter<PAFFY_NT, PAFFY_BLOCK_RING> BlockEmitter;
+/*
+ * One whole line (paf_write, impl/paf.c:317-389): the header piece from LDS, then the ops, then '\n'.
+ * Same structure as shatter_emit: every wave owns a contiguous share of the ops (starting byte from
+ * the sizing pass) and streams it through its own LDS ring in windows of WRITE_PER ops per lane, with
+ * no workgroup barrier; wave 0 first sends the header in 1 KiB windows.
+ */
+#define WRITE_PER 16u
 template <class OPS>
-__device__ __forceinline__ void write_emit(const View<OPS> &v, bool has_cigar, const uint64_t *H, uint32_t lenH, BlockEmitter &em, BlockComm &bc) {
-    /* header: 16 bytes per lane per window */
-    for (uint32_t base = 0; base < lenH; base += 16 * PAFFY_NT) {
-        uint32_t left = lenH - base;
-        uint32_t wbytes = left < 16 * PAFFY_NT ? left : 16 * PAFFY_NT;
-        uint32_t mine_off = 16 * threadIdx.x;
-        RingWriter rw;
-        if (mine_off < wbytes) {
-            uint32_t mine = wbytes - mine_off < 16 ? wbytes - mine_off : 16;
-            rw.init(em.ring, PAFFY_BLOCK_RING, em.pos_r, mine_off);
-            put_lds(rw, H + ((base + mine_off) >> 3), mine);
-        } else {
-            rw.init(em.ring, PAFFY_BLOCK_RING, em.pos_r, 0);
-            rw.nacc = rw.head = 0; /* nothing to write */
+__device__ __forceinline__ void write_emit(const View<OPS> &v, bool has_cigar, const uint64_t *H, uint32_t lenH, const RecPlan &pl,
+                                           uint8_t *ring, uint8_t *out, uint64_t rec_off) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool with_ops = has_cigar && v.n > 0;
+    const uint64_t span = 64ull * pl.chunk;
+    const uint32_t wb = !with_ops ? 0 : (span * wave < v.n ? (uint32_t)(span * wave) : v.n);
+    const uint32_t we = !with_ops ? 0 : (span * (wave + 1) < v.n ? (uint32_t)(span * (wave + 1)) : v.n);
+    Emitter<64, PAFFY_WAVE_RING> em;
+    /* wave 0 starts at the record's first byte (header first); the others after the header and the text before them */
+    em.start(ring + wave * PAFFY_WAVE_RING, out, rec_off + (wave == 0 ? 0 : lenH + (with_ops ? (uint64_t)pl.wo[wave] : 0)));
+    if (wave == 0) {
+        for (uint32_t base = 0; base < lenH; base += 16 * 64) {
+            const uint32_t left = lenH - base, wbytes = left < 16 * 64 ? left : 16 * 64;
+            const uint32_t mine_off = 16 * lane;
+            RingWriter rw;
+            if (mine_off < wbytes) {
+                const uint32_t mine = wbytes - mine_off < 16 ? wbytes - mine_off : 16;
+                rw.init(em.ring, PAFFY_WAVE_RING, em.pos_r, mine_off);
+                put_lds(rw, H + ((base + mine_off) >> 3), mine);
+            } else {
+                rw.init(em.ring, PAFFY_WAVE_RING, em.pos_r, 0);
+                rw.nacc = rw.head = 0; /* nothing to write */
+            }
+            em.sync();
+            rw.tail();
+            em.commit(wbytes);
         }
-        em.sync();
-        rw.tail();
-        em.commit(wbytes);
     }
-    if (!has_cigar || v.n == 0) return; /* the header piece already ends the line */
-    const uint32_t cap_bytes = PAFFY_BLOCK_RING - 32;
-    const uint32_t w_full = 16 * PAFFY_NT, w_safe = cap_bytes / 21; /* an op prints as at most 20 + 1 bytes */
-    uint32_t i = 0, w_try = w_full;
-    while (i < v.n) {
-        uint32_t w = v.n - i < w_try ? v.n - i : w_try;
-        uint32_t per = (w + PAFFY_NT - 1) / PAFFY_NT;
-        uint32_t b = i + threadIdx.x * per, e = b + per;
+    const uint32_t cap_bytes = PAFFY_WAVE_RING - 32;
+    const uint32_t w_full = 64 * WRITE_PER, w_safe = cap_bytes / 21; /* an op prints as at most 20 + 1 bytes */
+    uint32_t i = wb, w_try = w_full;
+    while (i < we) {
+        const uint32_t w = we - i < w_try ? we - i : w_try;
+        const uint32_t per = (w + 63) / 64;
+        uint32_t b = i + lane * per, e = b + per;
         if (b > i + w) b = i + w;
         if (e > i + w) e = i + w;
         const bool last = (i + w == v.n);
@@ -1307,13 +1324,13 @@ __device__ __forceinline__ void write_emit(const View<OPS> &v, bool has_cigar, c
             nb[0] += dec_len(len) + 1;
         }
         if (last && e == v.n && b < e) nb[0] += 1; /* '\n' goes with the last op */
-        block_excl_scan<1>(nb, nbt, bc);
+        wave_excl_scan<1>(nb, nbt);
         if (nbt[0] > (int64_t)cap_bytes && w > w_safe) {
             w_try = w_safe;
             continue;
         }
         RingWriter rw;
-        rw.init(em.ring, PAFFY_BLOCK_RING, em.pos_r, (uint32_t)nb[0]);
+        rw.init(em.ring, PAFFY_WAVE_RING, em.pos_r, (uint32_t)nb[0]);
         for (uint32_t j = b; j < e; j++) {
             int64_t len;
             int op;
@@ -1334,6 +1351,7 @@ __device__ __forceinline__ void write_emit(const View<OPS> &v, bool has_cigar, c
         i += w;
         w_try = w_full;
     }
+    em.finish();
 }
 
 /* ---------------- the record program ---------------- */
@@ -1521,7 +1539,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
             return true;
         }
         bytes = lenH;
-        if (!nl_in_header) bytes += cigar_text_len(v, L.bc) + 1;
+        if (!nl_in_header) bytes += cigar_text_len(v, plan, L.bc) + 1;
         rows = 1;
     }
     if (threadIdx.x == 0) {
@@ -1592,10 +1610,7 @@ __device__ __forceinline__ void emit_record(const KParams &P, uint32_t rec, cons
             build_header(w, s, P.in, nl_in_header);
         }
         __syncthreads();
-        BlockEmitter em;
-        em.start(L.ring, P.out, (uint64_t)P.out_off[rec]);
-        write_emit(v, s.has_cigar, L.pieces, lenH, em, L.bc);
-        em.finish();
+        write_emit(v, s.has_cigar, L.pieces, lenH, pl, L.ring, P.out, (uint64_t)P.out_off[rec]);
     }
 }
 

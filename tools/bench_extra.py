@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Side measurements for DESIGN.md (not the driver's bench contract): `tile` and single commands
+on the synthetic stream, records/s with inputs resident in HBM."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--records", type=int, default=200000)
+    ap.add_argument("--mean-ops", type=int, default=2048)
+    ap.add_argument("--cmd", default="tile", choices=["tile", "invert", "trim", "shatter", "remove"])
+    a = ap.parse_args()
+    import torch
+
+    import paffy_amd
+
+    eng = paffy_amd.Engine()
+    buf, nbytes = eng.synth(0x5EED0005, a.mean_ops, 0, a.records)
+    torch.cuda.synchronize()
+    kinds = {"invert": paffy_amd.INVERT, "trim": paffy_amd.TRIM_IDENTITY, "shatter": paffy_amd.SHATTER, "remove": paffy_amd.REMOVE_MISMATCHES}
+    res = []
+    for rep in range(3):
+        t0 = time.perf_counter()
+        info = eng.tile_plan(buf, nbytes) if a.cmd == "tile" else eng.plan([paffy_amd.stage(kinds[a.cmd])], buf, nbytes)
+        out = eng.alloc_out(info.out_bytes)
+        eng.emit(out)
+        eng.sync()
+        dt = time.perf_counter() - t0
+        assert info.error.code == 0
+        res.append(dt)
+    dt = min(res)
+    print(json.dumps({"cmd": a.cmd, "records": a.records, "mean_ops": a.mean_ops, "in_bytes": nbytes, "out_bytes": int(info.out_bytes),
+                      "seconds": round(dt, 4), "records_per_s": round(a.records / dt, 1),
+                      "GBps": round((nbytes + info.out_bytes) / dt / 1e9, 1)}))
+
+
+if __name__ == "__main__":
+    main()
