@@ -332,20 +332,20 @@ __global__ __launch_bounds__(PAFFY_NT) void k_tile_size(const RecMeta *meta, con
 __global__ __launch_bounds__(PAFFY_NT) void k_tile_emit(const uint8_t *in, const RecMeta *meta, const uint32_t *order, const int64_t *level,
                                                          const int64_t *out_off, uint8_t *out) {
     __shared__ uint8_t hdr[3 * PAFFY_TMPL_MAX + 8];
-    __shared__ uint32_t hlen;
     const RecMeta m = meta[order[blockIdx.x]];
+    uint8_t *o = out + out_off[blockIdx.x];
+    RecState s;
+    tile_state(m, level[order[blockIdx.x]], s);
+    const uint32_t hl = header_len(s, false) + (m.has_cg ? 6u : 0u), cl = m.has_cg ? m.cg_len : 0;
+    const bool direct = hl > 3 * PAFFY_TMPL_MAX; /* header longer than the LDS staging: built in place */
     if (threadIdx.x < 64) {
-        RecState s;
-        tile_state(m, level[order[blockIdx.x]], s);
-        Piece w{hdr, 0, 3 * PAFFY_TMPL_MAX, false};
+        Piece w{direct ? o : hdr, 0, direct ? hl : 3 * PAFFY_TMPL_MAX, false};
         build_header(w, s, in, false);
         if (m.has_cg) w.str("\tcg:Z:", 6);
-        if (threadIdx.x == 0) hlen = w.n;
     }
     __syncthreads();
-    uint8_t *o = out + out_off[blockIdx.x];
-    const uint32_t hl = hlen, cl = m.has_cg ? m.cg_len : 0;
-    for (uint32_t i = threadIdx.x; i < hl; i += PAFFY_NT) o[i] = hdr[i];
+    if (!direct)
+        for (uint32_t i = threadIdx.x; i < hl; i += PAFFY_NT) o[i] = hdr[i];
     for (uint32_t i = threadIdx.x; i < cl; i += PAFFY_NT) o[hl + i] = in[m.cg_off + i];
     if (threadIdx.x == 0) o[hl + cl] = '\n';
 }

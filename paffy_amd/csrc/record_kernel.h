@@ -1223,6 +1223,80 @@ __device__ __forceinline__ void shatter_emit(const RecState &s, const View<OPS> 
     em.finish();
 }
 
+/* Per-lane serial writers for the rare records whose pieces do not fit the LDS staging (names of
+ * many hundreds of bytes): bytes go straight to HBM, the pieces are re-derived from the input text. */
+struct DirectWriter {
+    uint8_t *p;
+    __device__ __forceinline__ void put(uint64_t w, uint32_t k) {
+        for (uint32_t b = 0; b < k; b++) p[b] = (uint8_t)(w >> (8 * b));
+        p += k;
+    }
+    __device__ __forceinline__ void put8(uint64_t w) { put(w, 8); }
+    __device__ __forceinline__ void bytes(const uint8_t *src, uint32_t n) {
+        for (uint32_t i = 0; i < n; i++) p[i] = src[i];
+        p += n;
+    }
+    __device__ __forceinline__ void lit(const char *s, uint32_t n) {
+        for (uint32_t i = 0; i < n; i++) p[i] = (uint8_t)s[i];
+        p += n;
+    }
+};
+__device__ __forceinline__ void direct_tags(DirectWriter &w, const RecState &s, int64_t s1) { /* impl/paf.c:343-365 */
+    if (s.type != 0 || s.tile_level != -1) {
+        uint32_t t = s.type;
+        if (t == 0) t = s.tile_level > 1 ? 'S' : 'P';
+        w.lit("\ttp:A:", 6);
+        w.put(t, 1);
+    }
+    if (s.score != 2147483647ll) { w.lit("\tAS:i:", 6); put_dec(w, s.score); }
+    if (s.tile_level != -1) { w.lit("\ttl:i:", 6); put_dec(w, s.tile_level); }
+    if (s.chain_id != -1) { w.lit("\tcn:i:", 6); put_dec(w, s.chain_id); }
+    if (s1 != -1) { w.lit("\ts1:i:", 6); put_dec(w, s1); }
+}
+template <class OPS>
+__device__ __forceinline__ void shatter_emit_direct(const KParams &P, const RecState &s, const View<OPS> &v, const ShatterConst &k,
+                                                    const RecPlan &pl, uint64_t rec_off) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t span = 64ull * pl.chunk;
+    const uint32_t wb = span * wave < v.n ? (uint32_t)(span * wave) : v.n;
+    const uint32_t we = span * (wave + 1) < v.n ? (uint32_t)(span * (wave + 1)) : v.n;
+    int64_t cq = pl.wq[wave], ct = pl.wt[wave];
+    uint64_t pos = rec_off + (uint64_t)pl.wo[wave];
+    for (uint32_t i = wb; i < we; i += 64) { /* one op per lane */
+        const uint32_t j = i + lane;
+        int64_t len = 0;
+        int op = -1;
+        if (j < we) v.get(j, len, op);
+        int64_t c[2] = {op >= 0 && op != OP_D ? len : 0, op >= 0 && op != OP_I ? len : 0}, tot[2];
+        wave_excl_scan<2>(c, tot);
+        const int64_t q0 = s.same ? s.qs + cq + c[0] : s.qe - (cq + c[0] + len), t0 = s.ts + ct + c[1];
+        int64_t nb[1] = {op == OP_M ? (int64_t)row_len(k, q0, t0, len) : 0}, nbt[1];
+        wave_excl_scan<1>(nb, nbt);
+        if (op == OP_M) {
+            DirectWriter w{P.out + pos + (uint64_t)nb[0]};
+            w.bytes(P.in + s.qn_off, s.qn_len);
+            w.put('\t', 1); put_dec(w, s.qlen);
+            w.put('\t', 1); put_dec(w, q0);
+            w.put('\t', 1); put_dec(w, q0 + len);
+            w.put('\t', 1); w.put(s.same ? '+' : '-', 1); w.put('\t', 1);
+            w.bytes(P.in + s.tn_off, s.tn_len);
+            w.put('\t', 1); put_dec(w, s.tlen);
+            w.put('\t', 1); put_dec(w, t0);
+            w.put('\t', 1); put_dec(w, t0 + len);
+            w.put('\t', 1); put_dec(w, len);
+            w.put('\t', 1); put_dec(w, len);
+            w.put('\t', 1); put_dec(w, s.mapq);
+            direct_tags(w, s, 0);
+            w.lit("\tcg:Z:", 6);
+            put_dec(w, len);
+            w.put((uint64_t)'M' | ((uint64_t)'\n' << 8), 2);
+        }
+        pos += (uint64_t)nbt[0];
+        cq += tot[0];
+        ct += tot[1];
+    }
+}
+
 /* Header of paf_write_to_buffer up to (and including) "\tcg:Z:" -- impl/paf.c:317-368. */
 __device__ __forceinline__ void build_header(Piece &w, const RecState &s, const uint8_t *in, bool newline) {
     w.name(in, s.qn_off, s.qn_len);
@@ -1279,7 +1353,7 @@ __device__ __forceinline__ int64_t cigar_text_len(const View<OPS> &v, RecPlan *p
 #define WRITE_PER 16u
 template <class OPS>
 __device__ __forceinline__ void write_emit(const View<OPS> &v, bool has_cigar, const uint64_t *H, uint32_t lenH, const RecPlan &pl,
-                                           uint8_t *ring, uint8_t *out, uint64_t rec_off) {
+                                           uint8_t *ring, uint8_t *out, uint64_t rec_off, bool header_done) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool with_ops = has_cigar && v.n > 0;
     const uint64_t span = 64ull * pl.chunk;
@@ -1287,8 +1361,8 @@ __device__ __forceinline__ void write_emit(const View<OPS> &v, bool has_cigar, c
     const uint32_t we = !with_ops ? 0 : (span * (wave + 1) < v.n ? (uint32_t)(span * (wave + 1)) : v.n);
     Emitter<64, PAFFY_WAVE_RING> em;
     /* wave 0 starts at the record's first byte (header first); the others after the header and the text before them */
-    em.start(ring + wave * PAFFY_WAVE_RING, out, rec_off + (wave == 0 ? 0 : lenH + (with_ops ? (uint64_t)pl.wo[wave] : 0)));
-    if (wave == 0) {
+    em.start(ring + wave * PAFFY_WAVE_RING, out, rec_off + ((wave == 0 && !header_done) ? 0 : lenH + (with_ops ? (uint64_t)pl.wo[wave] : 0)));
+    if (wave == 0 && !header_done) {
         for (uint32_t base = 0; base < lenH; base += 16 * 64) {
             const uint32_t left = lenH - base, wbytes = left < 16 * 64 ? left : 16 * 64;
             const uint32_t mine_off = 16 * lane;
@@ -1517,14 +1591,11 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
     }
     RecPlan *plan = static_cast<RecPlan *>(P.rec_plan) + rec;
     int64_t bytes, rows;
+    bool direct = false;
     if (shatter) {
         ShatterConst k;
         shatter_consts(s, k);
-        if (!shatter_fits(k)) {
-            if (threadIdx.x == 0) atomicOr(&P.info->internal, INTERNAL_TMPL_TOO_LONG);
-            report(P, rec, 0, si, 0, klass);
-            return true;
-        }
+        direct = !shatter_fits(k); /* pieces too long for the LDS staging: the emit pass writes this record's rows straight to HBM */
         int rc = shatter_size(s, v, k, bytes, rows, plan, checked, L.bc);
         if (rc) {
             report(P, rec, rc, si, 0, klass);
@@ -1533,11 +1604,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
     } else {
         const bool nl_in_header = !(s.has_cigar && v.n > 0);
         const uint32_t lenH = header_len(s, nl_in_header);
-        if (lenH > 3 * PAFFY_TMPL_MAX) {
-            if (threadIdx.x == 0) atomicOr(&P.info->internal, INTERNAL_TMPL_TOO_LONG);
-            report(P, rec, 0, P.n_stages, 0, klass);
-            return true;
-        }
+        direct = lenH > 3 * PAFFY_TMPL_MAX; /* header too long for the LDS staging: built straight in HBM */
         bytes = lenH;
         if (!nl_in_header) bytes += cigar_text_len(v, plan, L.bc) + 1;
         rows = 1;
@@ -1549,7 +1616,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
         plan->qs = s.qs; plan->qe = s.qe; plan->ts = s.ts; plan->te = s.te; plan->sub_lo = v.sub_lo; plan->sub_hi = v.sub_hi;
         plan->lo = v.lo; plan->n = v.n;
         plan->flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | (s.has_cigar ? 8u : 0u) | ((uint32_t)s.type << 8) |
-                      (shatter ? 16u : 0u);
+                      (shatter ? 16u : 0u) | (direct ? 32u : 0u);
         plan->chunk = ((v.n + PAFFY_NT - 1) / PAFFY_NT) | 1u; /* = sweep_bounds() */
     }
     return true;
@@ -1578,6 +1645,10 @@ __device__ __forceinline__ void emit_record(const KParams &P, uint32_t rec, cons
     if constexpr (SHATTER) {
         ShatterConst k;
         shatter_consts(s, k);
+        if (pl.flags & 32u) {
+            shatter_emit_direct(P, s, v, k, pl, (uint64_t)P.out_off[rec]);
+            return;
+        }
         uint64_t *A = L.pieces, *B = L.pieces + PAFFY_TMPL_MAX / 8, *C = L.pieces + 2 * (PAFFY_TMPL_MAX / 8);
         const uint32_t wave = threadIdx.x >> 6;
         if (wave == 0) {
@@ -1605,12 +1676,13 @@ __device__ __forceinline__ void emit_record(const KParams &P, uint32_t rec, cons
     } else {
         const bool nl_in_header = !(s.has_cigar && v.n > 0);
         const uint32_t lenH = header_len(s, nl_in_header);
-        if (threadIdx.x < 64) {
-            Piece w{(uint8_t *)L.pieces, 0, 3 * PAFFY_TMPL_MAX, false};
+        const bool direct = (pl.flags & 32u) != 0;
+        if (threadIdx.x < 64) { /* wave 0 builds the header: in LDS, or straight in the output when it is too long */
+            Piece w{direct ? P.out + P.out_off[rec] : (uint8_t *)L.pieces, 0, direct ? lenH : 3 * PAFFY_TMPL_MAX, false};
             build_header(w, s, P.in, nl_in_header);
         }
         __syncthreads();
-        write_emit(v, s.has_cigar, L.pieces, lenH, pl, L.ring, P.out, (uint64_t)P.out_off[rec]);
+        write_emit(v, s.has_cigar, L.pieces, lenH, pl, L.ring, P.out, (uint64_t)P.out_off[rec], direct);
     }
 }
 

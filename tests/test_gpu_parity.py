@@ -159,6 +159,10 @@ def test_edges(eng):
     rec = rec.replace(b"\t0\t5\t-", b"\t0\t5\t-", 1)
     for name in ("pass", "invert"):
         check(eng, PIPES[name], rec + ok, name)
+    # names far longer than the LDS staging of the line pieces: the direct-to-HBM paths
+    huge = b"Q" * 5000 + b"\t900\t3\t12\t-\t" + b"T" * 3000 + b"\t800\t5\t13\t7\t9\t60\ttp:A:S\tcg:Z:3M1D2M1I3M\n"
+    for name in ("pass", "invert", "shatter", "invert|trim|shatter", "trim -f -t 0.1"):
+        check(eng, PIPES[name], ok + huge + ok + huge, name)
     # many tiny records: every alignment of a line start modulo 16
     tiny = b"".join(kat_line("c%d" % i, 1000 + i, i, i + 5, "+-"[i & 1], "d", 2000, 7, 12, 5, 5, i, "2M1I2M1D1M" if i % 3 else "5M") for i in range(500))
     for name in ("pass", "invert", "shatter", "invert|trim|shatter", "trim -f -t 0.1"):

@@ -95,5 +95,7 @@ def test_errors_and_edges(eng):
                 ok.replace(b"cg:Z:5M", b"cg:Z:")):            # empty cigar with a non-empty span
         got, info = check(eng, ok + bad + ok)
         assert info.error.code != 0 and got == b""
+    # a name longer than the header staging
+    check(eng, ok + b"N" * 4000 + b"\t100\t0\t5\t+\tt\t100\t0\t5\t5\t5\t60\tAS:i:3\tcg:Z:5M\n")
     # zero aligned bases -> level 32767
     check(eng, b"q\t100\t3\t5\t+\tt\t100\t0\t0\t0\t0\t60\tcg:Z:2I\n")
