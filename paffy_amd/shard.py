@@ -53,3 +53,44 @@ def contig_partition(weights, world):
         owner[name] = r
         loads[r] += w
     return owner
+
+
+# ---- tile across ranks -------------------------------------------------------------------------
+#
+# `paffy tile` visits all records in (s1 desc, AS desc, input order) order but its state is per
+# QUERY sequence, so records of different query sequences never interact: rank r tiles the records
+# of the contigs it owns (same relative order), and the single-process output is the merge of the
+# per-rank outputs by the same key. Only the keys (24 bytes per record) are all-gathered to build
+# the merge; the lines themselves go to the writer (or are pwritten at their offsets).
+
+
+def query_name(line):
+    return line.split(b"\t", 1)[0]
+
+
+def _tag(line, tag, default):
+    i = line.find(b"\t" + tag + b":i:")
+    if i < 0:
+        return default
+    j = line.find(b"\t", i + 1)
+    return int(line[i + 6: j if j >= 0 else len(line)])
+
+
+def tile_key(line, index):
+    """Sort key of paf_cmp_by_descending_score (impl/paf_tile.c:28-34) + input index (stable)."""
+    return (-_tag(line, b"s1", -1), -_tag(line, b"AS", 0), index)
+
+
+def split_by_owner(lines, owner):
+    """lines: list of PAF lines of the whole input; owner: query name -> rank. Returns {rank: [(global index, line)]}."""
+    out = {}
+    for i, ln in enumerate(lines):
+        out.setdefault(owner[query_name(ln)], []).append((i, ln))
+    return out
+
+
+def merge_tiled(per_rank):
+    """per_rank: list over ranks of [(key, line)] in that rank's output order -> lines in global visiting order."""
+    import heapq
+
+    return [ln for _, ln in heapq.merge(*per_rank)]

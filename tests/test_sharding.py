@@ -79,3 +79,49 @@ def test_contig_partition_is_balanced_and_total():
     assert set(owner) == set(w) and set(owner.values()) == set(range(8))
     loads = [sum(w[k] for k in w if owner[k] == r) for r in range(8)]
     assert max(loads) - min(loads) <= max(w.values())
+
+
+def _tile_worker(rank, world, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    data = open(os.path.join(tmpdir, "in.paf"), "rb").read()
+    lines = data.splitlines(keepends=True)
+    weights = {}
+    for ln in lines:
+        weights[shard.query_name(ln)] = weights.get(shard.query_name(ln), 0) + len(ln)
+    owner = shard.contig_partition(weights, world)
+    mine = shard.split_by_owner(lines, owner).get(rank, [])
+    # this rank tiles only its contigs (the oracle stands in for the GPU worker); order of equal keys = input order
+    out, err = O.tile(b"".join(ln for _, ln in mine))
+    assert err.code == 0
+    out_lines = out.splitlines(keepends=True)
+    # keys of my output lines: my inputs sorted by key give the global indices in output order
+    order = sorted(range(len(mine)), key=lambda k: shard.tile_key(mine[k][1], mine[k][0]))
+    keyed = [(shard.tile_key(mine[k][1], mine[k][0]), out_lines[pos]) for pos, k in enumerate(order)]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, keyed)
+    if rank == 0:
+        with open(os.path.join(tmpdir, "tiled.paf"), "wb") as fh:
+            fh.write(b"".join(shard.merge_tiled(gathered)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_tile_equals_single_process(tmp_path):
+    import random
+
+    rng = random.Random(5)
+    recs = []
+    for r in range(400):
+        c = rng.randrange(6)
+        L = rng.choice([5, 40, 300])
+        qs = rng.randrange(0, 2000 - 2 * L - 10)
+        tags = [f"AS:i:{rng.choice([5, 5, 80, 900])}"] + ([f"s1:i:{rng.choice([3, 3, 70])}"] if rng.random() < 0.6 else [])
+        recs.append(f"c{c}\t2000\t{qs}\t{qs + 2 * L + 3}\t{rng.choice('+-')}\tt\t9000\t10\t{10 + 2 * L}\t{L}\t{L}\t60\t" +
+                    "\t".join(tags) + f"\tcg:Z:{L}M3I{L}M\n")
+    data = "".join(recs).encode()
+    (tmp_path / "in.paf").write_bytes(data)
+    mp.spawn(_tile_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    want, err = O.tile(data)
+    assert err.code == 0
+    assert (tmp_path / "tiled.paf").read_bytes() == want
