@@ -289,7 +289,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_scan_records(const int64_t *out_le
 /* ------------------------------------------------------------------ */
 
 struct TileKey {
-    int64_t chain_score, score, qlen;
+    int64_t chain_score, score, qlen, qs, qe;
     uint64_t name_hash;
     uint32_t name_len;
     int32_t err;
@@ -303,6 +303,8 @@ __global__ __launch_bounds__(PAFFY_NT) void k_tile_keys(const uint8_t *in, const
     k.chain_score = m.chain_score;
     k.score = m.score;
     k.qlen = m.qlen;
+    k.qs = m.qs;
+    k.qe = m.qe;
     k.name_len = m.qname_len;
     k.err = m.err;
     uint64_t h = 0xcbf29ce484222325ull; /* FNV-1a over the query name */
@@ -398,7 +400,7 @@ struct paffy_hip_ctx {
     std::string last_error;
     DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, b_list, b_list1, arena, info, synth_sizes, rec_plan, ops_mirror, seq_blob, seq_table, seq_names, seq_name_off, rec_qseq, rec_tseq;
     int32_t n_seqs = 0;
-    DevBuf tile_keys, tile_order, tile_rank, tile_coff, tile_cbase, tile_cov, tile_level, tile_len;
+    DevBuf tile_keys, tile_order, tile_rank, tile_coff, tile_cbase, tile_cov, tile_level, tile_len, tile_items, tile_slots, tile_parts;
     bool plan_is_tile = false;
     uint32_t tile_n = 0;
     const uint8_t *tile_in = nullptr;
@@ -491,6 +493,7 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
     (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     /* the record kernels use more than the default 64 KiB of LDS */
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile), hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_slices), hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emit_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_EMIT_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emit_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_EMIT_LDS_BYTES);
@@ -507,7 +510,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
                       &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
-                      &c->tile_cov, &c->tile_level, &c->tile_len};
+                      &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_info) (void)hipHostFree(c->h_info);
@@ -823,7 +826,6 @@ int paffy_hip_tile_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, paff
     if (ensure(c, c->tile_cov, sizeof(uint16_t) * (size_t)cov_total)) return PAFFY_E_HIP;
     if (ensure(c, c->tile_level, sizeof(int64_t) * (size_t)n)) return PAFFY_E_HIP;
     if (ensure(c, c->tile_len, sizeof(int64_t) * (size_t)(n + 2))) return PAFFY_E_HIP;
-    HIPCHK(c, hipMemcpyAsync(c->tile_order.p, flat.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->tile_rank.p, rank_of.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->tile_coff.p, coff.data(), sizeof(uint32_t) * coff.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->tile_cbase.p, cbase.data(), sizeof(uint64_t) * cbase.size(), hipMemcpyHostToDevice, c->stream));
@@ -834,9 +836,9 @@ int paffy_hip_tile_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, paff
         HIPCHK(c, hipMemcpyAsync(&static_cast<DevInfo *>(c->info.p)->first_err_key, &key, sizeof(key), hipMemcpyHostToDevice, c->stream));
     }
     TileParams tp;
+    memset(&tp, 0, sizeof(tp));
     tp.in = in;
     tp.meta = static_cast<const RecMeta *>(c->meta.p);
-    tp.order = static_cast<const uint32_t *>(c->tile_order.p);
     tp.contig_off = static_cast<const uint32_t *>(c->tile_coff.p);
     tp.contig_base = static_cast<const uint64_t *>(c->tile_cbase.p);
     tp.rank_of = static_cast<const uint32_t *>(c->tile_rank.p);
@@ -845,8 +847,84 @@ int paffy_hip_tile_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, paff
     tp.tile_level = static_cast<int64_t *>(c->tile_level.p);
     tp.info = static_cast<DevInfo *>(c->info.p);
     tp.err_aux = static_cast<int32_t *>(c->err_aux.p);
-    const uint32_t tgrid = tp.n_contigs < 2048 ? tp.n_contigs : 2048;
-    LAUNCH(c, "k_tile", k_tile, dim3(tgrid), dim3(PAFFY_NT), TILE_LDS_BYTES, tp);
+    /*
+     * Sliced mode: work items = (sequence, 1 Mi-base slice) with at least one record; every item lists,
+     * in visiting order, the records whose query range touches the slice.
+     */
+    bool sliced_ok = false;
+    {
+        std::vector<uint32_t> slot_base(n + 1);
+        uint64_t n_slots = 0;
+        for (uint32_t r = 0; r < n; r++) {
+            slot_base[r] = (uint32_t)n_slots;
+            n_slots += tile_last_slice(keys[r].qs, keys[r].qe, keys[r].qlen) - tile_first_slice(keys[r].qs, keys[r].qe, keys[r].qlen) + 1;
+        }
+        if (n_slots < (1ull << 31)) {
+            std::vector<uint32_t> item_off, item_contig, item_slice, item_recs;
+            item_off.push_back(0);
+            for (size_t ci = 0; ci < contigs.size(); ci++) {
+                /* bucket this sequence's records (already in visiting order) by slice */
+                std::vector<std::pair<uint32_t, uint32_t>> pairs; /* (slice, position in recs) */
+                const auto &recs = contigs[ci].recs;
+                for (uint32_t k = 0; k < recs.size(); k++) {
+                    const TileKey &key = keys[recs[k]];
+                    for (uint32_t sl = tile_first_slice(key.qs, key.qe, key.qlen); sl <= tile_last_slice(key.qs, key.qe, key.qlen); sl++)
+                        pairs.push_back({sl, k});
+                }
+                std::stable_sort(pairs.begin(), pairs.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) { return a.first < b.first; });
+                for (size_t i = 0; i < pairs.size(); i++) {
+                    if (i == 0 || pairs[i].first != pairs[i - 1].first) {
+                        if (i) item_off.push_back((uint32_t)item_recs.size());
+                        item_contig.push_back((uint32_t)ci);
+                        item_slice.push_back(pairs[i].first);
+                    }
+                    item_recs.push_back(recs[pairs[i].second]);
+                }
+                if (!pairs.empty()) item_off.push_back((uint32_t)item_recs.size());
+            }
+            const uint32_t n_items = (uint32_t)item_contig.size();
+            const size_t words = item_off.size() + 2 * (size_t)n_items + item_recs.size();
+            if (ensure(c, c->tile_items, sizeof(uint32_t) * (words + 4))) return PAFFY_E_HIP;
+            if (ensure(c, c->tile_slots, sizeof(uint32_t) * (size_t)(n + 1))) return PAFFY_E_HIP;
+            if (ensure(c, c->tile_parts, sizeof(TilePartial) * (size_t)(n_slots + 1))) return PAFFY_E_HIP;
+            uint32_t *d_items = static_cast<uint32_t *>(c->tile_items.p);
+            uint32_t *d_off = d_items, *d_contig = d_off + item_off.size(), *d_slice = d_contig + n_items, *d_recs = d_slice + n_items;
+            HIPCHK(c, hipMemcpyAsync(d_off, item_off.data(), sizeof(uint32_t) * item_off.size(), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(d_contig, item_contig.data(), sizeof(uint32_t) * n_items, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(d_slice, item_slice.data(), sizeof(uint32_t) * n_items, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(d_recs, item_recs.data(), sizeof(uint32_t) * item_recs.size(), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->tile_slots.p, slot_base.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->tile_parts.p, 0, sizeof(TilePartial) * (size_t)n_slots, c->stream));
+            TileParams ts = tp;
+            ts.order = d_recs;
+            ts.item_off = d_off;
+            ts.item_contig = d_contig;
+            ts.item_slice = d_slice;
+            ts.slot_base = static_cast<const uint32_t *>(c->tile_slots.p);
+            ts.partials = static_cast<TilePartial *>(c->tile_parts.p);
+            ts.n_items = n_items;
+            if (n_items > 0) LAUNCH(c, "k_tile_slices", k_tile_slices, dim3(n_items), dim3(PAFFY_NT), TILE_LDS_BYTES, ts);
+            LAUNCH(c, "k_tile_merge", k_tile_merge, dim3(grid), dim3(PAFFY_NT), 0, ts, n);
+            if (fetch_info(c)) return PAFFY_E_HIP; /* the vectors above must outlive the copies: synchronised here */
+            sliced_ok = (c->h_info->internal & 0x100u) == 0;
+        }
+    }
+    if (!sliced_ok) {
+        /* exact fallback: one workgroup per sequence (levels beyond the LDS window, too many distinct levels) */
+        DevInfo z = *c->h_info;
+        z.internal = 0;
+        z.first_err_key = ~0ull;
+        if (bad_rank != 0xffffffffu)
+            z.first_err_key = ((unsigned long long)bad_rank << 16) | (1ull << 8) | (unsigned long long)PAFFY_ERR_TILE_ASSERT;
+        HIPCHK(c, hipMemcpyAsync(c->info.p, &z, sizeof(z), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->tile_cov.p, 0, sizeof(uint16_t) * (size_t)cov_total, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->tile_level.p, 0xff, sizeof(int64_t) * (size_t)n, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->tile_order.p, flat.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        tp.order = static_cast<const uint32_t *>(c->tile_order.p);
+        const uint32_t tgrid = tp.n_contigs < 2048 ? tp.n_contigs : 2048;
+        LAUNCH(c, "k_tile", k_tile, dim3(tgrid), dim3(PAFFY_NT), TILE_LDS_BYTES, tp);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     /* sizes and offsets in visiting order (= the order array sorted by rank) */
     HIPCHK(c, hipMemcpyAsync(c->tile_order.p, order.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     int64_t *lens = static_cast<int64_t *>(c->tile_len.p);

@@ -24,6 +24,7 @@
 
 #define TILE_TEXT (PAFFY_NT * 8u) /* cigar bytes per round */
 #define TILE_HIST 4096u           /* histogram window (levels) held in LDS */
+#define TILE_UNROLL 8             /* counter loads in flight per lane */
 
 struct TileParams {
     const uint8_t *in;
@@ -37,7 +38,38 @@ struct TileParams {
     int64_t *tile_level; /* per record */
     DevInfo *info;
     int32_t *err_aux;
+    /* sliced mode: work item i = one TILE_SLICE-base range of one query sequence with >= 1 record */
+    const uint32_t *item_off;    /* [n_items + 1] ranges of `order` (records overlapping the slice, visiting order) */
+    const uint32_t *item_contig; /* [n_items] */
+    const uint32_t *item_slice;  /* [n_items] slice index inside the sequence */
+    const uint32_t *slot_base;   /* per record: first partial-histogram slot */
+    struct TilePartial *partials;
+    uint32_t n_items;
 };
+
+#define TILE_SLICE_SHIFT 20 /* 1 Mi bases per slice */
+#define TILE_PAIRS 16       /* distinct levels a (record, slice) partial histogram can hold */
+
+struct TilePartial {
+    uint32_t n, overflow;
+    uint32_t level[TILE_PAIRS], count[TILE_PAIRS];
+};
+
+/* first / last slice a record's query range touches (host and device use the same arithmetic) */
+__host__ __device__ inline uint32_t tile_first_slice(int64_t qs, int64_t qe, int64_t qlen) {
+    int64_t a = qs < 0 ? 0 : qs;
+    if (qlen > 0 && a >= qlen) a = qlen - 1;
+    (void)qe;
+    return (uint32_t)(a >> TILE_SLICE_SHIFT);
+}
+__host__ __device__ inline uint32_t tile_last_slice(int64_t qs, int64_t qe, int64_t qlen) {
+    int64_t b = qe > qlen ? qlen : qe;
+    b -= 1;
+    int64_t a = qs < 0 ? 0 : qs;
+    if (qlen > 0 && a >= qlen) a = qlen - 1;
+    if (b < a) b = a;
+    return (uint32_t)(b >> TILE_SLICE_SHIFT);
+}
 
 struct TileOp { /* one aligned op of the current text tile */
     uint64_t qpos;  /* first query position (absolute) */
@@ -58,7 +90,8 @@ __device__ __forceinline__ void tile_fail(const TileParams &P, uint32_t rec, int
  * are counted in *below. Returns 0, or an error code (bad cigar character / position assert).
  */
 __device__ int tile_walk(const TileParams &P, uint32_t rec, const RecMeta &m, uint16_t *counts, bool bump, uint32_t win, uint32_t *hist,
-                         TileOp *list, uint8_t *txt, BlockComm &bc, Shared *sh, int64_t *aligned_out, int64_t *below_out) {
+                         TileOp *list, uint8_t *txt, BlockComm &bc, Shared *sh, int64_t *aligned_out, int64_t *below_out,
+                         uint64_t clip_lo = 0, uint64_t clip_hi = ~0ull) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t cg_off = m.cg_off, end = m.cg_off + m.cg_len;
     const uint32_t a0 = cg_off & ~7u;
@@ -152,7 +185,7 @@ __device__ int tile_walk(const TileParams &P, uint32_t rec, const RecMeta &m, ui
             }
         }
         __syncthreads();
-        const uint32_t fl = sh->flags;
+        const uint32_t fl = sh->flags & 0xffffu;
         const uint32_t n_al = (uint32_t)tots[2];
         const int64_t a_tile = tots[1];
         if (fl == 0 && sh->err_pos == 0xffffffffu && n_al > 0 && a_tile > 0) {
@@ -162,26 +195,60 @@ __device__ int tile_walk(const TileParams &P, uint32_t rec, const RecMeta &m, ui
             if (s0 > (uint64_t)a_tile) s0 = (uint64_t)a_tile;
             if (s1 > (uint64_t)a_tile) s1 = (uint64_t)a_tile;
             if (s0 < s1) {
-                uint32_t lo = 0, hi = n_al - 1; /* last op with apos <= s0 */
+                /*
+                 * Lane l handles aligned bases s0 + l, s0 + l + 64, ...: 64 consecutive bases of an op are 64
+                 * consecutive counters (coalesced). A per-lane cursor follows the op list; TILE_UNROLL loads are
+                 * issued before the first increment so that the HBM latency is paid once per 8 steps, not per op.
+                 */
+                uint32_t lo = 0, hi = n_al - 1; /* last op with apos <= first base of this lane */
+                const uint64_t first = s0 + lane;
                 while (lo < hi) {
                     uint32_t mid = (lo + hi + 1) >> 1;
-                    if ((uint64_t)list[mid].apos <= s0) lo = mid;
+                    if ((uint64_t)list[mid].apos <= first) lo = mid;
                     else hi = mid - 1;
                 }
-                for (uint32_t oi = lo; oi < n_al; oi++) {
-                    const TileOp o = list[oi];
-                    if ((uint64_t)o.apos >= s1) break;
-                    uint64_t b0 = s0 > o.apos ? s0 - o.apos : 0, b1 = s1 - o.apos;
-                    if (b1 > o.len) b1 = o.len;
-                    for (uint64_t b = b0 + lane; b < b1; b += 64) {
-                        uint16_t *cp = counts + o.qpos + b;
-                        uint32_t cnt = *cp;
-                        if (bump && cnt < 32766u) { /* INT16_MAX - 1, impl/paf.c:700 */
-                            cnt++;
-                            *cp = (uint16_t)cnt;
+                uint32_t oi = lo;
+                for (uint64_t a = first; a < s1; a += 64ull * TILE_UNROLL) {
+                    uint16_t *cp[TILE_UNROLL];
+                    uint32_t cv[TILE_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < TILE_UNROLL; u++) {
+                        const uint64_t au = a + 64ull * u;
+                        cp[u] = nullptr;
+                        cv[u] = 0;
+                        if (au < s1) {
+                            while (oi + 1 < n_al && (uint64_t)list[oi + 1].apos <= au) oi++;
+                            const TileOp o = list[oi];
+                            const uint64_t rel = au - o.apos;
+                            if (rel < o.len && o.qpos + rel >= clip_lo && o.qpos + rel < clip_hi) { /* inside the op and inside this slice */
+                                cp[u] = counts + o.qpos + rel;
+                                cv[u] = *cp[u];
+                            }
                         }
-                        if (cnt >= win && cnt < win + TILE_HIST) atomicAdd(&hist[cnt - win], 1u);
-                        else if (cnt < win) below++;
+                    }
+#pragma unroll
+                    for (int u = 0; u < TILE_UNROLL; u++) {
+                        uint32_t cnt = cv[u];
+                        const bool valid = cp[u] != nullptr;
+                        if (valid && bump && cnt < 32766u) { /* INT16_MAX - 1, impl/paf.c:700 */
+                            cnt++;
+                            *cp[u] = (uint16_t)cnt;
+                        }
+                        /* level histogram: most bases share a level, so count equal levels with ballots and
+                           issue one LDS atomic per distinct level of the wave instead of 64 colliding ones */
+                        unsigned long long todo = __ballot(valid);
+                        while (todo) {
+                            const int leader = __ffsll((long long)todo) - 1;
+                            const uint32_t lv = (uint32_t)__builtin_amdgcn_readlane((int)cnt, leader);
+                            const unsigned long long same = __ballot(valid && cnt == lv);
+                            if ((int)lane == leader) {
+                                const uint32_t k = (uint32_t)__popcll(same);
+                                if (lv >= win && lv < win + TILE_HIST) atomicAdd(&hist[lv - win], k);
+                                else if (lv < win) below += k;
+                                else atomicOr(&sh->flags, 0x10000u); /* level beyond the window (sliced mode: fall back) */
+                            }
+                            todo &= ~same;
+                        }
                     }
                 }
             }
@@ -200,7 +267,7 @@ __device__ int tile_walk(const TileParams &P, uint32_t rec, const RecMeta &m, ui
         if (bump) tile_fail(P, rec, PAFFY_ERR_CIGAR_CHAR, ep < end ? P.in[ep] : 0);
         return PAFFY_ERR_CIGAR_CHAR;
     }
-    if (fl || qcur != m.qe) { /* position asserts / assert(i == query_end), impl/paf.c:708 */
+    if ((fl & 0xffffu) || qcur != m.qe) { /* position asserts / assert(i == query_end), impl/paf.c:708 */
         if (bump) tile_fail(P, rec, PAFFY_ERR_TILE_ASSERT, (int)fl);
         return PAFFY_ERR_TILE_ASSERT;
     }
@@ -225,13 +292,24 @@ __global__ __launch_bounds__(PAFFY_NT) void k_tile(TileParams P) {
             const uint32_t rec = P.order[k];
             if (threadIdx.x == 0) sh->bcast[0] = (int64_t)(P.info->first_err_key >> 16);
             __syncthreads();
-            const bool stop = (uint64_t)sh->bcast[0] < P.rank_of[rec]; /* an earlier record already failed: nothing is written */
+            const bool stop = (uint64_t)sh->bcast[0] <= P.rank_of[rec]; /* this or an earlier record already failed: nothing is written */
             __syncthreads();
             if (stop) break;
             const RecMeta m = P.meta[rec];
             if (!m.has_cg) { /* cigar_parse(NULL): the reference dereferences NULL, impl/paf_tile.c:166 */
                 tile_fail(P, rec, PAFFY_ERR_NULL_CIGAR, 0);
                 break;
+            }
+            /* pull the counter lines of the following records' query ranges towards L2 while this one is walked:
+               a single workgroup keeps too few bytes in flight to hide a cold HBM miss per step */
+            for (uint32_t ahead = 1; ahead <= 2 && k + ahead < P.contig_off[c + 1]; ahead++) {
+                const RecMeta &nx = P.meta[P.order[k + ahead]];
+                const int64_t q0 = nx.qs < 0 ? 0 : nx.qs, q1 = nx.qe > nx.qlen ? nx.qlen : nx.qe;
+                if ((ahead == 2 || k == P.contig_off[c]) && nx.qlen == m.qlen)
+                    for (int64_t pos = q0 + (int64_t)threadIdx.x * 64; pos < q1; pos += (int64_t)PAFFY_NT * 64) {
+                        uint32_t touch = counts[pos];
+                        asm volatile("" ::"v"(touch));
+                    }
             }
             int64_t aligned = 0, below = 0;
             int rc = tile_walk(P, rec, m, counts, true, 0, hist, list, txt, bc, sh, &aligned, &below);
@@ -276,6 +354,116 @@ __global__ __launch_bounds__(PAFFY_NT) void k_tile(TileParams P) {
         }
         __syncthreads();
     }
+}
+
+
+/*
+ * Sliced tiling: one workgroup per (query sequence, 1 Mi-base slice) that has records. It walks, in
+ * visiting order, every record overlapping the slice, touches only the counters inside the slice, and
+ * leaves for each (record, slice) the histogram of the new counts as at most TILE_PAIRS (level, count)
+ * pairs. Records of one sequence still meet every base in visiting order, so the counters evolve
+ * exactly as in the sequential reference. k_tile_merge then sums a record's partial histograms and
+ * takes the median level. Anything that does not fit (a level >= TILE_HIST, too many distinct levels)
+ * raises DevInfo.internal and the host repeats the batch with k_tile.
+ */
+__global__ __launch_bounds__(PAFFY_NT) void k_tile_slices(TileParams P) {
+    extern __shared__ uint4 smem4[];
+    uint8_t *smem = reinterpret_cast<uint8_t *>(smem4);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
+    TileOp *list = reinterpret_cast<TileOp *>(smem + TILE_HIST * 4);
+    uint8_t *txt = smem + TILE_HIST * 4 + (PAFFY_NT * 8) * 16;
+    BlockComm bc;
+    bc.scratch = reinterpret_cast<int64_t *>(txt + PAFFY_HALO + TILE_TEXT);
+    bc.flip = 0;
+    Shared *sh = reinterpret_cast<Shared *>(reinterpret_cast<uint8_t *>(bc.scratch) + 64 * 8);
+    const uint32_t item = blockIdx.x;
+    const uint32_t c = P.item_contig[item], slice = P.item_slice[item];
+    uint16_t *counts = P.counts + P.contig_base[c];
+    const uint64_t lo = (uint64_t)slice << TILE_SLICE_SHIFT, hi = lo + (1ull << TILE_SLICE_SHIFT);
+    for (uint32_t k = P.item_off[item]; k < P.item_off[item + 1]; k++) {
+        const uint32_t rec = P.order[k];
+        if (threadIdx.x == 0) sh->bcast[0] = (int64_t)(P.info->first_err_key >> 16);
+        __syncthreads();
+        const bool stop = (uint64_t)sh->bcast[0] <= P.rank_of[rec];
+        __syncthreads();
+        if (stop) break;
+        const RecMeta m = P.meta[rec];
+        if (!m.has_cg) {
+            tile_fail(P, rec, PAFFY_ERR_NULL_CIGAR, 0);
+            break;
+        }
+        int64_t aligned = 0, below = 0;
+        int rc = tile_walk(P, rec, m, counts, true, 0, hist, list, txt, bc, sh, &aligned, &below, lo, hi);
+        if (rc) break;
+        if (sh->flags & 0x10000u) {
+            if (threadIdx.x == 0) atomicOr(&P.info->internal, 0x100u);
+        }
+        /* compact the window into (level, count) pairs */
+        TilePartial *part = P.partials + P.slot_base[rec] + (slice - tile_first_slice(m.qs, m.qe, m.qlen));
+        uint32_t mine = 0;
+        const uint32_t base = threadIdx.x * (TILE_HIST / PAFFY_NT);
+        for (uint32_t i = 0; i < TILE_HIST / PAFFY_NT; i++) mine += hist[base + i] != 0;
+        int64_t pre[1] = {mine}, tot[1];
+        block_excl_scan<1>(pre, tot, bc);
+        uint32_t o = (uint32_t)pre[0];
+        for (uint32_t i = 0; i < TILE_HIST / PAFFY_NT; i++) {
+            const uint32_t h = hist[base + i];
+            if (h) {
+                if (o < TILE_PAIRS) {
+                    part->level[o] = base + i;
+                    part->count[o] = h;
+                }
+                o++;
+            }
+        }
+        if (threadIdx.x == 0) {
+            part->n = tot[0] < TILE_PAIRS ? (uint32_t)tot[0] : TILE_PAIRS;
+            part->overflow = tot[0] > TILE_PAIRS;
+            if (tot[0] > TILE_PAIRS) atomicOr(&P.info->internal, 0x100u);
+        }
+        __syncthreads();
+    }
+}
+
+/* one lane per record: sum its partial histograms, median level (impl/paf_tile.c:81-88) */
+__global__ __launch_bounds__(PAFFY_NT) void k_tile_merge(TileParams P, uint32_t n_rec) {
+    const uint32_t rec = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (rec >= n_rec) return;
+    if ((P.info->first_err_key >> 16) <= P.rank_of[rec]) return; /* nothing is written anyway */
+    const RecMeta &m = P.meta[rec];
+    const uint32_t s0 = tile_first_slice(m.qs, m.qe, m.qlen), s1 = tile_last_slice(m.qs, m.qe, m.qlen);
+    const TilePartial *part = P.partials + P.slot_base[rec];
+    uint64_t aligned = 0;
+    for (uint32_t s = 0; s <= s1 - s0; s++)
+        for (uint32_t i = 0; i < part[s].n; i++) aligned += part[s].count[i];
+    int64_t level = 32767; /* no aligned base */
+    if (aligned > 0) {
+        /* walk the levels in increasing order: repeatedly take the smallest level above the last one */
+        uint64_t acc = 0;
+        int64_t last = -1;
+        level = -1;
+        for (;;) {
+            uint32_t best = 0xffffffffu;
+            for (uint32_t s = 0; s <= s1 - s0; s++)
+                for (uint32_t i = 0; i < part[s].n; i++)
+                    if ((int64_t)part[s].level[i] > last && part[s].level[i] < best) best = part[s].level[i];
+            if (best == 0xffffffffu) break;
+            for (uint32_t s = 0; s <= s1 - s0; s++)
+                for (uint32_t i = 0; i < part[s].n; i++)
+                    if (part[s].level[i] == best) acc += part[s].count[i];
+            if (2 * acc >= aligned) {
+                level = best;
+                break;
+            }
+            last = best;
+        }
+        if (level <= 0) { /* assert(i > 0) / assert(0) */
+            P.err_aux[rec] = 3;
+            atomicMin(&P.info->first_err_key, ((unsigned long long)P.rank_of[rec] << 16) | (1ull << 8) | (unsigned long long)PAFFY_ERR_TILE_ASSERT);
+            return;
+        }
+    }
+    P.tile_level[rec] = level;
 }
 
 #endif

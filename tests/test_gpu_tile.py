@@ -99,3 +99,37 @@ def test_errors_and_edges(eng):
     check(eng, ok + b"N" * 4000 + b"\t100\t0\t5\t+\tt\t100\t0\t5\t5\t5\t60\tAS:i:3\tcg:Z:5M\n")
     # zero aligned bases -> level 32767
     check(eng, b"q\t100\t3\t5\t+\tt\t100\t0\t0\t0\t0\t60\tcg:Z:2I\n")
+
+
+def kernels_used(eng, data):
+    eng.profile(True)
+    check(eng, data)
+    names = set(eng.profile_read())
+    eng.profile(False)
+    return names
+
+
+def test_sliced_path_and_fallback(eng):
+    """Records spanning several 1 Mi-base slices stay on the sliced path; many distinct levels inside one
+    slice or levels beyond the LDS window repeat the batch on the one-workgroup-per-sequence kernel."""
+    rng = random.Random(5)
+    qlen = 5_000_000
+    lines = []
+    for r in range(400):
+        span = rng.choice([1000, 300_000, 1_048_576, 2_500_000])
+        qs = rng.randrange(0, qlen - span)
+        a = span // 3
+        cig = f"{a}M7D{span - 2 * a}=5I{a - 5}X" if a > 5 else f"{span}M"
+        tspan = span - 5 + 7 if a > 5 else span
+        lines.append(f"big{r % 2}\t{qlen}\t{qs}\t{qs + span}\t{rng.choice('+-')}\tt\t9000000\t10\t{10 + tspan}\t{span}\t{span}\t60\t"
+                     f"AS:i:{rng.randrange(50)}\tcg:Z:{cig}\n")
+    data = "".join(lines[:12]).encode()
+    used = kernels_used(eng, data)
+    assert "k_tile_slices" in used and "k_tile" not in used
+    data = "".join(lines).encode()      # deep, ragged pile: more than 16 distinct levels in a slice
+    used = kernels_used(eng, data)
+    assert "k_tile_slices" in used
+    # levels beyond the 4096-level window
+    one = b"deep\t10\t2\t3\t+\tt\t10\t0\t1\t1\t1\t60\tcg:Z:1M\n"
+    used = kernels_used(eng, one * 4200)
+    assert "k_tile" in used

@@ -26,6 +26,7 @@ def main():
     torch.cuda.synchronize()
     kinds = {"invert": paffy_amd.INVERT, "trim": paffy_amd.TRIM_IDENTITY, "shatter": paffy_amd.SHATTER, "remove": paffy_amd.REMOVE_MISMATCHES}
     res = []
+    eng.profile(True)
     for rep in range(3):
         t0 = time.perf_counter()
         info = eng.tile_plan(buf, nbytes) if a.cmd == "tile" else eng.plan([paffy_amd.stage(kinds[a.cmd])], buf, nbytes)
@@ -36,9 +37,10 @@ def main():
         assert info.error.code == 0
         res.append(dt)
     dt = min(res)
+    prof = {k: round(v[0] / max(1, v[1]), 3) for k, v in eng.profile_read().items()}
     print(json.dumps({"cmd": a.cmd, "records": a.records, "mean_ops": a.mean_ops, "in_bytes": nbytes, "out_bytes": int(info.out_bytes),
                       "seconds": round(dt, 4), "records_per_s": round(a.records / dt, 1),
-                      "GBps": round((nbytes + info.out_bytes) / dt / 1e9, 1)}))
+                      "GBps": round((nbytes + info.out_bytes) / dt / 1e9, 1), "kernel_ms": prof}))
 
 
 if __name__ == "__main__":
