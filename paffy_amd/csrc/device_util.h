@@ -53,6 +53,23 @@ __device__ __forceinline__ int64_t wave_last(int64_t x) { /* value held by lane 
     uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)x >> 32), 63);
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
+/* 32-bit variants: one v_add_u32 with a DPP operand per step */
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ uint32_t dpp_mov_u32(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    uint32_t x = v;
+    x += dpp_mov_u32<DPP_ROW_SHR(1), 0xf, 0xf>(v);
+    x += dpp_mov_u32<DPP_ROW_SHR(2), 0xf, 0xf>(v);
+    x += dpp_mov_u32<DPP_ROW_SHR(3), 0xf, 0xf>(v);
+    x += dpp_mov_u32<DPP_ROW_SHR(4), 0xf, 0xe>(x);
+    x += dpp_mov_u32<DPP_ROW_SHR(8), 0xf, 0xc>(x);
+    x += dpp_mov_u32<DPP_BCAST15, 0xa, 0xf>(x);
+    x += dpp_mov_u32<DPP_BCAST31, 0xc, 0xf>(x);
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_last_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, 63); }
 /* min over the wave (same 7-step pattern; lanes without a source keep their own value) */
 __device__ __forceinline__ int64_t wave_min(int64_t v) {
     int64_t x = v;

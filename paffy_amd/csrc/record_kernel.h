@@ -1223,6 +1223,428 @@ __device__ __forceinline__ void shatter_emit(const RecState &s, const View<OPS> 
     em.finish();
 }
 
+/* ---------------- rows through byte-aligned LDS stores ---------------- */
+
+/*
+ * gfx950 executes ds_write_b128 at any byte address (the kernel driver runs the LDS in unaligned mode);
+ * a wave instruction with misaligned lanes is serialised to one lane per cycle, 16 bytes each
+ * (tools/probes/lds_unaligned.hip: 64 cycles per instruction whatever the width). A lane can therefore
+ * drop the pieces of its row at their byte positions with one store per piece instead of funnelling
+ * the row through 64-bit shifts. One such store costs the CU as much as ~64 VALU instructions, so
+ * neighbouring pieces are first merged in registers whenever they are known to fit 16 bytes.
+ *
+ * Stores are 16 bytes wide whatever the piece's length. The surplus lands on bytes that are written
+ * later: the following pieces of the same row, or -- past the row's end -- the first bytes of the next
+ * row's piece A, which is why the first 16 bytes of every A are written last, after all rows of the
+ * window (lenA >= 16 is the condition for this path).
+ */
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
+__device__ __forceinline__ void store16(uint8_t *p, u32x4 v) { *reinterpret_cast<u32x4_unaligned *>(p) = v; }
+__device__ __forceinline__ void store16(uint8_t *p, uint64_t lo, uint64_t hi) {
+    const u32x4 v = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+    store16(p, v);
+}
+
+struct Txt16 { /* up to 16 characters, first character in the lowest byte, unused bytes zero */
+    uint64_t lo, hi;
+    uint32_t n;
+};
+/* decimal text of 0 <= v < 10^15 followed by the n_tail (0..2) characters of `tail` */
+__device__ __forceinline__ void txt16(uint64_t v, uint32_t tail, uint32_t n_tail, Txt16 &d) {
+    uint32_t top, low = 0;
+    bool two;
+    if ((v >> 32) == 0) {
+        const uint32_t x = (uint32_t)v;
+        two = x >= 100000000u;
+        const uint32_t q = x / 100000000u;
+        top = two ? q : x;
+        low = x - q * 100000000u;
+    } else {
+        const uint64_t q = v / 100000000ull;
+        top = (uint32_t)q;
+        low = (uint32_t)(v - q * 100000000ull);
+        two = true;
+    }
+    uint32_t nt;
+    d.lo = ascii_upto8(top, &nt);
+    d.hi = 0;
+    d.n = nt;
+    if (two) { /* top < 10^7: one to seven characters, then eight digits */
+        const uint64_t g = ascii8(low);
+        d.lo |= g << (8 * nt);
+        d.hi = g >> (64 - 8 * nt);
+        d.n = nt + 8;
+    }
+    const uint32_t sh = 8 * (d.n & 7u);
+    const uint64_t w = (uint64_t)tail << sh;
+    if (d.n < 8) {
+        d.lo |= w;
+        d.hi |= sh > 48 ? (uint64_t)tail >> (64 - sh) : 0;
+    } else {
+        d.hi |= w;
+    }
+    d.n += n_tail;
+}
+
+/*
+ * Coordinates of one window are base .. base + total with total small, so they share all digits but
+ * the last four (or those of the next ten-thousand): base = P * 10^4 + W, and a value base + d prints
+ * as text(P + e) followed by the four digits of W + d - 10^4 e, e in {0, 1}, as long as W + d < 2 * 10^4.
+ * The texts of P and P + 1 are wave-uniform and only change when a window crosses a multiple of 10^4.
+ */
+struct DigitBase {
+    uint32_t P, W;
+    uint64_t t0, t1; /* text(P) (empty for P = 0), text(P + 1); at most 7 characters: values < 10^11 */
+    uint32_t n0, n1;
+    __device__ __forceinline__ void texts() {
+        t0 = 0;
+        n0 = 0;
+        if (P) t0 = ascii_upto8(P, &n0);
+        t1 = ascii_upto8(P + 1, &n1);
+    }
+    __device__ __forceinline__ void set(uint64_t v) {
+        const uint64_t q = v / 10000ull;
+        P = (uint32_t)q;
+        W = (uint32_t)(v - q * 10000ull);
+        texts();
+    }
+    __device__ __forceinline__ uint64_t value() const { return (uint64_t)P * 10000ull + W; }
+    __device__ __forceinline__ void advance(uint32_t d) {
+        W += d;
+        if (W >= 10000u) {
+            const uint32_t c = W / 10000u;
+            W -= c * 10000u;
+            P += c;
+            texts();
+        }
+    }
+    __device__ __forceinline__ void retreat(uint32_t d) {
+        if (W >= d) {
+            W -= d;
+        } else {
+            const uint32_t c = (d - W + 9999u) / 10000u;
+            W = W + c * 10000u - d;
+            P -= c;
+            texts();
+        }
+    }
+    /* text of base + d (W + d < 20000) followed by `tail` (n_tail <= 2 characters) */
+    __device__ __forceinline__ void num(uint32_t d, uint32_t tail, uint32_t n_tail, Txt16 &o) const {
+        uint32_t x = W + d;
+        const bool e = x >= 10000u;
+        if (e) x -= 10000u;
+        uint32_t w4 = bcd4(x);
+        const uint64_t pt = e ? t1 : t0;
+        const uint32_t np = e ? n1 : n0;
+        uint64_t v5;
+        uint32_t n4 = 4;
+        if (np == 0) { /* value < 10^4: no leading zeros */
+            const uint32_t z = w4 ? ((uint32_t)__ffs((int)w4) - 1) >> 3 : 3u;
+            n4 = 4 - z;
+            v5 = (uint64_t)((w4 + 0x30303030u) >> (8 * z)) | ((uint64_t)tail << (8 * n4));
+        } else {
+            v5 = (uint64_t)(w4 + 0x30303030u) | ((uint64_t)tail << 32);
+        }
+        const uint32_t sh = 8 * np;
+        o.lo = pt | (v5 << sh);
+        o.hi = (v5 >> 1) >> (63 - sh);
+        o.n = np + n4 + n_tail;
+    }
+};
+
+/* a wave-uniform piece rest (r = 1..15 bytes, zero above) followed by t, r + t.n <= 16 */
+__device__ __forceinline__ void store_rest_then(uint8_t *p, uint64_t rest_lo, uint64_t rest_hi, uint32_t r, const Txt16 &t) {
+    if (r < 8) {
+        const uint32_t sh = 8 * r;
+        store16(p, rest_lo | (t.lo << sh), (t.hi << sh) | (t.lo >> (64 - sh)));
+    } else {
+        store16(p, rest_lo, rest_hi | (t.lo << (8 * (r - 8))));
+    }
+}
+
+/* One wave's contiguous output range through a linear LDS buffer: buffer byte 0 is output byte `base`
+ * (a multiple of 16); the incomplete last 16 bytes of a window are carried to the front. */
+struct WaveLinear {
+    uint8_t *buf, *out;
+    uint64_t begin, base;
+    uint32_t phase; /* bytes of the buffer already holding output (< 16) */
+    __device__ __forceinline__ void start(uint8_t *b, uint8_t *o, uint64_t off) {
+        buf = b;
+        out = o;
+        begin = off;
+        base = off & ~15ull;
+        phase = (uint32_t)(off & 15u);
+    }
+    __device__ __forceinline__ void store_chunk(uint64_t c, const uint4 &v) {
+        if (c >= begin) {
+            *reinterpret_cast<uint4 *>(out + c) = v;
+        } else { /* first chunk of the range: the bytes below `begin` belong to the previous wave or record */
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int b = 0; b < 16; b++)
+                if (c + b >= begin) out[c + b] = (uint8_t)(w[b >> 2] >> ((b & 3) * 8));
+        }
+    }
+    /* the window's rows lie at buf[phase, phase + bytes) */
+    __device__ __forceinline__ void commit(uint32_t bytes) {
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t total = phase + bytes, nch = total >> 4;
+        for (uint32_t ch = lane; ch < nch; ch += 128) {
+            const uint32_t ch2 = ch + 64;
+            const bool two = ch2 < nch;
+            const uint4 v = *reinterpret_cast<const uint4 *>(buf + 16 * ch);
+            uint4 v2 = make_uint4(0, 0, 0, 0);
+            if (two) v2 = *reinterpret_cast<const uint4 *>(buf + 16 * ch2);
+            store_chunk(base + 16ull * ch, v);
+            if (two) store_chunk(base + 16ull * ch2, v2);
+        }
+        if ((total & 15u) && nch > 0 && lane == 0) *reinterpret_cast<uint4 *>(buf) = *reinterpret_cast<const uint4 *>(buf + 16 * nch);
+        base += 16ull * nch;
+        phase = total & 15u;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void finish() {
+        const uint32_t lane = threadIdx.x & 63;
+        if (lane < phase && base + lane >= begin) out[base + lane] = buf[lane];
+    }
+};
+
+/* wave-uniform description of the constant pieces of a record's rows (the pieces themselves stay in LDS) */
+struct RowConst {
+    const u32x4 *A16, *B16, *C16;
+    uint32_t lenA, lenB, lenC;
+    bool fuseA, fuseB; /* rest of A + q0 + tab / rest of B + t0 + tab always fit one store */
+    uint32_t dt;
+};
+/* one row's numbers: offsets from the window's digit bases (near) or the values themselves */
+struct RowNums {
+    uint32_t dq, dt, len;
+};
+__device__ __forceinline__ uint32_t dec_len_u32(uint32_t x) {
+    return 1u + (x >= 10u) + (x >= 100u) + (x >= 1000u) + (x >= 10000u) + (x >= 100000u) + (x >= 1000000u) + (x >= 10000000u) + (x >= 100000000u) +
+           (x >= 1000000000u);
+}
+/* digits of base + d, W + d < 20000 */
+__device__ __forceinline__ uint32_t near_len(const DigitBase &b, uint32_t d) {
+    uint32_t x = b.W + d;
+    const bool e = x >= 10000u;
+    const uint32_t np = e ? b.n1 : b.n0;
+    return np ? np + 4u : 1u + (x >= 10u) + (x >= 100u) + (x >= 1000u);
+}
+template <bool NEAR>
+__device__ __forceinline__ uint32_t row_bytes(const RowConst &c, const DigitBase &bq, const DigitBase &bt, const RowNums &r) {
+    const uint32_t nl = dec_len_u32(r.len);
+    uint32_t n;
+    if (NEAR) {
+        n = near_len(bq, r.dq) + near_len(bq, r.dq + r.len) + near_len(bt, r.dt) + near_len(bt, r.dt + r.len);
+    } else {
+        const uint64_t q0 = bq.value() + r.dq, t0 = bt.value() + r.dt;
+        n = dec_len((int64_t)q0) + dec_len((int64_t)(q0 + r.len)) + dec_len((int64_t)t0) + dec_len((int64_t)(t0 + r.len));
+    }
+    return c.lenA + c.lenB + c.lenC + 6u + n + 3u * nl;
+}
+template <bool NEAR>
+__device__ __forceinline__ void coord_txt(const DigitBase &b, uint32_t d, uint32_t tail, uint32_t n_tail, Txt16 &o) {
+    if (NEAR) b.num(d, tail, n_tail, o);
+    else txt16(b.value() + d, tail, n_tail, o);
+}
+/*
+ * A row at p, everything but the first 16 bytes of piece A: each number is formatted right before its
+ * store so that no text stays live. `small`: every L of the window has at most two digits.
+ */
+template <bool NEAR>
+__device__ __forceinline__ void put_row_body(uint8_t *p, const RowConst &c, const DigitBase &bq, const DigitBase &bt, const RowNums &r, bool small) {
+    Txt16 t;
+    const uint32_t fullA = c.lenA >> 4, rA = c.lenA & 15u;
+#pragma unroll 1
+    for (uint32_t j = 1; j < fullA; j++) store16(p + 16 * j, c.A16[j]);
+    coord_txt<NEAR>(bq, r.dq, '\t', 1, t);
+    if (c.fuseA) {
+        const u32x4 a = c.A16[fullA];
+        store_rest_then(p + 16 * fullA, a.x | ((uint64_t)a.y << 32), a.z | ((uint64_t)a.w << 32), rA, t);
+    } else {
+        if (rA) store16(p + 16 * fullA, c.A16[fullA]);
+        store16(p + c.lenA, t.lo, t.hi);
+    }
+    p += c.lenA + t.n;
+    coord_txt<NEAR>(bq, r.dq + r.len, 0, 0, t);
+    store16(p, t.lo, t.hi);
+    p += t.n;
+    const uint32_t fullB = c.lenB >> 4, rB = c.lenB & 15u;
+#pragma unroll 1
+    for (uint32_t j = 0; j < fullB; j++) store16(p + 16 * j, c.B16[j]);
+    coord_txt<NEAR>(bt, r.dt, '\t', 1, t);
+    if (c.fuseB) {
+        const u32x4 b = c.B16[fullB];
+        store_rest_then(p + 16 * fullB, b.x | ((uint64_t)b.y << 32), b.z | ((uint64_t)b.w << 32), rB, t);
+    } else {
+        if (rB) store16(p + 16 * fullB, c.B16[fullB]);
+        store16(p + c.lenB, t.lo, t.hi);
+    }
+    p += c.lenB + t.n;
+    coord_txt<NEAR>(bt, r.dt + r.len, '\t', 1, t);
+    Txt16 lt;
+    txt16(r.len, '\t', 1, lt); /* "L\t" */
+    const uint32_t nl = lt.n - 1;
+    if (small && c.dt <= 10) { /* "t1\tL\tL": at most 11 + 5 characters in one store */
+        const uint64_t ltl = lt.lo | ((lt.lo & 0xffffull) << (8 * lt.n)); /* a second tab (one-digit L) sits where C's first byte, a tab, follows */
+        if (t.n < 8) {
+            t.lo |= ltl << (8 * t.n);
+            t.hi |= (ltl >> 1) >> (63 - 8 * t.n);
+        } else {
+            t.hi |= ltl << (8 * (t.n - 8));
+        }
+        store16(p, t.lo, t.hi);
+    } else {
+        store16(p, t.lo, t.hi);
+        store16(p + t.n, lt.lo, lt.hi);
+        store16(p + t.n + lt.n, lt.lo, lt.hi); /* its tab is C's first byte */
+    }
+    p += t.n + lt.n + nl;
+    const uint32_t fullC = c.lenC >> 4, rC = c.lenC & 15u;
+#pragma unroll 1
+    for (uint32_t j = 0; j < fullC; j++) store16(p + 16 * j, c.C16[j]);
+    if (rC) store16(p + 16 * fullC, c.C16[fullC]);
+    /* "LM\n" from "L\t": the tab becomes 'M', then '\n' */
+    if (nl < 8) {
+        const uint32_t sh = 8 * nl;
+        lt.lo ^= (uint64_t)('\t' ^ 'M') << sh;
+        if (sh < 56) lt.lo |= (uint64_t)'\n' << (sh + 8);
+        else lt.hi = (uint64_t)'\n';
+    } else {
+        const uint32_t sh = 8 * (nl - 8);
+        lt.hi = (lt.hi ^ ((uint64_t)('\t' ^ 'M') << sh)) | ((uint64_t)'\n' << (sh + 8));
+    }
+    store16(p + c.lenC, lt.lo, lt.hi);
+}
+__device__ __forceinline__ bool shatter_fast_ok(const RecState &s, const ShatterConst &k) {
+    /* rows of a valid record have 0 <= coordinates <= sequence length (child paf_check, impl/paf.c:624),
+       and the cigar's sums equal the spans, so window sums fit 32 bits when the spans do */
+    return k.lenA >= 16 && s.qlen < 100000000000ll && s.tlen < 100000000000ll && s.qe - s.qs < 0x7f000000ll && s.te - s.ts < 0x7f000000ll;
+}
+
+/*
+ * Same work split as shatter_emit (every wave owns a contiguous share of the ops, its start taken from
+ * the sizing pass; windows of up to 128 ops, two per lane; no workgroup barrier), rows written with
+ * byte-aligned 16-byte LDS stores, coordinates as 32-bit offsets from a wave-uniform base.
+ */
+template <class OPS>
+__device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<OPS> &v, const ShatterConst &k, const u32x4 *A16, const u32x4 *B16,
+                                                  const u32x4 *C16, const RecPlan &pl, uint8_t *lds, uint8_t *out, uint64_t rec_off) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t span = 64ull * pl.chunk;
+    const uint32_t wb = span * wave < v.n ? (uint32_t)(span * wave) : v.n;
+    const uint32_t we = span * (wave + 1) < v.n ? (uint32_t)(span * (wave + 1)) : v.n;
+    WaveLinear em;
+    em.start(lds + wave * PAFFY_WAVE_RING, out, rec_off + (uint64_t)pl.wo[wave]);
+    RowConst rc;
+    rc.A16 = A16; rc.B16 = B16; rc.C16 = C16;
+    rc.lenA = k.lenA; rc.lenB = k.lenB; rc.lenC = k.lenC;
+    rc.dt = dec_len(s.tlen);
+    rc.fuseA = (k.lenA & 15u) != 0 && (k.lenA & 15u) + dec_len(s.qlen) + 1 <= 16;
+    rc.fuseB = (k.lenB & 15u) != 0 && (k.lenB & 15u) + rc.dt + 1 <= 16;
+    /* digit bases: forward strand q = (qs + cq) + dq; reverse strand q0 = (qe - cq - total) + (total - dq - len) */
+    DigitBase bq, bt;
+    bq.set(s.same ? (uint64_t)(s.qs + pl.wq[wave]) : (uint64_t)(s.qe - pl.wq[wave]));
+    bt.set((uint64_t)(s.ts + pl.wt[wave]));
+    const uint32_t cap_bytes = PAFFY_WAVE_RING - 48;
+    const uint32_t rows_cap = cap_bytes / k.row_max; /* >= 1, checked by the sizing pass */
+    const uint32_t w_safe = rows_cap < 128 ? rows_cap : 128;
+    const uint32_t w_full = 2 * rows_cap < 128 ? 2 * rows_cap : 128;
+    uint32_t i = wb, w_try = w_full;
+    typename OPS::raw_t nraw0 = 0, nraw1 = 0;
+    uint32_t n_i = 0xffffffffu, n_w = 0; /* window the prefetched pair belongs to */
+    while (i < we) {
+        const uint32_t w = we - i < w_try ? we - i : w_try;
+        const uint32_t j0 = i + 2 * lane;
+        const bool has0 = j0 < i + w, has1 = j0 + 1 < i + w;
+        const uint32_t r0 = v.raw_index(j0), r1 = v.raw_index(j0 + 1);
+        typename OPS::raw_t raw0 = 0, raw1 = 0;
+        if (n_i == i && n_w == w) {
+            raw0 = nraw0;
+            raw1 = nraw1;
+        } else {
+            if (has0) raw0 = v.ops.raw(r0);
+            if (has1) raw1 = v.ops.raw(r1);
+        }
+        { /* the loads of the following window fly while this one is formatted */
+            n_i = i + w;
+            n_w = we - n_i < w_full ? we - n_i : w_full;
+            const uint32_t k0 = n_i + 2 * lane;
+            nraw0 = nraw1 = 0;
+            if (k0 < n_i + n_w) nraw0 = v.ops.raw(v.raw_index(k0));
+            if (k0 + 1 < n_i + n_w) nraw1 = v.ops.raw(v.raw_index(k0 + 1));
+        }
+        int64_t len0_64 = 0, len1_64 = 0;
+        int op0 = -1, op1 = -1;
+        if (has0) v.decode(raw0, r0, len0_64, op0);
+        if (has1) v.decode(raw1, r1, len1_64, op1);
+        const uint32_t len0 = (uint32_t)len0_64, len1 = (uint32_t)len1_64;
+        const uint32_t q_0 = (op0 >= 0 && op0 != OP_D) ? len0 : 0, t_0 = (op0 >= 0 && op0 != OP_I) ? len0 : 0;
+        const uint32_t q_1 = (op1 >= 0 && op1 != OP_D) ? len1 : 0, t_1 = (op1 >= 0 && op1 != OP_I) ? len1 : 0;
+        const uint32_t iq = wave_incl_scan_u32(q_0 + q_1), it = wave_incl_scan_u32(t_0 + t_1);
+        const uint32_t totq = wave_last_u32(iq), tott = wave_last_u32(it);
+        const uint32_t eq = iq - (q_0 + q_1), et = it - (t_0 + t_1);
+        /* a lane's first M op is its first row; two M ops in one pair (a second row) are rare */
+        const bool m0 = op0 == OP_M, m1 = op1 == OP_M;
+        const bool prim = m0 || m1, sec = m0 && m1;
+        const bool small = __all(!prim || ((m0 ? len0 : len1) < 100u && (!sec || len1 < 100u))) != 0;
+        const bool any_sec = __any(sec) != 0;
+        if (!s.same) bq.retreat(totq); /* the window's lowest query coordinate */
+        const bool near = bq.W + totq < 20000u && bt.W + tott < 20000u; /* wave-uniform */
+        RowNums rn0, rn1;
+        rn0.len = m0 ? len0 : len1;
+        rn0.dq = m0 ? eq : eq + q_0;
+        rn0.dt = m0 ? et : et + t_0;
+        rn1.len = len1;
+        rn1.dq = eq + q_0;
+        rn1.dt = et + t_0;
+        if (!s.same) {
+            rn0.dq = totq - rn0.dq - rn0.len;
+            rn1.dq = totq - rn1.dq - rn1.len;
+        }
+        uint32_t bytes0 = 0, bytes1 = 0;
+        if (prim) bytes0 = near ? row_bytes<true>(rc, bq, bt, rn0) : row_bytes<false>(rc, bq, bt, rn0);
+        if (sec) bytes1 = near ? row_bytes<true>(rc, bq, bt, rn1) : row_bytes<false>(rc, bq, bt, rn1);
+        const uint32_t mine = bytes0 + bytes1;
+        const uint32_t inc = wave_incl_scan_u32(mine), total = wave_last_u32(inc);
+        if (total > cap_bytes && w > w_safe) { /* unusually dense window: retry with the safe size */
+            if (!s.same) bq.advance(totq);
+            w_try = w_safe;
+            continue;
+        }
+        const uint32_t o = em.phase + inc - mine;
+#pragma unroll 1
+        for (int r = 0; r < 2; r++) {
+            if (r && !any_sec) break;
+            const bool on = r ? sec : prim;
+            if (on) {
+                uint8_t *p = em.buf + o + (r ? bytes0 : 0u);
+                RowNums x;
+                x.len = r ? rn1.len : rn0.len;
+                x.dq = r ? rn1.dq : rn0.dq;
+                x.dt = r ? rn1.dt : rn0.dt;
+                if (near) put_row_body<true>(p, rc, bq, bt, x, small);
+                else put_row_body<false>(p, rc, bq, bt, x, small);
+            }
+        }
+        /* the head of piece A of every row, last: it repairs what the previous row's wide stores spilled */
+        if (prim) {
+            const u32x4 a_head = A16[0];
+            store16(em.buf + o, a_head);
+            if (sec) store16(em.buf + o + bytes0, a_head);
+        }
+        em.commit(total);
+        if (s.same) bq.advance(totq);
+        bt.advance(tott);
+        i += w;
+        w_try = w_full;
+    }
+    em.finish();
+}
+
 /* Per-lane serial writers for the rare records whose pieces do not fit the LDS staging (names of
  * many hundreds of bytes): bytes go straight to HBM, the pieces are re-derived from the input text. */
 struct DirectWriter {
@@ -1655,21 +2077,26 @@ __device__ __forceinline__ void emit_record(const KParams &P, uint32_t rec, cons
             Piece w{(uint8_t *)A, 0, PAFFY_TMPL_MAX, false};
             w.name(P.in, s.qn_off, s.qn_len);
             w.ch('\t'); w.num(s.qlen); w.ch('\t');
-            w.pad_to(32);
+            w.pad_to(((w.n + 31u) & ~15u) < 32u ? 32u : ((w.n + 31u) & ~15u));
         } else if (wave == 1) {
             Piece w{(uint8_t *)B, 0, PAFFY_TMPL_MAX, false};
             w.ch('\t'); w.ch(s.same ? '+' : '-'); w.ch('\t');
             w.name(P.in, s.tn_off, s.tn_len);
             w.ch('\t'); w.num(s.tlen); w.ch('\t');
-            w.pad_to(32);
+            w.pad_to(((w.n + 31u) & ~15u) < 32u ? 32u : ((w.n + 31u) & ~15u));
         } else if (wave == 2) {
             Piece w{(uint8_t *)C, 0, PAFFY_TMPL_MAX, false};
             w.ch('\t'); w.num(s.mapq);
             piece_tags(w, s, 0);
             w.str("\tcg:Z:", 6);
-            w.pad_to(48);
+            w.pad_to(((w.n + 31u) & ~15u) < 48u ? 48u : ((w.n + 31u) & ~15u));
         }
         __syncthreads();
+        if (shatter_fast_ok(s, k)) {
+            shatter_emit_fast(s, v, k, reinterpret_cast<const u32x4 *>(A), reinterpret_cast<const u32x4 *>(B), reinterpret_cast<const u32x4 *>(C), pl,
+                              L.ring, P.out, (uint64_t)P.out_off[rec]);
+            return;
+        }
         RowPieces pieces;
         load_pieces(pieces, k, A, B, C);
         shatter_emit(s, v, k, pieces, pl, L.ring, P.out, (uint64_t)P.out_off[rec]);
