@@ -1363,49 +1363,57 @@ __device__ __forceinline__ void store_rest_then(uint8_t *p, uint64_t rest_lo, ui
     }
 }
 
-/* One wave's contiguous output range through a linear LDS buffer: buffer byte 0 is output byte `base`
- * (a multiple of 16); the incomplete last 16 bytes of a window are carried to the front. */
+/*
+ * One wave's contiguous output range through a linear LDS buffer: buffer byte 0 is output byte `base`
+ * (a multiple of 16); the incomplete last 16 bytes of a window are carried to the front. The flush of a
+ * window is issued after the sizing arithmetic of the next one (stage()/flush() are separate), so that
+ * a wave does not sit on the LDS queue behind its own stores.
+ */
 struct WaveLinear {
     uint8_t *buf, *out;
-    uint64_t begin, base;
-    uint32_t phase; /* bytes of the buffer already holding output (< 16) */
+    uint64_t begin, base; /* wave-uniform */
+    uint32_t phase;       /* bytes of the buffer already holding output (< 16) */
+    uint32_t pending;     /* bytes staged behind `phase` and not flushed yet */
     __device__ __forceinline__ void start(uint8_t *b, uint8_t *o, uint64_t off) {
         buf = b;
         out = o;
         begin = off;
         base = off & ~15ull;
         phase = (uint32_t)(off & 15u);
+        pending = 0;
     }
-    __device__ __forceinline__ void store_chunk(uint64_t c, const uint4 &v) {
-        if (c >= begin) {
-            *reinterpret_cast<uint4 *>(out + c) = v;
-        } else { /* first chunk of the range: the bytes below `begin` belong to the previous wave or record */
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int b = 0; b < 16; b++)
-                if (c + b >= begin) out[c + b] = (uint8_t)(w[b >> 2] >> ((b & 3) * 8));
-        }
-    }
-    /* the window's rows lie at buf[phase, phase + bytes) */
-    __device__ __forceinline__ void commit(uint32_t bytes) {
+    /* buffer offset at which the next window's rows start (valid before the pending flush has run) */
+    __device__ __forceinline__ uint32_t next_phase() const { return (phase + pending) & 15u; }
+    __device__ __forceinline__ void stage(uint32_t bytes) { pending = bytes; }
+    /* push the staged window's whole 16-byte chunks to HBM */
+    __device__ __forceinline__ void flush() {
+        if (pending == 0) return;
         __builtin_amdgcn_wave_barrier();
         const uint32_t lane = threadIdx.x & 63;
-        const uint32_t total = phase + bytes, nch = total >> 4;
-        for (uint32_t ch = lane; ch < nch; ch += 128) {
+        const uint32_t total = phase + pending, nch = total >> 4;
+        uint8_t *dst = out + base; /* wave-uniform: scalar base, 32-bit lane offsets */
+        uint32_t first = 0;
+        if (base < begin && nch > 0) { /* first chunk of the range: the bytes below `begin` belong to the previous wave or record */
+            if (lane >= (uint32_t)(begin - base) && lane < 16) dst[lane] = buf[lane];
+            first = 1;
+        }
+        for (uint32_t ch = first + lane; ch < nch; ch += 128) {
             const uint32_t ch2 = ch + 64;
             const bool two = ch2 < nch;
             const uint4 v = *reinterpret_cast<const uint4 *>(buf + 16 * ch);
             uint4 v2 = make_uint4(0, 0, 0, 0);
             if (two) v2 = *reinterpret_cast<const uint4 *>(buf + 16 * ch2);
-            store_chunk(base + 16ull * ch, v);
-            if (two) store_chunk(base + 16ull * ch2, v2);
+            *reinterpret_cast<uint4 *>(dst + 16 * ch) = v;
+            if (two) *reinterpret_cast<uint4 *>(dst + 16 * ch2) = v2;
         }
         if ((total & 15u) && nch > 0 && lane == 0) *reinterpret_cast<uint4 *>(buf) = *reinterpret_cast<const uint4 *>(buf + 16 * nch);
         base += 16ull * nch;
         phase = total & 15u;
+        pending = 0;
         __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ void finish() {
+        flush();
         const uint32_t lane = threadIdx.x & 63;
         if (lane < phase && base + lane >= begin) out[base + lane] = buf[lane];
     }
@@ -1538,7 +1546,7 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
     const uint32_t wb = span * wave < v.n ? (uint32_t)(span * wave) : v.n;
     const uint32_t we = span * (wave + 1) < v.n ? (uint32_t)(span * (wave + 1)) : v.n;
     WaveLinear em;
-    em.start(lds + wave * PAFFY_WAVE_RING, out, rec_off + (uint64_t)pl.wo[wave]);
+    em.start(lds + wave * PAFFY_WAVE_RING, out, uniform_u64(rec_off + (uint64_t)pl.wo[wave]));
     RowConst rc;
     rc.A16 = A16; rc.B16 = B16; rc.C16 = C16;
     rc.lenA = k.lenA; rc.lenB = k.lenB; rc.lenC = k.lenC;
@@ -1568,14 +1576,6 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
         } else {
             if (has0) raw0 = v.ops.raw(r0);
             if (has1) raw1 = v.ops.raw(r1);
-        }
-        { /* the loads of the following window fly while this one is formatted */
-            n_i = i + w;
-            n_w = we - n_i < w_full ? we - n_i : w_full;
-            const uint32_t k0 = n_i + 2 * lane;
-            nraw0 = nraw1 = 0;
-            if (k0 < n_i + n_w) nraw0 = v.ops.raw(v.raw_index(k0));
-            if (k0 + 1 < n_i + n_w) nraw1 = v.ops.raw(v.raw_index(k0 + 1));
         }
         int64_t len0_64 = 0, len1_64 = 0;
         int op0 = -1, op1 = -1;
@@ -1615,7 +1615,17 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
             w_try = w_safe;
             continue;
         }
-        const uint32_t o = em.phase + inc - mine;
+        const uint32_t o = em.next_phase() + inc - mine;
+        em.flush(); /* the previous window: its stores were issued before this window's arithmetic */
+        { /* the loads of the following window fly while this one is formatted. Issued behind the flush: the
+             counter wait at the top of the next iteration then covers these loads only, not newer stores */
+            n_i = i + w;
+            n_w = we - n_i < w_full ? we - n_i : w_full;
+            const uint32_t k0 = n_i + 2 * lane;
+            nraw0 = nraw1 = 0;
+            if (k0 < n_i + n_w) nraw0 = v.ops.raw(v.raw_index(k0));
+            if (k0 + 1 < n_i + n_w) nraw1 = v.ops.raw(v.raw_index(k0 + 1));
+        }
 #pragma unroll 1
         for (int r = 0; r < 2; r++) {
             if (r && !any_sec) break;
@@ -1636,7 +1646,7 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
             store16(em.buf + o, a_head);
             if (sec) store16(em.buf + o + bytes0, a_head);
         }
-        em.commit(total);
+        em.stage(total);
         if (s.same) bq.advance(totq);
         bt.advance(tott);
         i += w;

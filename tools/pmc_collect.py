@@ -16,7 +16,6 @@ GROUPS = [
     ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM"],
     ["SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA"],
     ["SQ_INST_LEVEL_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_UNALIGNED_STALL", "SQ_IFETCH", "SQ_ACTIVE_INST_ANY"],
-    ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_HIT_sum", "TCC_MISS_sum"],
 ]
 
 
@@ -29,7 +28,8 @@ def main():
     for gi, grp in enumerate(GROUPS):
         d = os.path.join(root, "gpurun_out", f"pmc_pass{gi}")
         cmd = ["rocprofv3", "--pmc", *grp, "-d", d, "--output-format", "csv", "--", sys.executable, os.path.join(root, "bench.py"), *bench_args]
-        r = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        print(f"pass {gi}: {' '.join(grp)}", flush=True)
+        r = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
         if r.returncode:
             print(f"pass {gi} failed:\n{r.stdout[-2000:]}", file=sys.stderr)
             continue
