@@ -972,6 +972,7 @@ int paffy_hip_emit(paffy_hip_ctx *c, void *d_out, int64_t out_cap) {
     kp.out = static_cast<uint8_t *>(d_out);
     const bool shatter = kp.n_stages > 0 && kp.stages[kp.n_stages - 1].kind == PAFFY_SHATTER;
     if (shatter) {
+        LAUNCH(c, "k_emit_rows", k_emit_rows, dim3(kp.n_rec), dim3(64), PAFFY_ROWS_LDS_BYTES, kp);
         LAUNCH(c, "k_emit_lds", k_emit_lds<true>, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
         if (c->h_info->w_count > 0) LAUNCH(c, "k_arena_emit", k_arena_emit<true>, dim3(512), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
     } else {

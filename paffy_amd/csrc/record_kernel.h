@@ -1224,6 +1224,14 @@ __device__ __forceinline__ void shatter_emit(const RecState &s, const View<OPS> 
 }
 
 /* ---------------- rows through byte-aligned LDS stores ---------------- */
+#if defined(PAFFY_ABL) && (PAFFY_ABL == 20 || PAFFY_ABL == 21)
+#define PT_DECL unsigned long long pt_t0 = __builtin_readcyclecounter(), pt_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned pt_n = 0;
+#define PT_MARK(k) { unsigned long long pt_t1 = __builtin_readcyclecounter(); pt_acc[k] += pt_t1 - pt_t0; pt_t0 = pt_t1; }
+#else
+#define PT_DECL
+#define PT_MARK(k)
+#endif
+
 
 /*
  * gfx950 executes ds_write_b128 at any byte address (the kernel driver runs the LDS in unaligned mode);
@@ -1397,14 +1405,16 @@ struct WaveLinear {
             if (lane >= (uint32_t)(begin - base) && lane < 16) dst[lane] = buf[lane];
             first = 1;
         }
-        for (uint32_t ch = first + lane; ch < nch; ch += 128) {
-            const uint32_t ch2 = ch + 64;
-            const bool two = ch2 < nch;
-            const uint4 v = *reinterpret_cast<const uint4 *>(buf + 16 * ch);
-            uint4 v2 = make_uint4(0, 0, 0, 0);
-            if (two) v2 = *reinterpret_cast<const uint4 *>(buf + 16 * ch2);
-            *reinterpret_cast<uint4 *>(dst + 16 * ch) = v;
-            if (two) *reinterpret_cast<uint4 *>(dst + 16 * ch2) = v2;
+        for (uint32_t ch = first + lane; ch < nch; ch += 256) { /* four chunks per step: the LDS reads fly together, one wait */
+            const uint32_t c1 = ch + 64, c2 = ch + 128, c3 = ch + 192;
+            uint4 v0 = *reinterpret_cast<const uint4 *>(buf + 16 * ch), v1, v2, v3;
+            if (c1 < nch) v1 = *reinterpret_cast<const uint4 *>(buf + 16 * c1);
+            if (c2 < nch) v2 = *reinterpret_cast<const uint4 *>(buf + 16 * c2);
+            if (c3 < nch) v3 = *reinterpret_cast<const uint4 *>(buf + 16 * c3);
+            *reinterpret_cast<uint4 *>(dst + 16 * ch) = v0;
+            if (c1 < nch) *reinterpret_cast<uint4 *>(dst + 16 * c1) = v1;
+            if (c2 < nch) *reinterpret_cast<uint4 *>(dst + 16 * c2) = v2;
+            if (c3 < nch) *reinterpret_cast<uint4 *>(dst + 16 * c3) = v3;
         }
         if ((total & 15u) && nch > 0 && lane == 0) *reinterpret_cast<uint4 *>(buf) = *reinterpret_cast<const uint4 *>(buf + 16 * nch);
         base += 16ull * nch;
@@ -1425,7 +1435,18 @@ struct RowConst {
     uint32_t lenA, lenB, lenC;
     bool fuseA, fuseB; /* rest of A + q0 + tab / rest of B + t0 + tab always fit one store */
     uint32_t dt;
+    /* the usual case, every piece at most 32 bytes: their chunks are held in scalar registers, so that a row needs no LDS read */
+    bool regs;
+    u32x4 a0, a1, b0, b1, c0, c1;
 };
+__device__ __forceinline__ u32x4 uniform_x4(u32x4 v) {
+    u32x4 r;
+    r.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.x);
+    r.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.y);
+    r.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.z);
+    r.w = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.w);
+    return r;
+}
 /* one row's numbers: offsets from the window's digit bases (near) or the values themselves */
 struct RowNums {
     uint32_t dq, dt, len;
@@ -1462,18 +1483,30 @@ __device__ __forceinline__ void coord_txt(const DigitBase &b, uint32_t d, uint32
  * A row at p, everything but the first 16 bytes of piece A: each number is formatted right before its
  * store so that no text stays live. `small`: every L of the window has at most two digits.
  */
+/* the chunks of a piece: from scalar registers (pieces of at most 32 bytes) or from LDS */
+#define PIECE_FULL_CHUNKS(P, R0, R1, PTR, LEN, FROM)                                       \
+    {                                                                                      \
+        const uint32_t full_ = (LEN) >> 4;                                                 \
+        if (c.regs) {                                                                      \
+            if ((FROM) == 0 && full_ >= 1) store16((P), c.R0);                             \
+            if (full_ == 2) store16((P) + 16, c.R1);                                       \
+        } else {                                                                           \
+            _Pragma("unroll 1") for (uint32_t j = (FROM); j < full_; j++) store16((P) + 16 * j, c.PTR[j]); \
+        }                                                                                  \
+    }
+#define PIECE_REST_CHUNK(R0, R1, PTR, LEN) (c.regs ? (((LEN) >> 4) ? c.R1 : c.R0) : c.PTR[(LEN) >> 4])
+
 template <bool NEAR>
 __device__ __forceinline__ void put_row_body(uint8_t *p, const RowConst &c, const DigitBase &bq, const DigitBase &bt, const RowNums &r, bool small) {
     Txt16 t;
     const uint32_t fullA = c.lenA >> 4, rA = c.lenA & 15u;
-#pragma unroll 1
-    for (uint32_t j = 1; j < fullA; j++) store16(p + 16 * j, c.A16[j]);
+    PIECE_FULL_CHUNKS(p, a0, a1, A16, c.lenA, 1)
     coord_txt<NEAR>(bq, r.dq, '\t', 1, t);
     if (c.fuseA) {
-        const u32x4 a = c.A16[fullA];
+        const u32x4 a = PIECE_REST_CHUNK(a0, a1, A16, c.lenA);
         store_rest_then(p + 16 * fullA, a.x | ((uint64_t)a.y << 32), a.z | ((uint64_t)a.w << 32), rA, t);
     } else {
-        if (rA) store16(p + 16 * fullA, c.A16[fullA]);
+        if (rA) store16(p + 16 * fullA, PIECE_REST_CHUNK(a0, a1, A16, c.lenA));
         store16(p + c.lenA, t.lo, t.hi);
     }
     p += c.lenA + t.n;
@@ -1481,14 +1514,13 @@ __device__ __forceinline__ void put_row_body(uint8_t *p, const RowConst &c, cons
     store16(p, t.lo, t.hi);
     p += t.n;
     const uint32_t fullB = c.lenB >> 4, rB = c.lenB & 15u;
-#pragma unroll 1
-    for (uint32_t j = 0; j < fullB; j++) store16(p + 16 * j, c.B16[j]);
+    PIECE_FULL_CHUNKS(p, b0, b1, B16, c.lenB, 0)
     coord_txt<NEAR>(bt, r.dt, '\t', 1, t);
     if (c.fuseB) {
-        const u32x4 b = c.B16[fullB];
+        const u32x4 b = PIECE_REST_CHUNK(b0, b1, B16, c.lenB);
         store_rest_then(p + 16 * fullB, b.x | ((uint64_t)b.y << 32), b.z | ((uint64_t)b.w << 32), rB, t);
     } else {
-        if (rB) store16(p + 16 * fullB, c.B16[fullB]);
+        if (rB) store16(p + 16 * fullB, PIECE_REST_CHUNK(b0, b1, B16, c.lenB));
         store16(p + c.lenB, t.lo, t.hi);
     }
     p += c.lenB + t.n;
@@ -1512,9 +1544,8 @@ __device__ __forceinline__ void put_row_body(uint8_t *p, const RowConst &c, cons
     }
     p += t.n + lt.n + nl;
     const uint32_t fullC = c.lenC >> 4, rC = c.lenC & 15u;
-#pragma unroll 1
-    for (uint32_t j = 0; j < fullC; j++) store16(p + 16 * j, c.C16[j]);
-    if (rC) store16(p + 16 * fullC, c.C16[fullC]);
+    PIECE_FULL_CHUNKS(p, c0, c1, C16, c.lenC, 0)
+    if (rC) store16(p + 16 * fullC, PIECE_REST_CHUNK(c0, c1, C16, c.lenC));
     /* "LM\n" from "L\t": the tab becomes 'M', then '\n' */
     if (nl < 8) {
         const uint32_t sh = 8 * nl;
@@ -1540,42 +1571,77 @@ __device__ __forceinline__ bool shatter_fast_ok(const RecState &s, const Shatter
  */
 template <class OPS>
 __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<OPS> &v, const ShatterConst &k, const u32x4 *A16, const u32x4 *B16,
-                                                  const u32x4 *C16, const RecPlan &pl, uint8_t *lds, uint8_t *out, uint64_t rec_off) {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t span = 64ull * pl.chunk;
-    const uint32_t wb = span * wave < v.n ? (uint32_t)(span * wave) : v.n;
-    const uint32_t we = span * (wave + 1) < v.n ? (uint32_t)(span * (wave + 1)) : v.n;
+                                                  const u32x4 *C16, uint32_t wb, uint32_t we, int64_t cq0, int64_t ct0, uint8_t *buf, uint8_t *out,
+                                                  uint64_t out_start) {
+    /* this wave emits the rows of ops [wb, we): cq0 / ct0 bases lie before op wb, its first output byte is out_start */
+    const uint32_t lane = threadIdx.x & 63;
     WaveLinear em;
-    em.start(lds + wave * PAFFY_WAVE_RING, out, uniform_u64(rec_off + (uint64_t)pl.wo[wave]));
+    em.start(buf, out, out_start);
     RowConst rc;
     rc.A16 = A16; rc.B16 = B16; rc.C16 = C16;
     rc.lenA = k.lenA; rc.lenB = k.lenB; rc.lenC = k.lenC;
     rc.dt = dec_len(s.tlen);
     rc.fuseA = (k.lenA & 15u) != 0 && (k.lenA & 15u) + dec_len(s.qlen) + 1 <= 16;
     rc.fuseB = (k.lenB & 15u) != 0 && (k.lenB & 15u) + rc.dt + 1 <= 16;
+    rc.regs = k.lenA <= 32 && k.lenB <= 32 && k.lenC <= 32; /* chunk index 2 is never read then (a length of 32 has no rest) */
+    if (rc.regs) {
+        rc.a0 = uniform_x4(A16[0]); rc.a1 = uniform_x4(A16[1]);
+        rc.b0 = uniform_x4(B16[0]); rc.b1 = uniform_x4(B16[1]);
+        rc.c0 = uniform_x4(C16[0]); rc.c1 = uniform_x4(C16[1]);
+    }
     /* digit bases: forward strand q = (qs + cq) + dq; reverse strand q0 = (qe - cq - total) + (total - dq - len) */
     DigitBase bq, bt;
-    bq.set(s.same ? (uint64_t)(s.qs + pl.wq[wave]) : (uint64_t)(s.qe - pl.wq[wave]));
-    bt.set((uint64_t)(s.ts + pl.wt[wave]));
+    bq.set(s.same ? (uint64_t)(s.qs + cq0) : (uint64_t)(s.qe - cq0));
+    bt.set((uint64_t)(s.ts + ct0));
     const uint32_t cap_bytes = PAFFY_WAVE_RING - 48;
     const uint32_t rows_cap = cap_bytes / k.row_max; /* >= 1, checked by the sizing pass */
     const uint32_t w_safe = rows_cap < 128 ? rows_cap : 128;
     const uint32_t w_full = 2 * rows_cap < 128 ? 2 * rows_cap : 128;
     uint32_t i = wb, w_try = w_full;
-    typename OPS::raw_t nraw0 = 0, nraw1 = 0;
-    uint32_t n_i = 0xffffffffu, n_w = 0; /* window the prefetched pair belongs to */
+    /*
+     * Raw ops of five windows at a time, two per lane and window, in registers. One counter tracks loads and
+     * stores in issue order, so a wait for a load is also a wait for every store issued before it -- and a
+     * flushed window is acknowledged only after microseconds when the write queues are full. The first block is
+     * loaded before the wave has stored anything; a wave whose share exceeds five windows pays that wait per block.
+     */
+    typedef typename OPS::raw_t raw_t;
+    raw_t b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0, b8 = 0, b9 = 0;
+    uint32_t slot = 5, blk_next = 0xffffffffu; /* next unused window of the block and the op index it starts at */
+    PT_DECL
     while (i < we) {
+        PT_MARK(5)
         const uint32_t w = we - i < w_try ? we - i : w_try;
         const uint32_t j0 = i + 2 * lane;
         const bool has0 = j0 < i + w, has1 = j0 + 1 < i + w;
         const uint32_t r0 = v.raw_index(j0), r1 = v.raw_index(j0 + 1);
-        typename OPS::raw_t raw0 = 0, raw1 = 0;
-        if (n_i == i && n_w == w) {
-            raw0 = nraw0;
-            raw1 = nraw1;
-        } else {
+        raw_t raw0 = 0, raw1 = 0;
+        if (w_try != w_full) { /* safe-size retry: plain loads */
             if (has0) raw0 = v.ops.raw(r0);
             if (has1) raw1 = v.ops.raw(r1);
+            slot = 5;
+        } else {
+            if (slot >= 5 || blk_next != i) {
+                uint32_t k0 = j0;
+                b0 = k0 < we ? v.ops.raw(v.raw_index(k0)) : (raw_t)0;
+                b1 = k0 + 1 < we ? v.ops.raw(v.raw_index(k0 + 1)) : (raw_t)0;
+                k0 += w_full;
+                b2 = k0 < we ? v.ops.raw(v.raw_index(k0)) : (raw_t)0;
+                b3 = k0 + 1 < we ? v.ops.raw(v.raw_index(k0 + 1)) : (raw_t)0;
+                k0 += w_full;
+                b4 = k0 < we ? v.ops.raw(v.raw_index(k0)) : (raw_t)0;
+                b5 = k0 + 1 < we ? v.ops.raw(v.raw_index(k0 + 1)) : (raw_t)0;
+                k0 += w_full;
+                b6 = k0 < we ? v.ops.raw(v.raw_index(k0)) : (raw_t)0;
+                b7 = k0 + 1 < we ? v.ops.raw(v.raw_index(k0 + 1)) : (raw_t)0;
+                k0 += w_full;
+                b8 = k0 < we ? v.ops.raw(v.raw_index(k0)) : (raw_t)0;
+                b9 = k0 + 1 < we ? v.ops.raw(v.raw_index(k0 + 1)) : (raw_t)0;
+                slot = 0;
+            }
+            raw0 = slot == 0 ? b0 : slot == 1 ? b2 : slot == 2 ? b4 : slot == 3 ? b6 : b8;
+            raw1 = slot == 0 ? b1 : slot == 1 ? b3 : slot == 2 ? b5 : slot == 3 ? b7 : b9;
+            slot++;
+            blk_next = i + w;
         }
         int64_t len0_64 = 0, len1_64 = 0;
         int op0 = -1, op1 = -1;
@@ -1584,6 +1650,7 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
         const uint32_t len0 = (uint32_t)len0_64, len1 = (uint32_t)len1_64;
         const uint32_t q_0 = (op0 >= 0 && op0 != OP_D) ? len0 : 0, t_0 = (op0 >= 0 && op0 != OP_I) ? len0 : 0;
         const uint32_t q_1 = (op1 >= 0 && op1 != OP_D) ? len1 : 0, t_1 = (op1 >= 0 && op1 != OP_I) ? len1 : 0;
+        PT_MARK(0)
         const uint32_t iq = wave_incl_scan_u32(q_0 + q_1), it = wave_incl_scan_u32(t_0 + t_1);
         const uint32_t totq = wave_last_u32(iq), tott = wave_last_u32(it);
         const uint32_t eq = iq - (q_0 + q_1), et = it - (t_0 + t_1);
@@ -1615,17 +1682,11 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
             w_try = w_safe;
             continue;
         }
+        PT_MARK(1)
         const uint32_t o = em.next_phase() + inc - mine;
-        em.flush(); /* the previous window: its stores were issued before this window's arithmetic */
-        { /* the loads of the following window fly while this one is formatted. Issued behind the flush: the
-             counter wait at the top of the next iteration then covers these loads only, not newer stores */
-            n_i = i + w;
-            n_w = we - n_i < w_full ? we - n_i : w_full;
-            const uint32_t k0 = n_i + 2 * lane;
-            nraw0 = nraw1 = 0;
-            if (k0 < n_i + n_w) nraw0 = v.ops.raw(v.raw_index(k0));
-            if (k0 + 1 < n_i + n_w) nraw1 = v.ops.raw(v.raw_index(k0 + 1));
-        }
+        em.flush();
+        PT_MARK(2)
+ /* the previous window: its stores were issued before this window's arithmetic */
 #pragma unroll 1
         for (int r = 0; r < 2; r++) {
             if (r && !any_sec) break;
@@ -1642,17 +1703,24 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
         }
         /* the head of piece A of every row, last: it repairs what the previous row's wide stores spilled */
         if (prim) {
-            const u32x4 a_head = A16[0];
+            const u32x4 a_head = rc.regs ? rc.a0 : A16[0];
             store16(em.buf + o, a_head);
             if (sec) store16(em.buf + o + bytes0, a_head);
         }
         em.stage(total);
+        PT_MARK(3)
         if (s.same) bq.advance(totq);
         bt.advance(tott);
         i += w;
         w_try = w_full;
     }
     em.finish();
+#if defined(PAFFY_ABL) && PAFFY_ABL == 20
+    PT_MARK(4)
+    if ((blockIdx.x & 8191u) == 77u && (threadIdx.x & 63) == 0)
+        printf("rec %u wave %u ops %u: load+decode %llu scans+sizes %llu flush %llu format+stores %llu finish %llu loop-top %llu\n", blockIdx.x, wave, we - wb,
+               pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4], pt_acc[5]);
+#endif
 }
 
 /* Per-lane serial writers for the rare records whose pieces do not fit the LDS staging (names of
@@ -1917,6 +1985,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
         report(P, rec, m.err, -1, m.err_aux, klass);
         return true;
     }
+    PT_DECL
     RecState s;
     load_state(m, s);
     uint32_t n = 0;
@@ -1941,6 +2010,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
         if (!fits) return false;
     }
     *n_ops_out = n;
+    PT_MARK(0)
     View<OPS> v;
     v.reset(ops, n);
     if (have_sums) { /* the parse already summed every op */
@@ -1962,9 +2032,12 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
             invert_view(s, v);
             swapped = !swapped;
             rc = check_record(s, v, L.bc);
+            PT_MARK(1)
         } else if (st.kind == PAFFY_TRIM_IDENTITY) {
             rc = trim_identity(s, v, st.p0, st.p1, L.bc, L.sh);
+            PT_MARK(2)
             if (!rc) rc = check_record(s, v, L.bc);
+            PT_MARK(3)
         } else if (st.kind == PAFFY_TRIM_FIXED) {
             rc = trim_fixed(s, v, st.p1, L.bc, L.sh);
             if (!rc) rc = check_record(s, v, L.bc);
@@ -2023,12 +2096,14 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
     }
     RecPlan *plan = static_cast<RecPlan *>(P.rec_plan) + rec;
     int64_t bytes, rows;
-    bool direct = false;
+    bool direct = false, rows_kernel = false;
     if (shatter) {
         ShatterConst k;
         shatter_consts(s, k);
-        direct = !shatter_fits(k); /* pieces too long for the LDS staging: the emit pass writes this record's rows straight to HBM */
+        direct = !shatter_fits(k);
+        rows_kernel = OPS::kNarrow && !direct && shatter_fast_ok(s, k) && k.lenA <= 48 && k.lenB <= 48 && k.lenC <= 48; /* emitted by k_emit_rows */ /* pieces too long for the LDS staging: the emit pass writes this record's rows straight to HBM */
         int rc = shatter_size(s, v, k, bytes, rows, plan, checked, L.bc);
+        PT_MARK(4)
         if (rc) {
             report(P, rec, rc, si, 0, klass);
             return true;
@@ -2048,9 +2123,15 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
         plan->qs = s.qs; plan->qe = s.qe; plan->ts = s.ts; plan->te = s.te; plan->sub_lo = v.sub_lo; plan->sub_hi = v.sub_hi;
         plan->lo = v.lo; plan->n = v.n;
         plan->flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | (s.has_cigar ? 8u : 0u) | ((uint32_t)s.type << 8) |
-                      (shatter ? 16u : 0u) | (direct ? 32u : 0u);
+                      (shatter ? 16u : 0u) | (direct ? 32u : 0u) | (rows_kernel ? 64u : 0u);
         plan->chunk = ((v.n + PAFFY_NT - 1) / PAFFY_NT) | 1u; /* = sweep_bounds() */
     }
+#if defined(PAFFY_ABL) && PAFFY_ABL == 21
+    PT_MARK(5)
+    if ((blockIdx.x & 8191u) == 77u && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 1)
+        printf("rec %u ops %u: parse %llu invert+check %llu trim %llu check %llu shatter_size %llu plan %llu\n", blockIdx.x, n, pt_acc[0], pt_acc[1], pt_acc[2],
+               pt_acc[3], pt_acc[4], pt_acc[5]);
+#endif
     return true;
 }
 
@@ -2103,8 +2184,12 @@ __device__ __forceinline__ void emit_record(const KParams &P, uint32_t rec, cons
         }
         __syncthreads();
         if (shatter_fast_ok(s, k)) {
-            shatter_emit_fast(s, v, k, reinterpret_cast<const u32x4 *>(A), reinterpret_cast<const u32x4 *>(B), reinterpret_cast<const u32x4 *>(C), pl,
-                              L.ring, P.out, (uint64_t)P.out_off[rec]);
+            const uint64_t span = 64ull * pl.chunk;
+            const uint32_t wb = span * wave < v.n ? (uint32_t)(span * wave) : v.n;
+            const uint32_t we = span * (wave + 1) < v.n ? (uint32_t)(span * (wave + 1)) : v.n;
+            shatter_emit_fast(s, v, k, reinterpret_cast<const u32x4 *>(A), reinterpret_cast<const u32x4 *>(B), reinterpret_cast<const u32x4 *>(C), wb, we,
+                              pl.wq[wave], pl.wt[wave], L.ring + wave * PAFFY_WAVE_RING, P.out,
+                              uniform_u64((uint64_t)P.out_off[rec] + (uint64_t)pl.wo[wave]));
             return;
         }
         RowPieces pieces;
@@ -2210,8 +2295,70 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_EMIT_OCC) void k_emit_lds(KParams P
     const uint32_t rec = blockIdx.x;
     if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return; /* nothing at or after the first failure */
     if ((P.status[rec] >> 16) != KLASS_LDS) return;
+    if (SHATTER && (static_cast<const RecPlan *>(P.rec_plan)[rec].flags & 64u)) return; /* k_emit_rows has it */
     OpsGlobal ops{P.ops_mirror + mirror_index(P.meta[rec])};
+#if defined(PAFFY_ABL) && PAFFY_ABL == 22
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+#endif
     emit_record<OpsGlobal, SHATTER>(P, rec, ops, L);
+#if defined(PAFFY_ABL) && PAFFY_ABL == 22
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    if ((rec & 4095u) == 99u && threadIdx.x == 0) printf("rec %u: %llu core cycles, %llu wall ticks (100 MHz) -> %.0f MHz\n", rec, c1 - c0, w1 - w0, (double)(c1 - c0) / (double)(w1 - w0) * 100.0);
+#endif
+}
+
+/*
+ * Row kernel: one WAVE per record for the usual shatter record (pieces of at most 48 bytes, coordinates below
+ * 10^11, ops in the HBM mirror). The per-record preparation runs once instead of once per wave of a workgroup,
+ * there is no barrier at all, and the kernel carries none of the general paths.
+ */
+#define PAFFY_ROWS_LDS_BYTES (PAFFY_WAVE_RING + 3 * 64 + 64)
+__global__ __launch_bounds__(64, PAFFY_EMIT_OCC) void k_emit_rows(KParams P) {
+    extern __shared__ uint4 smem4[];
+    uint8_t *smem = reinterpret_cast<uint8_t *>(smem4);
+    const uint32_t rec = blockIdx.x;
+    if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return; /* nothing at or after the first failure */
+    if ((P.status[rec] >> 16) != KLASS_LDS) return;
+    const RecPlan &pl = static_cast<const RecPlan *>(P.rec_plan)[rec];
+    if (!(pl.flags & 64u)) return;
+    const RecMeta &m = P.meta[rec];
+    RecState s;
+    load_state(m, s);
+    if (pl.flags & 4u) invert_state(s);
+    s.qs = pl.qs; s.qe = pl.qe; s.ts = pl.ts; s.te = pl.te;
+    s.has_cigar = (pl.flags & 8u) != 0;
+    s.type = (uint8_t)(pl.flags >> 8);
+    OpsGlobal ops{P.ops_mirror + mirror_index(m)};
+    View<OpsGlobal> v;
+    v.reset(ops, pl.n);
+    v.lo = pl.lo; v.rev = pl.flags & 1u; v.swp = (pl.flags & 2u) != 0;
+    v.sub_lo = pl.sub_lo; v.sub_hi = pl.sub_hi;
+    ShatterConst k;
+    shatter_consts(s, k);
+    uint8_t *A = smem + PAFFY_WAVE_RING, *B = A + 64, *C = B + 64;
+    {
+        Piece w{A, 0, 64, false};
+        w.name(P.in, s.qn_off, s.qn_len);
+        w.ch('\t'); w.num(s.qlen); w.ch('\t');
+        w.pad_to(64);
+    }
+    {
+        Piece w{B, 0, 64, false};
+        w.ch('\t'); w.ch(s.same ? '+' : '-'); w.ch('\t');
+        w.name(P.in, s.tn_off, s.tn_len);
+        w.ch('\t'); w.num(s.tlen); w.ch('\t');
+        w.pad_to(64);
+    }
+    {
+        Piece w{C, 0, 64, false};
+        w.ch('\t'); w.num(s.mapq);
+        piece_tags(w, s, 0);
+        w.str("\tcg:Z:", 6);
+        w.pad_to(64);
+    }
+    __builtin_amdgcn_wave_barrier();
+    shatter_emit_fast(s, v, k, reinterpret_cast<const u32x4 *>(A), reinterpret_cast<const u32x4 *>(B), reinterpret_cast<const u32x4 *>(C), 0u, v.n, 0ll, 0ll,
+                      smem, P.out, (uint64_t)P.out_off[rec]);
 }
 
 /* Arena class: records whose ops do not fit LDS; persistent workgroups walk the list. */
