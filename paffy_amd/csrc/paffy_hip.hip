@@ -262,19 +262,34 @@ __global__ __launch_bounds__(PAFFY_NT) void k_seq_lookup(const uint8_t *in, cons
 /* record sizes -> offsets                                              */
 /* ------------------------------------------------------------------ */
 
-/* single workgroup; records at or after the first failing one contribute nothing */
+/* single workgroup, 16 consecutive records per thread and round; records at or after the first failing one contribute nothing */
+#define SCAN_PER 16
 __global__ __launch_bounds__(PAFFY_NT) void k_scan_records(const int64_t *out_len, const int64_t *out_rows, uint32_t n, int64_t *out_off,
                                                             DevInfo *info) {
     __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
     BlockComm scratch{scratch_mem, 0};
     const uint32_t first_err = (uint32_t)(info->first_err_key >> 16);
+    const uint32_t live_n = n < first_err ? n : first_err;
     int64_t cb = 0, cr = 0;
-    for (uint32_t base = 0; base < n; base += PAFFY_NT) {
-        uint32_t i = base + threadIdx.x;
-        bool live = i < n && i < first_err;
-        int64_t v[2] = {live ? out_len[i] : 0, live ? out_rows[i] : 0}, tot[2];
+    for (uint32_t base = 0; base < n; base += PAFFY_NT * SCAN_PER) {
+        const uint32_t i0 = base + threadIdx.x * SCAN_PER;
+        int64_t len[SCAN_PER];
+        int64_t v[2] = {0, 0}, tot[2];
+#pragma unroll
+        for (int j = 0; j < SCAN_PER; j++) {
+            const uint32_t i = i0 + j;
+            len[j] = i < live_n ? out_len[i] : 0;
+            v[0] += len[j];
+            v[1] += i < live_n ? out_rows[i] : 0;
+        }
         block_excl_scan<2>(v, tot, scratch);
-        if (i < n) out_off[i] = cb + v[0];
+        int64_t run = cb + v[0];
+#pragma unroll
+        for (int j = 0; j < SCAN_PER; j++) {
+            const uint32_t i = i0 + j;
+            if (i < n) out_off[i] = run;
+            run += len[j];
+        }
         cb += tot[0];
         cr += tot[1];
     }

@@ -1109,6 +1109,9 @@ __device__ __forceinline__ int shatter_size(const RecState &s, const View<OPS> &
  * to 128 ops (two per lane, loaded from HBM, DPP scans, its own LDS ring, coalesced 16-byte
  * flushes). No workgroup barrier anywhere.
  */
+#ifndef PAFFY_ROWS_MAX_OPS
+#define PAFFY_ROWS_MAX_OPS 16384u /* one wave formats at most this many ops (128 windows) on its own */
+#endif
 #define PAFFY_WAVE_RING 9216u /* bytes of LDS ring per wave: 64 rows of the usual ~130-byte lines */
 template <class OPS>
 __device__ __forceinline__ void shatter_emit(const RecState &s, const View<OPS> &v, const ShatterConst &k, const RowPieces &pieces, const RecPlan &pl,
@@ -2101,7 +2104,8 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
         ShatterConst k;
         shatter_consts(s, k);
         direct = !shatter_fits(k);
-        rows_kernel = OPS::kNarrow && !direct && shatter_fast_ok(s, k) && k.lenA <= 48 && k.lenB <= 48 && k.lenC <= 48; /* emitted by k_emit_rows */ /* pieces too long for the LDS staging: the emit pass writes this record's rows straight to HBM */
+        rows_kernel = OPS::kNarrow && !direct && shatter_fast_ok(s, k) && k.lenA <= 48 && k.lenB <= 48 && k.lenC <= 48 &&
+                      v.n <= PAFFY_ROWS_MAX_OPS; /* emitted by k_emit_rows; longer records are split over the four waves of k_emit_lds */ /* pieces too long for the LDS staging: the emit pass writes this record's rows straight to HBM */
         int rc = shatter_size(s, v, k, bytes, rows, plan, checked, L.bc);
         PT_MARK(4)
         if (rc) {
