@@ -17,6 +17,8 @@
 #ifndef PAFFY_RECORD_KERNEL_H_
 #define PAFFY_RECORD_KERNEL_H_
 
+#include <type_traits>
+
 #include "device_util.h"
 #include "record_types.h"
 
@@ -270,6 +272,129 @@ __device__ __forceinline__ uint32_t parse_cigar(const uint8_t *in, uint32_t cg_o
     return n | ((fl & INTERNAL_DIGIT_RUN) ? 0x80000000u : 0u);
 }
 
+/*
+ * cigar_parse for the usual cigar -- at most 8 KiB of text, every number at most seven digits, no op without
+ * digits -- from registers: the text is cut into 8-byte words, every thread takes up to four consecutive words
+ * (two loads per word position, aligned, funnelled by the cigar's byte offset) and walks its bytes once with the
+ * running number in a register; the number a thread starts with is re-derived from the word before its range.
+ * No text in LDS, no LDS read in the loop, one scan for the op indices. Ops go to LDS only; the HBM mirror is a
+ * coalesced copy at the end. Returns 0xffffffff when the text needs the general parser (nothing it did matters then).
+ */
+#define PARSE_FAST_WORDS 4
+__device__ __forceinline__ uint32_t parse_cigar_fast(const uint8_t *in, uint32_t cg_off, uint32_t cg_len, const OpsLds &ops, uint32_t cap, BlockComm &bc,
+                                                     Shared *sh, bool *fits, uint32_t *err_pos, int64_t (&sums)[4]) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t end = cg_off + cg_len;
+    const uint32_t n_words = (cg_len + 7u) >> 3;
+    const uint32_t nb = (n_words + PAFFY_NT - 1) / PAFFY_NT; /* words per thread */
+    if (nb > PARSE_FAST_WORDS) return 0xffffffffu;
+    if (tid == 0) {
+        sh->err_pos = 0xffffffffu;
+        sh->flags = 0;
+    }
+    const uint32_t s0 = cg_off + 8u * nb * tid; /* my first byte */
+    const uint32_t my_bytes = s0 < end ? (end - s0 < 8u * nb ? end - s0 : 8u * nb) : 0u;
+    const uint32_t shb = 8u * (cg_off & 7u); /* bit offset of my words inside the aligned ones (wave-uniform) */
+    const uint32_t a_first = (cg_off & ~7u) + 8u * nb * tid;
+    /* aligned words: one before my range (the number I may start inside), my words, one more for the funnel */
+    uint64_t a[PARSE_FAST_WORDS + 2];
+#pragma unroll
+    for (int k = 0; k < PARSE_FAST_WORDS + 2; k++) {
+        a[k] = 0;
+        const uint32_t at = a_first + 8u * (uint32_t)k - 8u;
+        if ((uint32_t)k <= nb + 1 && (k > 0 || tid > 0) && at < end && my_bytes > 0) a[k] = *reinterpret_cast<const uint64_t *>(in + at);
+    }
+    uint64_t w[PARSE_FAST_WORDS + 1]; /* w[0]: the 8 bytes before my range */
+#pragma unroll
+    for (int k = 0; k < PARSE_FAST_WORDS + 1; k++) w[k] = shb ? (a[k] >> shb) | (a[k + 1] << (64u - shb)) : a[k];
+    /* ops in my range: bytes that are not digits */
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 1; k <= PARSE_FAST_WORDS; k++) {
+        if ((uint32_t)k > nb) break;
+        const uint32_t first = 8u * (uint32_t)(k - 1);
+        if (first >= my_bytes) break;
+        const uint64_t t = w[k] ^ 0x3030303030303030ull;
+        uint64_t nd = (((t & 0x7f7f7f7f7f7f7f7full) + 0x7676767676767676ull) | t) & 0x8080808080808080ull;
+        const uint32_t nv = my_bytes - first;
+        if (nv < 8u) nd &= (1ull << (8u * nv)) - 1ull;
+        cnt += (uint32_t)__popcll(nd);
+    }
+    int64_t c1[1] = {(int64_t)cnt}, tot[1];
+    block_excl_scan<1>(c1, tot, bc);
+    const uint32_t n = (uint32_t)tot[0];
+    uint32_t idx = (uint32_t)c1[0];
+    /* the number that runs into my range: digits at the end of the word before it */
+    uint32_t acc = 0, nd = 0;
+    if (tid > 0 && my_bytes > 0) {
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint32_t d = ((uint32_t)(w[0] >> (8 * b)) & 0xffu) - '0';
+            const bool dig = d < 10u;
+            acc = dig ? acc * 10u + d : 0u;
+            nd = dig ? nd + 1u : 0u;
+        }
+    }
+    uint32_t sm = 0, sx = 0, sq = 0, st = 0, bad = 0;
+#pragma unroll
+    for (int k = 1; k <= PARSE_FAST_WORDS; k++) {
+        if ((uint32_t)k > nb) break;
+#pragma unroll
+        for (int pair = 0; pair < 4; pair++) {
+            uint32_t op_acc = 0, op_c = 0, op_nd = 0, had = 0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t pos = 8u * (uint32_t)(k - 1) + 2u * (uint32_t)pair + (uint32_t)h;
+                const uint32_t c = (uint32_t)(w[k] >> (8 * (2 * pair + h))) & 0xffu;
+                const uint32_t d = c - '0';
+                const bool dig = d < 10u;
+                const bool is_op = !dig && pos < my_bytes;
+                if (is_op) {
+                    op_acc = acc;
+                    op_c = c;
+                    op_nd = nd;
+                    had++;
+                }
+                acc = dig ? acc * 10u + d : 0u;
+                nd = dig ? nd + 1u : 0u;
+            }
+            if (had) { /* at most one op per byte pair in the texts this parser accepts */
+                int code = op_code_of(op_c);
+                if (code < 0) { /* the general parser reports the exact offset */
+                    code = 0;
+                    bad |= 2u;
+                }
+                if (had == 2 || op_nd > 7u || op_nd == 0u) bad |= 1u;
+                if (idx < cap) ops.p[idx] = (op_acc << 3) | (uint32_t)code;
+                idx++;
+                if (code == OP_M || code == OP_EQ) sm += op_acc;
+                else sx += op_acc;
+                if (code != OP_D) sq += op_acc;
+                if (code != OP_I) st += op_acc;
+            }
+        }
+    }
+    /* a cigar that ends in digits: the reference's switch sees the NUL (impl/paf.c:96-103) */
+    if (my_bytes > 0 && s0 + my_bytes == end) {
+        const uint32_t lw = (my_bytes - 1u) >> 3; /* selects, not an indexed array: that would live in scratch memory */
+        const uint64_t wl = lw == 0 ? w[1] : lw == 1 ? w[2] : lw == 2 ? w[3] : w[4];
+        const uint32_t last = (uint32_t)(wl >> (8u * ((my_bytes - 1u) & 7u))) & 0xffu;
+        if (last - '0' < 10u) atomicMin(&sh->err_pos, end);
+    }
+    if (bad) atomicOr(&sh->flags, 0x200u); /* an odd text (or a bad character whose exact offset the general parser finds) */
+    sums[0] = sm; sums[1] = sx; sums[2] = sq; sums[3] = st;
+    block_sum<4>(sums, bc);
+    __syncthreads();
+    const uint32_t fl = sh->flags;
+    *err_pos = sh->err_pos;
+    __syncthreads();
+    if (fl & 0x200u) return 0xffffffffu;
+    *fits = n <= cap;
+    const uint32_t n_copy = n < cap ? (n < ops.g_cap ? n : ops.g_cap) : (cap < ops.g_cap ? cap : ops.g_cap);
+    for (uint32_t i = tid; i < n_copy; i += PAFFY_NT) ops.g[i] = ops.p[i];
+    return n;
+}
+
 /* Sequential fallback for digit runs longer than the LDS halo (leading zeros etc.). */
 template <class OPS>
 __device__ __forceinline__ uint32_t parse_cigar_serial(const uint8_t *in, uint32_t cg_off, uint32_t cg_len, const OPS &ops, uint32_t cap, Shared *sh,
@@ -391,9 +516,16 @@ __device__ __forceinline__ void trim_prefix(RecState &s, View<OPS> &v, float thr
         if (op == OP_EQ || op == OP_M) c[0] += len;
         else c[1] += len;
     }
+    const int64_t chunk_x = c[1];
     block_excl_scan<2>(c, tot, bc);
-    /* sweep B: last index (while cumulative <= max_trim) whose prefix identity < threshold */
+    /* sweep B: last index (while cumulative <= max_trim) whose prefix identity < threshold.
+       Inside a chunk every prefix identity is at least m0 / (m0 + x0 + chunk_x) (m0, x0: sums before the chunk;
+       worst case all of the chunk's mismatches first). float32 conversions and the divide are off by < 2e-7
+       relative, so a chunk whose bound clears the threshold by 1e-5 cannot hold a hit: whole waves deep inside a
+       record skip the sweep and its divides. */
     int64_t cm = c[0], cx = c[1], found = -1;
+    const bool may_hit = e > b && !(c[0] > 0 && (double)c[0] >= thr * 1.00001 * (double)(c[0] + c[1] + chunk_x));
+    if (may_hit)
     for (uint32_t i = b; i < e; i++) {
         int64_t len;
         int op;
@@ -1998,7 +2130,9 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
         bool fits;
         uint32_t err_pos;
         uint32_t r;
-        r = parse_cigar(P.in, m.cg_off, m.cg_len, ops, cap, L.ring, L.bc, L.sh, &fits, &err_pos, parse_sums);
+        r = 0xffffffffu;
+        if constexpr (std::is_same<OPS, OpsLds>::value) r = parse_cigar_fast(P.in, m.cg_off, m.cg_len, ops, cap, L.bc, L.sh, &fits, &err_pos, parse_sums);
+        if (r == 0xffffffffu) r = parse_cigar(P.in, m.cg_off, m.cg_len, ops, cap, L.ring, L.bc, L.sh, &fits, &err_pos, parse_sums);
         have_sums = true;
         if (r & 0x80000000u) {
             r = parse_cigar_serial(P.in, m.cg_off, m.cg_len, ops, cap, L.sh, &fits, &err_pos);
