@@ -509,7 +509,8 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
     /* the record kernels use more than the default 64 KiB of LDS */
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile), hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_slices), hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_LEAN>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emit_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_EMIT_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emit_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_EMIT_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_arena_size), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
@@ -609,6 +610,8 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             return PAFFY_E_UNSUPPORTED;
         }
     }
+    bool lean = true; /* only stage kinds the lean sizing kernel knows */
+    for (int32_t i = 0; i < n_stages; i++) lean = lean && ((PAFFY_MASK_LEAN >> stages[i].kind) & 1u);
     c->planned = false;
     c->plan_is_tile = false;
     memset(info, 0, sizeof(*info));
@@ -674,18 +677,21 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
                 k1.ops_cap = PAFFY_OPS_CAP_MID;
                 k1.next_cap = PAFFY_OPS_CAP_BIG;
                 k1.level = 1;
-                hipLaunchKernelGGL(k_size_lds, dim3(768), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_MID), c->side, k1);
+                if (lean) hipLaunchKernelGGL(k_size_lds<PAFFY_MASK_LEAN>, dim3(768), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_MID), c->side, k1);
+                else hipLaunchKernelGGL(k_size_lds<PAFFY_MASK_ALL>, dim3(768), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_MID), c->side, k1);
                 k1.ops_cap = PAFFY_OPS_CAP_BIG;
                 k1.next_cap = 0;
                 k1.level = 2;
-                hipLaunchKernelGGL(k_size_lds, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), c->side, k1);
+                if (lean) hipLaunchKernelGGL(k_size_lds<PAFFY_MASK_LEAN>, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), c->side, k1);
+                else hipLaunchKernelGGL(k_size_lds<PAFFY_MASK_ALL>, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), c->side, k1);
                 HIPCHK(c, hipGetLastError());
                 HIPCHK(c, hipEventRecord(c->ev_join, c->side));
             }
             kp.ops_cap = PAFFY_OPS_CAP;
             kp.next_cap = 0;
             kp.level = 0;
-            LAUNCH(c, "k_size_lds", k_size_lds, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
+            if (lean) LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_LEAN>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
+            else LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_ALL>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); /* join */
             LAUNCH(c, "k_arena_size", k_arena_size, dim3(512), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             if (fetch_info(c)) return PAFFY_E_HIP;

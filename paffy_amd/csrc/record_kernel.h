@@ -2112,7 +2112,15 @@ __device__ __forceinline__ void load_state(const RecMeta &m, RecState &s) {
  * record the exact output size, the first failing check and the RecPlan the emit pass resumes
  * from. Returns false when the record does not fit this op store (LDS class only).
  */
-template <class OPS>
+/*
+ * MASK: the stage kinds this instantiation knows (bit = kind). The host picks the lean instantiation when the
+ * pipe only has invert / identity trim / shatter / pass stages: a kernel without the other transforms is a third
+ * smaller (instruction cache, registers).
+ */
+#define PAFFY_MASK_ALL 0xffffffffu
+#define PAFFY_MASK_LEAN ((1u << PAFFY_INVERT) | (1u << PAFFY_TRIM_IDENTITY) | (1u << PAFFY_SHATTER) | (1u << PAFFY_PASS))
+#define STAGE_ON(kind) ((MASK >> (kind)) & 1u)
+template <class OPS, uint32_t MASK = PAFFY_MASK_ALL>
 __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t cap, const RecLds &L, uint32_t klass,
                             uint32_t *n_ops_out) {
     const RecMeta m = P.meta[rec];
@@ -2164,21 +2172,21 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
             if (s.type == 0 && s.tile_level != -1) s.type = s.tile_level > 1 ? 'S' : 'P';
         }
         int rc = 0;
-        if (st.kind == PAFFY_INVERT) {
+        if (STAGE_ON(PAFFY_INVERT) && st.kind == PAFFY_INVERT) {
             invert_state(s);
             invert_view(s, v);
             swapped = !swapped;
             rc = check_record(s, v, L.bc);
             PT_MARK(1)
-        } else if (st.kind == PAFFY_TRIM_IDENTITY) {
+        } else if (STAGE_ON(PAFFY_TRIM_IDENTITY) && st.kind == PAFFY_TRIM_IDENTITY) {
             rc = trim_identity(s, v, st.p0, st.p1, L.bc, L.sh);
             PT_MARK(2)
             if (!rc) rc = check_record(s, v, L.bc);
             PT_MARK(3)
-        } else if (st.kind == PAFFY_TRIM_FIXED) {
+        } else if (STAGE_ON(PAFFY_TRIM_FIXED) && st.kind == PAFFY_TRIM_FIXED) {
             rc = trim_fixed(s, v, st.p1, L.bc, L.sh);
             if (!rc) rc = check_record(s, v, L.bc);
-        } else if (st.kind == PAFFY_REMOVE_MISMATCHES) {
+        } else if (STAGE_ON(PAFFY_REMOVE_MISMATCHES) && st.kind == PAFFY_REMOVE_MISMATCHES) {
             if (s.has_cigar) {
                 bool narrow_ok = true;
                 uint32_t n2;
@@ -2201,7 +2209,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
                 v.reset(ops, n2);
             }
             rc = check_record(s, v, L.bc);
-        } else if (st.kind == PAFFY_ADD_MISMATCHES) {
+        } else if (STAGE_ON(PAFFY_ADD_MISMATCHES) && st.kind == PAFFY_ADD_MISMATCHES) {
             if constexpr (OPS::kNarrow) {
                 return false; /* the new op array lives in the arena: arena class */
             } else {
@@ -2221,7 +2229,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
                 }
                 if (!rc) rc = check_record(s, v, L.bc);
             }
-        } else if (st.kind == PAFFY_SHATTER) {
+        } else if (STAGE_ON(PAFFY_SHATTER) && st.kind == PAFFY_SHATTER) {
             shatter = true;
             break;
         }
@@ -2383,11 +2391,12 @@ __device__ __forceinline__ uint32_t mirror_index(const RecMeta &m) { return m.cg
  * CU), what did not fit with 12288 ops (3 per CU), then with 36864 ops (1 per CU). What still does
  * not fit (lengths >= 2^29, rebuilt op arrays) goes to the arena kernel.
  */
+template <uint32_t MASK>
 __device__ __forceinline__ void size_lds_one(const KParams &P, uint32_t rec, uint32_t *ops_lds, const RecLds &L) {
     const RecMeta &m = P.meta[rec];
     OpsLds ops{ops_lds, P.ops_mirror + mirror_index(m), (m.cg_len + 1) >> 1};
     uint32_t n_ops = 0;
-    bool ok = size_record<OpsLds>(P, rec, ops, P.ops_cap, L, KLASS_LDS, &n_ops);
+    bool ok = size_record<OpsLds, MASK>(P, rec, ops, P.ops_cap, L, KLASS_LDS, &n_ops);
     if (ok && n_ops > ((m.cg_len + 1) >> 1)) ok = false; /* digit-less ops overran the mirror: arena class */
     if (!ok && threadIdx.x == 0) {
         P.out_len[rec] = 0;
@@ -2405,6 +2414,7 @@ __device__ __forceinline__ void size_lds_one(const KParams &P, uint32_t rec, uin
 #ifndef PAFFY_SIZE_OCC
 #define PAFFY_SIZE_OCC 4
 #endif
+template <uint32_t MASK>
 __global__ __launch_bounds__(PAFFY_NT, PAFFY_SIZE_OCC) void k_size_lds(KParams P) {
     extern __shared__ uint4 smem4[];
     uint32_t *ops_lds;
@@ -2412,11 +2422,11 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_SIZE_OCC) void k_size_lds(KParams P
     if (P.level == 0) {
         /* records whose cigar text promises more ops than this store holds were queued for level 1 by k_header */
         if ((P.meta[blockIdx.x].cg_len >> 1) > PAFFY_OPS_CAP && P.meta[blockIdx.x].err == 0) return;
-        size_lds_one(P, blockIdx.x, ops_lds, L);
+        size_lds_one<MASK>(P, blockIdx.x, ops_lds, L);
     } else {
         const uint32_t count = P.info->b_count[P.level - 1];
         for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
-            size_lds_one(P, P.b_list[P.level - 1][li], ops_lds, L);
+            size_lds_one<MASK>(P, P.b_list[P.level - 1][li], ops_lds, L);
             __syncthreads();
         }
     }
