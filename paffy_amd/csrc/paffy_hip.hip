@@ -694,6 +694,9 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             else LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_ALL>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); /* join */
             LAUNCH(c, "k_arena_size", k_arena_size, dim3(512), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
+            /* the scan rides along: one host synchronisation per plan in the usual case (the arena was big enough) */
+            LAUNCH(c, "k_scan_records", k_scan_records, dim3(1), dim3(PAFFY_NT), 0, kp.out_len, kp.out_rows, n_lines,
+                   static_cast<int64_t *>(c->out_off.p), kp.info);
             if (fetch_info(c)) return PAFFY_E_HIP;
             if (c->h_info->arena_used <= kp.arena_cap) break;
             /* arena too small: grow to the demand seen so far and redo the sizing pass */
@@ -702,8 +705,10 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             DevInfo z = *c->h_info;
             z.arena_used = 0;
             z.w_count = 0;
+            z.g_count = 0;
             z.b_count[1] = 0; /* b_count[0] was filled by k_header and stays */
             z.first_err_key = ~0ull;
+            z.out_bytes = z.out_rows = 0;
             HIPCHK(c, hipMemcpyAsync(c->info.p, &z, sizeof(z), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (attempt == 2) {
@@ -711,10 +716,9 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
                 return PAFFY_E_HIP;
             }
         }
-        LAUNCH(c, "k_scan_records", k_scan_records, dim3(1), dim3(PAFFY_NT), 0, kp.out_len, kp.out_rows, n_lines,
-               static_cast<int64_t *>(c->out_off.p), kp.info);
+    } else if (fetch_info(c)) {
+        return PAFFY_E_HIP;
     }
-    if (fetch_info(c)) return PAFFY_E_HIP;
     if (c->profile) prof_collect(c);
     if (c->h_info->internal) {
         char buf[128];
@@ -994,7 +998,7 @@ int paffy_hip_emit(paffy_hip_ctx *c, void *d_out, int64_t out_cap) {
     const bool shatter = kp.n_stages > 0 && kp.stages[kp.n_stages - 1].kind == PAFFY_SHATTER;
     if (shatter) {
         LAUNCH(c, "k_emit_rows", k_emit_rows, dim3(kp.n_rec), dim3(64), PAFFY_ROWS_LDS_BYTES, kp);
-        LAUNCH(c, "k_emit_lds", k_emit_lds<true>, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
+        if (c->h_info->g_count > 0) LAUNCH(c, "k_emit_lds", k_emit_lds<true>, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
         if (c->h_info->w_count > 0) LAUNCH(c, "k_arena_emit", k_arena_emit<true>, dim3(512), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
     } else {
         LAUNCH(c, "k_emit_lds<line>", k_emit_lds<false>, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);

@@ -2263,6 +2263,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
         rows = 1;
     }
     if (threadIdx.x == 0) {
+        if (shatter && klass == KLASS_LDS && !rows_kernel) atomicAdd(&P.info->g_count, 1u);
         P.status[rec] = klass << 16;
         P.out_len[rec] = bytes;
         P.out_rows[rec] = rows;

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""HBM traffic per kernel launch from rocprofv3 PMC passes, written in the format bench.py reads (profiles/traffic.json).
+
+usage (GPU box, repo root):  python tools/traffic_collect.py OUT.json [--workload cfg3 --batch 65536]
+FETCH_SIZE and WRITE_SIZE are collected in passes of their own (they do not fit one pass, and counters are never
+combined with a trace domain). Corrections per MI355X_MICROARCH.md: both are KB counters; on gfx950 FETCH_SIZE
+reports half of the bytes of wide coalesced reads and is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores.
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import re
+import subprocess
+import sys
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("out")
+    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--steps", type=int, default=6)
+    args = ap.parse_args()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.environ.setdefault("TMPDIR", "/tmp")
+    sums, launches = {}, {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(root, "gpurun_out", f"traffic_{counter.lower()}")
+        cmd = ["rocprofv3", "--pmc", counter, "-d", d, "--output-format", "csv", "--", sys.executable, os.path.join(root, "bench.py"), "--steps", str(args.steps),
+               "--warmup", "2", "--cpu-sample", "0", "--no-kernel-events", "--workload", args.workload, "--batch", str(args.batch)]
+        print("pass", counter, flush=True)
+        r = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        if r.returncode:
+            print(r.stdout[-3000:], file=sys.stderr)
+            sys.exit(1)
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()
+                    name = {"k_emit_lds<true>": "k_emit_lds", "k_emit_lds<false>": "k_emit_lds<line>"}.get(name, name)
+                    name = re.sub(r"^k_size_lds<.*>$", "k_size_lds", name)
+                    sums.setdefault(name, {}).setdefault(counter, 0.0)
+                    sums[name][counter] += float(row["Counter_Value"])
+                    launches.setdefault(name, {}).setdefault(counter, 0)
+                    launches[name][counter] += 1
+    kernels = {}
+    for name, v in sorted(sums.items()):
+        n_f = max(1, launches[name].get("FETCH_SIZE", 1))
+        n_w = max(1, launches[name].get("WRITE_SIZE", 1))
+        if name == "k_size_lds" and "k_scan_records" in launches:
+            # three launches per plan (whole batch, then the two bigger LDS stores for the long records): count them as one
+            n_f = max(1, launches["k_scan_records"].get("FETCH_SIZE", 1))
+            n_w = max(1, launches["k_scan_records"].get("WRITE_SIZE", 1))
+        fetch = int(v.get("FETCH_SIZE", 0.0) * 1024 * 2 / n_f)
+        write = int(v.get("WRITE_SIZE", 0.0) * 1024 / n_w)
+        kernels[name] = {"fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write, "launches_sampled": n_w}
+    out = {"workload": args.workload, "batch": args.batch, "kernels": kernels,
+           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes on `bench.py --steps %d --warmup 2 --cpu-sample 0 --no-kernel-events`; "
+                   "per-launch averages; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); KB counters * 1024" % args.steps}
+    with open(args.out, "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    for k in ("k_size_lds", "k_emit_rows", "k_emit_lds"):
+        if k in kernels:
+            print(k, kernels[k])
+
+
+if __name__ == "__main__":
+    main()
