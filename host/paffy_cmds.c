@@ -118,6 +118,53 @@ int paffy_trim_main(int argc, char *argv[]) {
     return run_stream_cmd(&o, &st, 1, "trim");
 }
 
+/* paffy filter: options and their conversions as in impl/paf_filter.c:45-100 (-s -t -w through atoi, -u -v through atof). */
+int paffy_filter_main(int argc, char *argv[]) {
+    static struct option opts[] = {{"logLevel", required_argument, 0, 'l'}, {"inputFile", required_argument, 0, 'i'},
+                                   {"outputFile", required_argument, 0, 'o'}, {"minChainScore", required_argument, 0, 's'},
+                                   {"minAlignmentScore", required_argument, 0, 't'}, {"minIdentity", required_argument, 0, 'u'},
+                                   {"minIdentityWithGaps", required_argument, 0, 'v'}, {"maxTileLevel", required_argument, 0, 'w'},
+                                   {"invert", no_argument, 0, 'x'}, {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+    cmd_opts o;
+    memset(&o, 0, sizeof(o));
+    paffy_filter f = {-1, -1, -1.0, -1.0, -1, 0};
+    optind = 1;
+    for (;;) {
+        int idx = 0;
+        int key = getopt_long(argc, argv, "l:i:o:s:t:u:v:w:xh", opts, &idx);
+        if (key == -1) break;
+        switch (key) {
+            case 'l': o.log_level = optarg; break;
+            case 'i': o.in_path = optarg; break;
+            case 'o': o.out_path = optarg; break;
+            case 's': f.min_chain_score = atoi(optarg); break;
+            case 't': f.min_alignment_score = atoi(optarg); break;
+            case 'u': f.min_identity = atof(optarg); break;
+            case 'v': f.min_identity_with_gaps = atof(optarg); break;
+            case 'w': f.max_tile_level = atoi(optarg); break;
+            case 'x': f.invert = 1; break;
+            case 'h':
+            default:
+                usage_common("filter", "Filter pafs based on alignment stats");
+                fprintf(stderr, "-s --minChainScore : Filter alignments with a chain score less than this\n");
+                fprintf(stderr, "-t --minAlignmentScore : Filter alignments with an alignment score less than this\n");
+                fprintf(stderr, "-u --minIdentity : Filter alignments with an identity less than this, exclude indels\n");
+                fprintf(stderr, "-v --minIdentityWithGaps : Filter alignments with an identity less than this, including indels\n");
+                fprintf(stderr, "-w --maxTileLevel : Filter alignments with a tile level greater than this\n");
+                fprintf(stderr, "-x --invert : Only output alignments that don't pass filters\n");
+                usage_tail();
+                return key == 'h' ? 0 : 1;
+        }
+    }
+    host_set_log_level(o.log_level);
+    host_log_info("Filtering paf with min chain score:%lld min alignment score:%lld min identity:%f min identity with gaps:%f max tile level:%lld invert:%s\n",
+                  (long long)f.min_chain_score, (long long)f.min_alignment_score, f.min_identity, f.min_identity_with_gaps,
+                  (long long)f.max_tile_level, f.invert ? "True" : "False");
+    host_set_filter(&f);
+    paffy_stage st = {PAFFY_FILTER, 0.05f, 1.0f};
+    return run_stream_cmd(&o, &st, 1, "filter");
+}
+
 /* FASTA -> (header, sequence) pairs. Key = the whole header line after '>', sequence = all
  * non-whitespace characters up to the next header (the fastaReadToFunction /
  * fastaRead_readToMapFunction behaviour assumed in SURVEY Appendix C; parity unpinned). */

@@ -15,6 +15,7 @@
 
 int paffy_shatter_main(int argc, char *argv[]);
 int paffy_invert_main(int argc, char *argv[]);
+int paffy_filter_main(int argc, char *argv[]);
 int paffy_trim_main(int argc, char *argv[]);
 int paffy_add_mismatches_main(int argc, char *argv[]);
 int paffy_tile_main(int argc, char *argv[]);
@@ -30,6 +31,8 @@ void host_log_info(const char *fmt, ...);
  * the way the reference does (exit 1, SIGABRT or SIGSEGV). Returns 0 on success.
  */
 int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out);
+/* Thresholds handed to the context that host_stream creates (paffy filter). */
+void host_set_filter(const paffy_filter *f);
 
 /* `paffy tile`: reads all of `in`, one tile_plan + emit, writes `out`. */
 int host_tile(FILE *in, FILE *out);

@@ -20,7 +20,7 @@ static const struct {
     {"chain", NULL, "Chain alignments (not in this build)"},
     {"dechunk", NULL, "Map chunk coordinates back (not in this build)"},
     {"dedupe", NULL, "Drop duplicate alignments (not in this build)"},
-    {"filter", NULL, "Filter alignments on their stats (not in this build)"},
+    {"filter", paffy_filter_main, "Filter alignments on their stats"},
     {"invert", paffy_invert_main, "Switch query and target coordinates"},
     {"shatter", paffy_shatter_main, "Break alignments into gapless blocks"},
     {"tile", paffy_tile_main, "Give alignments tile levels along the query"},

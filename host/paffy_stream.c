@@ -65,12 +65,16 @@ static void die_like_reference(const paffy_error *e, int64_t record_base) {
     exit(status ? status : 1);
 }
 
+static paffy_filter g_filter = {-1, -1, -1.0, -1.0, -1, 0};
+void host_set_filter(const paffy_filter *f) { g_filter = *f; }
+
 int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out) {
     paffy_hip_ctx *ctx = NULL;
     if (paffy_hip_create(&ctx, -1) != 0) {
         fprintf(stderr, "paffy: no usable GPU (this build has no CPU path)\n");
         return 1;
     }
+    paffy_hip_set_filter(ctx, &g_filter);
     if (g_seq_n > 0 && paffy_hip_set_sequences(ctx, g_seq_n, g_seq_names, g_seq_data, g_seq_lens) != 0) {
         fprintf(stderr, "paffy: could not load the sequences onto the GPU: %s\n", paffy_hip_last_error(ctx));
         return 1;

@@ -35,7 +35,8 @@ enum {
     PAFFY_SHATTER = 4,           /* impl/paf_shatter.c:88-95: paf_shatter, write each block (last stage only) */
     PAFFY_ADD_MISMATCHES = 5,    /* impl/paf_add_mismatches.c:113-131: paf_encode_mismatches          */
     PAFFY_REMOVE_MISMATCHES = 6, /* impl/paf_add_mismatches.c:110-112: paf_remove_mismatches          */
-    PAFFY_PASS = 7               /* paf_read -> paf_write only (normalises tags, impl/paf.c:317-389)  */
+    PAFFY_PASS = 7,              /* paf_read -> paf_write only (normalises tags, impl/paf.c:317-389)  */
+    PAFFY_FILTER = 8             /* impl/paf_filter.c:120-156: records failing the thresholds of paffy_hip_set_filter vanish */
 };
 #define PAFFY_MAX_STAGES 8
 
@@ -134,6 +135,23 @@ int paffy_hip_run_host(paffy_hip_ctx *ctx, const paffy_stage *stages, int32_t n_
  * header used as key, seqs[i] / lens[i] the bases (host memory; copied to HBM here).
  */
 int paffy_hip_set_sequences(paffy_hip_ctx *ctx, int64_t n, const char *const *names, const char *const *seqs, const int64_t *lens);
+
+/*
+ * Thresholds of `paffy filter` as its main() holds them (impl/paf_filter.c:27-32; -s -t -w pass through atoi, -u -v
+ * through atof). A record is kept when score >= min_alignment_score && chain_score >= min_chain_score &&
+ * (max_tile_level == -1 || tile_level <= max_tile_level) && identity >= min_identity && identity_with_gaps >=
+ * min_identity_with_gaps, the identities being float32 quotients of paf_stats_calc sums (impl/paf_filter.c:129-133);
+ * `invert` keeps the others instead. Used by every PAFFY_FILTER stage of later plans; defaults -1, -1, -1.0, -1.0, -1, 0.
+ */
+typedef struct {
+    int64_t min_chain_score;
+    int64_t min_alignment_score;
+    double min_identity;
+    double min_identity_with_gaps;
+    int64_t max_tile_level;
+    int32_t invert;
+} paffy_filter;
+int paffy_hip_set_filter(paffy_hip_ctx *ctx, const paffy_filter *f);
 
 /* Exit status the reference process ends with for a record error (1, 134 or 139). */
 int paffy_hip_error_exit_status(int32_t code);

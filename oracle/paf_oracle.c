@@ -595,6 +595,31 @@ static void reparse_normalise(rec *r) {
 
 static int run_from(run_ctx *c, rec *r, int32_t s);
 
+/* paffy filter, impl/paf_filter.c:120-156: 1 = the record is written, 0 = it is dropped. */
+static po_filter g_filter = {-1, -1, -1.0, -1.0, -1, 0};
+void po_set_filter(const po_filter *f) {
+    po_filter d = {-1, -1, -1.0, -1.0, -1, 0};
+    g_filter = f ? *f : d;
+}
+static int filter_keeps(const rec *r) {
+    /* paf_stats_calc, impl/paf.c:236-260 (a NULL cigar has no ops, inc/paf.h:75) */
+    int64_t matches = 0, mismatches = 0, qi_bases = 0, qd_bases = 0;
+    for (int64_t k = 0; r->has_cigar && k < r->n; k++) {
+        const oop *o = &r->ops[r->lo + k];
+        if (o->op == OP_EQ || o->op == OP_M) matches += o->len;
+        else if (o->op == OP_X) mismatches += o->len;
+        else if (o->op == OP_I) qi_bases += o->len;
+        else qd_bases += o->len;
+    }
+    /* float32 quotients widened to double, impl/paf_filter.c:129-130 (0/0 is NaN: every >= fails) */
+    double identity = (float)matches / (matches + mismatches);
+    double identity_with_gaps = (float)matches / (matches + mismatches + qi_bases + qd_bases);
+    int pass = r->score >= g_filter.min_alignment_score && r->chain_score >= g_filter.min_chain_score &&
+               (g_filter.max_tile_level == -1 || r->tile_level <= g_filter.max_tile_level) && identity >= g_filter.min_identity &&
+               identity_with_gaps >= g_filter.min_identity_with_gaps;
+    return g_filter.invert ? !pass : pass;
+}
+
 /* paf_shatter + paf_shatter2, impl/paf.c:600-663, then the driver loop impl/paf_shatter.c:88-95. */
 static int shatter_stage(run_ctx *c, rec *r, int32_t s) {
     int64_t qc = r->same_strand ? r->qs : r->qe;
@@ -691,6 +716,9 @@ static int run_from(run_ctx *c, rec *r, int32_t s) {
                 rc = check_rec(r);
                 break;
             case PO_PASS:
+                break;
+            case PO_FILTER:
+                if (!filter_keeps(r)) return PO_OK; /* nothing is written, nothing reaches the later stages */
                 break;
             default:
                 rc = -1;

@@ -34,7 +34,8 @@ enum {
     PO_SHATTER = 4,           /* paffy shatter           impl/paf_shatter.c:88-95 */
     PO_ADD_MISMATCHES = 5,    /* paffy add_mismatches    impl/paf_add_mismatches.c:113-131 */
     PO_REMOVE_MISMATCHES = 6, /* paffy add_mismatches -a impl/paf_add_mismatches.c:110-112 */
-    PO_PASS = 7               /* parse + write only (paf_read -> paf_write)       */
+    PO_PASS = 7,              /* parse + write only (paf_read -> paf_write)       */
+    PO_FILTER = 8             /* paffy filter            impl/paf_filter.c:120-156 (thresholds: po_set_filter) */
 };
 
 /* Error codes; the exit status the reference would give is in po_error_exit_status(). */
@@ -68,6 +69,18 @@ typedef struct {
     float p0; /* trim: trim_by_identity_fraction (-r), float as in impl/paf_trim.c:16 */
     float p1; /* trim: trim_end_fraction (-t),        float as in impl/paf_trim.c:14 */
 } po_stage;
+
+/* `paffy filter` options as its main() holds them (impl/paf_filter.c:27-32; -s -t -w go through atoi, -u -v through atof). */
+typedef struct {
+    int64_t min_chain_score;       /* -s, default -1 */
+    int64_t min_alignment_score;   /* -t, default -1 */
+    double min_identity;           /* -u, default -1.0 */
+    double min_identity_with_gaps; /* -v, default -1.0 */
+    int64_t max_tile_level;        /* -w, default -1 (no limit) */
+    int32_t invert;                /* -x */
+} po_filter;
+/* thresholds used by every PO_FILTER stage of later po_run calls (NULL: defaults) */
+void po_set_filter(const po_filter *f);
 
 typedef struct {
     const char *name; /* NUL-terminated key (FASTA header) */

@@ -415,6 +415,7 @@ struct paffy_hip_ctx {
     std::string last_error;
     DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, b_list, b_list1, arena, info, synth_sizes, rec_plan, ops_mirror, seq_blob, seq_table, seq_names, seq_name_off, rec_qseq, rec_tseq;
     int32_t n_seqs = 0;
+    paffy_filter filter = {-1, -1, -1.0, -1.0, -1, 0};
     DevBuf tile_keys, tile_order, tile_rank, tile_coff, tile_cbase, tile_cov, tile_level, tile_len, tile_items, tile_slots, tile_parts;
     bool plan_is_tile = false;
     uint32_t tile_n = 0;
@@ -601,7 +602,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     bool need_seqs = false;
     for (int32_t i = 0; i < n_stages; i++) {
         int k = stages[i].kind;
-        bool ok = k == PAFFY_INVERT || k == PAFFY_TRIM_IDENTITY || k == PAFFY_TRIM_FIXED || k == PAFFY_PASS ||
+        bool ok = k == PAFFY_INVERT || k == PAFFY_TRIM_IDENTITY || k == PAFFY_TRIM_FIXED || k == PAFFY_PASS || k == PAFFY_FILTER ||
                   k == PAFFY_REMOVE_MISMATCHES || (k == PAFFY_ADD_MISMATCHES && c->n_seqs > 0) ||
                   (k == PAFFY_SHATTER && i == n_stages - 1);
         if (k == PAFFY_ADD_MISMATCHES) need_seqs = true;
@@ -664,6 +665,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     kp.b_list[0] = static_cast<uint32_t *>(c->b_list.p);
     kp.b_list[1] = static_cast<uint32_t *>(c->b_list1.p);
     kp.info = static_cast<DevInfo *>(c->info.p);
+    kp.filter = c->filter;
 
     if (n_lines > 0) {
         for (int attempt = 0; attempt < 3; attempt++) {
@@ -1081,6 +1083,13 @@ int paffy_hip_set_sequences(paffy_hip_ctx *c, int64_t n, const char *const *name
     if (!blob.empty()) HIPCHK(c, hipMemcpy(c->seq_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->seq_name_off.p, name_off.data(), sizeof(uint32_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
     c->n_seqs = (int32_t)n;
+    return 0;
+}
+
+int paffy_hip_set_filter(paffy_hip_ctx *c, const paffy_filter *f) {
+    if (!c) return PAFFY_E_ARG;
+    const paffy_filter d = {-1, -1, -1.0, -1.0, -1, 0};
+    c->filter = f ? *f : d;
     return 0;
 }
 

@@ -2229,6 +2229,30 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
                 }
                 if (!rc) rc = check_record(s, v, L.bc);
             }
+        } else if (STAGE_ON(PAFFY_FILTER) && st.kind == PAFFY_FILTER) {
+            /* paffy filter, impl/paf_filter.c:120-156: paf_stats_calc sums from the view's running totals
+               (matches = M and =; tx = X + I + D, I = all - tt, D = all - tq) */
+            int64_t mm = 0, mx = 0;
+            if (s.has_cigar) match_stats(v, mm, mx, L.bc);
+            const int64_t all = mm + mx;
+            const int64_t ins = s.has_cigar ? all - v.tt : 0, del = s.has_cigar ? all - v.tq : 0;
+            const double identity = ratio_f32(mm, mm + (mx - ins - del));
+            const double identity_with_gaps = ratio_f32(mm, all);
+            const paffy_filter &f = P.filter;
+            const bool pass = s.score >= f.min_alignment_score && s.chain_score >= f.min_chain_score &&
+                              (f.max_tile_level == -1 || s.tile_level <= f.max_tile_level) && identity >= f.min_identity &&
+                              identity_with_gaps >= f.min_identity_with_gaps;
+            if (pass == (f.invert != 0)) { /* dropped: no output, later stages never see the record */
+                if (threadIdx.x == 0) {
+                    RecPlan *dp = static_cast<RecPlan *>(P.rec_plan) + rec;
+                    P.status[rec] = klass << 16;
+                    P.out_len[rec] = 0;
+                    P.out_rows[rec] = 0;
+                    dp->flags = 128u;
+                    dp->n = 0;
+                }
+                return true;
+            }
         } else if (STAGE_ON(PAFFY_SHATTER) && st.kind == PAFFY_SHATTER) {
             shatter = true;
             break;
@@ -2237,7 +2261,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
             report(P, rec, rc, si, 0, klass);
             return true;
         }
-        checked = st.kind != PAFFY_PASS; /* every other stage ends with a passed paf_check */
+        checked = st.kind != PAFFY_PASS && st.kind != PAFFY_FILTER; /* every other stage ends with a passed paf_check */
     }
     RecPlan *plan = static_cast<RecPlan *>(P.rec_plan) + rec;
     int64_t bytes, rows;
@@ -2292,6 +2316,7 @@ __device__ __forceinline__ void emit_record(const KParams &P, uint32_t rec, cons
     /* by reference: a by-value copy of these structs (indexed per wave below) would live in scratch memory */
     const RecMeta &m = P.meta[rec];
     const RecPlan &pl = static_cast<const RecPlan *>(P.rec_plan)[rec];
+    if (pl.flags & 128u) return; /* dropped by a filter stage */
     RecState s;
     load_state(m, s);
     if (pl.flags & 4u) invert_state(s);

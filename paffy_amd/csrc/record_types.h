@@ -85,6 +85,7 @@ struct KParams {
     uint32_t next_cap;   /* store of the next level (0: none, overflow goes to the arena) */
     uint32_t level;      /* 0: whole batch; 1, 2: walk b_list[level - 1] */
     DevInfo *info;
+    paffy_filter filter; /* thresholds of PAFFY_FILTER stages */
 };
 
 #endif

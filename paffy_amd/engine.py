@@ -12,11 +12,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 _LIB = os.environ.get("PAFFY_HIP_LIB", os.path.join(HERE, "libpaffy_hip.so"))  # override for A/B experiments only
 
-INVERT, TRIM_IDENTITY, TRIM_FIXED, SHATTER, ADD_MISMATCHES, REMOVE_MISMATCHES, PASS = 1, 2, 3, 4, 5, 6, 7
+INVERT, TRIM_IDENTITY, TRIM_FIXED, SHATTER, ADD_MISMATCHES, REMOVE_MISMATCHES, PASS, FILTER = 1, 2, 3, 4, 5, 6, 7, 8
 
 
 class Stage(C.Structure):
     _fields_ = [("kind", C.c_int32), ("p0", C.c_float), ("p1", C.c_float)]
+
+
+class Filter(C.Structure):
+    """Thresholds of `paffy filter` (impl/paf_filter.c:27-32): -s, -t, -u, -v, -w, -x."""
+    _fields_ = [("min_chain_score", C.c_int64), ("min_alignment_score", C.c_int64), ("min_identity", C.c_double),
+                ("min_identity_with_gaps", C.c_double), ("max_tile_level", C.c_int64), ("invert", C.c_int32)]
 
 
 class _Error(C.Structure):
@@ -74,6 +80,7 @@ def lib():
         L.paffy_hip_tile_plan.argtypes = [vp, vp, i64, C.POINTER(PlanInfo)]
         L.paffy_hip_sync.argtypes = [vp]
         L.paffy_hip_set_sequences.argtypes = [vp, i64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(i64)]
+        L.paffy_hip_set_filter.argtypes = [vp, C.POINTER(Filter)]
         L.paffy_hip_error_exit_status.argtypes = [i32]
         L.paffy_hip_error_string.restype = C.c_char_p
         L.paffy_hip_error_string.argtypes = [i32]
@@ -126,6 +133,12 @@ class Engine:
     def _check(self, rc, what):
         if rc:
             raise RuntimeError(f"{what} failed ({rc}): {lib().paffy_hip_last_error(self._ctx).decode()}")
+
+    def set_filter(self, min_chain_score=-1, min_alignment_score=-1, min_identity=-1.0, min_identity_with_gaps=-1.0, max_tile_level=-1,
+                   invert=False):
+        """Thresholds used by FILTER stages of later plans (`paffy filter -s -t -u -v -w -x`)."""
+        f = Filter(min_chain_score, min_alignment_score, min_identity, min_identity_with_gaps, max_tile_level, 1 if invert else 0)
+        self._check(lib().paffy_hip_set_filter(self._ctx, C.byref(f)), "paffy_hip_set_filter")
 
     # ---- device-buffer level (what bench.py times) ----
     def to_device(self, data):
@@ -270,3 +283,10 @@ def tile(data):
 def trim(data, trim_identity=0.05, trim_fraction=1.0, fixed_trim=False):
     """paffy trim [-r trim_identity] [-t trim_fraction] [-f] (impl/paf_trim.c)."""
     return pipe([stage(TRIM_FIXED if fixed_trim else TRIM_IDENTITY, trim_identity, trim_fraction)], data)
+
+
+def filter(data, **thresholds):  # noqa: A001 -- named after the reference command
+    """paffy filter [-s -t -u -v -w -x] (impl/paf_filter.c); keyword arguments as in Engine.set_filter."""
+    e = _engine()
+    e.set_filter(**thresholds)
+    return e.run([stage(FILTER)], data)[0]

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "libpaf_oracle.so")
 
-INVERT, TRIM_IDENTITY, TRIM_FIXED, SHATTER, ADD_MISMATCHES, REMOVE_MISMATCHES, PASS = 1, 2, 3, 4, 5, 6, 7
+INVERT, TRIM_IDENTITY, TRIM_FIXED, SHATTER, ADD_MISMATCHES, REMOVE_MISMATCHES, PASS, FILTER = 1, 2, 3, 4, 5, 6, 7, 8
 
 
 class Stage(C.Structure):
@@ -19,6 +19,11 @@ class Stage(C.Structure):
 
 class Seq(C.Structure):
     _fields_ = [("name", C.c_char_p), ("seq", C.c_char_p), ("len", C.c_int64)]
+
+
+class Filter(C.Structure):
+    _fields_ = [("min_chain_score", C.c_int64), ("min_alignment_score", C.c_int64), ("min_identity", C.c_double),
+                ("min_identity_with_gaps", C.c_double), ("max_tile_level", C.c_int64), ("invert", C.c_int32)]
 
 
 class Error(C.Structure):
@@ -46,6 +51,8 @@ def lib():
         L.po_tile.restype = C.c_int
         L.po_tile.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(Error)]
         L.po_free.argtypes = [C.c_void_p]
+        L.po_set_filter.argtypes = [C.POINTER(Filter)]
+        L.po_set_filter.restype = None
         L.po_error_exit_status.argtypes = [C.c_int32]
         L.po_cigar_parse.restype = C.c_int64
         L.po_cigar_parse.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int64]
@@ -89,6 +96,17 @@ def run(stages, data, seqs=None):
     out, n, err = C.c_void_p(), C.c_int64(), Error()
     L.po_run(arr, len(stages), data, len(data), sarr, ns, C.byref(out), C.byref(n), C.byref(err))
     return _take(out, n), err
+
+
+def set_filter(min_chain_score=-1, min_alignment_score=-1, min_identity=-1.0, min_identity_with_gaps=-1.0, max_tile_level=-1, invert=False):
+    """Thresholds of the FILTER stages of later run() calls (`paffy filter -s -t -u -v -w -x`)."""
+    f = Filter(min_chain_score, min_alignment_score, min_identity, min_identity_with_gaps, max_tile_level, 1 if invert else 0)
+    lib().po_set_filter(C.byref(f))
+
+
+def filter(data, **thresholds):  # noqa: A001
+    set_filter(**thresholds)
+    return run([stage(FILTER)], data)
 
 
 def tile(data):

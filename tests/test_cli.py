@@ -35,12 +35,13 @@ def test_dispatcher_contract():
         assert name in err
     rc, _, err = run(["frobnicate"])
     assert rc == 1 and b"frobnicate is not a valid paffy command" in err
-    for cmd in ("shatter", "invert", "trim", "tile", "add_mismatches"):
+    for cmd in ("shatter", "invert", "trim", "tile", "add_mismatches", "filter"):
         rc, out, err = run([cmd, "-h"])
         assert rc == 0 and out == b"" and b"--inputFile" in err and b"--logLevel" in err
         assert run([cmd, "--help"])[0] == 0
         assert run([cmd, "-Z"])[0] == 1
     assert b"--trimIdentity" in run(["trim", "-h"])[2] and b"--fixedTrim" in run(["trim", "-h"])[2]
+    assert b"--minIdentityWithGaps" in run(["filter", "-h"])[2] and b"--maxTileLevel" in run(["filter", "-h"])[2]
     assert run(["dedupe"])[0] == 1  # outside the hot path
 
 
@@ -95,3 +96,17 @@ def test_cli_tile_and_mismatches(human_chimp, tmp_path):
     assert rc == 0 and out == O.run([S(O.ADD_MISMATCHES)], rec, seqs)[0] and b"X" in out
     rc, out, err = run(["add_mismatches", str(tmp_path / "q.fa")], rec)  # target sequence missing: exit(1)
     assert rc == 1 and out == b"" and b"No target sequence" in err
+
+
+@pytest.mark.gpu
+def test_cli_filter(human_chimp):
+    """paffy filter flags (impl/paf_filter.c:45-100) and the tile | filter -w 1 step of the reference pipeline
+    (tests/paf_pipeline_test.sh:79)."""
+    for args, kw in ((["-t", "5000"], dict(min_alignment_score=5000)), (["-t", "5000", "-x"], dict(min_alignment_score=5000, invert=True)),
+                     (["--minIdentity", "0.9"], dict(min_identity=0.9)), (["-v", "0.85", "-s", "-1"], dict(min_identity_with_gaps=0.85))):
+        rc, out, err = run(["filter"] + args, human_chimp)
+        assert rc == 0, err
+        assert out == O.filter(human_chimp, **kw)[0], args
+    p = subprocess.run(f"{PAFFY} tile | {PAFFY} filter -w 1", shell=True, input=human_chimp, stdout=subprocess.PIPE)
+    assert p.returncode == 0 and p.stdout == O.filter(O.tile(human_chimp)[0], max_tile_level=1)[0] and 0 < p.stdout.count(b"\n") < 207
+    O.set_filter()
