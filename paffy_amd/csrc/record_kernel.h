@@ -2441,20 +2441,23 @@ __device__ __forceinline__ void size_lds_one(const KParams &P, uint32_t rec, uin
 #define PAFFY_SIZE_OCC 4
 #endif
 template <uint32_t MASK>
-__global__ __launch_bounds__(PAFFY_NT, PAFFY_SIZE_OCC) void k_size_lds(KParams P) {
+__global__ __launch_bounds__(PAFFY_NT, PAFFY_SIZE_OCC) void k_size_lds(KParams P) { /* the whole batch, 8192-op store */
     extern __shared__ uint4 smem4[];
     uint32_t *ops_lds;
     RecLds L = carve_size_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds, P.ops_cap);
-    if (P.level == 0) {
-        /* records whose cigar text promises more ops than this store holds were queued for level 1 by k_header */
-        if ((P.meta[blockIdx.x].cg_len >> 1) > PAFFY_OPS_CAP && P.meta[blockIdx.x].err == 0) return;
-        size_lds_one<MASK>(P, blockIdx.x, ops_lds, L);
-    } else {
-        const uint32_t count = P.info->b_count[P.level - 1];
-        for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
-            size_lds_one<MASK>(P, P.b_list[P.level - 1][li], ops_lds, L);
-            __syncthreads();
-        }
+    /* records whose cigar text promises more ops than this store holds were queued for level 1 by k_header */
+    if ((P.meta[blockIdx.x].cg_len >> 1) > PAFFY_OPS_CAP && P.meta[blockIdx.x].err == 0) return;
+    size_lds_one<MASK>(P, blockIdx.x, ops_lds, L);
+}
+template <uint32_t MASK>
+__global__ __launch_bounds__(PAFFY_NT, PAFFY_SIZE_OCC) void k_size_lds_long(KParams P) { /* levels 1 and 2: the queued long records */
+    extern __shared__ uint4 smem4[];
+    uint32_t *ops_lds;
+    RecLds L = carve_size_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds, P.ops_cap);
+    const uint32_t count = P.info->b_count[P.level - 1];
+    for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
+        size_lds_one<MASK>(P, P.b_list[P.level - 1][li], ops_lds, L);
+        __syncthreads();
     }
 }
 

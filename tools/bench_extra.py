@@ -15,7 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--records", type=int, default=200000)
     ap.add_argument("--mean-ops", type=int, default=2048)
-    ap.add_argument("--cmd", default="tile", choices=["tile", "invert", "trim", "shatter", "remove"])
+    ap.add_argument("--cmd", default="tile", choices=["tile", "invert", "trim", "shatter", "remove", "filter"])
     a = ap.parse_args()
     import torch
 
@@ -24,7 +24,8 @@ def main():
     eng = paffy_amd.Engine()
     buf, nbytes = eng.synth(0x5EED0005, a.mean_ops, 0, a.records)
     torch.cuda.synchronize()
-    kinds = {"invert": paffy_amd.INVERT, "trim": paffy_amd.TRIM_IDENTITY, "shatter": paffy_amd.SHATTER, "remove": paffy_amd.REMOVE_MISMATCHES}
+    kinds = {"invert": paffy_amd.INVERT, "trim": paffy_amd.TRIM_IDENTITY, "shatter": paffy_amd.SHATTER, "remove": paffy_amd.REMOVE_MISMATCHES, "filter": paffy_amd.FILTER}
+    eng.set_filter(min_identity=0.9)
     res = []
     eng.profile(True)
     for rep in range(3):

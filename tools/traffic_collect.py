@@ -42,7 +42,7 @@ def main():
                         continue
                     name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()
                     name = {"k_emit_lds<true>": "k_emit_lds", "k_emit_lds<false>": "k_emit_lds<line>"}.get(name, name)
-                    name = re.sub(r"^k_size_lds<.*>$", "k_size_lds", name)
+                    name = re.sub(r"^(k_size_lds(?:_long)?)<.*>$", r"\1", name)
                     sums.setdefault(name, {}).setdefault(counter, 0.0)
                     sums[name][counter] += float(row["Counter_Value"])
                     launches.setdefault(name, {}).setdefault(counter, 0)
@@ -51,10 +51,6 @@ def main():
     for name, v in sorted(sums.items()):
         n_f = max(1, launches[name].get("FETCH_SIZE", 1))
         n_w = max(1, launches[name].get("WRITE_SIZE", 1))
-        if name == "k_size_lds" and "k_scan_records" in launches:
-            # three launches per plan (whole batch, then the two bigger LDS stores for the long records): count them as one
-            n_f = max(1, launches["k_scan_records"].get("FETCH_SIZE", 1))
-            n_w = max(1, launches["k_scan_records"].get("WRITE_SIZE", 1))
         fetch = int(v.get("FETCH_SIZE", 0.0) * 1024 * 2 / n_f)
         write = int(v.get("WRITE_SIZE", 0.0) * 1024 / n_w)
         kernels[name] = {"fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write, "launches_sampled": n_w}
