@@ -8,7 +8,7 @@
  *   k_header                   one lane per record: fixed fields and tags (paf_parse, impl/paf.c:137-209)
  *   k_size_lds                 one workgroup per record: cigar -> LDS ops (mirrored to HBM) -> transforms -> exact size + plan
  *   k_arena_size               same for records whose ops do not fit LDS (ops in an HBM arena)
- *   k_scan_records             exclusive prefix sum of the sizes up to the first failing record
+ *   k_scan_part / k_scan_fix   exclusive prefix sum of the sizes up to the first failing record (two levels)
  *   k_emit_lds<rows|line> / k_arena_emit   the lines: each wave formats its share of the record through its own
  *                              LDS ring and flushes 16-byte coalesced stores
  */
@@ -262,40 +262,65 @@ __global__ __launch_bounds__(PAFFY_NT) void k_seq_lookup(const uint8_t *in, cons
 /* record sizes -> offsets                                              */
 /* ------------------------------------------------------------------ */
 
-/* single workgroup, 16 consecutive records per thread and round; records at or after the first failing one contribute nothing */
-#define SCAN_PER 16
-__global__ __launch_bounds__(PAFFY_NT) void k_scan_records(const int64_t *out_len, const int64_t *out_rows, uint32_t n, int64_t *out_off,
-                                                            DevInfo *info) {
+/*
+ * Exclusive prefix sum of the record sizes up to the first failing record (records at or after it contribute
+ * nothing), two levels: k_scan_part sums and scans blocks of SCAN_BLOCK records, k_scan_fix adds the block bases
+ * (at most a few hundred of them, re-added by every workgroup) and leaves the totals in DevInfo.
+ */
+#define SCAN_PER 8
+#define SCAN_BLOCK (PAFFY_NT * SCAN_PER)
+__global__ __launch_bounds__(PAFFY_NT) void k_scan_part(const int64_t *out_len, const int64_t *out_rows, uint32_t n, int64_t *out_off, int64_t *part,
+                                                         const DevInfo *info) {
     __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
     BlockComm scratch{scratch_mem, 0};
     const uint32_t first_err = (uint32_t)(info->first_err_key >> 16);
     const uint32_t live_n = n < first_err ? n : first_err;
-    int64_t cb = 0, cr = 0;
-    for (uint32_t base = 0; base < n; base += PAFFY_NT * SCAN_PER) {
-        const uint32_t i0 = base + threadIdx.x * SCAN_PER;
-        int64_t len[SCAN_PER];
-        int64_t v[2] = {0, 0}, tot[2];
+    const uint32_t i0 = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER;
+    int64_t len[SCAN_PER];
+    int64_t v[2] = {0, 0}, tot[2];
 #pragma unroll
-        for (int j = 0; j < SCAN_PER; j++) {
-            const uint32_t i = i0 + j;
-            len[j] = i < live_n ? out_len[i] : 0;
-            v[0] += len[j];
-            v[1] += i < live_n ? out_rows[i] : 0;
-        }
-        block_excl_scan<2>(v, tot, scratch);
-        int64_t run = cb + v[0];
+    for (int j = 0; j < SCAN_PER; j++) {
+        const uint32_t i = i0 + j;
+        len[j] = i < live_n ? out_len[i] : 0;
+        v[0] += len[j];
+        v[1] += i < live_n ? out_rows[i] : 0;
+    }
+    block_excl_scan<2>(v, tot, scratch);
+    int64_t run = v[0];
 #pragma unroll
-        for (int j = 0; j < SCAN_PER; j++) {
-            const uint32_t i = i0 + j;
-            if (i < n) out_off[i] = run;
-            run += len[j];
-        }
-        cb += tot[0];
-        cr += tot[1];
+    for (int j = 0; j < SCAN_PER; j++) {
+        const uint32_t i = i0 + j;
+        if (i < n) out_off[i] = run; /* block-local; k_scan_fix adds the base */
+        run += len[j];
     }
     if (threadIdx.x == 0) {
-        info->out_bytes = (unsigned long long)cb;
-        info->out_rows = (unsigned long long)cr;
+        part[2 * blockIdx.x] = tot[0];
+        part[2 * blockIdx.x + 1] = tot[1];
+    }
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_scan_fix(uint32_t n, uint32_t n_blocks, int64_t *out_off, const int64_t *part, DevInfo *info) {
+    __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
+    BlockComm scratch{scratch_mem, 0};
+    /* base of this block = sum of the totals of the blocks before it; the last workgroup also sees the grand totals */
+    int64_t v[2] = {0, 0};
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += PAFFY_NT) {
+        if (b < blockIdx.x) v[0] += part[2 * b];
+    }
+    int64_t t[2] = {0, 0};
+    if (blockIdx.x == n_blocks - 1)
+        for (uint32_t b = threadIdx.x; b < n_blocks; b += PAFFY_NT) {
+            t[0] += part[2 * b];
+            t[1] += part[2 * b + 1];
+        }
+    int64_t s[3] = {v[0], t[0], t[1]};
+    block_sum<3>(s, scratch);
+    const uint32_t i0 = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER;
+#pragma unroll
+    for (int j = 0; j < SCAN_PER; j++)
+        if (i0 + j < n) out_off[i0 + j] += s[0];
+    if (blockIdx.x == n_blocks - 1 && threadIdx.x == 0) {
+        info->out_bytes = (unsigned long long)s[1];
+        info->out_rows = (unsigned long long)s[2];
     }
 }
 
@@ -416,7 +441,7 @@ struct paffy_hip_ctx {
     DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, b_list, b_list1, arena, info, synth_sizes, rec_plan, ops_mirror, seq_blob, seq_table, seq_names, seq_name_off, rec_qseq, rec_tseq;
     int32_t n_seqs = 0;
     paffy_filter filter = {-1, -1, -1.0, -1.0, -1, 0};
-    DevBuf tile_keys, tile_order, tile_rank, tile_coff, tile_cbase, tile_cov, tile_level, tile_len, tile_items, tile_slots, tile_parts;
+    DevBuf scan_part, tile_keys, tile_order, tile_rank, tile_coff, tile_cbase, tile_cov, tile_level, tile_len, tile_items, tile_slots, tile_parts;
     bool plan_is_tile = false;
     uint32_t tile_n = 0;
     const uint8_t *tile_in = nullptr;
@@ -529,7 +554,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
                       &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
-                      &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts};
+                      &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts, &c->scan_part};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_info) (void)hipHostFree(c->h_info);
@@ -699,8 +724,14 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); /* join */
             LAUNCH(c, "k_arena_size", k_arena_size, dim3(512), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             /* the scan rides along: one host synchronisation per plan in the usual case (the arena was big enough) */
-            LAUNCH(c, "k_scan_records", k_scan_records, dim3(1), dim3(PAFFY_NT), 0, kp.out_len, kp.out_rows, n_lines,
-                   static_cast<int64_t *>(c->out_off.p), kp.info);
+            {
+                const uint32_t n_blocks = (n_lines + SCAN_BLOCK - 1) / SCAN_BLOCK;
+                if (ensure(c, c->scan_part, sizeof(int64_t) * 2 * (size_t)n_blocks)) return PAFFY_E_HIP;
+                LAUNCH(c, "k_scan_part", k_scan_part, dim3(n_blocks), dim3(PAFFY_NT), 0, kp.out_len, kp.out_rows, n_lines,
+                       static_cast<int64_t *>(c->out_off.p), static_cast<int64_t *>(c->scan_part.p), kp.info);
+                LAUNCH(c, "k_scan_fix", k_scan_fix, dim3(n_blocks), dim3(PAFFY_NT), 0, n_lines, n_blocks, static_cast<int64_t *>(c->out_off.p),
+                       static_cast<const int64_t *>(c->scan_part.p), kp.info);
+            }
             if (fetch_info(c)) return PAFFY_E_HIP;
             if (c->h_info->arena_used <= kp.arena_cap) break;
             /* arena too small: grow to the demand seen so far and redo the sizing pass */
