@@ -179,6 +179,80 @@ __device__ __forceinline__ int64_t block_min_i64(int64_t x, BlockComm &bc) {
 }
 __device__ __forceinline__ int64_t block_max_i64(int64_t x, BlockComm &bc) { return -block_min_i64(-x, bc); }
 
+/* 32-bit collectives for records whose sums fit 31 bits: a quarter of the DPP instructions of the 64-bit ones */
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    uint32_t x = v;
+#define PAFFY_MIN32_STEP(CTRL, RM, BM, SRC)                                                              \
+    {                                                                                                    \
+        uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)(SRC), CTRL, RM, BM, false);      \
+        x = t < x ? t : x;                                                                               \
+    }
+    PAFFY_MIN32_STEP(DPP_ROW_SHR(1), 0xf, 0xf, v)
+    PAFFY_MIN32_STEP(DPP_ROW_SHR(2), 0xf, 0xf, v)
+    PAFFY_MIN32_STEP(DPP_ROW_SHR(3), 0xf, 0xf, v)
+    PAFFY_MIN32_STEP(DPP_ROW_SHR(4), 0xf, 0xe, x)
+    PAFFY_MIN32_STEP(DPP_ROW_SHR(8), 0xf, 0xc, x)
+    PAFFY_MIN32_STEP(DPP_BCAST15, 0xa, 0xf, x)
+    PAFFY_MIN32_STEP(DPP_BCAST31, 0xc, 0xf, x)
+#undef PAFFY_MIN32_STEP
+    return wave_last_u32(x);
+}
+__device__ __forceinline__ uint32_t block_min_u32(uint32_t x, BlockComm &bc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *sl = reinterpret_cast<uint32_t *>(bc.slots());
+    const uint32_t m = wave_min_u32(x);
+    if (lane == 0) sl[wave] = m;
+    __syncthreads();
+    uint32_t r = sl[0];
+#pragma unroll
+    for (int w = 1; w < PAFFY_NWAVE; w++) r = sl[w] < r ? sl[w] : r;
+    return r;
+}
+/* max of values >= -1 (indices, -1 = none) */
+__device__ __forceinline__ int32_t block_max_idx(int32_t x, BlockComm &bc) { return (int32_t)(0xfffffffeu - block_min_u32(0xfffffffeu - (uint32_t)(x + 1), bc)) - 1; }
+template <int K>
+__device__ __forceinline__ void block_excl_scan_u32(uint32_t (&v)[K], uint32_t (&tot)[K], BlockComm &bc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc[K];
+    uint32_t *sl = reinterpret_cast<uint32_t *>(bc.slots());
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        inc[k] = wave_incl_scan_u32(v[k]);
+        if (lane == 63) sl[wave * K + k] = inc[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < PAFFY_NWAVE; w++) {
+            const uint32_t s = sl[w * K + k];
+            if (w < wave) base += s;
+            total += s;
+        }
+        tot[k] = total;
+        v[k] = base + inc[k] - v[k];
+    }
+}
+template <int K>
+__device__ __forceinline__ void block_sum_u32(uint32_t (&v)[K], BlockComm &bc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *sl = reinterpret_cast<uint32_t *>(bc.slots());
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const uint32_t t = wave_last_u32(wave_incl_scan_u32(v[k]));
+        if (lane == 0) sl[wave * K + k] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < PAFFY_NWAVE; w++) total += sl[w * K + k];
+        v[k] = total;
+    }
+}
+
 /* ---------------- decimal helpers ---------------- */
 
 __device__ __constant__ uint64_t PAFFY_P10[20] = {1ull,

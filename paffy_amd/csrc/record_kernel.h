@@ -26,6 +26,8 @@
 #define INTERNAL_ROW_TOO_LONG 2u
 #define INTERNAL_DIGIT_RUN 4u
 
+__device__ __forceinline__ uint32_t dec_len_u32(uint32_t x);
+
 /* ---------------- op stores ---------------- */
 
 struct OpsLds { /* 4-byte ops in LDS (len << 3 | op, len < 2^29), mirrored to HBM for the emit pass */
@@ -586,6 +588,86 @@ __device__ __forceinline__ void trim_prefix(RecState &s, View<OPS> &v, float thr
     v.drop_front((uint32_t)count);
 }
 
+/* The same pass for records whose match + mismatch total fits 31 bits: 32-bit sums, scans and quotient operands. */
+__device__ __forceinline__ double ratio_f32_u32(uint32_t num, uint32_t den) {
+    return (double)__fdiv_rn(__uint2float_rn(num), __uint2float_rn(den));
+}
+template <class OPS>
+__device__ __forceinline__ void trim_prefix32(RecState &s, View<OPS> &v, float thr_f, float id_f, int64_t max_trim, BlockComm &bc, Shared *sh) {
+    const double thr = (double)thr_f, idd = (double)id_f;
+    uint32_t b, e;
+    sweep_bounds(v.n, b, e);
+    uint32_t c[2] = {0, 0}, tot[2];
+    for (uint32_t i = b; i < e; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        if (op == OP_EQ || op == OP_M) c[0] += (uint32_t)len;
+        else c[1] += (uint32_t)len;
+    }
+    const uint32_t chunk_x = c[1];
+    block_excl_scan_u32<2>(c, tot, bc);
+    uint32_t cm = c[0], cx = c[1];
+    int32_t found = -1;
+    const bool may_hit = e > b && !(c[0] > 0 && (double)c[0] >= thr * 1.00001 * (double)(c[0] + c[1] + chunk_x));
+    if (may_hit)
+        for (uint32_t i = b; i < e; i++) {
+            int64_t len;
+            int op;
+            v.get(i, len, op);
+            if (op == OP_EQ || op == OP_M) cm += (uint32_t)len;
+            else cx += (uint32_t)len;
+            if (max_trim >= 0 && (int64_t)(cm + cx) > max_trim) break;
+            if (ratio_f32_u32(cm, cm + cx) < thr) found = (int32_t)i;
+        }
+    const int32_t trim_idx = block_max_idx(found, bc);
+    if (trim_idx < 0) return;
+    if (trim_idx >= (int32_t)b && trim_idx < (int32_t)e) {
+        uint32_t am = c[0], ax = c[1];
+        for (uint32_t i = b; i <= (uint32_t)trim_idx; i++) {
+            int64_t len;
+            int op;
+            v.get(i, len, op);
+            if (op == OP_EQ || op == OP_M) am += (uint32_t)len;
+            else ax += (uint32_t)len;
+        }
+        sh->bcast[0] = am;
+        sh->bcast[1] = ax;
+    }
+    __syncthreads();
+    const uint32_t tm = (uint32_t)sh->bcast[0], tx = (uint32_t)sh->bcast[1];
+    __syncthreads();
+    uint32_t em = c[0], ex = c[1], best = 0xffffffffu;
+    for (uint32_t i = b; i < e && (int32_t)i <= trim_idx; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        const uint32_t sm = tm - em, sx = tx - ex;
+        if (best == 0xffffffffu && ratio_f32_u32(sm, sm + sx) >= idd) best = i;
+        if (op == OP_EQ || op == OP_M) em += (uint32_t)len;
+        else ex += (uint32_t)len;
+    }
+    best = block_min_u32(best, bc);
+    const uint32_t count = best != 0xffffffffu ? best : (uint32_t)trim_idx + 1u;
+    if (count == 0) return;
+    uint32_t d[4] = {0, 0, 0, 0};
+    for (uint32_t i = b; i < e && i < count; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        if (op != OP_I) d[0] += (uint32_t)len;
+        if (op != OP_D) d[1] += (uint32_t)len;
+        if (op == OP_EQ || op == OP_M) d[2] += (uint32_t)len;
+        else d[3] += (uint32_t)len;
+    }
+    block_sum_u32<4>(d, bc);
+    s.ts += d[0];
+    if (s.same) s.qs += d[1];
+    else s.qe -= d[1];
+    v.tt -= d[0]; v.tq -= d[1]; v.tm -= d[2]; v.tx -= d[3];
+    v.drop_front(count);
+}
+
 /* paf_trim_unreliable_tails, impl/paf.c:906-953. Returns 0 or PAFFY_ERR_TRIM_IDENTITY_ASSERT. */
 template <class OPS>
 __device__ __forceinline__ int trim_identity(RecState &s, View<OPS> &v, float score_fraction, float max_fraction, BlockComm &bc, Shared *sh) {
@@ -599,6 +681,7 @@ __device__ __forceinline__ int trim_identity(RecState &s, View<OPS> &v, float sc
        pass scans the very same op sequence with the same thresholds, so when the first pass removed
        nothing the second one cannot either */
     const uint32_t n_before = v.n;
+    const bool small_sums = OPS::kNarrow && m >= 0 && x >= 0 && m + x < 0x7fffffffll; /* 4-byte ops have lengths >= 0, all in these sums: every partial sum fits 31 bits */
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {
         if (pass == 1) {
@@ -606,7 +689,8 @@ __device__ __forceinline__ int trim_identity(RecState &s, View<OPS> &v, float sc
             invert_state(s);
             invert_view(s, v);
         }
-        trim_prefix(s, v, thr_f, id_f, max_trim, bc, sh);
+        if (small_sums) trim_prefix32(s, v, thr_f, id_f, max_trim, bc, sh);
+        else trim_prefix(s, v, thr_f, id_f, max_trim, bc, sh);
         if (pass == 1) {
             invert_state(s);
             invert_view(s, v);
@@ -1151,6 +1235,36 @@ __device__ __forceinline__ int shatter_size(const RecState &s, const View<OPS> &
          * start and end print with the same number of digits a row's size depends on L only.
          */
         const uint32_t dq0 = dec_len(s.qs), dt0 = dec_len(s.ts);
+        if (OPS::kNarrow && checked && dq0 == (uint32_t)dec_len(s.qe) && dt0 == (uint32_t)dec_len(s.te) && s.qe - s.qs < 0x7fffffffll &&
+            s.te - s.ts < 0x7fffffffll) { /* the same sweep with 32-bit sums: 4-byte ops, spans (= the cigar's sums) below 2^31 */
+            const uint32_t fixed = k.row_const + 2 * dq0 + 2 * dt0;
+            uint32_t a[4] = {0, 0, 0, 0}, at[4], err = 0xffffffffu;
+            for (uint32_t i = b; i < e; i++) {
+                int64_t len;
+                int op;
+                v.get(i, len, op);
+                int code = 0;
+                if (!(len >= 1)) code = PAFFY_ERR_SHATTER_ZERO_LEN;
+                else if (op == OP_M) {
+                    a[2] += fixed + 3 * dec_len_u32((uint32_t)len);
+                    a[3] += 1;
+                } else if (op != OP_I && op != OP_D) code = PAFFY_ERR_SHATTER_BAD_OP;
+                if (code && err == 0xffffffffu) err = i * 32u + (uint32_t)code;
+                if (op != OP_D) a[0] += (uint32_t)len;
+                if (op != OP_I) a[1] += (uint32_t)len;
+            }
+            err = block_min_u32(err, bc);
+            block_excl_scan_u32<4>(a, at, bc);
+            bytes = at[2];
+            rows = at[3];
+            if ((threadIdx.x & 63) == 0) {
+                const uint32_t w = threadIdx.x >> 6;
+                plan_out->wq[w] = a[0];
+                plan_out->wt[w] = a[1];
+                plan_out->wo[w] = a[2];
+            }
+            return err != 0xffffffffu ? (int)(err & 31u) : 0;
+        }
         if (checked && dq0 == (uint32_t)dec_len(s.qe) && dt0 == (uint32_t)dec_len(s.te)) {
             const uint32_t fixed = k.row_const + 2 * dq0 + 2 * dt0;
             int64_t a[4] = {0, 0, 0, 0}, at[4], err = INT64_MAX;
