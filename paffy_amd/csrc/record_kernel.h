@@ -1358,7 +1358,9 @@ __device__ __forceinline__ int shatter_size(const RecState &s, const View<OPS> &
 #ifndef PAFFY_ROWS_MAX_OPS
 #define PAFFY_ROWS_MAX_OPS 16384u /* one wave formats at most this many ops (128 windows) on its own */
 #endif
-#define PAFFY_WAVE_RING 9216u /* bytes of LDS ring per wave: 64 rows of the usual ~130-byte lines */
+#ifndef PAFFY_WAVE_RING
+#define PAFFY_WAVE_RING 9216u
+#endif /* bytes of LDS ring per wave: 64 rows of the usual ~130-byte lines */
 template <class OPS>
 __device__ __forceinline__ void shatter_emit(const RecState &s, const View<OPS> &v, const ShatterConst &k, const RowPieces &pieces, const RecPlan &pl,
                              uint8_t *ring, uint8_t *out, uint64_t rec_off) {
@@ -1559,6 +1561,9 @@ struct DigitBase {
         n0 = 0;
         if (P) t0 = ascii_upto8(P, &n0);
         t1 = ascii_upto8(P + 1, &n1);
+        /* wave-uniform, but only ever operands of per-lane selects: kept in vector registers (there are spare ones),
+           the scalar file is what overflows in the row kernel */
+        asm volatile("" : "+v"(t0), "+v"(t1), "+v"(n0), "+v"(n1));
     }
     __device__ __forceinline__ void set(uint64_t v) {
         const uint64_t q = v / 10000ull;
@@ -1684,18 +1689,7 @@ struct RowConst {
     uint32_t lenA, lenB, lenC;
     bool fuseA, fuseB; /* rest of A + q0 + tab / rest of B + t0 + tab always fit one store */
     uint32_t dt;
-    /* the usual case, every piece at most 32 bytes: their chunks are held in scalar registers, so that a row needs no LDS read */
-    bool regs;
-    u32x4 a0, a1, b0, b1, c0, c1;
 };
-__device__ __forceinline__ u32x4 uniform_x4(u32x4 v) {
-    u32x4 r;
-    r.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.x);
-    r.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.y);
-    r.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.z);
-    r.w = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.w);
-    return r;
-}
 /* one row's numbers: offsets from the window's digit bases (near) or the values themselves */
 struct RowNums {
     uint32_t dq, dt, len;
@@ -1732,30 +1726,25 @@ __device__ __forceinline__ void coord_txt(const DigitBase &b, uint32_t d, uint32
  * A row at p, everything but the first 16 bytes of piece A: each number is formatted right before its
  * store so that no text stays live. `small`: every L of the window has at most two digits.
  */
-/* the chunks of a piece: from scalar registers (pieces of at most 32 bytes) or from LDS */
-#define PIECE_FULL_CHUNKS(P, R0, R1, PTR, LEN, FROM)                                       \
-    {                                                                                      \
-        const uint32_t full_ = (LEN) >> 4;                                                 \
-        if (c.regs) {                                                                      \
-            if ((FROM) == 0 && full_ >= 1) store16((P), c.R0);                             \
-            if (full_ == 2) store16((P) + 16, c.R1);                                       \
-        } else {                                                                           \
-            _Pragma("unroll 1") for (uint32_t j = (FROM); j < full_; j++) store16((P) + 16 * j, c.PTR[j]); \
-        }                                                                                  \
+/* the chunks of a piece, from LDS (wave-uniform addresses: broadcast reads) */
+#define PIECE_FULL_CHUNKS(P, PTR, LEN, FROM)                                                                  \
+    {                                                                                                         \
+        const uint32_t full_ = (LEN) >> 4;                                                                    \
+        _Pragma("unroll 1") for (uint32_t j = (FROM); j < full_; j++) store16((P) + 16 * j, c.PTR[j]);        \
     }
-#define PIECE_REST_CHUNK(R0, R1, PTR, LEN) (c.regs ? (((LEN) >> 4) ? c.R1 : c.R0) : c.PTR[(LEN) >> 4])
+#define PIECE_REST_CHUNK(PTR, LEN) (c.PTR[(LEN) >> 4])
 
 template <bool NEAR>
 __device__ __forceinline__ void put_row_body(uint8_t *p, const RowConst &c, const DigitBase &bq, const DigitBase &bt, const RowNums &r, bool small) {
     Txt16 t;
     const uint32_t fullA = c.lenA >> 4, rA = c.lenA & 15u;
-    PIECE_FULL_CHUNKS(p, a0, a1, A16, c.lenA, 1)
+    PIECE_FULL_CHUNKS(p, A16, c.lenA, 1)
     coord_txt<NEAR>(bq, r.dq, '\t', 1, t);
     if (c.fuseA) {
-        const u32x4 a = PIECE_REST_CHUNK(a0, a1, A16, c.lenA);
+        const u32x4 a = PIECE_REST_CHUNK(A16, c.lenA);
         store_rest_then(p + 16 * fullA, a.x | ((uint64_t)a.y << 32), a.z | ((uint64_t)a.w << 32), rA, t);
     } else {
-        if (rA) store16(p + 16 * fullA, PIECE_REST_CHUNK(a0, a1, A16, c.lenA));
+        if (rA) store16(p + 16 * fullA, PIECE_REST_CHUNK(A16, c.lenA));
         store16(p + c.lenA, t.lo, t.hi);
     }
     p += c.lenA + t.n;
@@ -1763,13 +1752,13 @@ __device__ __forceinline__ void put_row_body(uint8_t *p, const RowConst &c, cons
     store16(p, t.lo, t.hi);
     p += t.n;
     const uint32_t fullB = c.lenB >> 4, rB = c.lenB & 15u;
-    PIECE_FULL_CHUNKS(p, b0, b1, B16, c.lenB, 0)
+    PIECE_FULL_CHUNKS(p, B16, c.lenB, 0)
     coord_txt<NEAR>(bt, r.dt, '\t', 1, t);
     if (c.fuseB) {
-        const u32x4 b = PIECE_REST_CHUNK(b0, b1, B16, c.lenB);
+        const u32x4 b = PIECE_REST_CHUNK(B16, c.lenB);
         store_rest_then(p + 16 * fullB, b.x | ((uint64_t)b.y << 32), b.z | ((uint64_t)b.w << 32), rB, t);
     } else {
-        if (rB) store16(p + 16 * fullB, PIECE_REST_CHUNK(b0, b1, B16, c.lenB));
+        if (rB) store16(p + 16 * fullB, PIECE_REST_CHUNK(B16, c.lenB));
         store16(p + c.lenB, t.lo, t.hi);
     }
     p += c.lenB + t.n;
@@ -1793,8 +1782,8 @@ __device__ __forceinline__ void put_row_body(uint8_t *p, const RowConst &c, cons
     }
     p += t.n + lt.n + nl;
     const uint32_t fullC = c.lenC >> 4, rC = c.lenC & 15u;
-    PIECE_FULL_CHUNKS(p, c0, c1, C16, c.lenC, 0)
-    if (rC) store16(p + 16 * fullC, PIECE_REST_CHUNK(c0, c1, C16, c.lenC));
+    PIECE_FULL_CHUNKS(p, C16, c.lenC, 0)
+    if (rC) store16(p + 16 * fullC, PIECE_REST_CHUNK(C16, c.lenC));
     /* "LM\n" from "L\t": the tab becomes 'M', then '\n' */
     if (nl < 8) {
         const uint32_t sh = 8 * nl;
@@ -1832,12 +1821,6 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
     rc.dt = dec_len(s.tlen);
     rc.fuseA = (k.lenA & 15u) != 0 && (k.lenA & 15u) + dec_len(s.qlen) + 1 <= 16;
     rc.fuseB = (k.lenB & 15u) != 0 && (k.lenB & 15u) + rc.dt + 1 <= 16;
-    rc.regs = k.lenA <= 32 && k.lenB <= 32 && k.lenC <= 32; /* chunk index 2 is never read then (a length of 32 has no rest) */
-    if (rc.regs) {
-        rc.a0 = uniform_x4(A16[0]); rc.a1 = uniform_x4(A16[1]);
-        rc.b0 = uniform_x4(B16[0]); rc.b1 = uniform_x4(B16[1]);
-        rc.c0 = uniform_x4(C16[0]); rc.c1 = uniform_x4(C16[1]);
-    }
     /* digit bases: forward strand q = (qs + cq) + dq; reverse strand q0 = (qe - cq - total) + (total - dq - len) */
     DigitBase bq, bt;
     bq.set(s.same ? (uint64_t)(s.qs + cq0) : (uint64_t)(s.qe - cq0));
@@ -1952,7 +1935,7 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
         }
         /* the head of piece A of every row, last: it repairs what the previous row's wide stores spilled */
         if (prim) {
-            const u32x4 a_head = rc.regs ? rc.a0 : A16[0];
+            const u32x4 a_head = A16[0];
             store16(em.buf + o, a_head);
             if (sec) store16(em.buf + o + bytes0, a_head);
         }
@@ -2604,7 +2587,10 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_EMIT_OCC) void k_emit_lds(KParams P
  * there is no barrier at all, and the kernel carries none of the general paths.
  */
 #define PAFFY_ROWS_LDS_BYTES (PAFFY_WAVE_RING + 3 * 64 + 64)
-__global__ __launch_bounds__(64, PAFFY_EMIT_OCC) void k_emit_rows(KParams P) {
+#ifndef PAFFY_ROWS_OCC
+#define PAFFY_ROWS_OCC 4
+#endif
+__global__ __launch_bounds__(64, PAFFY_ROWS_OCC) void k_emit_rows(KParams P) {
     extern __shared__ uint4 smem4[];
     uint8_t *smem = reinterpret_cast<uint8_t *>(smem4);
     const uint32_t rec = blockIdx.x;
