@@ -97,16 +97,19 @@ __global__ __launch_bounds__(PAFFY_NT) void k_sep_write(const uint8_t *in, uint3
                                                          uint32_t *nl_idx) {
     __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
     BlockComm scratch{scratch_mem, 0};
-    const uint32_t tile0 = blockIdx.x * SEP_TILE;
-    uint2 base = tile_off[blockIdx.x];
+    /* tiles in reverse launch order: k_sep_count read the end of the text last, so it is the part most likely still in
+       the Infinity Cache */
+    const uint32_t tile = gridDim.x - 1 - blockIdx.x;
+    const uint32_t tile0 = tile * SEP_TILE;
+    uint2 base = tile_off[tile];
     uint32_t sbase = base.x, lbase = base.y;
     for (uint32_t off = threadIdx.x * 16; off < SEP_TILE; off += PAFFY_NT * 16) {
         uint32_t a, b;
         const uint32_t g = tile0 + off;
         sep_masks(in, in_len, g, a, b);
-        int64_t v[2] = {__popc(a), __popc(b)}, tot[2];
-        block_excl_scan<2>(v, tot, scratch);
-        uint32_t si = sbase + (uint32_t)v[0], li = lbase + (uint32_t)v[1];
+        uint32_t v[2] = {(uint32_t)__popc(a), (uint32_t)__popc(b)}, tot[2];
+        block_excl_scan_u32<2>(v, tot, scratch);
+        uint32_t si = sbase + v[0], li = lbase + v[1];
         while (a) {
             int j = __ffs((int)a) - 1;
             a &= a - 1;
@@ -114,10 +117,10 @@ __global__ __launch_bounds__(PAFFY_NT) void k_sep_write(const uint8_t *in, uint3
             if (b & (1u << j)) nl_idx[li++] = si;
             si++;
         }
-        sbase += (uint32_t)tot[0];
-        lbase += (uint32_t)tot[1];
+        sbase += tot[0];
+        lbase += tot[1];
     }
-    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && in_len > 0 && in[in_len - 1] != '\n') {
+    if (threadIdx.x == 0 && tile == gridDim.x - 1 && in_len > 0 && in[in_len - 1] != '\n') {
         sep_pos[sbase] = in_len;
         nl_idx[lbase] = sbase;
     }
