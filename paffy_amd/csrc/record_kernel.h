@@ -1783,7 +1783,6 @@ __device__ __forceinline__ void put_row_body(uint8_t *p, const RowConst &c, cons
     p += t.n + lt.n + nl;
     const uint32_t fullC = c.lenC >> 4, rC = c.lenC & 15u;
     PIECE_FULL_CHUNKS(p, C16, c.lenC, 0)
-    if (rC) store16(p + 16 * fullC, PIECE_REST_CHUNK(C16, c.lenC));
     /* "LM\n" from "L\t": the tab becomes 'M', then '\n' */
     if (nl < 8) {
         const uint32_t sh = 8 * nl;
@@ -1794,7 +1793,14 @@ __device__ __forceinline__ void put_row_body(uint8_t *p, const RowConst &c, cons
         const uint32_t sh = 8 * (nl - 8);
         lt.hi = (lt.hi ^ ((uint64_t)('\t' ^ 'M') << sh)) | ((uint64_t)'\n' << (sh + 8));
     }
-    store16(p + c.lenC, lt.lo, lt.hi);
+    lt.n = nl + 2;
+    if (small && rC != 0 && rC <= 12) { /* rest of C + "LM\n" (at most four characters) in one store */
+        const u32x4 cr = PIECE_REST_CHUNK(C16, c.lenC);
+        store_rest_then(p + 16 * fullC, cr.x | ((uint64_t)cr.y << 32), cr.z | ((uint64_t)cr.w << 32), rC, lt);
+    } else {
+        if (rC) store16(p + 16 * fullC, PIECE_REST_CHUNK(C16, c.lenC));
+        store16(p + c.lenC, lt.lo, lt.hi);
+    }
 }
 __device__ __forceinline__ bool shatter_fast_ok(const RecState &s, const ShatterConst &k) {
     /* rows of a valid record have 0 <= coordinates <= sequence length (child paf_check, impl/paf.c:624),
