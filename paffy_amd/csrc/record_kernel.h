@@ -2128,12 +2128,22 @@ __device__ __forceinline__ void write_emit(const View<OPS> &v, bool has_cigar, c
         if (b > i + w) b = i + w;
         if (e > i + w) e = i + w;
         const bool last = (i + w == v.n);
+        /* the lane's ops of this window, loaded together (independent loads, one wait) and kept in registers for both passes */
+        typename OPS::raw_t raw[WRITE_PER];
+#pragma unroll
+        for (int jj = 0; jj < WRITE_PER; jj++) {
+            raw[jj] = 0;
+            if (b + jj < e) raw[jj] = v.ops.raw(v.raw_index(b + jj));
+        }
         int64_t nb[1] = {0}, nbt[1];
-        for (uint32_t j = b; j < e; j++) {
-            int64_t len;
-            int op;
-            v.get(j, len, op);
-            nb[0] += dec_len(len) + 1;
+#pragma unroll
+        for (int jj = 0; jj < WRITE_PER; jj++) {
+            if (b + jj < e) {
+                int64_t len;
+                int op;
+                v.decode(raw[jj], v.raw_index(b + jj), len, op);
+                nb[0] += dec_len(len) + 1;
+            }
         }
         if (last && e == v.n && b < e) nb[0] += 1; /* '\n' goes with the last op */
         wave_excl_scan<1>(nb, nbt);
@@ -2143,17 +2153,20 @@ __device__ __forceinline__ void write_emit(const View<OPS> &v, bool has_cigar, c
         }
         RingWriter rw;
         rw.init(em.ring, PAFFY_WAVE_RING, em.pos_r, (uint32_t)nb[0]);
-        for (uint32_t j = b; j < e; j++) {
-            int64_t len;
-            int op;
-            v.get(j, len, op);
-            DecText d;
-            dec_text(len, d);
-            if (d.groups == 0 && !d.neg_separate && d.ntop <= 7) { /* digits + op letter in one word */
-                rw.put(d.top | ((uint64_t)op_char_of(op) << (8 * d.ntop)), d.ntop + 1);
-            } else {
-                put_text(rw, d, 0);
-                rw.put(op_char_of(op), 1);
+#pragma unroll 2
+        for (int jj = 0; jj < WRITE_PER; jj++) {
+            if (b + jj < e) {
+                int64_t len;
+                int op;
+                v.decode(raw[jj], v.raw_index(b + jj), len, op);
+                DecText d;
+                dec_text(len, d);
+                if (d.groups == 0 && !d.neg_separate && d.ntop <= 7) { /* digits + op letter in one word */
+                    rw.put(d.top | ((uint64_t)op_char_of(op) << (8 * d.ntop)), d.ntop + 1);
+                } else {
+                    put_text(rw, d, 0);
+                    rw.put(op_char_of(op), 1);
+                }
             }
         }
         if (last && e == v.n && b < e) rw.put('\n', 1);
