@@ -234,6 +234,36 @@ __device__ __forceinline__ void block_excl_scan_u32(uint32_t (&v)[K], uint32_t (
         v[k] = base + inc[k] - v[k];
     }
 }
+/* exclusive scan of four sums and the minimum of a fifth value with a single barrier */
+__device__ __forceinline__ void block_excl_scan4_min_u32(uint32_t (&v)[4], uint32_t (&tot)[4], uint32_t &mn, BlockComm &bc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc[4];
+    uint32_t *sl = reinterpret_cast<uint32_t *>(bc.slots());
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        inc[k] = wave_incl_scan_u32(v[k]);
+        if (lane == 63) sl[wave * 5 + k] = inc[k];
+    }
+    const uint32_t wm = wave_min_u32(mn);
+    if (lane == 0) sl[wave * 5 + 4] = wm;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < PAFFY_NWAVE; w++) {
+            const uint32_t s = sl[w * 5 + k];
+            if (w < wave) base += s;
+            total += s;
+        }
+        tot[k] = total;
+        v[k] = base + inc[k] - v[k];
+    }
+    uint32_t r = sl[4];
+#pragma unroll
+    for (int w = 1; w < PAFFY_NWAVE; w++) r = sl[w * 5 + 4] < r ? sl[w * 5 + 4] : r;
+    mn = r;
+}
 template <int K>
 __device__ __forceinline__ void block_sum_u32(uint32_t (&v)[K], BlockComm &bc) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

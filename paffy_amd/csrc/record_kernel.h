@@ -322,10 +322,10 @@ __device__ __forceinline__ uint32_t parse_cigar_fast(const uint8_t *in, uint32_t
         if (nv < 8u) nd &= (1ull << (8u * nv)) - 1ull;
         cnt += (uint32_t)__popcll(nd);
     }
-    int64_t c1[1] = {(int64_t)cnt}, tot[1];
-    block_excl_scan<1>(c1, tot, bc);
-    const uint32_t n = (uint32_t)tot[0];
-    uint32_t idx = (uint32_t)c1[0];
+    uint32_t c1[1] = {cnt}, tot[1];
+    block_excl_scan_u32<1>(c1, tot, bc);
+    const uint32_t n = tot[0];
+    uint32_t idx = c1[0];
     /* the number that runs into my range: digits at the end of the word before it */
     uint32_t acc = 0, nd = 0;
     if (tid > 0 && my_bytes > 0) {
@@ -377,19 +377,22 @@ __device__ __forceinline__ uint32_t parse_cigar_fast(const uint8_t *in, uint32_t
         }
     }
     /* a cigar that ends in digits: the reference's switch sees the NUL (impl/paf.c:96-103) */
+    uint32_t trailing = 0;
     if (my_bytes > 0 && s0 + my_bytes == end) {
         const uint32_t lw = (my_bytes - 1u) >> 3; /* selects, not an indexed array: that would live in scratch memory */
         const uint64_t wl = lw == 0 ? w[1] : lw == 1 ? w[2] : lw == 2 ? w[3] : w[4];
         const uint32_t last = (uint32_t)(wl >> (8u * ((my_bytes - 1u) & 7u))) & 0xffu;
-        if (last - '0' < 10u) atomicMin(&sh->err_pos, end);
+        trailing = last - '0' < 10u ? 1u : 0u;
     }
-    if (bad) atomicOr(&sh->flags, 0x200u); /* an odd text (or a bad character whose exact offset the general parser finds) */
-    sums[0] = sm; sums[1] = sx; sums[2] = sq; sums[3] = st;
+    /* one collective: the four sums (each below 2^44 for the block), how many threads met an odd text (bits 48..56) and
+       the trailing-digits flag (bit 60) */
+    sums[0] = (int64_t)((uint64_t)sm | ((uint64_t)(bad ? 1u : 0u) << 48) | ((uint64_t)trailing << 60));
+    sums[1] = sx; sums[2] = sq; sums[3] = st;
     block_sum<4>(sums, bc);
-    __syncthreads();
-    const uint32_t fl = sh->flags;
-    *err_pos = sh->err_pos;
-    __syncthreads();
+    const uint64_t packed = (uint64_t)sums[0];
+    sums[0] = (int64_t)(packed & ((1ull << 48) - 1ull));
+    const uint32_t fl = ((packed >> 48) & 0xfffull) ? 0x200u : 0u;
+    *err_pos = (packed >> 60) ? end : 0xffffffffu;
     if (fl & 0x200u) return 0xffffffffu;
     *fits = n <= cap;
     const uint32_t n_copy = n < cap ? (n < ops.g_cap ? n : ops.g_cap) : (cap < ops.g_cap ? cap : ops.g_cap);
@@ -1253,8 +1256,7 @@ __device__ __forceinline__ int shatter_size(const RecState &s, const View<OPS> &
                 if (op != OP_D) a[0] += (uint32_t)len;
                 if (op != OP_I) a[1] += (uint32_t)len;
             }
-            err = block_min_u32(err, bc);
-            block_excl_scan_u32<4>(a, at, bc);
+            block_excl_scan4_min_u32(a, at, err, bc);
             bytes = at[2];
             rows = at[3];
             if ((threadIdx.x & 63) == 0) {
