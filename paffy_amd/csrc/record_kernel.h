@@ -2501,7 +2501,9 @@ __device__ __forceinline__ void emit_record(const KParams &P, uint32_t rec, cons
 /* LDS budgets: both kernels fit four workgroups per CU (160 KiB). */
 #define PAFFY_SIZE_LDS_BYTES_FOR(cap) ((cap) * 4 + (PAFFY_HALO + PAFFY_NT * 16) + 64 * 8 + 64)
 #define PAFFY_SIZE_LDS_BYTES PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP)
-#define PAFFY_OPS_CAP_MID 12288u /* second sizing level: 48 KiB of ops, three workgroups per CU */
+#ifndef PAFFY_OPS_CAP_MID
+#define PAFFY_OPS_CAP_MID 16384u /* second sizing level: 64 KiB of ops, two workgroups per CU */
+#endif
 #define PAFFY_OPS_CAP_BIG 36864u /* third sizing level: 144 KiB of ops, one workgroup per CU */
 #define PAFFY_EMIT_LDS_BYTES (PAFFY_NWAVE * PAFFY_WAVE_RING + 3 * PAFFY_TMPL_MAX + 64 * 8 + 64)
 
@@ -2532,7 +2534,7 @@ __device__ __forceinline__ uint32_t mirror_index(const RecMeta &m) { return m.cg
 /*
  * Sizing, LDS class: one workgroup per record, ops parsed from the text into LDS (and mirrored).
  * Launched three times with growing LDS stores: the whole batch with 8192 ops (4 workgroups per
- * CU), what did not fit with 12288 ops (3 per CU), then with 36864 ops (1 per CU). What still does
+ * CU), what did not fit with 16384 ops (2 per CU), then with 36864 ops (1 per CU). What still does
  * not fit (lengths >= 2^29, rebuilt op arrays) goes to the arena kernel.
  */
 template <uint32_t MASK>
@@ -2568,7 +2570,7 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_SIZE_OCC) void k_size_lds(KParams P
     size_lds_one<MASK>(P, blockIdx.x, ops_lds, L);
 }
 template <uint32_t MASK>
-__global__ __launch_bounds__(PAFFY_NT, PAFFY_SIZE_OCC) void k_size_lds_long(KParams P) { /* levels 1 and 2: the queued long records */
+__global__ __launch_bounds__(PAFFY_NT, 2) void k_size_lds_long(KParams P) { /* two workgroups per CU at most (LDS): room for 256 registers, no spills */ /* levels 1 and 2: the queued long records */
     extern __shared__ uint4 smem4[];
     uint32_t *ops_lds;
     RecLds L = carve_size_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds, P.ops_cap);
