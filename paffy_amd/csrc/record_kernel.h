@@ -1807,7 +1807,10 @@ __device__ __forceinline__ void put_row_body(uint8_t *p, const RowConst &c, cons
 __device__ __forceinline__ bool shatter_fast_ok(const RecState &s, const ShatterConst &k) {
     /* rows of a valid record have 0 <= coordinates <= sequence length (child paf_check, impl/paf.c:624),
        and the cigar's sums equal the spans, so window sums fit 32 bits when the spans do */
-    return k.lenA >= 16 && s.qlen < 100000000000ll && s.tlen < 100000000000ll && s.qe - s.qs < 0x7f000000ll && s.te - s.ts < 0x7f000000ll;
+    /* the bases of the digit arithmetic are the record's own coordinates: they must be sane themselves (shatter does not
+       check its parent: a record with target_start -1 whose first op is a deletion still has valid rows) */
+    return k.lenA >= 16 && s.qlen < 100000000000ll && s.tlen < 100000000000ll && s.qs >= 0 && s.qs <= s.qe && s.qe <= s.qlen && s.ts >= 0 &&
+           s.ts <= s.te && s.te <= s.tlen && s.qe - s.qs < 0x7f000000ll && s.te - s.ts < 0x7f000000ll;
 }
 
 /*

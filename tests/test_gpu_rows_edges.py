@@ -126,3 +126,17 @@ def test_register_parser_limits(eng):
         want, werr = O.run([O.stage(O.INVERT)], line)
         got, info = eng.run([paffy_amd.stage(paffy_amd.INVERT)], line, raise_on_error=False)
         assert info.error.code == werr.code and got == want, line[:80]
+
+
+def test_fuzz_regressions(eng):
+    """Inputs the soak test (tools/fuzz_gpu.py) once caught: case1 = a parent with target_start -1 whose first op is a
+    deletion (valid rows, negative base for the row kernel's digit arithmetic)."""
+    import glob
+    import os
+
+    from conftest import GOLDEN
+
+    for path in sorted(glob.glob(os.path.join(GOLDEN, "fuzz", "*.paf"))):
+        with open(path, "rb") as fh:
+            data = fh.read()
+        run_both(eng, data, ([O.SHATTER], [O.PASS], [O.INVERT, O.SHATTER]))

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Soak test (GPU box): random records through random pipes, HIP path vs the CPU oracle, for a time budget.
+usage: python tools/fuzz_gpu.py [seconds] [seed]   -- prints the first mismatch (and saves it under gpurun_out/) or a summary."""
+import hashlib
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle_lib as O  # noqa: E402
+import paffy_amd  # noqa: E402
+
+
+def rand_record(rng):
+    qn = "".join(rng.choice("abcXYZ.09_") for _ in range(rng.choice([1, 3, 7, 8, 12, 15, 16, 17, 30, 33, 47, 49, 70])))
+    tn = "".join(rng.choice("tgcaN|-") for _ in range(rng.choice([1, 2, 9, 14, 15, 16, 31, 32, 48, 60])))
+    n_ops = rng.choice([0, 1, 2, 3, 10, 63, 64, 65, 127, 128, 129, 300, 700, 2100, 5000, 9000])
+    lens = rng.choice([[1], [1, 2, 3], [1, 9, 10, 99, 100], [5, 40, 400], [1, 1000, 100000], [7, 12345678]])
+    alphabet = rng.choice(["MID", "MID", "MMID", "M=XID", "MI", "MD"])
+    ops, q, t, prev = [], 0, 0, ""
+    for _ in range(n_ops):
+        op = rng.choice(alphabet)
+        if rng.random() < 0.7 and op == prev:
+            op = rng.choice(alphabet)
+        L = rng.choice(lens)
+        ops.append(f"{L}{op}")
+        q += L if op != "D" else 0
+        t += L if op != "I" else 0
+        prev = op
+    scale = rng.choice([1, 1, 1000, 10**6, 10**9])
+    qlen = q + rng.randrange(1, 50) * scale + rng.choice([0, 10**4 - q % 10**4 if q else 0])
+    tlen = t + rng.randrange(1, 50) * scale
+    qs = rng.randrange(0, qlen - q + 1) if rng.random() < 0.8 else max(0, min(qlen - q, rng.choice([9990, 99995, 10**8 - 3, 10**9 - 50])))
+    ts = rng.randrange(0, tlen - t + 1)
+    if rng.random() < 0.03:  # inconsistent coordinates: paf_check failures must agree too
+        ts += rng.choice([-1, 1, 5])
+    tags = []
+    if rng.random() < 0.7:
+        tags.append(f"tp:A:{rng.choice('PSI')}")
+    if rng.random() < 0.8:
+        tags.append(f"AS:i:{rng.randrange(-5, 10**rng.randrange(1, 9))}")
+    if rng.random() < 0.4:
+        tags.append(f"NM:i:{rng.randrange(99)}")
+    if rng.random() < 0.3:
+        tags.append(f"tl:i:{rng.randrange(1, 5)}")
+    if rng.random() < 0.3:
+        tags.append(f"cn:i:{rng.randrange(10**6)}")
+    if rng.random() < 0.5:
+        tags.append(f"s1:i:{rng.randrange(10**7)}")
+    if n_ops or rng.random() < 0.5:
+        tags.append("cg:Z:" + "".join(ops))
+    rng.shuffle(tags)
+    return (f"{qn}\t{qlen}\t{qs}\t{qs + q}\t{rng.choice('+-')}\t{tn}\t{tlen}\t{ts}\t{ts + t}\t{q}\t{max(q, t)}\t{rng.randrange(256)}"
+            + "".join("\t" + x for x in tags) + "\n")
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = random.Random(seed)
+    eng = paffy_amd.Engine()
+    kinds = [O.INVERT, O.TRIM_IDENTITY, O.TRIM_FIXED, O.REMOVE_MISMATCHES, O.PASS, O.FILTER]
+    t0, rounds, nbytes = time.time(), 0, 0
+    while time.time() - t0 < budget:
+        data = "".join(rand_record(rng) for _ in range(rng.choice([1, 5, 40, 200]))).encode()
+        pipe = [rng.choice(kinds) for _ in range(rng.randrange(0, 4))]
+        if rng.random() < 0.7:
+            pipe.append(O.SHATTER)
+        params = (rng.choice([0.05, 0.2, 0.9]), rng.choice([1.0, 0.5, 0.1]))
+        f = dict(min_identity=rng.choice([-1.0, 0.5, 0.9]), min_alignment_score=rng.choice([-1, 100, 10**5]), invert=rng.random() < 0.3)
+        O.set_filter(**f)
+        eng.set_filter(**f)
+        want, werr = O.run([O.stage(k, *params) for k in pipe], data)
+        got, info = eng.run([paffy_amd.stage(k, *params) for k in pipe], data, raise_on_error=False)
+        if info.error.code != werr.code or (werr.code and info.error.record != werr.record) or got != want:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "fuzz_fail.paf"), "wb") as fh:
+                fh.write(data)
+            print("MISMATCH", dict(pipe=pipe, params=params, filter=f, gpu=(info.error.code, info.error.record, len(got)), cpu=(werr.code, werr.record, len(want)),
+                                   sha_gpu=hashlib.sha256(got).hexdigest()[:12], sha_cpu=hashlib.sha256(want).hexdigest()[:12]))
+            sys.exit(1)
+        rounds += 1
+        nbytes += len(want)
+    print(f"fuzz ok: {rounds} rounds, {nbytes / 1e6:.1f} MB of output compared, seed {seed}")
+
+
+if __name__ == "__main__":
+    main()
