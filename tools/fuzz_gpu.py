@@ -58,11 +58,91 @@ def rand_record(rng):
             + "".join("\t" + x for x in tags) + "\n")
 
 
+def consistent_record(rng, qn, qlen, tn, tlen, n_ops, lens, alphabet="MID", strand=None):
+    ops, q, t = [], 0, 0
+    for k in range(n_ops):
+        op = "M" if k % 2 == 0 else rng.choice(alphabet)
+        L = rng.choice(lens)
+        if (op != "D" and q + L >= qlen - 2) or (op != "I" and t + L >= tlen - 2):
+            break
+        ops.append(f"{L}{op}")
+        q += L if op != "D" else 0
+        t += L if op != "I" else 0
+    if not ops:
+        ops, q, t = ["1M"], 1, 1
+    qs, ts = rng.randrange(0, qlen - q), rng.randrange(0, tlen - t)
+    tags = [f"AS:i:{rng.choice([5, 5, 40, 900])}"] + ([f"s1:i:{rng.choice([3, 3, 77])}"] if rng.random() < 0.6 else [])
+    return f"{qn}\t{qlen}\t{qs}\t{qs + q}\t{strand or rng.choice('+-')}\t{tn}\t{tlen}\t{ts}\t{ts + t}\t{q}\t{q}\t60\t" + "\t".join(tags + ["cg:Z:" + "".join(ops)]) + "\n"
+
+
+def fuzz_tile(eng, rng, budget):
+    t0, rounds = time.time(), 0
+    while time.time() - t0 < budget:
+        contigs = [(f"ctg{i}", rng.choice([300, 5000, 70000, 1200000, 3000000])) for i in range(rng.randrange(1, 5))]
+        recs = []
+        for _ in range(rng.choice([1, 10, 200, 1500])):
+            qn, qlen = rng.choice(contigs)
+            recs.append(consistent_record(rng, qn, qlen, "t", 4000000, rng.choice([1, 5, 60, 900]), rng.choice([[1, 3], [5, 50, 300], [1000, 20000]])))
+        data = "".join(recs).encode()
+        want, werr = O.tile(data)
+        got, info = eng.tile(data, raise_on_error=False)
+        if got != want or info.error.code != werr.code:
+            with open(os.path.join(ROOT, "gpurun_out", "fuzz_tile_fail.paf"), "wb") as fh:
+                fh.write(data)
+            print("TILE MISMATCH", info.error.code, werr.code, len(got), len(want))
+            sys.exit(1)
+        rounds += 1
+    print(f"tile fuzz ok: {rounds} rounds")
+
+
+def fuzz_mismatches(eng, rng, budget):
+    t0, rounds = time.time(), 0
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    while time.time() - t0 < budget:
+        seqs = {}
+        for i in range(rng.randrange(1, 4)):
+            L = rng.choice([50, 2000, 60000])
+            tseq = "".join(rng.choice("ACGTacgtN" if rng.random() < 0.2 else "ACGT") for _ in range(L))
+            seqs[f"t{i}"] = tseq
+            q = list(tseq)
+            for _ in range(L // 20):
+                q[rng.randrange(L)] = rng.choice("ACGT")
+            seqs[f"q{i}"] = "".join(q)
+        recs = []
+        for _ in range(rng.choice([1, 20, 120])):
+            i = rng.randrange(len(seqs) // 2)
+            L = len(seqs[f"t{i}"])
+            recs.append(consistent_record(rng, f"q{i}", L, f"t{i}", L, rng.choice([1, 9, 200]), rng.choice([[1, 2], [7, 30], [100, 900]])))
+        data = "".join(recs).encode()
+        want, werr = O.run([O.stage(O.ADD_MISMATCHES)], data, seqs)
+        eng.set_sequences(seqs)
+        got, info = eng.run([paffy_amd.stage(paffy_amd.ADD_MISMATCHES)], data, raise_on_error=False)
+        ok = got == want and info.error.code == werr.code
+        if ok and not werr.code:
+            want2 = O.run([O.stage(O.ADD_MISMATCHES), O.stage(O.REMOVE_MISMATCHES), O.stage(O.SHATTER)], data, seqs)[0]
+            got2 = eng.run([paffy_amd.stage(paffy_amd.ADD_MISMATCHES), paffy_amd.stage(paffy_amd.REMOVE_MISMATCHES), paffy_amd.stage(paffy_amd.SHATTER)], data,
+                           raise_on_error=False)[0]
+            ok = got2 == want2
+        if not ok:
+            with open(os.path.join(ROOT, "gpurun_out", "fuzz_mism_fail.paf"), "wb") as fh:
+                fh.write(data)
+            print("MISMATCHES MISMATCH", info.error.code, werr.code, len(got), len(want))
+            sys.exit(1)
+        rounds += 1
+    print(f"add_mismatches fuzz ok: {rounds} rounds")
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    mode = sys.argv[3] if len(sys.argv) > 3 else "pipe"
     rng = random.Random(seed)
     eng = paffy_amd.Engine()
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    if mode == "tile":
+        return fuzz_tile(eng, rng, budget)
+    if mode == "mism":
+        return fuzz_mismatches(eng, rng, budget)
     kinds = [O.INVERT, O.TRIM_IDENTITY, O.TRIM_FIXED, O.REMOVE_MISMATCHES, O.PASS, O.FILTER]
     t0, rounds, nbytes = time.time(), 0, 0
     while time.time() - t0 < budget:
