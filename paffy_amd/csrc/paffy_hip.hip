@@ -725,7 +725,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             if (lean) LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_LEAN>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             else LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_ALL>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); /* join */
-            LAUNCH(c, "k_arena_size", k_arena_size, dim3(512), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
+            LAUNCH(c, "k_arena_size", k_arena_size, dim3(2048), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             /* the scan rides along: one host synchronisation per plan in the usual case (the arena was big enough) */
             {
                 const uint32_t n_blocks = (n_lines + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -1037,10 +1037,10 @@ int paffy_hip_emit(paffy_hip_ctx *c, void *d_out, int64_t out_cap) {
     if (shatter) {
         LAUNCH(c, "k_emit_rows", k_emit_rows, dim3(kp.n_rec), dim3(64), PAFFY_ROWS_LDS_BYTES, kp);
         if (c->h_info->g_count > 0) LAUNCH(c, "k_emit_lds", k_emit_lds<true>, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
-        if (c->h_info->w_count > 0) LAUNCH(c, "k_arena_emit", k_arena_emit<true>, dim3(512), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
+        if (c->h_info->w_count > 0) LAUNCH(c, "k_arena_emit", k_arena_emit<true>, dim3(2048), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
     } else {
         LAUNCH(c, "k_emit_lds<line>", k_emit_lds<false>, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
-        if (c->h_info->w_count > 0) LAUNCH(c, "k_arena_emit<line>", k_arena_emit<false>, dim3(512), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
+        if (c->h_info->w_count > 0) LAUNCH(c, "k_arena_emit<line>", k_arena_emit<false>, dim3(2048), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
     }
     return 0;
 }

@@ -884,6 +884,31 @@ __device__ __forceinline__ uint32_t rc_base(uint32_t c) {
 __device__ __forceinline__ uint32_t up_base(uint32_t c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; } /* toupper, C locale */
 
 /*
+ * Match mask of up to eight alignment columns: bit j = toupper(T[tj + j]) == toupper(query base j), the query base being
+ * Q[qoff + j] on the + strand and the complement of Q[qoff - j] on the - strand (impl/paf.c:752-757). Eight bytes of each
+ * sequence per load (byte-aligned loads; the sequence store is padded behind its last byte); only a - strand chunk that
+ * would reach in front of the store falls back to single bytes.
+ */
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+__device__ __forceinline__ uint32_t match_mask8(const uint8_t *base, const uint8_t *Q, const uint8_t *T, int64_t qoff, int64_t tj, uint32_t nb, bool same) {
+    const uint64_t tw = *reinterpret_cast<const u64_unaligned *>(T + tj);
+    uint32_t m = 0;
+    if (same) {
+        const uint64_t qw = *reinterpret_cast<const u64_unaligned *>(Q + qoff);
+#pragma unroll
+        for (int j = 0; j < 8; j++) m |= (up_base((uint32_t)(tw >> (8 * j)) & 0xffu) == up_base((uint32_t)(qw >> (8 * j)) & 0xffu) ? 1u : 0u) << j;
+    } else if (Q + qoff - 7 >= base) {
+        const uint64_t qw = *reinterpret_cast<const u64_unaligned *>(Q + qoff - 7); /* byte 7 - j is Q[qoff - j] */
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            m |= (up_base((uint32_t)(tw >> (8 * j)) & 0xffu) == up_base(rc_base((uint32_t)(qw >> (8 * (7 - j))) & 0xffu)) ? 1u : 0u) << j;
+    } else {
+        for (uint32_t j = 0; j < nb; j++) m |= (up_base((uint32_t)(tw >> (8 * j)) & 0xffu) == up_base(rc_base(Q[qoff - (int64_t)j])) ? 1u : 0u) << j;
+    }
+    return m & ((1u << nb) - 1u);
+}
+
+/*
  * paf_encode_mismatches, impl/paf.c:739-784: each M op becomes its maximal runs of matching (=)
  * and mismatching (X) columns against the two sequences; other ops are copied. Two walks over the
  * bases (count, then fill) with one lane per op chunk. The new array goes to a fresh arena block.
@@ -918,12 +943,14 @@ __device__ __forceinline__ int encode_mismatch_runs(const KParams &P, const RecS
                 if (!in_range) {
                     if (bad == INT64_MAX) bad = i;
                 } else {
-                    bool prev = false;
-                    for (int64_t k = 0; k < len; k++) {
-                        uint32_t qc = s.same ? Q[qoff + k] : rc_base(Q[qoff - k]);
-                        bool m = up_base(T[tj + k]) == up_base(qc);
-                        if (k == 0 || m != prev) cnt[0]++;
-                        prev = m;
+                    uint32_t prev = 0; /* match bit of the column before the chunk */
+                    for (int64_t k = 0; k < len; k += 8) {
+                        const uint32_t nb = len - k < 8 ? (uint32_t)(len - k) : 8u;
+                        const uint32_t m = match_mask8(P.seq_base, Q, T, s.same ? qoff + k : qoff - k, tj + k, nb, s.same);
+                        uint32_t starts = (m ^ ((m << 1) | prev)) & ((1u << nb) - 1u); /* columns that differ from the one before */
+                        if (k == 0) starts |= 1u;
+                        cnt[0] += __popc(starts);
+                        prev = (m >> (nb - 1)) & 1u;
                     }
                 }
             } else {
@@ -957,19 +984,23 @@ __device__ __forceinline__ int encode_mismatch_runs(const KParams &P, const RecS
             v.get(i, len, op);
             if (op == OP_M) {
                 const int64_t qoff = s.same ? s.qs + qi : s.qe - (qi + 1);
-                bool prev = false;
-                int64_t run = 0;
-                for (int64_t k = 0; k < len; k++) {
-                    uint32_t qc = s.same ? Q[qoff + k] : rc_base(Q[qoff - k]);
-                    bool m = up_base(T[tj + k]) == up_base(qc);
-                    if (k > 0 && m != prev) {
-                        dst.set(o++, run, prev ? OP_EQ : OP_X);
-                        run = 0;
+                uint32_t prev = 0;
+                int64_t run_start = 0;
+                for (int64_t k = 0; k < len; k += 8) {
+                    const uint32_t nb = len - k < 8 ? (uint32_t)(len - k) : 8u;
+                    const uint32_t m = match_mask8(P.seq_base, Q, T, s.same ? qoff + k : qoff - k, tj + k, nb, s.same);
+                    uint32_t starts = (m ^ ((m << 1) | prev)) & ((1u << nb) - 1u);
+                    if (k == 0) starts &= ~1u; /* the first column opens the first run: nothing to close */
+                    while (starts) { /* a run ends in front of every other start */
+                        const int j = __ffs((int)starts) - 1;
+                        starts &= starts - 1;
+                        const uint32_t before = j ? (m >> (j - 1)) & 1u : prev;
+                        dst.set(o++, k + j - run_start, before ? OP_EQ : OP_X);
+                        run_start = k + j;
                     }
-                    run++;
-                    prev = m;
+                    prev = (m >> (nb - 1)) & 1u;
                 }
-                if (len > 0) dst.set(o++, run, prev ? OP_EQ : OP_X);
+                if (len > 0) dst.set(o++, len - run_start, prev ? OP_EQ : OP_X);
             } else {
                 dst.set(o++, len, op);
             }
