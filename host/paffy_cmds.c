@@ -165,6 +165,36 @@ int paffy_filter_main(int argc, char *argv[]) {
     return run_stream_cmd(&o, &st, 1, "filter");
 }
 
+/* paffy dedupe [-a], impl/paf_dedupe.c:48-100 */
+int paffy_dedupe_main(int argc, char *argv[]) {
+    static struct option opts[] = {{"logLevel", required_argument, 0, 'l'}, {"inputFile", required_argument, 0, 'i'},
+                                   {"outputFile", required_argument, 0, 'o'}, {"checkInverse", no_argument, 0, 'a'},
+                                   {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+    cmd_opts o;
+    memset(&o, 0, sizeof(o));
+    int check_inverse = 0;
+    optind = 1;
+    for (;;) {
+        int idx = 0;
+        int key = getopt_long(argc, argv, "l:i:o:ha", opts, &idx);
+        if (key == -1) break;
+        switch (key) {
+            case 'l': o.log_level = optarg; break;
+            case 'i': o.in_path = optarg; break;
+            case 'o': o.out_path = optarg; break;
+            case 'a': check_inverse = 1; break;
+            case 'h':
+            default:
+                usage_common("dedupe", "Remove alignments with the same names, strand and coordinates as an earlier one");
+                fprintf(stderr, "-a --checkInverse : Also deduplicate alignments that are the same, but with query and target reversed\n");
+                usage_tail();
+                return key == 'h' ? 0 : 1;
+        }
+    }
+    host_set_dedupe(check_inverse);
+    return run_stream_cmd(&o, NULL, 0, "dedupe");
+}
+
 /* FASTA -> (header, sequence) pairs. Key = the whole header line after '>', sequence = all
  * non-whitespace characters up to the next header (the fastaReadToFunction /
  * fastaRead_readToMapFunction behaviour assumed in SURVEY Appendix C; parity unpinned). */

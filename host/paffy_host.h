@@ -16,6 +16,7 @@
 int paffy_shatter_main(int argc, char *argv[]);
 int paffy_invert_main(int argc, char *argv[]);
 int paffy_filter_main(int argc, char *argv[]);
+int paffy_dedupe_main(int argc, char *argv[]);
 int paffy_trim_main(int argc, char *argv[]);
 int paffy_add_mismatches_main(int argc, char *argv[]);
 int paffy_tile_main(int argc, char *argv[]);
@@ -33,6 +34,8 @@ void host_log_info(const char *fmt, ...);
 int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out);
 /* Thresholds handed to the context that host_stream creates (paffy filter). */
 void host_set_filter(const paffy_filter *f);
+/* paffy dedupe: host_stream runs paffy_hip_dedupe_plan per chunk on one context (which remembers the records written). */
+void host_set_dedupe(int check_inverse);
 
 /* `paffy tile`: reads all of `in`, one tile_plan + emit, writes `out`. */
 int host_tile(FILE *in, FILE *out);

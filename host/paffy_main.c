@@ -19,7 +19,7 @@ static const struct {
     {"add_mismatches", paffy_add_mismatches_main, "Replace Ms with =/Xs in the cigar (or -a: the reverse)"},
     {"chain", NULL, "Chain alignments (not in this build)"},
     {"dechunk", NULL, "Map chunk coordinates back (not in this build)"},
-    {"dedupe", NULL, "Drop duplicate alignments (not in this build)"},
+    {"dedupe", paffy_dedupe_main, "Drop duplicate alignments"},
     {"filter", paffy_filter_main, "Filter alignments on their stats"},
     {"invert", paffy_invert_main, "Switch query and target coordinates"},
     {"shatter", paffy_shatter_main, "Break alignments into gapless blocks"},

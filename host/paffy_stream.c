@@ -68,6 +68,31 @@ static void die_like_reference(const paffy_error *e, int64_t record_base) {
 static paffy_filter g_filter = {-1, -1, -1.0, -1.0, -1, 0};
 void host_set_filter(const paffy_filter *f) { g_filter = *f; }
 
+/* paffy dedupe: the chunks of the stream go through paffy_hip_dedupe_plan of one context, which remembers what it wrote */
+static int g_dedupe_mode = 0; /* 0: stage list, 1: dedupe, 2: dedupe -a */
+void host_set_dedupe(int check_inverse) { g_dedupe_mode = check_inverse ? 2 : 1; }
+static int dedupe_chunk(paffy_hip_ctx *ctx, const char *h_in, int64_t in_len, char **h_out, int64_t *out_len, paffy_plan_info *info) {
+    void *d_in = NULL, *d_out = NULL;
+    int rc = -1;
+    *h_out = NULL;
+    *out_len = 0;
+    if (paffy_hip_malloc(&d_in, in_len + 64) == 0 && paffy_hip_memcpy_h2d(d_in, h_in, in_len) == 0 &&
+        paffy_hip_dedupe_plan(ctx, d_in, in_len, g_dedupe_mode == 2, info) == 0) {
+        rc = 0;
+        if (info->out_bytes > 0) {
+            *h_out = (char *)malloc((size_t)info->out_bytes);
+            if (paffy_hip_malloc(&d_out, info->out_bytes + 64) == 0 && paffy_hip_emit(ctx, d_out, info->out_bytes + 64) == 0 &&
+                paffy_hip_sync(ctx) == 0 && paffy_hip_memcpy_d2h(*h_out, d_out, info->out_bytes) == 0)
+                *out_len = info->out_bytes;
+            else
+                rc = -1;
+        }
+    }
+    if (d_in) paffy_hip_free(d_in);
+    if (d_out) paffy_hip_free(d_out);
+    return rc;
+}
+
 int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out) {
     paffy_hip_ctx *ctx = NULL;
     if (paffy_hip_create(&ctx, -1) != 0) {
@@ -104,7 +129,8 @@ int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out) {
         char *h_out = NULL;
         int64_t out_len = 0;
         paffy_plan_info info;
-        int r = paffy_hip_run_host(ctx, stages, n_stages, buf, (int64_t)use, &h_out, &out_len, &info);
+        int r = g_dedupe_mode ? dedupe_chunk(ctx, buf, (int64_t)use, &h_out, &out_len, &info)
+                              : paffy_hip_run_host(ctx, stages, n_stages, buf, (int64_t)use, &h_out, &out_len, &info);
         if (r != 0) {
             fprintf(stderr, "paffy: GPU call failed (%d): %s\n", r, paffy_hip_last_error(ctx));
             rc = 1;

@@ -119,6 +119,16 @@ int paffy_hip_plan(paffy_hip_ctx *ctx, const paffy_stage *stages, int32_t n_stag
 int paffy_hip_tile_plan(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len, paffy_plan_info *info);
 
 /*
+ * dedupe_plan: `paffy dedupe [-a]` (impl/paf_dedupe.c:117-143). A record is kept unless a record kept earlier -- in this
+ * batch or in an earlier batch of the same context since the last paffy_hip_dedupe_reset -- has the same query name,
+ * target name, strand and four coordinates (with check_inverse: or equals it with query and target swapped; paf_check
+ * then runs on the record, as in the reference). Kept records are written in input order with the cigar text verbatim.
+ * Keys are compared as 128-bit hashes of those fields (two independent 64-bit hashes). Followed by paffy_hip_emit().
+ */
+int paffy_hip_dedupe_plan(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len, int check_inverse, paffy_plan_info *info);
+int paffy_hip_dedupe_reset(paffy_hip_ctx *ctx);
+
+/*
  * emit: write the planned output to d_out (16-byte aligned, out_cap >= info.out_bytes). Returns
  * after enqueueing; paffy_hip_sync() or any synchronisation of the stream completes it.
  */

@@ -785,6 +785,88 @@ static int cmp_rank(const void *a, const void *b) {
     return i < j ? -1 : (i > j ? 1 : 0);
 }
 
+/* paffy dedupe, impl/paf_dedupe.c:27-46,117-143. A linear probe table of the written records (exact key compare). */
+static int dedupe_same(const rec *a, const rec *b, int b_swapped) {
+    const char *bq = b_swapped ? b->tname : b->qname, *bt = b_swapped ? b->qname : b->tname;
+    int64_t bql = b_swapped ? b->tname_len : b->qname_len, btl = b_swapped ? b->qname_len : b->tname_len;
+    int64_t bqs = b_swapped ? b->ts : b->qs, bqe = b_swapped ? b->te : b->qe, bts = b_swapped ? b->qs : b->ts, bte = b_swapped ? b->qe : b->te;
+    return a->qname_len == bql && a->tname_len == btl && memcmp(a->qname, bq, (size_t)bql) == 0 && memcmp(a->tname, bt, (size_t)btl) == 0 &&
+           a->same_strand == b->same_strand && a->ts == bts && a->te == bte && a->qs == bqs && a->qe == bqe;
+}
+int po_dedupe(const char *in, int64_t in_len, int check_inverse, char **out, int64_t *out_len, po_error *err) {
+    run_ctx c;
+    memset(&c, 0, sizeof(c));
+    c.err = err;
+    if (err) memset(err, 0, sizeof(*err));
+    int rc = PO_OK;
+    int64_t nkept = 0, kcap = 1024;
+    rec *kept = (rec *)malloc(sizeof(rec) * (size_t)kcap);
+    int64_t tcap = 4096; /* open addressing on the coordinate sum, as paf_hash_key (impl/paf_dedupe.c:27-35) keys on it */
+    int64_t *table = (int64_t *)malloc(sizeof(int64_t) * (size_t)tcap);
+    for (int64_t i = 0; i < tcap; i++) table[i] = -1;
+    const char *p = in, *end = in + in_len;
+    while (p < end && !rc) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        rec r;
+        int64_t aux = 0;
+        rc = parse_line(p, le, 0, &r, &aux); /* paf_read_with_buffer(input, 0, ...): the cigar stays text */
+        if (rc) {
+            fail(&c, rc, -1, aux);
+            break;
+        }
+        uint64_t key = (uint64_t)(r.qs + r.qe + r.ts + r.te);
+        int found = 0;
+        for (uint64_t h = key % (uint64_t)tcap;; h = (h + 1) % (uint64_t)tcap) {
+            if (table[h] < 0) break;
+            if (dedupe_same(&r, &kept[table[h]], 0)) { found = 1; break; }
+        }
+        if (!found && check_inverse) { /* the inverse has the same coordinate sum */
+            for (uint64_t h = key % (uint64_t)tcap;; h = (h + 1) % (uint64_t)tcap) {
+                if (table[h] < 0) break;
+                if (dedupe_same(&r, &kept[table[h]], 1)) { found = 1; break; }
+            }
+            rc = check_rec(&r); /* paf_check after inverting back, impl/paf_dedupe.c:126 (the cigar is not parsed: coordinates only) */
+            if (rc) {
+                fail(&c, rc, 0, 0);
+                rec_free(&r);
+                break;
+            }
+        }
+        if (!found) {
+            if (nkept == kcap) {
+                kcap *= 2;
+                kept = (rec *)realloc(kept, sizeof(rec) * (size_t)kcap);
+            }
+            if ((nkept + 1) * 2 > tcap) { /* grow and rehash */
+                tcap *= 4;
+                table = (int64_t *)realloc(table, sizeof(int64_t) * (size_t)tcap);
+                for (int64_t i = 0; i < tcap; i++) table[i] = -1;
+                for (int64_t k = 0; k < nkept; k++) {
+                    uint64_t h = (uint64_t)(kept[k].qs + kept[k].qe + kept[k].ts + kept[k].te) % (uint64_t)tcap;
+                    while (table[h] >= 0) h = (h + 1) % (uint64_t)tcap;
+                    table[h] = k;
+                }
+            }
+            kept[nkept] = r;
+            uint64_t h = key % (uint64_t)tcap;
+            while (table[h] >= 0) h = (h + 1) % (uint64_t)tcap;
+            table[h] = nkept++;
+            write_rec(&r, &c.out);
+        } else {
+            rec_free(&r);
+        }
+        c.record++;
+        p = nl ? nl + 1 : end;
+    }
+    for (int64_t k = 0; k < nkept; k++) rec_free(&kept[k]);
+    free(kept);
+    free(table);
+    *out = c.out.p;
+    *out_len = c.out.n;
+    return rc;
+}
+
 int po_tile(const char *in, int64_t in_len, char **out, int64_t *out_len, po_error *err) {
     run_ctx c;
     memset(&c, 0, sizeof(c));

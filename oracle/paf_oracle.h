@@ -107,6 +107,14 @@ int po_run(const po_stage *stages, int32_t n_stages, const char *in, int64_t in_
 /* `paffy tile` over a whole buffer (impl/paf_tile.c:156-178). */
 int po_tile(const char *in, int64_t in_len, char **out, int64_t *out_len, po_error *err);
 
+/*
+ * `paffy dedupe [-a]` over a whole buffer (impl/paf_dedupe.c:117-143): records are read without parsing the cigar; a
+ * record is written (cigar text verbatim) unless an earlier written record has the same query name, target name, strand
+ * and four coordinates; with check_inverse also unless an earlier one equals it with query and target swapped -- in that
+ * case paf_check runs on the record (impl/paf_dedupe.c:122-127: only then).
+ */
+int po_dedupe(const char *in, int64_t in_len, int check_inverse, char **out, int64_t *out_len, po_error *err);
+
 void po_free(void *p);
 
 /* Exit status the reference process would end with for an error code (1, 134 or 139). */

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/paffy_hip.h"
@@ -356,6 +357,56 @@ __global__ __launch_bounds__(PAFFY_NT) void k_tile_keys(const uint8_t *in, const
     keys[r] = k;
 }
 
+/* dedupe: 128-bit key of (query name, target name, strand, four coordinates), the same for the swapped record, the
+ * coordinate part of paf_check (impl/paf.c:427-438; the cigar is not parsed here) and the record's own tile level */
+struct DedupeKey {
+    uint64_t a, b;   /* key */
+    uint64_t ia, ib; /* key of the record with query and target swapped */
+    int32_t err;     /* parse error (PAFFY_ERR_*) */
+    int32_t check;   /* paf_check code on the coordinates, 0 = fine */
+};
+__device__ __forceinline__ void dedupe_mix(uint64_t &h1, uint64_t &h2, uint64_t x) {
+    h1 = (h1 ^ x) * 0x100000001b3ull;
+    h1 ^= h1 >> 29;
+    h2 = (h2 + x) * 0x9e3779b97f4a7c15ull;
+    h2 ^= h2 >> 32;
+}
+__device__ __forceinline__ void dedupe_name(const uint8_t *in, uint32_t off, uint32_t len, uint64_t &h1, uint64_t &h2) {
+    h1 = 0xcbf29ce484222325ull;
+    h2 = 0x6a09e667f3bcc909ull;
+    for (uint32_t i = 0; i < len; i++) dedupe_mix(h1, h2, in[off + i]);
+    dedupe_mix(h1, h2, 0x100u + len);
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_dedupe_keys(const uint8_t *in, const RecMeta *meta, uint32_t n, DedupeKey *keys, int64_t *level) {
+    uint32_t r = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (r >= n) return;
+    const RecMeta &m = meta[r];
+    DedupeKey k;
+    k.err = m.err;
+    uint64_t q1, q2, t1, t2;
+    dedupe_name(in, m.qname_off, m.qname_len, q1, q2);
+    dedupe_name(in, m.tname_off, m.tname_len, t1, t2);
+    uint64_t a = q1, b = q2, ia = t1, ib = t2;
+    dedupe_mix(a, b, t1); dedupe_mix(a, b, t2);
+    dedupe_mix(ia, ib, q1); dedupe_mix(ia, ib, q2);
+    const uint64_t strand = m.same_strand ? 1 : 2;
+    const uint64_t f[4] = {(uint64_t)m.qs, (uint64_t)m.qe, (uint64_t)m.ts, (uint64_t)m.te};
+    dedupe_mix(a, b, strand); dedupe_mix(ia, ib, strand);
+    for (int i = 0; i < 4; i++) {
+        dedupe_mix(a, b, f[i]);
+        dedupe_mix(ia, ib, f[i ^ 2]); /* the swapped record's query coordinates are this one's target coordinates */
+    }
+    k.a = a; k.b = b; k.ia = ia; k.ib = ib;
+    int chk = 0;
+    if (m.qs < 0 || m.qs >= m.qlen) chk = PAFFY_ERR_CHECK_QSTART;
+    else if (m.qs > m.qe || m.qe > m.qlen) chk = PAFFY_ERR_CHECK_QEND;
+    else if (m.ts < 0 || m.ts >= m.tlen) chk = PAFFY_ERR_CHECK_TSTART;
+    else if (m.ts > m.te || m.te > m.tlen) chk = PAFFY_ERR_CHECK_TEND;
+    k.check = chk;
+    keys[r] = k;
+    level[r] = m.tile_level;
+}
+
 __device__ __forceinline__ void tile_state(const RecMeta &m, int64_t level, RecState &s) {
     load_state(m, s);
     s.has_cigar = false; /* the cigar is written verbatim from the text, impl/paf.c:381-385 */
@@ -444,6 +495,8 @@ struct paffy_hip_ctx {
     DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, b_list, b_list1, arena, info, synth_sizes, rec_plan, ops_mirror, seq_blob, seq_table, seq_names, seq_name_off, rec_qseq, rec_tseq;
     int32_t n_seqs = 0;
     paffy_filter filter = {-1, -1, -1.0, -1.0, -1, 0};
+    DevBuf dedupe_keys;
+    std::unordered_set<std::string> dedupe_seen; /* 16-byte keys of the records written so far */
     DevBuf scan_part, tile_keys, tile_order, tile_rank, tile_coff, tile_cbase, tile_cov, tile_level, tile_len, tile_items, tile_slots, tile_parts;
     bool plan_is_tile = false;
     uint32_t tile_n = 0;
@@ -557,7 +610,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
                       &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
-                      &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts, &c->scan_part};
+                      &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts, &c->scan_part, &c->dedupe_keys};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_info) (void)hipHostFree(c->h_info);
@@ -1013,6 +1066,99 @@ int paffy_hip_tile_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, paff
         c->plan.n_rows = n;
     }
     c->tile_n = c->plan.out_bytes ? n : 0;
+    c->tile_in = in;
+    *info = c->plan;
+    c->planned = true;
+    return 0;
+}
+
+int paffy_hip_dedupe_reset(paffy_hip_ctx *c) {
+    if (!c) return PAFFY_E_ARG;
+    c->dedupe_seen.clear();
+    return 0;
+}
+
+int paffy_hip_dedupe_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, int check_inverse, paffy_plan_info *info) {
+    if (!c || !info) return PAFFY_E_ARG;
+    if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
+    c->planned = false;
+    c->plan_is_tile = true; /* same writer as tile: header + the cigar text as it was read */
+    memset(info, 0, sizeof(*info));
+    memset(&c->plan, 0, sizeof(c->plan));
+    info->in_bytes = c->plan.in_bytes = in_len;
+    memset(&c->kp, 0, sizeof(c->kp));
+    c->tile_n = 0;
+    if (in_len == 0) {
+        c->planned = true;
+        return 0;
+    }
+    const uint8_t *in = static_cast<const uint8_t *>(d_in);
+    uint32_t n = 0;
+    {
+        int rc = index_and_parse(c, in, (uint32_t)in_len, &n);
+        if (rc) return rc;
+    }
+    c->plan.n_records = n;
+    if (n == 0) {
+        *info = c->plan;
+        c->planned = true;
+        return 0;
+    }
+    const uint32_t grid = (n + PAFFY_NT - 1) / PAFFY_NT;
+    if (ensure(c, c->dedupe_keys, sizeof(DedupeKey) * (size_t)n)) return PAFFY_E_HIP;
+    if (ensure(c, c->tile_level, sizeof(int64_t) * (size_t)n)) return PAFFY_E_HIP;
+    if (ensure(c, c->tile_order, sizeof(uint32_t) * (size_t)n)) return PAFFY_E_HIP;
+    if (ensure(c, c->tile_len, sizeof(int64_t) * (size_t)(n + 2))) return PAFFY_E_HIP;
+    LAUNCH(c, "k_dedupe_keys", k_dedupe_keys, dim3(grid), dim3(PAFFY_NT), 0, in, static_cast<const RecMeta *>(c->meta.p), n,
+           static_cast<DedupeKey *>(c->dedupe_keys.p), static_cast<int64_t *>(c->tile_level.p));
+    std::vector<DedupeKey> keys(n);
+    HIPCHK(c, hipMemcpyAsync(keys.data(), c->dedupe_keys.p, sizeof(DedupeKey) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    /* the reference's loop, record by record (impl/paf_dedupe.c:117-143): first seen wins */
+    std::vector<uint32_t> kept;
+    kept.reserve(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const DedupeKey &k = keys[i];
+        if (k.err) {
+            c->plan.error.code = k.err;
+            c->plan.error.stage = -1;
+            c->plan.error.record = i;
+            RecMeta m;
+            HIPCHK(c, hipMemcpy(&m, static_cast<RecMeta *>(c->meta.p) + i, sizeof(m), hipMemcpyDeviceToHost));
+            c->plan.error.aux = m.err_aux;
+            break;
+        }
+        std::string key(reinterpret_cast<const char *>(&k.a), 16);
+        bool found = c->dedupe_seen.count(key) != 0;
+        if (!found && check_inverse) {
+            found = c->dedupe_seen.count(std::string(reinterpret_cast<const char *>(&k.ia), 16)) != 0;
+            if (k.check) { /* paf_check(paf), impl/paf_dedupe.c:126 */
+                c->plan.error.code = k.check;
+                c->plan.error.stage = 0;
+                c->plan.error.record = i;
+                break;
+            }
+        }
+        if (!found) {
+            c->dedupe_seen.insert(std::move(key));
+            kept.push_back(i);
+        }
+    }
+    const uint32_t nk = (uint32_t)kept.size();
+    int64_t total = 0;
+    if (nk > 0) {
+        HIPCHK(c, hipMemcpyAsync(c->tile_order.p, kept.data(), sizeof(uint32_t) * (size_t)nk, hipMemcpyHostToDevice, c->stream));
+        int64_t *lens = static_cast<int64_t *>(c->tile_len.p);
+        LAUNCH(c, "k_tile_size", k_tile_size, dim3((nk + PAFFY_NT - 1) / PAFFY_NT), dim3(PAFFY_NT), 0, static_cast<const RecMeta *>(c->meta.p),
+               static_cast<const uint32_t *>(c->tile_order.p), static_cast<const int64_t *>(c->tile_level.p), nk, lens);
+        LAUNCH(c, "k_scan_i64", k_scan_i64, dim3(1), dim3(PAFFY_NT), 0, lens, nk, static_cast<int64_t *>(c->out_off.p), lens + nk);
+        HIPCHK(c, hipMemcpyAsync(&total, lens + nk, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream)); /* `kept` must outlive the copy */
+    }
+    if (c->profile) prof_collect(c);
+    c->plan.out_bytes = total;
+    c->plan.n_rows = nk;
+    c->tile_n = total ? nk : 0;
     c->tile_in = in;
     *info = c->plan;
     c->planned = true;

@@ -79,6 +79,8 @@ def lib():
         L.paffy_hip_emit.argtypes = [vp, vp, i64]
         L.paffy_hip_tile_plan.argtypes = [vp, vp, i64, C.POINTER(PlanInfo)]
         L.paffy_hip_sync.argtypes = [vp]
+        L.paffy_hip_dedupe_plan.argtypes = [vp, vp, i64, C.c_int, C.POINTER(PlanInfo)]
+        L.paffy_hip_dedupe_reset.argtypes = [vp]
         L.paffy_hip_set_sequences.argtypes = [vp, i64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(i64)]
         L.paffy_hip_set_filter.argtypes = [vp, C.POINTER(Filter)]
         L.paffy_hip_error_exit_status.argtypes = [i32]
@@ -165,6 +167,30 @@ class Engine:
         """paffy tile (impl/paf_tile.c) over PAF text; returns (output bytes, PlanInfo)."""
         d_in = self.to_device(data)
         info = self.tile_plan(d_in, len(data))
+        out = b""
+        if info.out_bytes:
+            d_out = self.alloc_out(info.out_bytes)
+            self.emit(d_out)
+            self.sync()
+            out = bytes(d_out[: info.out_bytes].cpu().numpy().tobytes())
+        if info.error.code and raise_on_error:
+            L = lib()
+            raise PafError(f"record {info.error.record}: {L.paffy_hip_error_string(info.error.code).decode()}", info,
+                           L.paffy_hip_error_exit_status(info.error.code))
+        return out, info
+
+    def dedupe_plan(self, d_in, in_len, check_inverse=False):
+        info = PlanInfo()
+        self._check(lib().paffy_hip_dedupe_plan(self._ctx, C.c_void_p(d_in.data_ptr()), in_len, 1 if check_inverse else 0, C.byref(info)),
+                    "paffy_hip_dedupe_plan")
+        return info
+
+    def dedupe(self, data, check_inverse=False, reset=True, raise_on_error=True):
+        """paffy dedupe [-a] (impl/paf_dedupe.c) over PAF text; with reset=False the records written by earlier calls count too."""
+        if reset:
+            lib().paffy_hip_dedupe_reset(self._ctx)
+        d_in = self.to_device(data)
+        info = self.dedupe_plan(d_in, len(data), check_inverse)
         out = b""
         if info.out_bytes:
             d_out = self.alloc_out(info.out_bytes)
@@ -290,3 +316,8 @@ def filter(data, **thresholds):  # noqa: A001 -- named after the reference comma
     e = _engine()
     e.set_filter(**thresholds)
     return e.run([stage(FILTER)], data)[0]
+
+
+def dedupe(data, check_inverse=False):
+    """paffy dedupe [-a] (impl/paf_dedupe.c)."""
+    return _engine().dedupe(data, check_inverse)[0]

@@ -51,6 +51,8 @@ def lib():
         L.po_tile.restype = C.c_int
         L.po_tile.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(Error)]
         L.po_free.argtypes = [C.c_void_p]
+        L.po_dedupe.restype = C.c_int
+        L.po_dedupe.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(Error)]
         L.po_set_filter.argtypes = [C.POINTER(Filter)]
         L.po_set_filter.restype = None
         L.po_error_exit_status.argtypes = [C.c_int32]
@@ -113,6 +115,13 @@ def tile(data):
     L = lib()
     out, n, err = C.c_void_p(), C.c_int64(), Error()
     L.po_tile(data, len(data), C.byref(out), C.byref(n), C.byref(err))
+    return _take(out, n), err
+
+
+def dedupe(data, check_inverse=False):
+    L = lib()
+    out, n, err = C.c_void_p(), C.c_int64(), Error()
+    L.po_dedupe(data, len(data), 1 if check_inverse else 0, C.byref(out), C.byref(n), C.byref(err))
     return _take(out, n), err
 
 

@@ -35,14 +35,14 @@ def test_dispatcher_contract():
         assert name in err
     rc, _, err = run(["frobnicate"])
     assert rc == 1 and b"frobnicate is not a valid paffy command" in err
-    for cmd in ("shatter", "invert", "trim", "tile", "add_mismatches", "filter"):
+    for cmd in ("shatter", "invert", "trim", "tile", "add_mismatches", "filter", "dedupe"):
         rc, out, err = run([cmd, "-h"])
         assert rc == 0 and out == b"" and b"--inputFile" in err and b"--logLevel" in err
         assert run([cmd, "--help"])[0] == 0
         assert run([cmd, "-Z"])[0] == 1
     assert b"--trimIdentity" in run(["trim", "-h"])[2] and b"--fixedTrim" in run(["trim", "-h"])[2]
     assert b"--minIdentityWithGaps" in run(["filter", "-h"])[2] and b"--maxTileLevel" in run(["filter", "-h"])[2]
-    assert run(["dedupe"])[0] == 1  # outside the hot path
+    assert run(["chain"])[0] == 1  # outside the hot path
 
 
 @pytest.mark.gpu
