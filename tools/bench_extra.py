@@ -15,7 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--records", type=int, default=200000)
     ap.add_argument("--mean-ops", type=int, default=2048)
-    ap.add_argument("--cmd", default="tile", choices=["tile", "invert", "trim", "shatter", "remove", "filter", "add"])
+    ap.add_argument("--cmd", default="tile", choices=["tile", "invert", "trim", "shatter", "remove", "filter", "add", "dedupe"])
     a = ap.parse_args()
     import torch
 
@@ -53,7 +53,11 @@ def main():
     eng.profile(True)
     for rep in range(3):
         t0 = time.perf_counter()
-        info = eng.tile_plan(buf, nbytes) if a.cmd == "tile" else eng.plan([paffy_amd.stage(kinds[a.cmd])], buf, nbytes)
+        if a.cmd == "dedupe":
+            paffy_amd.engine.lib().paffy_hip_dedupe_reset(eng._ctx)
+            info = eng.dedupe_plan(buf, nbytes, True)
+        else:
+            info = eng.tile_plan(buf, nbytes) if a.cmd == "tile" else eng.plan([paffy_amd.stage(kinds[a.cmd])], buf, nbytes)
         out = eng.alloc_out(info.out_bytes)
         eng.emit(out)
         eng.sync()
