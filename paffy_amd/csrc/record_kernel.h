@@ -145,7 +145,8 @@ struct RecState {
 struct RecPlan {
     int64_t qs, qe, ts, te, sub_lo, sub_hi;
     uint32_t lo, n;
-    uint32_t flags; /* bit0 rev, bit1 swp, bit2 query/target swapped, bit3 has_cigar, bit4 shatter, bits 8-15 type */
+    uint32_t flags; /* bit0 rev, bit1 swp, bit2 query/target swapped, bit3 has_cigar, bit4 shatter, bit5 direct, bit6 k_emit_rows,
+                       bit7 dropped by a filter, bits 8-15 type, bit16 k_emit_line */
     uint32_t chunk; /* ops per lane in the sizing sweep: wave w owns view ops [64*w*chunk, 64*(w+1)*chunk) */
     /* shatter: query / target bases consumed and output bytes produced before each wave's range */
     int64_t wq[PAFFY_NWAVE], wt[PAFFY_NWAVE], wo[PAFFY_NWAVE];
@@ -2126,17 +2127,13 @@ __device__ __forceinline__ int64_t cigar_text_len(const View<OPS> &v, RecPlan *p
  */
 #define WRITE_PER 16u
 template <class OPS>
-__device__ __forceinline__ void write_emit(const View<OPS> &v, bool has_cigar, const uint64_t *H, uint32_t lenH, const RecPlan &pl,
-                                           uint8_t *ring, uint8_t *out, uint64_t rec_off, bool header_done) {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool with_ops = has_cigar && v.n > 0;
-    const uint64_t span = 64ull * pl.chunk;
-    const uint32_t wb = !with_ops ? 0 : (span * wave < v.n ? (uint32_t)(span * wave) : v.n);
-    const uint32_t we = !with_ops ? 0 : (span * (wave + 1) < v.n ? (uint32_t)(span * (wave + 1)) : v.n);
+__device__ __forceinline__ void write_emit_range(const View<OPS> &v, uint32_t wb, uint32_t we, bool with_header, const uint64_t *H, uint32_t lenH,
+                                                 uint8_t *ring, uint8_t *out, uint64_t start_off) {
+    /* this wave writes [the header and] the text of ops [wb, we) from output byte start_off on, through its own LDS ring */
+    const uint32_t lane = threadIdx.x & 63;
     Emitter<64, PAFFY_WAVE_RING> em;
-    /* wave 0 starts at the record's first byte (header first); the others after the header and the text before them */
-    em.start(ring + wave * PAFFY_WAVE_RING, out, rec_off + ((wave == 0 && !header_done) ? 0 : lenH + (with_ops ? (uint64_t)pl.wo[wave] : 0)));
-    if (wave == 0 && !header_done) {
+    em.start(ring, out, start_off);
+    if (with_header) {
         for (uint32_t base = 0; base < lenH; base += 16 * 64) {
             const uint32_t left = lenH - base, wbytes = left < 16 * 64 ? left : 16 * 64;
             const uint32_t mine_off = 16 * lane;
@@ -2213,6 +2210,19 @@ __device__ __forceinline__ void write_emit(const View<OPS> &v, bool has_cigar, c
         w_try = w_full;
     }
     em.finish();
+}
+template <class OPS>
+__device__ __forceinline__ void write_emit(const View<OPS> &v, bool has_cigar, const uint64_t *H, uint32_t lenH, const RecPlan &pl,
+                                           uint8_t *ring, uint8_t *out, uint64_t rec_off, bool header_done) {
+    /* four waves: wave 0 starts at the record's first byte (header first); the others after the header and the text before them */
+    const uint32_t wave = threadIdx.x >> 6;
+    const bool with_ops = has_cigar && v.n > 0;
+    const uint64_t span = 64ull * pl.chunk;
+    const uint32_t wb = !with_ops ? 0 : (span * wave < v.n ? (uint32_t)(span * wave) : v.n);
+    const uint32_t we = !with_ops ? 0 : (span * (wave + 1) < v.n ? (uint32_t)(span * (wave + 1)) : v.n);
+    const bool with_header = wave == 0 && !header_done;
+    write_emit_range(v, wb, we, with_header, H, lenH, ring + wave * PAFFY_WAVE_RING, out,
+                     rec_off + (with_header ? 0 : lenH + (with_ops ? (uint64_t)pl.wo[wave] : 0)));
 }
 
 /* ---------------- the record program ---------------- */
@@ -2417,7 +2427,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
     }
     RecPlan *plan = static_cast<RecPlan *>(P.rec_plan) + rec;
     int64_t bytes, rows;
-    bool direct = false, rows_kernel = false;
+    bool direct = false, rows_kernel = false, line_kernel = false;
     if (shatter) {
         ShatterConst k;
         shatter_consts(s, k);
@@ -2434,19 +2444,20 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
         const bool nl_in_header = !(s.has_cigar && v.n > 0);
         const uint32_t lenH = header_len(s, nl_in_header);
         direct = lenH > 3 * PAFFY_TMPL_MAX; /* header too long for the LDS staging: built straight in HBM */
+        line_kernel = OPS::kNarrow && lenH + 8 <= PAFFY_TMPL_MAX && v.n <= PAFFY_ROWS_MAX_OPS; /* written by k_emit_line */
         bytes = lenH;
         if (!nl_in_header) bytes += cigar_text_len(v, plan, L.bc) + 1;
         rows = 1;
     }
     if (threadIdx.x == 0) {
-        if (shatter && klass == KLASS_LDS && !rows_kernel) atomicAdd(&P.info->g_count, 1u);
+        if (klass == KLASS_LDS && (shatter ? !rows_kernel : !line_kernel)) atomicAdd(&P.info->g_count, 1u);
         P.status[rec] = klass << 16;
         P.out_len[rec] = bytes;
         P.out_rows[rec] = rows;
         plan->qs = s.qs; plan->qe = s.qe; plan->ts = s.ts; plan->te = s.te; plan->sub_lo = v.sub_lo; plan->sub_hi = v.sub_hi;
         plan->lo = v.lo; plan->n = v.n;
         plan->flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | (s.has_cigar ? 8u : 0u) | ((uint32_t)s.type << 8) |
-                      (shatter ? 16u : 0u) | (direct ? 32u : 0u) | (rows_kernel ? 64u : 0u);
+                      (shatter ? 16u : 0u) | (direct ? 32u : 0u) | (rows_kernel ? 64u : 0u) | (line_kernel ? 0x10000u : 0u);
         plan->chunk = ((v.n + PAFFY_NT - 1) / PAFFY_NT) | 1u; /* = sweep_bounds() */
     }
 #if defined(PAFFY_ABL) && PAFFY_ABL == 21
@@ -2626,7 +2637,7 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_EMIT_OCC) void k_emit_lds(KParams P
     const uint32_t rec = blockIdx.x;
     if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return; /* nothing at or after the first failure */
     if ((P.status[rec] >> 16) != KLASS_LDS) return;
-    if (SHATTER && (static_cast<const RecPlan *>(P.rec_plan)[rec].flags & 64u)) return; /* k_emit_rows has it */
+    if (static_cast<const RecPlan *>(P.rec_plan)[rec].flags & (SHATTER ? 64u : 0x10000u)) return; /* k_emit_rows / k_emit_line has it */
     OpsGlobal ops{P.ops_mirror + mirror_index(P.meta[rec])};
 #if defined(PAFFY_ABL) && PAFFY_ABL == 22
     const unsigned long long c0 = clock64(), w0 = wall_clock64();
@@ -2693,6 +2704,42 @@ __global__ __launch_bounds__(64, PAFFY_ROWS_OCC) void k_emit_rows(KParams P) {
     __builtin_amdgcn_wave_barrier();
     shatter_emit_fast(s, v, k, reinterpret_cast<const u32x4 *>(A), reinterpret_cast<const u32x4 *>(B), reinterpret_cast<const u32x4 *>(C), 0u, v.n, 0ll, 0ll,
                       smem, P.out, (uint64_t)P.out_off[rec]);
+}
+
+/*
+ * Line kernel: one WAVE per record for the whole-line pipes (invert, trim, filter, add_mismatches -a ...) when the header
+ * fits 768 bytes and the ops are in the HBM mirror: preparation once per record, no barrier.
+ */
+#define PAFFY_LINE_LDS_BYTES (PAFFY_WAVE_RING + PAFFY_TMPL_MAX + 64)
+__global__ __launch_bounds__(64, PAFFY_EMIT_OCC) void k_emit_line(KParams P) {
+    extern __shared__ uint4 smem4[];
+    uint8_t *smem = reinterpret_cast<uint8_t *>(smem4);
+    const uint32_t rec = blockIdx.x;
+    if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return;
+    if ((P.status[rec] >> 16) != KLASS_LDS) return;
+    const RecPlan &pl = static_cast<const RecPlan *>(P.rec_plan)[rec];
+    if (!(pl.flags & 0x10000u)) return; /* long header or dropped: k_emit_lds<line> */
+    const RecMeta &m = P.meta[rec];
+    RecState s;
+    load_state(m, s);
+    if (pl.flags & 4u) invert_state(s);
+    s.qs = pl.qs; s.qe = pl.qe; s.ts = pl.ts; s.te = pl.te;
+    s.has_cigar = (pl.flags & 8u) != 0;
+    s.type = (uint8_t)(pl.flags >> 8);
+    OpsGlobal ops{P.ops_mirror + mirror_index(m)};
+    View<OpsGlobal> v;
+    v.reset(ops, pl.n);
+    v.lo = pl.lo; v.rev = pl.flags & 1u; v.swp = (pl.flags & 2u) != 0;
+    v.sub_lo = pl.sub_lo; v.sub_hi = pl.sub_hi;
+    const bool nl_in_header = !(s.has_cigar && v.n > 0);
+    const uint32_t lenH = header_len(s, nl_in_header);
+    uint64_t *H = reinterpret_cast<uint64_t *>(smem + PAFFY_WAVE_RING);
+    {
+        Piece w{(uint8_t *)H, 0, PAFFY_TMPL_MAX, false};
+        build_header(w, s, P.in, nl_in_header);
+    }
+    __builtin_amdgcn_wave_barrier();
+    write_emit_range(v, 0u, nl_in_header ? 0u : v.n, true, H, lenH, smem, P.out, (uint64_t)P.out_off[rec]);
 }
 
 /* Arena class: records whose ops do not fit LDS; persistent workgroups walk the list. */
