@@ -1760,6 +1760,18 @@ __device__ __forceinline__ void coord_txt(const DigitBase &b, uint32_t d, uint32
  * A row at p, everything but the first 16 bytes of piece A: each number is formatted right before its
  * store so that no text stays live. `small`: every L of the window has at most two digits.
  */
+/* The chunks of the three pieces for the usual shape (A 16..31 bytes, B at most 31, C at most 47), read from LDS at the top of a
+   window's formatting: a read issued between the byte-aligned stores would wait for all of them (the LDS executes a wave's
+   operations in order and those stores take 64 cycles each). */
+struct RowPre {
+    u32x4 a_rest, b0, b_rest, c0, c1, c_rest; /* rest: the chunk holding a piece's last len % 16 bytes */
+};
+__device__ __forceinline__ bool row_pre_ok(const RowConst &c) { return c.lenA < 32 && c.lenB < 32 && c.lenC < 48; }
+__device__ __forceinline__ void row_pre_load(const RowConst &c, RowPre &r) {
+    r.a_rest = c.A16[1];
+    r.b0 = c.B16[0]; r.b_rest = c.B16[c.lenB >> 4];
+    r.c0 = c.C16[0]; r.c1 = c.C16[1]; r.c_rest = c.C16[c.lenC >> 4];
+}
 /* the chunks of a piece, from LDS (wave-uniform addresses: broadcast reads) */
 #define PIECE_FULL_CHUNKS(P, PTR, LEN, FROM)                                                                  \
     {                                                                                                         \
@@ -1768,17 +1780,19 @@ __device__ __forceinline__ void coord_txt(const DigitBase &b, uint32_t d, uint32
     }
 #define PIECE_REST_CHUNK(PTR, LEN) (c.PTR[(LEN) >> 4])
 
-template <bool NEAR>
+template <bool NEAR, bool PRE>
 __device__ __forceinline__ void put_row_body(uint8_t *p, const RowConst &c, const DigitBase &bq, const DigitBase &bt, const RowNums &r, bool small) {
+    RowPre pre;
+    if (PRE) row_pre_load(c, pre); /* before the row's first byte-aligned store */
     Txt16 t;
     const uint32_t fullA = c.lenA >> 4, rA = c.lenA & 15u;
-    PIECE_FULL_CHUNKS(p, A16, c.lenA, 1)
+    if (!PRE) PIECE_FULL_CHUNKS(p, A16, c.lenA, 1)
     coord_txt<NEAR>(bq, r.dq, '\t', 1, t);
     if (c.fuseA) {
-        const u32x4 a = PIECE_REST_CHUNK(A16, c.lenA);
+        const u32x4 a = PRE ? pre.a_rest : PIECE_REST_CHUNK(A16, c.lenA);
         store_rest_then(p + 16 * fullA, a.x | ((uint64_t)a.y << 32), a.z | ((uint64_t)a.w << 32), rA, t);
     } else {
-        if (rA) store16(p + 16 * fullA, PIECE_REST_CHUNK(A16, c.lenA));
+        if (rA) store16(p + 16 * fullA, PRE ? pre.a_rest : PIECE_REST_CHUNK(A16, c.lenA));
         store16(p + c.lenA, t.lo, t.hi);
     }
     p += c.lenA + t.n;
@@ -1786,13 +1800,17 @@ __device__ __forceinline__ void put_row_body(uint8_t *p, const RowConst &c, cons
     store16(p, t.lo, t.hi);
     p += t.n;
     const uint32_t fullB = c.lenB >> 4, rB = c.lenB & 15u;
-    PIECE_FULL_CHUNKS(p, B16, c.lenB, 0)
+    if (PRE) {
+        if (fullB) store16(p, pre.b0);
+    } else {
+        PIECE_FULL_CHUNKS(p, B16, c.lenB, 0)
+    }
     coord_txt<NEAR>(bt, r.dt, '\t', 1, t);
     if (c.fuseB) {
-        const u32x4 b = PIECE_REST_CHUNK(B16, c.lenB);
+        const u32x4 b = PRE ? pre.b_rest : PIECE_REST_CHUNK(B16, c.lenB);
         store_rest_then(p + 16 * fullB, b.x | ((uint64_t)b.y << 32), b.z | ((uint64_t)b.w << 32), rB, t);
     } else {
-        if (rB) store16(p + 16 * fullB, PIECE_REST_CHUNK(B16, c.lenB));
+        if (rB) store16(p + 16 * fullB, PRE ? pre.b_rest : PIECE_REST_CHUNK(B16, c.lenB));
         store16(p + c.lenB, t.lo, t.hi);
     }
     p += c.lenB + t.n;
@@ -1816,7 +1834,12 @@ __device__ __forceinline__ void put_row_body(uint8_t *p, const RowConst &c, cons
     }
     p += t.n + lt.n + nl;
     const uint32_t fullC = c.lenC >> 4, rC = c.lenC & 15u;
-    PIECE_FULL_CHUNKS(p, C16, c.lenC, 0)
+    if (PRE) {
+        if (fullC >= 1) store16(p, pre.c0);
+        if (fullC >= 2) store16(p + 16, pre.c1);
+    } else {
+        PIECE_FULL_CHUNKS(p, C16, c.lenC, 0)
+    }
     /* "LM\n" from "L\t": the tab becomes 'M', then '\n' */
     if (nl < 8) {
         const uint32_t sh = 8 * nl;
@@ -1829,10 +1852,10 @@ __device__ __forceinline__ void put_row_body(uint8_t *p, const RowConst &c, cons
     }
     lt.n = nl + 2;
     if (small && rC != 0 && rC <= 12) { /* rest of C + "LM\n" (at most four characters) in one store */
-        const u32x4 cr = PIECE_REST_CHUNK(C16, c.lenC);
+        const u32x4 cr = PRE ? pre.c_rest : PIECE_REST_CHUNK(C16, c.lenC);
         store_rest_then(p + 16 * fullC, cr.x | ((uint64_t)cr.y << 32), cr.z | ((uint64_t)cr.w << 32), rC, lt);
     } else {
-        if (rC) store16(p + 16 * fullC, PIECE_REST_CHUNK(C16, c.lenC));
+        if (rC) store16(p + 16 * fullC, PRE ? pre.c_rest : PIECE_REST_CHUNK(C16, c.lenC));
         store16(p + c.lenC, lt.lo, lt.hi);
     }
 }
@@ -1864,6 +1887,7 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
     rc.dt = dec_len(s.tlen);
     rc.fuseA = (k.lenA & 15u) != 0 && (k.lenA & 15u) + dec_len(s.qlen) + 1 <= 16;
     rc.fuseB = (k.lenB & 15u) != 0 && (k.lenB & 15u) + rc.dt + 1 <= 16;
+    const bool pre_ok = row_pre_ok(rc);
     /* digit bases: forward strand q = (qs + cq) + dq; reverse strand q0 = (qe - cq - total) + (total - dq - len) */
     DigitBase bq, bt;
     bq.set(s.same ? (uint64_t)(s.qs + cq0) : (uint64_t)(s.qe - cq0));
@@ -1972,8 +1996,13 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
                 x.len = r ? rn1.len : rn0.len;
                 x.dq = r ? rn1.dq : rn0.dq;
                 x.dt = r ? rn1.dt : rn0.dt;
-                if (near) put_row_body<true>(p, rc, bq, bt, x, small);
-                else put_row_body<false>(p, rc, bq, bt, x, small);
+                if (pre_ok) {
+                    if (near) put_row_body<true, true>(p, rc, bq, bt, x, small);
+                    else put_row_body<false, true>(p, rc, bq, bt, x, small);
+                } else {
+                    if (near) put_row_body<true, false>(p, rc, bq, bt, x, small);
+                    else put_row_body<false, false>(p, rc, bq, bt, x, small);
+                }
             }
         }
         /* the head of piece A of every row, last: it repairs what the previous row's wide stores spilled */
@@ -1993,7 +2022,7 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
 #if defined(PAFFY_ABL) && PAFFY_ABL == 20
     PT_MARK(4)
     if ((blockIdx.x & 8191u) == 77u && (threadIdx.x & 63) == 0)
-        printf("rec %u wave %u ops %u: load+decode %llu scans+sizes %llu flush %llu format+stores %llu finish %llu loop-top %llu\n", blockIdx.x, wave, we - wb,
+        printf("rec %u wave %u ops %u: load+decode %llu scans+sizes %llu flush %llu format+stores %llu finish %llu loop-top %llu\n", blockIdx.x, (unsigned)(threadIdx.x >> 6), we - wb,
                pt_acc[0], pt_acc[1], pt_acc[2], pt_acc[3], pt_acc[4], pt_acc[5]);
 #endif
 }
