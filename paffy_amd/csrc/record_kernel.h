@@ -1898,14 +1898,28 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
     const uint32_t w_full = 2 * rows_cap < 128 ? 2 * rows_cap : 128;
     uint32_t i = wb, w_try = w_full;
     /*
-     * Raw ops of five windows at a time, two per lane and window, in registers. One counter tracks loads and
-     * stores in issue order, so a wait for a load is also a wait for every store issued before it -- and a
-     * flushed window is acknowledged only after microseconds when the write queues are full. The first block is
-     * loaded before the wave has stored anything; a wave whose share exceeds five windows pays that wait per block.
+     * Raw ops of five windows at a time, two per lane and window, in registers, and the block after it already on
+     * its way. One counter (vmcnt) tracks loads and stores in issue order, so an ordinary wait for a load is also a
+     * wait for every store issued before it -- and a flushed window is acknowledged only after ~10 us when the write
+     * queues are full. The next block's loads are therefore issued a whole block ahead (inline asm: the compiler must
+     * not put its own vmcnt(0) in front of their use) and waited for with s_waitcnt vmcnt(N), N = a lower bound of the
+     * store instructions issued since: everything older than the newest N operations, the loads included, is done.
      */
     typedef typename OPS::raw_t raw_t;
+    constexpr bool kAhead = std::is_same<OPS, OpsGlobal>::value; /* 4-byte ops in the HBM mirror */
     raw_t b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0, b8 = 0, b9 = 0;
+    raw_t n0 = 0, n1 = 0, n2 = 0, n3 = 0, n4 = 0, n5 = 0, n6 = 0, n7 = 0, n8 = 0, n9 = 0; /* the block after */
     uint32_t slot = 5, blk_next = 0xffffffffu; /* next unused window of the block and the op index it starts at */
+    uint32_t ahead_at = 0xffffffffu;           /* op index the block in n0..n9 starts at (none: 0xffffffff) */
+    uint32_t stores_since = 0;                 /* store instructions issued after the loads of n0..n9 */
+#define PAFFY_LOAD_AHEAD(dst, idx)                                                                                   \
+    {                                                                                                                \
+        dst = 0;                                                                                                     \
+        if ((idx) < we) {                                                                                            \
+            const uint32_t *ptr_ = v.ops.p + v.raw_index(idx);                                                       \
+            asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr_) : "memory");                       \
+        }                                                                                                            \
+    }
     PT_DECL
     while (i < we) {
         PT_MARK(5)
@@ -1920,21 +1934,60 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
             slot = 5;
         } else {
             if (slot >= 5 || blk_next != i) {
-                uint32_t k0 = j0;
-                b0 = k0 < we ? v.ops.raw(v.raw_index(k0)) : (raw_t)0;
-                b1 = k0 + 1 < we ? v.ops.raw(v.raw_index(k0 + 1)) : (raw_t)0;
-                k0 += w_full;
-                b2 = k0 < we ? v.ops.raw(v.raw_index(k0)) : (raw_t)0;
-                b3 = k0 + 1 < we ? v.ops.raw(v.raw_index(k0 + 1)) : (raw_t)0;
-                k0 += w_full;
-                b4 = k0 < we ? v.ops.raw(v.raw_index(k0)) : (raw_t)0;
-                b5 = k0 + 1 < we ? v.ops.raw(v.raw_index(k0 + 1)) : (raw_t)0;
-                k0 += w_full;
-                b6 = k0 < we ? v.ops.raw(v.raw_index(k0)) : (raw_t)0;
-                b7 = k0 + 1 < we ? v.ops.raw(v.raw_index(k0 + 1)) : (raw_t)0;
-                k0 += w_full;
-                b8 = k0 < we ? v.ops.raw(v.raw_index(k0)) : (raw_t)0;
-                b9 = k0 + 1 < we ? v.ops.raw(v.raw_index(k0 + 1)) : (raw_t)0;
+                if constexpr (kAhead) {
+                    if (ahead_at == i) { /* the block is (almost) here */
+                        if (stores_since >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                        else if (stores_since >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                        else if (stores_since >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        b0 = n0; b1 = n1; b2 = n2; b3 = n3; b4 = n4; b5 = n5; b6 = n6; b7 = n7; b8 = n8; b9 = n9;
+                    } else {
+                        if (ahead_at != 0xffffffffu) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* a stale block in flight */
+                        uint32_t k0 = j0;
+                        PAFFY_LOAD_AHEAD(b0, k0) PAFFY_LOAD_AHEAD(b1, k0 + 1)
+                        k0 += w_full;
+                        PAFFY_LOAD_AHEAD(b2, k0) PAFFY_LOAD_AHEAD(b3, k0 + 1)
+                        k0 += w_full;
+                        PAFFY_LOAD_AHEAD(b4, k0) PAFFY_LOAD_AHEAD(b5, k0 + 1)
+                        k0 += w_full;
+                        PAFFY_LOAD_AHEAD(b6, k0) PAFFY_LOAD_AHEAD(b7, k0 + 1)
+                        k0 += w_full;
+                        PAFFY_LOAD_AHEAD(b8, k0) PAFFY_LOAD_AHEAD(b9, k0 + 1)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    /* the block after this one */
+                    ahead_at = 0xffffffffu;
+                    if ((uint64_t)i + 5ull * w_full < we) {
+                        ahead_at = i + 5 * w_full;
+                        stores_since = 0;
+                        uint32_t k0 = ahead_at + 2 * lane;
+                        PAFFY_LOAD_AHEAD(n0, k0) PAFFY_LOAD_AHEAD(n1, k0 + 1)
+                        k0 += w_full;
+                        PAFFY_LOAD_AHEAD(n2, k0) PAFFY_LOAD_AHEAD(n3, k0 + 1)
+                        k0 += w_full;
+                        PAFFY_LOAD_AHEAD(n4, k0) PAFFY_LOAD_AHEAD(n5, k0 + 1)
+                        k0 += w_full;
+                        PAFFY_LOAD_AHEAD(n6, k0) PAFFY_LOAD_AHEAD(n7, k0 + 1)
+                        k0 += w_full;
+                        PAFFY_LOAD_AHEAD(n8, k0) PAFFY_LOAD_AHEAD(n9, k0 + 1)
+                    }
+                } else {
+                    uint32_t k0 = j0;
+                    b0 = k0 < we ? v.ops.raw(v.raw_index(k0)) : (raw_t)0;
+                    b1 = k0 + 1 < we ? v.ops.raw(v.raw_index(k0 + 1)) : (raw_t)0;
+                    k0 += w_full;
+                    b2 = k0 < we ? v.ops.raw(v.raw_index(k0)) : (raw_t)0;
+                    b3 = k0 + 1 < we ? v.ops.raw(v.raw_index(k0 + 1)) : (raw_t)0;
+                    k0 += w_full;
+                    b4 = k0 < we ? v.ops.raw(v.raw_index(k0)) : (raw_t)0;
+                    b5 = k0 + 1 < we ? v.ops.raw(v.raw_index(k0 + 1)) : (raw_t)0;
+                    k0 += w_full;
+                    b6 = k0 < we ? v.ops.raw(v.raw_index(k0)) : (raw_t)0;
+                    b7 = k0 + 1 < we ? v.ops.raw(v.raw_index(k0 + 1)) : (raw_t)0;
+                    k0 += w_full;
+                    b8 = k0 < we ? v.ops.raw(v.raw_index(k0)) : (raw_t)0;
+                    b9 = k0 + 1 < we ? v.ops.raw(v.raw_index(k0 + 1)) : (raw_t)0;
+                }
                 slot = 0;
             }
             raw0 = slot == 0 ? b0 : slot == 1 ? b2 : slot == 2 ? b4 : slot == 3 ? b6 : b8;
@@ -2018,6 +2071,7 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
         i += w;
         w_try = w_full;
     }
+#undef PAFFY_LOAD_AHEAD
     em.finish();
 #if defined(PAFFY_ABL) && PAFFY_ABL == 20
     PT_MARK(4)
