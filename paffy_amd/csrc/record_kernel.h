@@ -1708,6 +1708,9 @@ struct WaveLinear {
         base += 16ull * nch;
         phase = total & 15u;
         pending = 0;
+#if defined(PAFFY_STORE_WINDOW)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PAFFY_STORE_WINDOW) : "memory");
+#endif
         __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ void finish() {
