@@ -166,7 +166,7 @@ def main():
                         "avg_kernel_ms": round(ms / launches, 4),
                         "algorithmic_bytes_per_launch": int(per_launch_bytes)}
         cpu = None
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:  # the CPU leg runs on rank 0 of the one-GPU run only
             cpu = cpu_baseline(eng, wl, stages, args.cpu_sample)
         line = {
             "metric": "PAF records/sec (shatter+invert+trim pipe); % HBM roofline at 1/2/4/8 GPU",
