@@ -195,6 +195,51 @@ int paffy_dedupe_main(int argc, char *argv[]) {
     return run_stream_cmd(&o, NULL, 0, "dedupe");
 }
 
+/* paffy split_file, impl/paf_split_file.c:58-120 */
+int paffy_split_file_main(int argc, char *argv[]) {
+    static struct option opts[] = {{"logLevel", required_argument, 0, 'l'}, {"inputFile", required_argument, 0, 'i'},
+                                   {"prefix", required_argument, 0, 'p'}, {"query", no_argument, 0, 'q'},
+                                   {"minLength", required_argument, 0, 'm'}, {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+    const char *log_level = NULL, *in_path = NULL, *prefix = "split_";
+    int by_query = 0;
+    int64_t min_length = 0;
+    optind = 1;
+    for (;;) {
+        int idx = 0;
+        int key = getopt_long(argc, argv, "l:i:p:qm:h", opts, &idx);
+        if (key == -1) break;
+        switch (key) {
+            case 'l': log_level = optarg; break;
+            case 'i': in_path = optarg; break;
+            case 'p': prefix = optarg; break;
+            case 'q': by_query = 1; break;
+            case 'm': min_length = atol(optarg); break;
+            case 'h':
+            default:
+                fprintf(stderr, "paffy split_file [options], MI355X build\nSplit PAF file into separate output files by target (default) or query contig name\n");
+                fprintf(stderr, "-i --inputFile : Input paf file. If not specified reads from stdin\n");
+                fprintf(stderr, "-p --prefix : Output file prefix (may include directory path). Default: split_\n");
+                fprintf(stderr, "-q --query : Split by query contig name instead of target contig name\n");
+                fprintf(stderr, "-m --minLength : Contigs shorter than m share <prefix>small_<k>.paf files of at most m bases each. Default: 0 (disabled)\n");
+                usage_tail();
+                return key == 'h' ? 0 : 1;
+        }
+    }
+    host_set_log_level(log_level);
+    host_log_info("Input file string : %s\n", in_path ? in_path : "(stdin)");
+    host_log_info("Output prefix : %s\n", prefix);
+    host_log_info("Split by : %s\n", by_query ? "query" : "target");
+    host_log_info("Min contig length : %lld\n", (long long)min_length);
+    FILE *in = in_path ? fopen(in_path, "r") : stdin;
+    if (!in) {
+        fprintf(stderr, "paffy split_file: cannot open %s\n", in_path);
+        return 1;
+    }
+    int rc = host_split_file(in, prefix, by_query, min_length);
+    if (in_path) fclose(in);
+    return rc;
+}
+
 /* FASTA -> (header, sequence) pairs. Key = the whole header line after '>', sequence = all
  * non-whitespace characters up to the next header (the fastaReadToFunction /
  * fastaRead_readToMapFunction behaviour assumed in SURVEY Appendix C; parity unpinned). */

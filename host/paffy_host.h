@@ -17,6 +17,7 @@ int paffy_shatter_main(int argc, char *argv[]);
 int paffy_invert_main(int argc, char *argv[]);
 int paffy_filter_main(int argc, char *argv[]);
 int paffy_dedupe_main(int argc, char *argv[]);
+int paffy_split_file_main(int argc, char *argv[]);
 int paffy_trim_main(int argc, char *argv[]);
 int paffy_add_mismatches_main(int argc, char *argv[]);
 int paffy_tile_main(int argc, char *argv[]);
@@ -39,6 +40,8 @@ void host_set_dedupe(int check_inverse);
 
 /* `paffy tile`: reads all of `in`, one tile_plan + emit, writes `out`. */
 int host_tile(FILE *in, FILE *out);
+/* paffy split_file: normalised lines (cigar text verbatim) routed to "<prefix><contig>.paf" / "<prefix>small_<k>.paf" */
+int host_split_file(FILE *in, const char *prefix, int by_query, int64_t min_length);
 
 /* Sequences handed to the context that host_stream creates (add_mismatches); pointers must stay valid. */
 void host_set_sequences(const char *const *names, const char *const *seqs, const int64_t *lens, int64_t n);

@@ -27,7 +27,7 @@ static const struct {
     {"to_bed", NULL, "Coverage map in BED format (not in this build)"},
     {"trim", paffy_trim_main, "Slice off lower identity tails"},
     {"upconvert", NULL, "Convert coordinates to extracted subsequences (not in this build)"},
-    {"split_file", NULL, "Split a PAF file per contig (not in this build)"},
+    {"split_file", paffy_split_file_main, "Split a PAF file per contig"},
     {"view", NULL, "Pretty print alignments (not in this build)"},
 };
 

@@ -150,6 +150,184 @@ int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out) {
     return rc;
 }
 
+/* ---- paffy split_file (impl/paf_split_file.c:131-173): the GPU normalises the lines, the host routes them ---- */
+typedef struct { char *name; size_t len; FILE *fh; } split_slot;
+typedef struct { split_slot *v; size_t n, cap; } split_map;
+static FILE *split_find(const split_map *m, const char *name, size_t len) {
+    for (size_t i = 0; i < m->n; i++)
+        if (m->v[i].len == len && memcmp(m->v[i].name, name, len) == 0) return m->v[i].fh;
+    return NULL;
+}
+static void split_add(split_map *m, const char *name, size_t len, FILE *fh) {
+    if (m->n == m->cap) {
+        m->cap = m->cap ? m->cap * 2 : 64;
+        m->v = (split_slot *)realloc(m->v, sizeof(split_slot) * m->cap);
+    }
+    m->v[m->n].name = (char *)malloc(len + 1);
+    memcpy(m->v[m->n].name, name, len);
+    m->v[m->n].len = len;
+    m->v[m->n].fh = fh;
+    m->n++;
+}
+/* field `want` (0-based) of a PAF line split the way strtok_r(.., "\t") splits it (runs of tabs are one separator) */
+static int line_field(const char *p, const char *e, int want, const char **fs, size_t *fl) {
+    int f = 0;
+    while (p < e) {
+        while (p < e && *p == '\t') p++;
+        if (p >= e) break;
+        const char *q = p;
+        while (q < e && *q != '\t') q++;
+        if (f == want) {
+            *fs = p;
+            *fl = (size_t)(q - p);
+            return 1;
+        }
+        f++;
+        p = q;
+    }
+    return 0;
+}
+static FILE *open_or_die(const char *path) {
+    FILE *fh = fopen(path, "w");
+    if (!fh) {
+        fprintf(stderr, "Could not open output file: %s\n", path);
+        exit(1);
+    }
+    host_log_info("Opened output file: %s\n", path);
+    return fh;
+}
+
+int host_split_file(FILE *in, const char *prefix, int by_query, int64_t min_length) {
+    paffy_hip_ctx *ctx = NULL;
+    if (paffy_hip_create(&ctx, -1) != 0) {
+        fprintf(stderr, "paffy: no usable GPU (this build has no CPU path)\n");
+        return 1;
+    }
+    split_map big = {0, 0, 0}, small = {0, 0, 0};
+    FILE **small_files = NULL;
+    size_t n_small_files = 0;
+    FILE *current = NULL;
+    int64_t current_len = 0, records_done = 0;
+    const size_t cap = chunk_bytes();
+    size_t buf_cap = cap + (1 << 20), have = 0;
+    char *buf = (char *)malloc(buf_cap);
+    int eof = 0, rc = 0;
+    while (!eof || have > 0) {
+        if (!eof) {
+            if (have == buf_cap) {
+                buf_cap *= 2;
+                buf = (char *)realloc(buf, buf_cap);
+            }
+            size_t want = (have < cap ? cap : buf_cap) - have;
+            size_t got = fread(buf + have, 1, want, in);
+            have += got;
+            if (got < want) eof = 1;
+        }
+        size_t use = have;
+        if (!eof) {
+            while (use > 0 && buf[use - 1] != '\n') use--;
+            if (use == 0) continue;
+        }
+        if (use == 0) break;
+        void *d_in = NULL, *d_out = NULL;
+        paffy_plan_info info;
+        char *h_out = NULL;
+        uint32_t *rows = NULL;
+        int64_t *offs = NULL;
+        int64_t n_rows = 0;
+        int ok = paffy_hip_malloc(&d_in, (int64_t)use + 64) == 0 && paffy_hip_memcpy_h2d(d_in, buf, (int64_t)use) == 0 &&
+                 paffy_hip_dedupe_plan(ctx, d_in, (int64_t)use, PAFFY_DEDUPE_KEEP_ALL, &info) == 0;
+        if (ok && info.out_bytes > 0) {
+            h_out = (char *)malloc((size_t)info.out_bytes);
+            rows = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(info.n_rows + 1));
+            offs = (int64_t *)malloc(sizeof(int64_t) * (size_t)(info.n_rows + 1));
+            ok = paffy_hip_malloc(&d_out, info.out_bytes + 64) == 0 && paffy_hip_emit(ctx, d_out, info.out_bytes + 64) == 0 &&
+                 paffy_hip_sync(ctx) == 0 && paffy_hip_memcpy_d2h(h_out, d_out, info.out_bytes) == 0 &&
+                 (n_rows = paffy_hip_plan_rows(ctx, info.n_rows + 1, rows, offs)) >= 0;
+        }
+        if (!ok) {
+            fprintf(stderr, "paffy split_file: GPU call failed: %s\n", paffy_hip_last_error(ctx));
+            rc = 1;
+        } else {
+            /* line starts of the chunk, then every written line to the file of its contig */
+            const char *p = buf, *e = buf + use;
+            int64_t line = 0, k = 0;
+            while (p < e && k < n_rows) {
+                const char *nl = (const char *)memchr(p, '\n', (size_t)(e - p));
+                const char *le = nl ? nl : e;
+                if ((int64_t)rows[k] == line) {
+                    const char *name = NULL, *lens = NULL;
+                    size_t name_len = 0, lens_len = 0;
+                    line_field(p, le, by_query ? 0 : 5, &name, &name_len);
+                    line_field(p, le, by_query ? 1 : 6, &lens, &lens_len);
+                    int64_t contig_len = 0; /* str_to_int64, impl/paf.c:37-48 */
+                    {
+                        size_t i = 0;
+                        int neg = 0;
+                        if (i < lens_len && lens[i] == '-') { neg = 1; i++; }
+                        uint64_t v = 0;
+                        for (; i < lens_len && lens[i] >= '0' && lens[i] <= '9'; i++) v = v * 10 + (uint64_t)(lens[i] - '0');
+                        contig_len = neg ? -(int64_t)v : (int64_t)v;
+                    }
+                    FILE *fh;
+                    if (min_length > 0 && contig_len < min_length) {
+                        fh = split_find(&small, name, name_len);
+                        if (!fh) {
+                            if (!current || current_len + contig_len > min_length) {
+                                char path[4096];
+                                snprintf(path, sizeof(path), "%ssmall_%lld.paf", prefix, (long long)n_small_files);
+                                current = open_or_die(path);
+                                small_files = (FILE **)realloc(small_files, sizeof(FILE *) * (n_small_files + 1));
+                                small_files[n_small_files++] = current;
+                                current_len = 0;
+                            }
+                            current_len += contig_len;
+                            split_add(&small, name, name_len, current);
+                            fh = current;
+                        }
+                    } else {
+                        fh = split_find(&big, name, name_len);
+                        if (!fh) {
+                            char path[4096];
+                            int w = snprintf(path, sizeof(path), "%s", prefix);
+                            for (size_t i = 0; i < name_len && w < (int)sizeof(path) - 8; i++) path[w++] = name[i] == '/' ? '_' : name[i];
+                            snprintf(path + w, sizeof(path) - (size_t)w, ".paf");
+                            fh = open_or_die(path);
+                            split_add(&big, name, name_len, fh);
+                        }
+                    }
+                    fwrite(h_out + offs[k], 1, (size_t)(offs[k + 1] - offs[k]), fh);
+                    k++;
+                }
+                line++;
+                p = nl ? nl + 1 : e;
+            }
+        }
+        if (d_in) paffy_hip_free(d_in);
+        if (d_out) paffy_hip_free(d_out);
+        free(h_out);
+        free(rows);
+        free(offs);
+        if (rc) break;
+        if (info.error.code) {
+            for (size_t i = 0; i < big.n; i++) fclose(big.v[i].fh);
+            for (size_t i = 0; i < n_small_files; i++) fclose(small_files[i]);
+            die_like_reference(&info.error, records_done);
+        }
+        records_done += info.n_records;
+        memmove(buf, buf + use, have - use);
+        have -= use;
+    }
+    for (size_t i = 0; i < big.n; i++) { fclose(big.v[i].fh); free(big.v[i].name); }
+    for (size_t i = 0; i < small.n; i++) free(small.v[i].name);
+    for (size_t i = 0; i < n_small_files; i++) fclose(small_files[i]);
+    free(big.v); free(small.v); free(small_files);
+    free(buf);
+    paffy_hip_destroy(ctx);
+    host_log_info("Split %lld records\n", (long long)records_done);
+    return rc;
+}
+
 int host_tile(FILE *in, FILE *out) {
     size_t cap = 1 << 20, have = 0;
     char *buf = (char *)malloc(cap);

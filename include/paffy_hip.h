@@ -127,6 +127,16 @@ int paffy_hip_tile_plan(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len, pa
  */
 int paffy_hip_dedupe_plan(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len, int check_inverse, paffy_plan_info *info);
 int paffy_hip_dedupe_reset(paffy_hip_ctx *ctx);
+/* check_inverse value that keeps every record: `paf_read(.., 0)` -> `paf_write` (the normalised line, cigar text verbatim),
+ * the read/write pair of `paffy split_file` (impl/paf_split_file.c:131-173). The context's dedupe memory is not touched. */
+#define PAFFY_DEDUPE_KEEP_ALL 2
+
+/*
+ * After a tile or dedupe plan: the lines emit will write, in output order -- record[k] = zero-based input record of line k,
+ * out_off[k] = its first output byte, out_off[n] = the total (cap >= n + 1 entries each). Returns n, or a negative error.
+ * This is what a router such as `paffy split_file` needs to send every written line to the file of its contig.
+ */
+int64_t paffy_hip_plan_rows(paffy_hip_ctx *ctx, int64_t cap, uint32_t *record, int64_t *out_off);
 
 /*
  * emit: write the planned output to d_out (16-byte aligned, out_cap >= info.out_bytes). Returns

@@ -11,6 +11,7 @@
  */
 #include "paf_oracle.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -864,6 +865,90 @@ int po_dedupe(const char *in, int64_t in_len, int check_inverse, char **out, int
     free(table);
     *out = c.out.p;
     *out_len = c.out.n;
+    return rc;
+}
+
+/* paffy split_file, impl/paf_split_file.c:27-56,131-173 */
+typedef struct { char *name; int64_t name_len; FILE *fh; } split_slot;
+static FILE *split_find(split_slot *v, int64_t n, const char *name, int64_t len) {
+    for (int64_t i = 0; i < n; i++)
+        if (v[i].name_len == len && memcmp(v[i].name, name, (size_t)len) == 0) return v[i].fh;
+    return NULL;
+}
+static void split_add(split_slot **v, int64_t *n, int64_t *cap, const char *name, int64_t len, FILE *fh) {
+    if (*n == *cap) {
+        *cap = *cap ? *cap * 2 : 64;
+        *v = (split_slot *)realloc(*v, sizeof(split_slot) * (size_t)*cap);
+    }
+    (*v)[*n].name = (char *)malloc((size_t)len + 1);
+    memcpy((*v)[*n].name, name, (size_t)len);
+    (*v)[*n].name_len = len;
+    (*v)[*n].fh = fh;
+    (*n)++;
+}
+int po_split_file(const char *in, int64_t in_len, const char *prefix, int by_query, int64_t min_length, po_error *err) {
+    run_ctx c;
+    memset(&c, 0, sizeof(c));
+    c.err = err;
+    if (err) memset(err, 0, sizeof(*err));
+    int rc = PO_OK;
+    split_slot *big = NULL, *small = NULL;
+    int64_t nbig = 0, cbig = 0, nsmall = 0, csmall = 0;
+    FILE **small_files = NULL;
+    int64_t n_small_files = 0, current_len = 0;
+    FILE *current = NULL;
+    const char *p = in, *end = in + in_len;
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        rec r;
+        int64_t aux = 0;
+        rc = parse_line(p, le, 0, &r, &aux);
+        if (rc) {
+            fail(&c, rc, -1, aux);
+            break;
+        }
+        const char *name = by_query ? r.qname : r.tname;
+        int64_t name_len = by_query ? r.qname_len : r.tname_len, contig_len = by_query ? r.qlen : r.tlen;
+        FILE *fh;
+        if (min_length > 0 && contig_len < min_length) {
+            fh = split_find(small, nsmall, name, name_len);
+            if (!fh) {
+                if (!current || current_len + contig_len > min_length) {
+                    char path[4096];
+                    snprintf(path, sizeof(path), "%ssmall_%lld.paf", prefix, (long long)n_small_files);
+                    current = fopen(path, "w");
+                    small_files = (FILE **)realloc(small_files, sizeof(FILE *) * (size_t)(n_small_files + 1));
+                    small_files[n_small_files++] = current;
+                    current_len = 0;
+                }
+                current_len += contig_len;
+                split_add(&small, &nsmall, &csmall, name, name_len, current);
+                fh = current;
+            }
+        } else {
+            fh = split_find(big, nbig, name, name_len);
+            if (!fh) {
+                char path[4096];
+                int k = snprintf(path, sizeof(path), "%s", prefix);
+                for (int64_t i = 0; i < name_len && k < (int)sizeof(path) - 8; i++) path[k++] = name[i] == '/' ? '_' : name[i];
+                snprintf(path + k, sizeof(path) - (size_t)k, ".paf");
+                fh = fopen(path, "w");
+                split_add(&big, &nbig, &cbig, name, name_len, fh);
+            }
+        }
+        obuf b = {0, 0, 0};
+        write_rec(&r, &b);
+        if (fh) fwrite(b.p, 1, (size_t)b.n, fh);
+        free(b.p);
+        rec_free(&r);
+        c.record++;
+        p = nl ? nl + 1 : end;
+    }
+    for (int64_t i = 0; i < nbig; i++) { if (big[i].fh) fclose(big[i].fh); free(big[i].name); }
+    for (int64_t i = 0; i < nsmall; i++) free(small[i].name);
+    for (int64_t i = 0; i < n_small_files; i++) if (small_files[i]) fclose(small_files[i]);
+    free(big); free(small); free(small_files);
     return rc;
 }
 

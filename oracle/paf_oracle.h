@@ -115,6 +115,14 @@ int po_tile(const char *in, int64_t in_len, char **out, int64_t *out_len, po_err
  */
 int po_dedupe(const char *in, int64_t in_len, int check_inverse, char **out, int64_t *out_len, po_error *err);
 
+/*
+ * `paffy split_file` (impl/paf_split_file.c:131-173): every record (cigar text verbatim) goes to "<prefix><contig>.paf"
+ * ('/' in the name becomes '_'), the contig being the target name, or the query name with by_query; contigs shorter than
+ * min_length (> 0) share "<prefix>small_<k>.paf" files filled in first-seen order up to min_length bases each. Files are
+ * created by this call (test infrastructure: point the prefix into a scratch directory).
+ */
+int po_split_file(const char *in, int64_t in_len, const char *prefix, int by_query, int64_t min_length, po_error *err);
+
 void po_free(void *p);
 
 /* Exit status the reference process would end with for an error code (1, 134 or 139). */

@@ -1128,9 +1128,13 @@ int paffy_hip_dedupe_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, in
             c->plan.error.aux = m.err_aux;
             break;
         }
+        if (check_inverse == PAFFY_DEDUPE_KEEP_ALL) {
+            kept.push_back(i);
+            continue;
+        }
         std::string key(reinterpret_cast<const char *>(&k.a), 16);
         bool found = c->dedupe_seen.count(key) != 0;
-        if (!found && check_inverse) {
+        if (!found && check_inverse == 1) {
             found = c->dedupe_seen.count(std::string(reinterpret_cast<const char *>(&k.ia), 16)) != 0;
             if (k.check) { /* paf_check(paf), impl/paf_dedupe.c:126 */
                 c->plan.error.code = k.check;
@@ -1163,6 +1167,20 @@ int paffy_hip_dedupe_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, in
     *info = c->plan;
     c->planned = true;
     return 0;
+}
+
+int64_t paffy_hip_plan_rows(paffy_hip_ctx *c, int64_t cap, uint32_t *record, int64_t *out_off) {
+    if (!c || !record || !out_off) return PAFFY_E_ARG;
+    if (!c->planned || !c->plan_is_tile) return PAFFY_E_STATE;
+    const int64_t n = c->tile_n;
+    if (cap < n + 1) return PAFFY_E_CAPACITY;
+    if (n > 0) {
+        HIPCHK(c, hipMemcpyAsync(record, c->tile_order.p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out_off, c->out_off.p, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    out_off[n] = c->plan.out_bytes;
+    return n;
 }
 
 int paffy_hip_emit(paffy_hip_ctx *c, void *d_out, int64_t out_cap) {

@@ -51,6 +51,8 @@ def lib():
         L.po_tile.restype = C.c_int
         L.po_tile.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(Error)]
         L.po_free.argtypes = [C.c_void_p]
+        L.po_split_file.restype = C.c_int
+        L.po_split_file.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int, C.c_int64, C.POINTER(Error)]
         L.po_dedupe.restype = C.c_int
         L.po_dedupe.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(Error)]
         L.po_set_filter.argtypes = [C.POINTER(Filter)]
@@ -123,6 +125,13 @@ def dedupe(data, check_inverse=False):
     out, n, err = C.c_void_p(), C.c_int64(), Error()
     L.po_dedupe(data, len(data), 1 if check_inverse else 0, C.byref(out), C.byref(n), C.byref(err))
     return _take(out, n), err
+
+
+def split_file(data, prefix, by_query=False, min_length=0):
+    """paffy split_file into files "<prefix>...paf" (the prefix may include a directory); returns the Error."""
+    err = Error()
+    lib().po_split_file(data, len(data), prefix.encode(), 1 if by_query else 0, min_length, C.byref(err))
+    return err
 
 
 def exit_status(code):

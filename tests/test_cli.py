@@ -31,7 +31,7 @@ def test_dispatcher_contract():
     """paffy_main.c:46-84: no args -> usage rc 0; unknown command -> rc 1; -h -> rc 0; bad flag -> rc 1."""
     rc, out, err = run([])
     assert rc == 0 and out == b"" and b"usage: paffy <command>" in err
-    for name in (b"add_mismatches", b"invert", b"shatter", b"tile", b"trim", b"chain", b"view", b"split_file"):
+    for name in (b"add_mismatches", b"invert", b"shatter", b"tile", b"trim", b"chain", b"view", b"split_file", b"dedupe", b"filter"):
         assert name in err
     rc, _, err = run(["frobnicate"])
     assert rc == 1 and b"frobnicate is not a valid paffy command" in err
