@@ -328,6 +328,53 @@ __global__ __launch_bounds__(PAFFY_NT) void k_scan_fix(uint32_t n, uint32_t n_bl
     }
 }
 
+/*
+ * Launch order of the record kernels: records in 64 classes of size (the sizing pass: 512 bytes of cigar text per class,
+ * the writers: 16 KiB of output), largest class first, so that the long records do not start last and stretch the kernel's tail (longest-processing-time-first, coarse).
+ * k_order_count histograms the classes, k_order_scatter gives every record its slot.
+ */
+#define ORDER_CLASSES 64u
+__device__ __forceinline__ uint32_t order_class(int64_t out_len, uint32_t shift) {
+    const uint64_t c = (uint64_t)(out_len < 0 ? 0 : out_len) >> shift;
+    return c < ORDER_CLASSES ? (uint32_t)c : ORDER_CLASSES - 1;
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_cigar_bytes(const RecMeta *meta, uint32_t n, int64_t *out) {
+    const uint32_t r = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (r < n) out[r] = meta[r].has_cg ? (int64_t)meta[r].cg_len : 0;
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_order_count(const int64_t *out_len, uint32_t n, uint32_t shift, uint32_t *counts) {
+    __shared__ uint32_t h[ORDER_CLASSES];
+    if (threadIdx.x < ORDER_CLASSES) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t r = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (r < n) atomicAdd(&h[order_class(out_len[r], shift)], 1u);
+    __syncthreads();
+    if (threadIdx.x < ORDER_CLASSES && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_order_scatter(const int64_t *out_len, uint32_t n, uint32_t shift, const uint32_t *counts, uint32_t *cursor,
+                                                             uint32_t *order) {
+    __shared__ uint32_t base[ORDER_CLASSES], mine[ORDER_CLASSES], got[ORDER_CLASSES];
+    if (threadIdx.x < ORDER_CLASSES) mine[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { /* classes in descending order */
+        uint32_t run = 0;
+        for (int c = (int)ORDER_CLASSES - 1; c >= 0; c--) {
+            base[c] = run;
+            run += counts[c];
+        }
+    }
+    __syncthreads();
+    const uint32_t r = blockIdx.x * PAFFY_NT + threadIdx.x;
+    uint32_t c = 0, local = 0;
+    if (r < n) {
+        c = order_class(out_len[r], shift);
+        local = atomicAdd(&mine[c], 1u); /* slot inside this workgroup's share of the class */
+    }
+    __syncthreads();
+    if (threadIdx.x < ORDER_CLASSES && mine[threadIdx.x]) got[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], mine[threadIdx.x]); /* one global atomic per class */
+    __syncthreads();
+    if (r < n) order[base[c] + got[c] + local] = r;
+}
+
 /* ------------------------------------------------------------------ */
 /* tile: keys for the host ordering, sizes and the verbatim writer       */
 /* ------------------------------------------------------------------ */
@@ -497,7 +544,7 @@ struct paffy_hip_ctx {
     paffy_filter filter = {-1, -1, -1.0, -1.0, -1, 0};
     DevBuf dedupe_keys;
     std::unordered_set<std::string> dedupe_seen; /* 16-byte keys of the records written so far */
-    DevBuf scan_part, tile_keys, tile_order, tile_rank, tile_coff, tile_cbase, tile_cov, tile_level, tile_len, tile_items, tile_slots, tile_parts;
+    DevBuf scan_part, emit_order, order_cnt, tile_keys, tile_order, tile_rank, tile_coff, tile_cbase, tile_cov, tile_level, tile_len, tile_items, tile_slots, tile_parts;
     bool plan_is_tile = false;
     uint32_t tile_n = 0;
     const uint8_t *tile_in = nullptr;
@@ -610,7 +657,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
                       &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
-                      &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts, &c->scan_part, &c->dedupe_keys};
+                      &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts, &c->scan_part, &c->dedupe_keys, &c->emit_order, &c->order_cnt};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_info) (void)hipHostFree(c->h_info);
@@ -751,6 +798,18 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     kp.filter = c->filter;
 
     if (n_lines > 0) {
+        { /* launch order of the sizing workgroups: long cigars first (out_len is scratch until the sizing pass fills it) */
+            if (ensure(c, c->emit_order, sizeof(uint32_t) * (size_t)n_lines)) return PAFFY_E_HIP;
+            if (ensure(c, c->order_cnt, sizeof(uint32_t) * 2 * ORDER_CLASSES)) return PAFFY_E_HIP;
+            uint32_t *cnt = static_cast<uint32_t *>(c->order_cnt.p);
+            HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * ORDER_CLASSES, c->stream));
+            const uint32_t g = (n_lines + PAFFY_NT - 1) / PAFFY_NT;
+            LAUNCH(c, "k_cigar_bytes", k_cigar_bytes, dim3(g), dim3(PAFFY_NT), 0, kp.meta, n_lines, kp.out_len);
+            LAUNCH(c, "k_order_count", k_order_count, dim3(g), dim3(PAFFY_NT), 0, kp.out_len, n_lines, 9u, cnt);
+            LAUNCH(c, "k_order_scatter", k_order_scatter, dim3(g), dim3(PAFFY_NT), 0, kp.out_len, n_lines, 9u, cnt, cnt + ORDER_CLASSES,
+                   static_cast<uint32_t *>(c->emit_order.p));
+            kp.size_order = static_cast<const uint32_t *>(c->emit_order.p); /* any permutation serves a repeated sizing pass too */
+        }
         for (int attempt = 0; attempt < 3; attempt++) {
             kp.arena = static_cast<uint64_t *>(c->arena.p);
             kp.arena_cap = c->arena.cap / 8;
@@ -787,6 +846,17 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
                        static_cast<int64_t *>(c->out_off.p), static_cast<int64_t *>(c->scan_part.p), kp.info);
                 LAUNCH(c, "k_scan_fix", k_scan_fix, dim3(n_blocks), dim3(PAFFY_NT), 0, n_lines, n_blocks, static_cast<int64_t *>(c->out_off.p),
                        static_cast<const int64_t *>(c->scan_part.p), kp.info);
+            }
+            {
+                if (ensure(c, c->emit_order, sizeof(uint32_t) * (size_t)n_lines)) return PAFFY_E_HIP;
+                if (ensure(c, c->order_cnt, sizeof(uint32_t) * 2 * ORDER_CLASSES)) return PAFFY_E_HIP;
+                uint32_t *cnt = static_cast<uint32_t *>(c->order_cnt.p);
+                HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * ORDER_CLASSES, c->stream));
+                const uint32_t g = (n_lines + PAFFY_NT - 1) / PAFFY_NT;
+                LAUNCH(c, "k_order_count", k_order_count, dim3(g), dim3(PAFFY_NT), 0, kp.out_len, n_lines, 14u, cnt);
+                LAUNCH(c, "k_order_scatter", k_order_scatter, dim3(g), dim3(PAFFY_NT), 0, kp.out_len, n_lines, 14u, cnt, cnt + ORDER_CLASSES,
+                       static_cast<uint32_t *>(c->emit_order.p));
+                kp.emit_order = static_cast<const uint32_t *>(c->emit_order.p);
             }
             if (fetch_info(c)) return PAFFY_E_HIP;
             if (c->h_info->arena_used <= kp.arena_cap) break;

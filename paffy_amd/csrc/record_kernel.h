@@ -2696,9 +2696,10 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_SIZE_OCC) void k_size_lds(KParams P
     extern __shared__ uint4 smem4[];
     uint32_t *ops_lds;
     RecLds L = carve_size_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds, P.ops_cap);
+    const uint32_t rec = P.size_order ? P.size_order[blockIdx.x] : blockIdx.x; /* long cigars first */
     /* records whose cigar text promises more ops than this store holds were queued for level 1 by k_header */
-    if ((P.meta[blockIdx.x].cg_len >> 1) > PAFFY_OPS_CAP && P.meta[blockIdx.x].err == 0) return;
-    size_lds_one<MASK>(P, blockIdx.x, ops_lds, L);
+    if ((P.meta[rec].cg_len >> 1) > PAFFY_OPS_CAP && P.meta[rec].err == 0) return;
+    size_lds_one<MASK>(P, rec, ops_lds, L);
 }
 template <uint32_t MASK>
 __global__ __launch_bounds__(PAFFY_NT, 2) void k_size_lds_long(KParams P) { /* two workgroups per CU at most (LDS): room for 256 registers, no spills */ /* levels 1 and 2: the queued long records */
@@ -2747,7 +2748,7 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_EMIT_OCC) void k_emit_lds(KParams P
 __global__ __launch_bounds__(64, PAFFY_ROWS_OCC) void k_emit_rows(KParams P) {
     extern __shared__ uint4 smem4[];
     uint8_t *smem = reinterpret_cast<uint8_t *>(smem4);
-    const uint32_t rec = blockIdx.x;
+    const uint32_t rec = P.emit_order ? P.emit_order[blockIdx.x] : blockIdx.x; /* long records first */
     if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return; /* nothing at or after the first failure */
     if ((P.status[rec] >> 16) != KLASS_LDS) return;
     const RecPlan &pl = static_cast<const RecPlan *>(P.rec_plan)[rec];
@@ -2800,7 +2801,7 @@ __global__ __launch_bounds__(64, PAFFY_ROWS_OCC) void k_emit_rows(KParams P) {
 __global__ __launch_bounds__(64, PAFFY_EMIT_OCC) void k_emit_line(KParams P) {
     extern __shared__ uint4 smem4[];
     uint8_t *smem = reinterpret_cast<uint8_t *>(smem4);
-    const uint32_t rec = blockIdx.x;
+    const uint32_t rec = P.emit_order ? P.emit_order[blockIdx.x] : blockIdx.x; /* long records first */
     if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return;
     if ((P.status[rec] >> 16) != KLASS_LDS) return;
     const RecPlan &pl = static_cast<const RecPlan *>(P.rec_plan)[rec];

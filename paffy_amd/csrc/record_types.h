@@ -86,6 +86,8 @@ struct KParams {
     uint32_t level;      /* 0: whole batch; 1, 2: walk b_list[level - 1] */
     DevInfo *info;
     paffy_filter filter; /* thresholds of PAFFY_FILTER stages */
+    const uint32_t *emit_order; /* records by descending output size (coarse): the one-wave-per-record writers start the long ones first */
+    const uint32_t *size_order; /* records by descending cigar length (coarse), for the sizing launch */
 };
 
 #endif
