@@ -42,9 +42,9 @@ def stages_for(pipe, mod):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=150, help="timed batches per GPU (150 x 65536 = the 10M-record stream of cfg3)")
+    ap.add_argument("--steps", type=int, default=75, help="timed batches per GPU (75 x 131072 = the 10M-record stream of cfg3)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=65536, help="records per step per GPU")
+    ap.add_argument("--batch", type=int, default=131072, help="records per step per GPU")
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a one-GPU rehearsal)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")

@@ -9,12 +9,12 @@ tag=${1:-round}
 export TMPDIR=/tmp
 out=gpurun_out/profile_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 bench.py --steps 30 --cpu-sample 0 > $out/bench_under_rocprof.json 2> $out/rocprof.log
-cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/${tag}_kernel_stats_cfg3_b65536.csv
+rocprofv3 --kernel-trace --stats -d $out/stats --output-format csv -- python3 bench.py --steps 20 --cpu-sample 0 > $out/bench_under_rocprof.json 2> $out/rocprof.log
+cp $(ls $out/stats/*/*kernel_stats.csv | head -1) $out/${tag}_kernel_stats_cfg3_b131072.csv
 echo "kernel stats done"
 python3 tools/traffic_collect.py $out/traffic.json > $out/traffic.log 2>&1
 echo "traffic done"
-python3 tools/pmc_collect.py $out/${tag}_pmc_record_kernels_cfg3_b65536.json > $out/pmc.log 2>&1
+python3 tools/pmc_collect.py $out/${tag}_pmc_record_kernels_cfg3_b131072.json > $out/pmc.log 2>&1
 echo "pmc done"
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 tail -1 $out/bench_default.json

@@ -20,7 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("out")
     ap.add_argument("--workload", default="cfg3")
-    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--batch", type=int, default=131072)
     ap.add_argument("--steps", type=int, default=6)
     args = ap.parse_args()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
