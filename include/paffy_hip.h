@@ -199,6 +199,18 @@ int paffy_hip_device_count(void);
 int paffy_hip_synth(paffy_hip_ctx *ctx, uint64_t seed, uint32_t mean_ops, uint64_t r0, uint64_t n, void *d_out,
                     int64_t out_cap, int64_t *bytes);
 
+/*
+ * cfg4 workload (records + two genomes for PAFFY_ADD_MISMATCHES), generated on the device: every
+ * contig pair (hs.chr<k>, pt.chr<k>) has one master alignment and a record is a window of it, so the aligned columns pair
+ * homologous bases (2 % substitutions; a quarter of the contigs hold the query reverse-complemented and give '-' records).
+ * setup builds the master tables for target contigs of tlen_min + hash % (tlen_span + 1) bases and, with with_genomes,
+ * writes both genomes into the context's sequence store (replacing paffy_hip_set_sequences' content). synth4 then writes
+ * records [r0, r0+n) like paffy_hip_synth. Same bytes as the host build in tools/paf_synth.c.
+ */
+int paffy_hip_synth4_setup(paffy_hip_ctx *ctx, uint64_t seed, uint32_t mean_ops, uint32_t n_contigs, int64_t tlen_min, int64_t tlen_span,
+                           int with_genomes);
+int paffy_hip_synth4(paffy_hip_ctx *ctx, uint64_t r0, uint64_t n, void *d_out, int64_t out_cap, int64_t *bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,7 +154,7 @@ __device__ int64_t parse_i64_dev(const uint8_t *in, uint32_t p, uint32_t e) {
  * recognised (documented deviation: the reference reads past the token there).
  */
 __global__ __launch_bounds__(PAFFY_NT) void k_header(const uint8_t *in, const uint32_t *sep_pos, const uint32_t *nl_idx, uint32_t n_lines,
-                                                      RecMeta *meta, uint32_t *big_list, DevInfo *info) {
+                                                      RecMeta *meta, uint32_t *big_list, DevInfo *info, uint32_t lvl0_max) {
     const uint32_t r = blockIdx.x * PAFFY_NT + threadIdx.x;
     if (r >= n_lines) return;
     const uint32_t s_end = nl_idx[r];
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_header(const uint8_t *in, const ui
     if (m.err == 0 && field < 12) m.err = PAFFY_ERR_FEW_FIELDS;
     meta[r] = m;
     /* long cigars go straight to the sizing launch with the bigger LDS store (runs beside the main one) */
-    if (m.err == 0 && (m.cg_len >> 1) > PAFFY_OPS_CAP) big_list[atomicAdd(&info->b_count[0], 1u)] = r;
+    if (m.err == 0 && (m.cg_len >> 1) > lvl0_max) big_list[atomicAdd(&info->b_count[0], 1u)] = r;
 }
 
 /* ------------------------------------------------------------------ */
@@ -519,6 +519,84 @@ __global__ __launch_bounds__(PAFFY_NT) void k_scan_i64(const int64_t *in, uint32
     if (threadIdx.x == 0) *total = carry;
 }
 
+/* ---- cfg4 workload: master alignments, genomes, records (paf_synth_core.h; host twin in tools/paf_synth.c) ---- */
+
+/* one wave per contig pair walks the master ops 64 at a time: op count, query length, checkpoints */
+__global__ __launch_bounds__(64) void k_synth4_master(psynth4_cfg cfg, psynth4_contig *contigs, int64_t *ckpt_q, int64_t *ckpt_t) {
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    psynth4_contig ct = contigs[c];
+    const uint64_t mkey = psynth4_mkey(cfg.seed, c);
+    int64_t q = 0, t = 0, best_q = 0;
+    uint64_t best_n = 0;
+    for (uint64_t base = 0; base < ct.ckpt_cap * PSYNTH4_G; base += 64) {
+        if (base % PSYNTH4_G == 0 && lane == 0) {
+            ckpt_q[ct.ckpt_base + base / PSYNTH4_G] = q;
+            ckpt_t[ct.ckpt_base + base / PSYNTH4_G] = t;
+        }
+        int op;
+        const int64_t len = psynth_op(mkey, base + lane, &op);
+        const int64_t qi = q + wave_incl_scan(op != 2 ? len : 0), ti = t + wave_incl_scan(op != 1 ? len : 0);
+        const uint64_t ok = __ballot(ti <= ct.tlen); /* a prefix of the lanes: the offsets only grow */
+        const uint64_t even_ok = ok & 0x5555555555555555ull;
+        if (even_ok) {
+            const int top = 63 - __clzll((long long)even_ok);
+            best_n = base + (uint64_t)top + 1;
+            best_q = __shfl(qi, top);
+        }
+        if (ok != ~0ull) break;
+        q = wave_last(qi);
+        t = wave_last(ti);
+    }
+    if (lane == 0) {
+        contigs[c].n_ops = best_n;
+        contigs[c].qlen = best_q;
+    }
+}
+
+/* target genome: one thread per 32 bases */
+__global__ __launch_bounds__(PAFFY_NT) void k_synth4_target(psynth4_cfg cfg, uint32_t c, int64_t tlen, uint8_t *out) {
+    const int64_t p0 = ((int64_t)blockIdx.x * PAFFY_NT + threadIdx.x) * 32;
+    for (int64_t p = p0; p < p0 + 32 && p < tlen; p++) {
+        int lower;
+        const uint32_t b = psynth4_tbase(cfg.seed, c, p, &lower);
+        out[p] = (uint8_t)psynth4_letter(b, lower, 0);
+    }
+}
+
+/* query genome: one wave per checkpoint block of master ops, one lane per op */
+__global__ __launch_bounds__(64) void k_synth4_query(psynth4_cfg cfg, uint32_t c, psynth4_tab tab, uint8_t *out) {
+    const psynth4_contig ct = tab.contigs[c];
+    const uint64_t mkey = psynth4_mkey(cfg.seed, c);
+    const int minus = psynth4_minus(c);
+    int64_t q = tab.ckpt_q[ct.ckpt_base + blockIdx.x], t = tab.ckpt_t[ct.ckpt_base + blockIdx.x];
+    for (uint64_t base = (uint64_t)blockIdx.x * PSYNTH4_G; base < ((uint64_t)blockIdx.x + 1) * PSYNTH4_G && base < ct.n_ops; base += 64) {
+        const uint64_t j = base + threadIdx.x;
+        int op;
+        int64_t len = psynth_op(mkey, j, &op);
+        const int64_t dq = op != 2 ? len : 0, dt = op != 1 ? len : 0;
+        const int64_t qi = wave_incl_scan(dq), ti = wave_incl_scan(dt);
+        if (j < ct.n_ops && op != 2) {
+            const int64_t q0 = q + qi - dq, t0 = t + ti - dt;
+            for (int64_t i = 0; i < len; i++) {
+                int lower;
+                const uint32_t b = psynth4_qbase(cfg.seed, c, q0 + i, op == 0 ? t0 + i : -1, &lower);
+                out[minus ? ct.qlen - 1 - (q0 + i) : q0 + i] = (uint8_t)psynth4_letter(b, lower, minus);
+            }
+        }
+        q += wave_last(qi);
+        t += wave_last(ti);
+    }
+}
+
+__global__ __launch_bounds__(PAFFY_NT) void k_synth4_size(psynth4_cfg cfg, psynth4_tab tab, uint64_t r0, uint32_t n, int64_t *sizes) {
+    uint32_t i = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (i < n) sizes[i] = psynth4_emit_record(&cfg, &tab, r0 + i, nullptr);
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_synth4_fill(psynth4_cfg cfg, psynth4_tab tab, uint64_t r0, uint32_t n, const int64_t *off, uint8_t *out) {
+    uint32_t i = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (i < n) psynth4_emit_record(&cfg, &tab, r0 + i, reinterpret_cast<char *>(out) + off[i]);
+}
+
 /* ------------------------------------------------------------------ */
 /* host side                                                            */
 /* ------------------------------------------------------------------ */
@@ -541,6 +619,8 @@ struct paffy_hip_ctx {
     std::string last_error;
     DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, b_list, b_list1, arena, info, synth_sizes, rec_plan, ops_mirror, seq_blob, seq_table, seq_names, seq_name_off, rec_qseq, rec_tseq;
     int32_t n_seqs = 0;
+    DevBuf synth4_contigs, synth4_q, synth4_t; /* cfg4 workload tables (paffy_hip_synth4_setup) */
+    psynth4_cfg synth4_cfg = {0, 0, 0, 0, 0};
     paffy_filter filter = {-1, -1, -1.0, -1.0, -1, 0};
     DevBuf dedupe_keys;
     std::unordered_set<std::string> dedupe_seen; /* 16-byte keys of the records written so far */
@@ -655,7 +735,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     if (!c) return;
     prof_collect(c);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
-                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off,
+                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
                       &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts, &c->scan_part, &c->dedupe_keys, &c->emit_order, &c->order_cnt};
     for (DevBuf *b : bufs)
@@ -682,7 +762,7 @@ static int fetch_info(paffy_hip_ctx *c) {
 }
 
 /* Separator index + header parse shared by plan and tile_plan. */
-static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, uint32_t *n_lines_out) {
+static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, uint32_t *n_lines_out, uint32_t lvl0_max = PAFFY_OPS_CAP) {
     const uint32_t n_tiles = (len + SEP_TILE - 1) / SEP_TILE;
 
     DevInfo zero;
@@ -720,7 +800,7 @@ static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, ui
     if (n_lines > 0)
         LAUNCH(c, "k_header", k_header, dim3((n_lines + PAFFY_NT - 1) / PAFFY_NT), dim3(PAFFY_NT), 0, in,
                static_cast<const uint32_t *>(c->sep_pos.p), static_cast<const uint32_t *>(c->nl_idx.p), n_lines,
-               static_cast<RecMeta *>(c->meta.p), static_cast<uint32_t *>(c->b_list.p), static_cast<DevInfo *>(c->info.p));
+               static_cast<RecMeta *>(c->meta.p), static_cast<uint32_t *>(c->b_list.p), static_cast<DevInfo *>(c->info.p), lvl0_max);
 
     return 0;
 }
@@ -759,10 +839,14 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     const uint8_t *in = static_cast<const uint8_t *>(d_in);
     const uint32_t len = (uint32_t)in_len;
     uint32_t n_lines = 0;
+    /* add_mismatches makes more ops of a cigar (about 1.8 x at 2 % substitutions, 1.45 per two cigar bytes): its records start one
+       store level up at 5/8 of the usual length, so that the rebuilt array usually fits the level the record was parsed at */
+    const uint32_t lvl0_max = need_seqs ? PAFFY_OPS_CAP * 5 / 8 : PAFFY_OPS_CAP;
     {
-        int rc = index_and_parse(c, in, len, &n_lines);
+        int rc = index_and_parse(c, in, len, &n_lines, lvl0_max);
         if (rc) return rc;
     }
+    kp.lvl0_max = lvl0_max;
 
     kp.in = in;
     kp.in_len = len;
@@ -1314,10 +1398,10 @@ int paffy_hip_run_host(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_st
     return rc;
 }
 
-int paffy_hip_set_sequences(paffy_hip_ctx *c, int64_t n, const char *const *names, const char *const *seqs, const int64_t *lens) {
-    if (!c || n < 0 || (n > 0 && (!names || !seqs || !lens))) return PAFFY_E_ARG;
+/* Lays the sequence store out for n named sequences (sorted by name for the lookup kernel) and uploads the name tables;
+ * blob_off[i] = where sequence i starts in seq_blob. The bases are written by the caller. */
+static int seq_store_layout(paffy_hip_ctx *c, int64_t n, const char *const *names, const int64_t *lens, std::vector<uint64_t> &blob_off) {
     c->n_seqs = 0;
-    if (n == 0) return 0;
     std::vector<int64_t> order((size_t)n);
     for (int64_t i = 0; i < n; i++) order[(size_t)i] = i;
     std::vector<size_t> nlen((size_t)n);
@@ -1331,6 +1415,7 @@ int paffy_hip_set_sequences(paffy_hip_ctx *c, int64_t n, const char *const *name
     std::vector<uint32_t> name_off((size_t)n + 1);
     std::string blob;
     std::vector<SeqEntry> table((size_t)n);
+    blob_off.assign((size_t)n, 0);
     uint64_t total = 0;
     for (int64_t k = 0; k < n; k++) {
         int64_t i = order[(size_t)k];
@@ -1338,6 +1423,7 @@ int paffy_hip_set_sequences(paffy_hip_ctx *c, int64_t n, const char *const *name
         blob.append(names[i], nlen[(size_t)i]);
         table[(size_t)k].off = total;
         table[(size_t)k].len = lens[i];
+        blob_off[(size_t)i] = total;
         total += (uint64_t)lens[i];
     }
     name_off[(size_t)n] = (uint32_t)blob.size();
@@ -1345,14 +1431,22 @@ int paffy_hip_set_sequences(paffy_hip_ctx *c, int64_t n, const char *const *name
     if (ensure(c, c->seq_table, sizeof(SeqEntry) * (size_t)n)) return PAFFY_E_HIP;
     if (ensure(c, c->seq_names, blob.size() + 16)) return PAFFY_E_HIP;
     if (ensure(c, c->seq_name_off, sizeof(uint32_t) * ((size_t)n + 1))) return PAFFY_E_HIP;
-    for (int64_t k = 0; k < n; k++) {
-        int64_t i = order[(size_t)k];
-        if (lens[i] > 0)
-            HIPCHK(c, hipMemcpy(static_cast<uint8_t *>(c->seq_blob.p) + table[(size_t)k].off, seqs[i], (size_t)lens[i], hipMemcpyHostToDevice));
-    }
     HIPCHK(c, hipMemcpy(c->seq_table.p, table.data(), sizeof(SeqEntry) * (size_t)n, hipMemcpyHostToDevice));
     if (!blob.empty()) HIPCHK(c, hipMemcpy(c->seq_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->seq_name_off.p, name_off.data(), sizeof(uint32_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int paffy_hip_set_sequences(paffy_hip_ctx *c, int64_t n, const char *const *names, const char *const *seqs, const int64_t *lens) {
+    if (!c || n < 0 || (n > 0 && (!names || !seqs || !lens))) return PAFFY_E_ARG;
+    c->n_seqs = 0;
+    if (n == 0) return 0;
+    std::vector<uint64_t> blob_off;
+    int rc = seq_store_layout(c, n, names, lens, blob_off);
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; i++)
+        if (lens[i] > 0)
+            HIPCHK(c, hipMemcpy(static_cast<uint8_t *>(c->seq_blob.p) + blob_off[(size_t)i], seqs[i], (size_t)lens[i], hipMemcpyHostToDevice));
     c->n_seqs = (int32_t)n;
     return 0;
 }
@@ -1463,6 +1557,91 @@ int paffy_hip_synth(paffy_hip_ctx *c, uint64_t seed, uint32_t mean_ops, uint64_t
     if (!d_out) return 0;
     if (out_cap < h_total) return PAFFY_E_CAPACITY;
     LAUNCH(c, "k_synth_fill", k_synth_fill, dim3(grid), dim3(PAFFY_NT), 0, cfg, r0, nn, offs, static_cast<uint8_t *>(d_out));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static psynth4_tab synth4_tab(paffy_hip_ctx *c) {
+    psynth4_tab t;
+    t.contigs = static_cast<const psynth4_contig *>(c->synth4_contigs.p);
+    t.ckpt_q = static_cast<const int64_t *>(c->synth4_q.p);
+    t.ckpt_t = static_cast<const int64_t *>(c->synth4_t.p);
+    return t;
+}
+
+int paffy_hip_synth4_setup(paffy_hip_ctx *c, uint64_t seed, uint32_t mean_ops, uint32_t n_contigs, int64_t tlen_min, int64_t tlen_span,
+                           int with_genomes) {
+    if (!c || n_contigs < 1 || n_contigs > 4096 || tlen_min < 2048 || tlen_span < 0) return PAFFY_E_ARG;
+    psynth4_cfg cfg;
+    cfg.seed = seed;
+    cfg.mean_ops = mean_ops;
+    cfg.n_contigs = n_contigs;
+    cfg.tlen_min = tlen_min;
+    cfg.tlen_span = tlen_span;
+    c->synth4_cfg.n_contigs = 0;
+    std::vector<psynth4_contig> ct(n_contigs);
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < n_contigs; k++) {
+        memset(&ct[k], 0, sizeof(psynth4_contig));
+        ct[k].tlen = psynth4_tlen(&cfg, k);
+        ct[k].ckpt_cap = psynth4_ckpt_cap(ct[k].tlen);
+        ct[k].ckpt_base = total;
+        total += ct[k].ckpt_cap;
+    }
+    if (ensure(c, c->synth4_contigs, sizeof(psynth4_contig) * n_contigs)) return PAFFY_E_HIP;
+    if (ensure(c, c->synth4_q, sizeof(int64_t) * total)) return PAFFY_E_HIP;
+    if (ensure(c, c->synth4_t, sizeof(int64_t) * total)) return PAFFY_E_HIP;
+    HIPCHK(c, hipMemcpyAsync(c->synth4_contigs.p, ct.data(), sizeof(psynth4_contig) * n_contigs, hipMemcpyHostToDevice, c->stream));
+    LAUNCH(c, "k_synth4_master", k_synth4_master, dim3(n_contigs), dim3(64), 0, cfg, static_cast<psynth4_contig *>(c->synth4_contigs.p),
+           static_cast<int64_t *>(c->synth4_q.p), static_cast<int64_t *>(c->synth4_t.p));
+    HIPCHK(c, hipMemcpyAsync(ct.data(), c->synth4_contigs.p, sizeof(psynth4_contig) * n_contigs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->synth4_cfg = cfg;
+    if (!with_genomes) return 0;
+    std::vector<std::string> names;
+    std::vector<int64_t> lens;
+    for (int g = 0; g < 2; g++)
+        for (uint32_t k = 0; k < n_contigs; k++) {
+            names.push_back(std::string(g ? "pt.chr" : "hs.chr") + std::to_string(k + 1));
+            lens.push_back(g ? ct[k].tlen : ct[k].qlen);
+        }
+    std::vector<const char *> name_ptr;
+    for (const std::string &s : names) name_ptr.push_back(s.c_str());
+    std::vector<uint64_t> blob_off;
+    int rc = seq_store_layout(c, (int64_t)names.size(), name_ptr.data(), lens.data(), blob_off);
+    if (rc) return rc;
+    uint8_t *blob = static_cast<uint8_t *>(c->seq_blob.p);
+    const psynth4_tab tab = synth4_tab(c);
+    for (uint32_t k = 0; k < n_contigs; k++) {
+        const uint32_t q_blocks = (uint32_t)((ct[k].n_ops + PSYNTH4_G - 1) / PSYNTH4_G);
+        LAUNCH(c, "k_synth4_query", k_synth4_query, dim3(q_blocks), dim3(64), 0, cfg, k, tab, blob + blob_off[k]);
+        const uint32_t t_blocks = (uint32_t)((ct[k].tlen + 32ll * PAFFY_NT - 1) / (32ll * PAFFY_NT));
+        LAUNCH(c, "k_synth4_target", k_synth4_target, dim3(t_blocks), dim3(PAFFY_NT), 0, cfg, k, ct[k].tlen, blob + blob_off[n_contigs + k]);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->n_seqs = (int32_t)names.size();
+    return 0;
+}
+
+int paffy_hip_synth4(paffy_hip_ctx *c, uint64_t r0, uint64_t n, void *d_out, int64_t out_cap, int64_t *bytes) {
+    if (!c || !bytes || n >= (1ull << 31)) return PAFFY_E_ARG;
+    if (c->synth4_cfg.n_contigs == 0) return PAFFY_E_STATE;
+    *bytes = 0;
+    if (n == 0) return 0;
+    const psynth4_cfg cfg = c->synth4_cfg;
+    const psynth4_tab tab = synth4_tab(c);
+    if (ensure(c, c->synth_sizes, sizeof(int64_t) * (size_t)(2 * n + 2))) return PAFFY_E_HIP;
+    int64_t *sizes = static_cast<int64_t *>(c->synth_sizes.p), *offs = sizes + n, *total = offs + n;
+    const uint32_t nn = (uint32_t)n, grid = (nn + PAFFY_NT - 1) / PAFFY_NT;
+    LAUNCH(c, "k_synth4_size", k_synth4_size, dim3(grid), dim3(PAFFY_NT), 0, cfg, tab, r0, nn, sizes);
+    LAUNCH(c, "k_scan_i64", k_scan_i64, dim3(1), dim3(PAFFY_NT), 0, sizes, nn, offs, total);
+    int64_t h_total = 0;
+    HIPCHK(c, hipMemcpyAsync(&h_total, total, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *bytes = h_total;
+    if (!d_out) return 0;
+    if (out_cap < h_total) return PAFFY_E_CAPACITY;
+    LAUNCH(c, "k_synth4_fill", k_synth4_fill, dim3(grid), dim3(PAFFY_NT), 0, cfg, tab, r0, nn, offs, static_cast<uint8_t *>(d_out));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }

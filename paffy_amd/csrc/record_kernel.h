@@ -146,7 +146,8 @@ struct RecPlan {
     int64_t qs, qe, ts, te, sub_lo, sub_hi;
     uint32_t lo, n;
     uint32_t flags; /* bit0 rev, bit1 swp, bit2 query/target swapped, bit3 has_cigar, bit4 shatter, bit5 direct, bit6 k_emit_rows,
-                       bit7 dropped by a filter, bits 8-15 type, bit16 k_emit_line */
+                       bit7 dropped by a filter, bits 8-15 type, bit16 k_emit_line,
+                       bit17 the 4-byte ops live in the arena block arena_off[rec] (rebuilt by add_mismatches), not in the mirror */
     uint32_t chunk; /* ops per lane in the sizing sweep: wave w owns view ops [64*w*chunk, 64*(w+1)*chunk) */
     /* shatter: query / target bases consumed and output bytes produced before each wave's range */
     int64_t wq[PAFFY_NWAVE], wt[PAFFY_NWAVE], wo[PAFFY_NWAVE];
@@ -1010,6 +1011,269 @@ __device__ __forceinline__ int encode_mismatch_runs(const KParams &P, const RecS
         }
     }
     __syncthreads();
+    return 0;
+}
+
+/*
+ * The same encoding for LDS-class records, wave-parallel over 16-column chunks.
+ *
+ * A wave owns the view ops [64 * w * chunk, 64 * (w + 1) * chunk) and walks them in windows of 64 (one lane per op: offsets
+ * on both sequences by a wave scan, range check). The window's work is a list of ITEMS in op order -- every M op contributes
+ * ceil(len / 16) chunks of 16 alignment columns, every other op one item -- and the lanes take 64 consecutive items at a
+ * time (item -> op by a binary search over the lanes' item offsets), so that long and short ops fill the wave alike.
+ * A chunk's match mask comes from two 16-byte loads compared as packed bytes (toupper and complement as SWAR on 32-bit
+ * words). A column starts a run when its match bit differs from the column before (the chunk before is the lane before;
+ * the first column of an op always starts one), so the number of runs is a sum over items and the run that ENDS in front of
+ * a start needs only the position of the previous start: the nearest lane before with any start (a max scan), carried
+ * over iterations. Walk 1 counts, walk 2 writes 4-byte ops at their final index.
+ */
+__device__ __forceinline__ uint32_t upper4(uint32_t w) { /* toupper of four bytes (C locale: a-z only) */
+    const uint32_t hm = w & 0x7f7f7f7fu;
+    const uint32_t m = (hm + 0x1f1f1f1fu) & ~(hm + 0x05050505u) & ~w & 0x80808080u; /* 0x61 <= byte <= 0x7a */
+    return w ^ (m >> 2);
+}
+__device__ __forceinline__ uint32_t nonzero4(uint32_t x) { return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u; }
+__device__ __forceinline__ uint32_t comp4(uint32_t x) { /* complement of four upper-case bytes: A<->T, C<->G, others kept */
+    const uint32_t at = ~(nonzero4(x ^ 0x41414141u) & nonzero4(x ^ 0x54545454u)) & 0x80808080u;
+    const uint32_t cg = ~(nonzero4(x ^ 0x43434343u) & nonzero4(x ^ 0x47474747u)) & 0x80808080u;
+    const uint32_t a = at >> 7;
+    return x ^ (a | (a << 2) | (a << 4)) ^ (cg >> 5);
+}
+__device__ __forceinline__ uint32_t equal4(uint32_t a, uint32_t b) { /* bit j = byte j equal */
+    const uint32_t r = (~nonzero4(a ^ b) & 0x80808080u) >> 7;
+    return (r | (r >> 7) | (r >> 14) | (r >> 21)) & 0xfu;
+}
+/* bit j = toupper(T[tj + j]) == toupper(query base of column j), j < 16; q points at Q[qoff] (+ strand: columns go up; - strand:
+ * column j is the complement of Q[qoff - j]). `lowest`: first byte of the sequence store (nothing in front of it is read). */
+__device__ __forceinline__ uint32_t match_mask16(const uint8_t *lowest, const uint8_t *q, const uint8_t *t, bool same) {
+    const uint64_t t0 = *reinterpret_cast<const u64_unaligned *>(t), t1 = *reinterpret_cast<const u64_unaligned *>(t + 8);
+    const uint32_t tw[4] = {upper4((uint32_t)t0), upper4((uint32_t)(t0 >> 32)), upper4((uint32_t)t1), upper4((uint32_t)(t1 >> 32))};
+    uint32_t qw[4];
+    if (same) {
+        const uint64_t q0 = *reinterpret_cast<const u64_unaligned *>(q), q1 = *reinterpret_cast<const u64_unaligned *>(q + 8);
+        qw[0] = upper4((uint32_t)q0); qw[1] = upper4((uint32_t)(q0 >> 32)); qw[2] = upper4((uint32_t)q1); qw[3] = upper4((uint32_t)(q1 >> 32));
+    } else if (q - 15 >= lowest) {
+        const uint64_t q0 = *reinterpret_cast<const u64_unaligned *>(q - 15), q1 = *reinterpret_cast<const u64_unaligned *>(q - 7);
+        /* byte 15 - j of the 16 loaded is Q[qoff - j] */
+        qw[0] = comp4(upper4(__builtin_bswap32((uint32_t)(q1 >> 32)))); qw[1] = comp4(upper4(__builtin_bswap32((uint32_t)q1)));
+        qw[2] = comp4(upper4(__builtin_bswap32((uint32_t)(q0 >> 32)))); qw[3] = comp4(upper4(__builtin_bswap32((uint32_t)q0)));
+    } else { /* the chunk would reach in front of the store: single bytes (the caller masks the columns beyond the op) */
+        qw[0] = qw[1] = qw[2] = qw[3] = 0;
+        for (int j = 0; j < 16; j++)
+            if (q - j >= lowest) qw[j >> 2] |= up_base(rc_base(*(q - j))) << (8 * (j & 3));
+    }
+    return equal4(tw[0], qw[0]) | (equal4(tw[1], qw[1]) << 4) | (equal4(tw[2], qw[2]) << 8) | (equal4(tw[3], qw[3]) << 12);
+}
+__device__ __forceinline__ int64_t shfl_i64(int64_t x, int src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)x, src), hi = (uint32_t)__shfl((int)(uint32_t)((uint64_t)x >> 32), src);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int64_t wave_first_i64(int64_t x) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)x >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+/* inclusive max over the lanes before and including this one (DPP; lanes without a source keep their own value) */
+__device__ __forceinline__ int32_t wave_incl_max_i32(int32_t v) {
+    int32_t x = v;
+#define PAFFY_MAX32_STEP(CTRL, RM, BM, SRC)                                                              \
+    {                                                                                                    \
+        int32_t t = __builtin_amdgcn_update_dpp((int)x, (int)(SRC), CTRL, RM, BM, false);                 \
+        x = t > x ? t : x;                                                                               \
+    }
+    PAFFY_MAX32_STEP(DPP_ROW_SHR(1), 0xf, 0xf, v)
+    PAFFY_MAX32_STEP(DPP_ROW_SHR(2), 0xf, 0xf, v)
+    PAFFY_MAX32_STEP(DPP_ROW_SHR(3), 0xf, 0xf, v)
+    PAFFY_MAX32_STEP(DPP_ROW_SHR(4), 0xf, 0xe, x)
+    PAFFY_MAX32_STEP(DPP_ROW_SHR(8), 0xf, 0xc, x)
+    PAFFY_MAX32_STEP(DPP_BCAST15, 0xa, 0xf, x)
+    PAFFY_MAX32_STEP(DPP_BCAST31, 0xc, 0xf, x)
+#undef PAFFY_MAX32_STEP
+    return x;
+}
+
+/* One walk over this wave's ops. FILL = false: computes every chunk's match mask (kept in masks[], one 16-bit word per item,
+ * for the second walk) and returns the number of ops the wave's range becomes (*bad = first op whose bases lie outside a
+ * sequence, INT64_MAX none). FILL = true: writes the ops at blk[out_base ..) from the masks. q0 / t0: bases consumed on the
+ * query / target before the wave's first op (below 2^30 for the whole record); masks: the wave's first item. */
+template <bool FILL, class OPS>
+__device__ __forceinline__ uint32_t mismatch_runs_wave(const KParams &P, const RecState &s, const View<OPS> &v, const uint8_t *Q, int64_t qseq_len,
+                                                       const uint8_t *T, int64_t tseq_len, uint32_t wb, uint32_t we, int64_t q0, int64_t t0,
+                                                       uint32_t out_base, uint32_t *blk, uint16_t *masks, int64_t *bad) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t qpos = (uint32_t)q0, tpos = (uint32_t)t0; /* wave-uniform */
+    uint32_t done = out_base; /* ops written so far; wave-uniform */
+    uint32_t lane_cnt = 0;
+    int64_t first_bad = INT64_MAX;
+    for (uint32_t base = wb; base < we; base += 64) {
+        const uint32_t i = base + lane;
+        int64_t len = 0;
+        int op = OP_I;
+        if (i < we) v.get(i, len, op);
+        const uint32_t dq = (i < we && op != OP_D) ? (uint32_t)len : 0u, dt = (i < we && op != OP_I) ? (uint32_t)len : 0u;
+        const uint32_t qinc = wave_incl_scan_u32(dq), tinc = wave_incl_scan_u32(dt);
+        const uint32_t qrel = qinc - dq, trel = tinc - dt; /* columns in front of this op, from the window's first */
+        /* the window's first column on both sequences (wave-uniform); the - strand walks the query downwards from qe - 1 */
+        const int64_t tj0 = s.ts + (int64_t)tpos, qoff0 = s.same ? s.qs + (int64_t)qpos : s.qe - 1 - (int64_t)qpos;
+        bool is_m = false;
+        if (!FILL) {
+            is_m = i < we && op == OP_M && len > 0;
+            if (is_m) {
+                const int64_t tj = tj0 + trel, qoff = s.same ? qoff0 + qrel : qoff0 - qrel;
+                const bool in_range = tj >= 0 && tj + len <= tseq_len && (s.same ? (qoff >= 0 && qoff + len <= qseq_len) : (qoff < qseq_len && qoff - (len - 1) >= 0));
+                if (!in_range) {
+                    if (first_bad == INT64_MAX) first_bad = i;
+                    is_m = false;
+                }
+            }
+        } else {
+            is_m = i < we && op == OP_M && len > 0; /* the count walk found every op in range */
+        }
+        qpos += wave_last_u32(qinc);
+        tpos += wave_last_u32(tinc);
+        /* items of this op: chunks of an M op; one for any other op; none for an M op of length 0 (impl/paf.c:747-779 writes nothing) */
+        const uint32_t nch = (i < we && op == OP_M) ? (is_m || FILL ? (uint32_t)((len + 15) >> 4) : 0u) : (i < we ? 1u : 0u);
+        const uint32_t iinc = wave_incl_scan_u32(nch);
+        const uint32_t ioff = iinc - nch, n_items = wave_last_u32(iinc);
+        const uint32_t opw = ((uint32_t)len << 3) | (uint32_t)op;
+        const uint8_t *Tw = T + tj0, *Qw = Q + qoff0;
+        uint32_t carry_m = 0;      /* mask of the last item of the iteration before */
+        int32_t carry_start = 0;   /* column of the last run start seen in the op under way */
+        for (uint32_t c0 = 0; c0 < n_items; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            const bool act = c < n_items;
+            uint32_t ol = 0; /* the op of item c: the last lane whose first item is <= c */
+#pragma unroll
+            for (uint32_t step = 32; step; step >>= 1) {
+                const uint32_t cand = ol + step;
+                const uint32_t vv = __shfl(ioff, (int)(cand & 63u));
+                if (cand < 64 && vv <= c) ol = cand;
+            }
+            const uint32_t ow = __shfl(opw, (int)ol);
+            const uint32_t o_first = __shfl(ioff, (int)ol);
+            const uint32_t olen = ow >> 3;
+            const int oop = (int)(ow & 7u);
+            const bool item_m = act && oop == OP_M;
+            const uint32_t k = (c - o_first) << 4;
+            const uint32_t nb = item_m ? (olen - k < 16u ? olen - k : 16u) : 0u;
+            uint32_t m = 0;
+            if (!FILL) {
+                const uint32_t oq = __shfl(qrel, (int)ol), ot = __shfl(trel, (int)ol); /* by every lane: the source lanes must be live */
+                if (item_m) {
+                    m = match_mask16(P.seq_base, s.same ? Qw + (oq + k) : Qw - (oq + k), Tw + (ot + k), s.same) & ((1u << nb) - 1u);
+                    masks[c] = (uint16_t)m;
+                }
+            } else if (item_m) {
+                m = __hip_atomic_load(masks + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* past the L1: a line may predate the stores */
+            }
+            uint32_t pm = __shfl_up(m, 1);
+            if (lane == 0) pm = carry_m;
+            const uint32_t prevbit = (pm >> 15) & 1u; /* the chunk before is full when this one is not the first of its op */
+            uint32_t starts = 0;
+            if (item_m) {
+                starts = (m ^ ((m << 1) | prevbit)) & ((1u << nb) - 1u);
+                if (k == 0) starts |= 1u;
+            }
+            const uint32_t cnt = item_m ? (uint32_t)__popc(starts) : (act ? 1u : 0u);
+            if (!FILL) {
+                lane_cnt += cnt;
+            } else {
+                const uint32_t cinc = wave_incl_scan_u32(cnt);
+                uint32_t idx = done + cinc - cnt; /* ops in front of this item's first start */
+                done += wave_last_u32(cinc);
+                /* column of the previous start: the nearest lane before with a start, or the carry */
+                const int32_t my_last = starts ? (int32_t)(k + 31u - (uint32_t)__clz((int)starts)) : 0;
+                const int32_t src_incl = wave_incl_max_i32(starts ? (int32_t)lane : -1);
+                int32_t src = __shfl_up(src_incl, 1);
+                if (lane == 0) src = -1;
+                const int32_t from = __shfl(my_last, src < 0 ? 0 : src);
+                int32_t prev = src < 0 ? carry_start : from;
+                if (item_m) {
+                    uint32_t st = starts;
+                    while (st) {
+                        const uint32_t j = (uint32_t)__ffs((int)st) - 1u;
+                        st &= st - 1u;
+                        const int32_t pos = (int32_t)(k + j);
+                        if (pos != 0) {
+                            const uint32_t before = j ? (m >> (j - 1u)) & 1u : prevbit;
+                            blk[idx - 1u] = ((uint32_t)(pos - prev) << 3) | (before ? (uint32_t)OP_EQ : (uint32_t)OP_X);
+                        }
+                        prev = pos;
+                        idx++;
+                    }
+                    if (k + 16u >= olen) blk[idx - 1u] = ((olen - (uint32_t)prev) << 3) | (((m >> (nb - 1u)) & 1u) ? (uint32_t)OP_EQ : (uint32_t)OP_X);
+                } else if (act) {
+                    blk[idx] = ow;
+                }
+                const int32_t top = __builtin_amdgcn_readlane(src_incl, 63);
+                if (top >= 0) carry_start = __shfl(my_last, top);
+            }
+            carry_m = __builtin_amdgcn_readlane((int)m, 63);
+        }
+        masks += n_items;
+    }
+    if (!FILL) {
+        *bad = first_bad;
+        return wave_last_u32(wave_incl_scan_u32(lane_cnt));
+    }
+    return done;
+}
+
+/*
+ * LDS class: returns 0 / PAFFY_ERR_SEQ_RANGE / -1 (does not fit the narrow path: arena class) / -2 (arena full, repeated by
+ * the host) / -3 (more than `cap` ops: *n_out says how many). On 0 the new ops are in LDS and in the arena block *blk_off
+ * (4-byte ops), which replaces the record's mirror.
+ */
+__device__ __forceinline__ int encode_mismatch_runs_lds(const KParams &P, const RecState &s, View<OpsLds> &v, OpsLds &ops, uint32_t cap, const uint8_t *Q,
+                                                        int64_t qseq_len, const uint8_t *T, int64_t tseq_len, BlockComm &bc, Shared *sh, uint32_t *n_out,
+                                                        uint64_t *blk_off) {
+    uint32_t b, e;
+    sweep_bounds(v.n, b, e);
+    int64_t c[3] = {0, 0, 0}, tot[3]; /* query bases, target bases, items (16-column chunks of M ops + the other ops) */
+    for (uint32_t i = b; i < e; i++) {
+        int64_t len;
+        int op;
+        v.get(i, len, op);
+        if (op != OP_D) c[0] += len;
+        if (op != OP_I) c[1] += len;
+        c[2] += op == OP_M ? (len + 15) >> 4 : 1;
+    }
+    block_excl_scan<3>(c, tot, bc);
+    if (tot[0] >= (1ll << 30) || tot[1] >= (1ll << 30)) return -1; /* 32-bit columns and op counts below */
+    /* scratch for the match masks: 2 bytes per item, in the arena */
+    const uint64_t mslots = ((uint64_t)tot[2] + 3) >> 2;
+    if (threadIdx.x == 0) sh->bcast[3] = (int64_t)atomicAdd(&P.info->arena_used, (unsigned long long)mslots);
+    __syncthreads();
+    const uint64_t moff = (uint64_t)sh->bcast[3];
+    __syncthreads();
+    if (moff + mslots > P.arena_cap) return -2;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t span = 64ull * (((v.n + PAFFY_NT - 1) / PAFFY_NT) | 1u); /* = sweep_bounds(): the wave's ops are its lanes' chunks */
+    const uint32_t wb = span * wave < v.n ? (uint32_t)(span * wave) : v.n, we = span * (wave + 1) < v.n ? (uint32_t)(span * (wave + 1)) : v.n;
+    const int64_t q0 = wave_first_i64(c[0]), t0 = wave_first_i64(c[1]);
+    uint16_t *masks = reinterpret_cast<uint16_t *>(P.arena + moff) + wave_first_i64(c[2]);
+    int64_t bad = INT64_MAX;
+    const uint32_t wcnt = mismatch_runs_wave<false>(P, s, v, Q, qseq_len, T, tseq_len, wb, we, q0, t0, 0u, nullptr, masks, &bad);
+    bad = block_min_i64(wave_min(bad), bc);
+    uint32_t cw[1] = {lane == 0 ? wcnt : 0u}, ctot[1];
+    block_excl_scan_u32<1>(cw, ctot, bc);
+    const uint32_t out_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[0]);
+    *n_out = ctot[0];
+    if (bad != INT64_MAX) return PAFFY_ERR_SEQ_RANGE;
+    if (ctot[0] > cap) return -3;
+    const uint64_t slots = ((uint64_t)ctot[0] + 1) >> 1; /* 8-byte arena slots holding 4-byte ops */
+    if (threadIdx.x == 0) sh->bcast[3] = (int64_t)atomicAdd(&P.info->arena_used, (unsigned long long)slots);
+    __syncthreads();
+    const uint64_t off = (uint64_t)sh->bcast[3];
+    __syncthreads();
+    if (off + slots > P.arena_cap) return -2;
+    uint32_t *blk = reinterpret_cast<uint32_t *>(P.arena + off);
+    mismatch_runs_wave<true>(P, s, v, Q, qseq_len, T, tseq_len, wb, we, q0, t0, out_base, blk, masks, &bad);
+    __syncthreads(); /* every op of the old array has been read, every op of the new one written */
+    for (uint32_t i = threadIdx.x; i < ctot[0]; i += PAFFY_NT) ops.p[i] = __hip_atomic_load(blk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    ops.g = blk;
+    ops.g_cap = ctot[0];
+    *blk_off = off;
     return 0;
 }
 
@@ -2370,7 +2634,7 @@ __device__ __forceinline__ void load_state(const RecMeta &m, RecState &s) {
 #define STAGE_ON(kind) ((MASK >> (kind)) & 1u)
 template <class OPS, uint32_t MASK = PAFFY_MASK_ALL>
 __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t cap, const RecLds &L, uint32_t klass,
-                            uint32_t *n_ops_out) {
+                            uint32_t *n_ops_out, uint32_t *need_out = nullptr) {
     const RecMeta m = P.meta[rec];
     if (m.err) {
         report(P, rec, m.err, -1, m.err_aux, klass);
@@ -2411,6 +2675,8 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
         v.totals_ok = true;
     }
     bool swapped = false, shatter = false;
+    bool ops_in_arena = false; /* LDS class whose op array was rebuilt: 4-byte ops in an arena block instead of the mirror */
+    uint64_t arena_block = 0;
     bool checked = false; /* a paf_check has passed since the record last changed */
     int32_t si = 0;
     for (; si < P.n_stages; si++) {
@@ -2458,8 +2724,29 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
             }
             rc = check_record(s, v, L.bc);
         } else if (STAGE_ON(PAFFY_ADD_MISMATCHES) && st.kind == PAFFY_ADD_MISMATCHES) {
-            if constexpr (OPS::kNarrow) {
-                return false; /* the new op array lives in the arena: arena class */
+            if constexpr (std::is_same<OPS, OpsLds>::value) {
+                const int32_t qi = swapped ? P.rec_tseq[rec] : P.rec_qseq[rec], ti = swapped ? P.rec_qseq[rec] : P.rec_tseq[rec];
+                if (qi < 0) rc = PAFFY_ERR_MISSING_QUERY_SEQ;   /* impl/paf_add_mismatches.c:117-120 */
+                else if (ti < 0) rc = PAFFY_ERR_MISSING_TARGET_SEQ; /* :123-127 */
+                else if (s.has_cigar) {
+                    uint32_t n2 = 0;
+                    const int r = encode_mismatch_runs_lds(P, s, v, ops, cap, P.seq_base + P.seqs[qi].off, P.seqs[qi].len, P.seq_base + P.seqs[ti].off,
+                                                           P.seqs[ti].len, L.bc, L.sh, &n2, &arena_block);
+                    if (r == -1) return false; /* wider than the narrow path: arena class */
+                    if (r == -2) return true;  /* arena full: repeated by the host */
+                    if (r == -3) {             /* more ops than this store holds */
+                        if (need_out) *need_out = n2;
+                        return false;
+                    }
+                    if (r > 0) rc = r;
+                    else {
+                        v.reset(ops, n2);
+                        ops_in_arena = true;
+                    }
+                }
+                if (!rc) rc = check_record(s, v, L.bc);
+            } else if constexpr (OPS::kNarrow) {
+                return false;
             } else {
                 const int32_t qi = swapped ? P.rec_tseq[rec] : P.rec_qseq[rec], ti = swapped ? P.rec_qseq[rec] : P.rec_tseq[rec];
                 if (qi < 0) rc = PAFFY_ERR_MISSING_QUERY_SEQ;   /* impl/paf_add_mismatches.c:117-120 */
@@ -2543,7 +2830,9 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
         plan->qs = s.qs; plan->qe = s.qe; plan->ts = s.ts; plan->te = s.te; plan->sub_lo = v.sub_lo; plan->sub_hi = v.sub_hi;
         plan->lo = v.lo; plan->n = v.n;
         plan->flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | (s.has_cigar ? 8u : 0u) | ((uint32_t)s.type << 8) |
-                      (shatter ? 16u : 0u) | (direct ? 32u : 0u) | (rows_kernel ? 64u : 0u) | (line_kernel ? 0x10000u : 0u);
+                      (shatter ? 16u : 0u) | (direct ? 32u : 0u) | (rows_kernel ? 64u : 0u) | (line_kernel ? 0x10000u : 0u) |
+                      (ops_in_arena ? 0x20000u : 0u);
+        if (ops_in_arena) P.arena_off[rec] = arena_block;
         plan->chunk = ((v.n + PAFFY_NT - 1) / PAFFY_NT) | 1u; /* = sweep_bounds() */
     }
 #if defined(PAFFY_ABL) && PAFFY_ABL == 21
@@ -2661,6 +2950,10 @@ __device__ __forceinline__ RecLds carve_emit_lds(uint8_t *smem) {
 /* Where the HBM mirror of a record's 4-byte ops lives: cigars do not overlap and an op takes at
  * least two text bytes (digits + letter), so index cg_off / 2 is private to the record. */
 __device__ __forceinline__ uint32_t mirror_index(const RecMeta &m) { return m.cg_off >> 1; }
+/* the 4-byte ops the emit pass reads for an LDS-class record */
+__device__ __forceinline__ const uint32_t *emit_ops_of(const KParams &P, uint32_t rec, const RecMeta &m, const RecPlan &pl) {
+    return (pl.flags & 0x20000u) ? reinterpret_cast<const uint32_t *>(P.arena + P.arena_off[rec]) : P.ops_mirror + mirror_index(m);
+}
 
 /*
  * Sizing, LDS class: one workgroup per record, ops parsed from the text into LDS (and mirrored).
@@ -2672,14 +2965,15 @@ template <uint32_t MASK>
 __device__ __forceinline__ void size_lds_one(const KParams &P, uint32_t rec, uint32_t *ops_lds, const RecLds &L) {
     const RecMeta &m = P.meta[rec];
     OpsLds ops{ops_lds, P.ops_mirror + mirror_index(m), (m.cg_len + 1) >> 1};
-    uint32_t n_ops = 0;
-    bool ok = size_record<OpsLds, MASK>(P, rec, ops, P.ops_cap, L, KLASS_LDS, &n_ops);
+    uint32_t n_ops = 0, need = 0; /* need: ops of an array rebuilt by add_mismatches that did not fit this level's store */
+    bool ok = size_record<OpsLds, MASK>(P, rec, ops, P.ops_cap, L, KLASS_LDS, &n_ops, &need);
     if (ok && n_ops > ((m.cg_len + 1) >> 1)) ok = false; /* digit-less ops overran the mirror: arena class */
     if (!ok && threadIdx.x == 0) {
         P.out_len[rec] = 0;
         P.out_rows[rec] = 0;
         /* too many ops for this level's store only: try the next, bigger store; anything else needs the arena */
-        const bool try_next = P.next_cap != 0 && n_ops > P.ops_cap && n_ops <= PAFFY_OPS_CAP_BIG && n_ops <= ((m.cg_len + 1) >> 1);
+        const bool try_next = P.next_cap != 0 && (need ? need <= PAFFY_OPS_CAP_BIG
+                                                        : (n_ops > P.ops_cap && n_ops <= PAFFY_OPS_CAP_BIG && n_ops <= ((m.cg_len + 1) >> 1)));
         if (try_next) {
             P.b_list[P.level][atomicAdd(&P.info->b_count[P.level], 1u)] = rec;
         } else {
@@ -2698,7 +2992,7 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_SIZE_OCC) void k_size_lds(KParams P
     RecLds L = carve_size_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds, P.ops_cap);
     const uint32_t rec = P.size_order ? P.size_order[blockIdx.x] : blockIdx.x; /* long cigars first */
     /* records whose cigar text promises more ops than this store holds were queued for level 1 by k_header */
-    if ((P.meta[rec].cg_len >> 1) > PAFFY_OPS_CAP && P.meta[rec].err == 0) return;
+    if ((P.meta[rec].cg_len >> 1) > P.lvl0_max && P.meta[rec].err == 0) return;
     size_lds_one<MASK>(P, rec, ops_lds, L);
 }
 template <uint32_t MASK>
@@ -2725,7 +3019,7 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_EMIT_OCC) void k_emit_lds(KParams P
     if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return; /* nothing at or after the first failure */
     if ((P.status[rec] >> 16) != KLASS_LDS) return;
     if (static_cast<const RecPlan *>(P.rec_plan)[rec].flags & (SHATTER ? 64u : 0x10000u)) return; /* k_emit_rows / k_emit_line has it */
-    OpsGlobal ops{P.ops_mirror + mirror_index(P.meta[rec])};
+    OpsGlobal ops{emit_ops_of(P, rec, P.meta[rec], static_cast<const RecPlan *>(P.rec_plan)[rec])};
 #if defined(PAFFY_ABL) && PAFFY_ABL == 22
     const unsigned long long c0 = clock64(), w0 = wall_clock64();
 #endif
@@ -2760,7 +3054,7 @@ __global__ __launch_bounds__(64, PAFFY_ROWS_OCC) void k_emit_rows(KParams P) {
     s.qs = pl.qs; s.qe = pl.qe; s.ts = pl.ts; s.te = pl.te;
     s.has_cigar = (pl.flags & 8u) != 0;
     s.type = (uint8_t)(pl.flags >> 8);
-    OpsGlobal ops{P.ops_mirror + mirror_index(m)};
+    OpsGlobal ops{emit_ops_of(P, rec, m, pl)};
     View<OpsGlobal> v;
     v.reset(ops, pl.n);
     v.lo = pl.lo; v.rev = pl.flags & 1u; v.swp = (pl.flags & 2u) != 0;
@@ -2813,7 +3107,7 @@ __global__ __launch_bounds__(64, PAFFY_EMIT_OCC) void k_emit_line(KParams P) {
     s.qs = pl.qs; s.qe = pl.qe; s.ts = pl.ts; s.te = pl.te;
     s.has_cigar = (pl.flags & 8u) != 0;
     s.type = (uint8_t)(pl.flags >> 8);
-    OpsGlobal ops{P.ops_mirror + mirror_index(m)};
+    OpsGlobal ops{emit_ops_of(P, rec, m, pl)};
     View<OpsGlobal> v;
     v.reset(ops, pl.n);
     v.lo = pl.lo; v.rev = pl.flags & 1u; v.swp = (pl.flags & 2u) != 0;

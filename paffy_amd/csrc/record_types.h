@@ -84,6 +84,7 @@ struct KParams {
     uint32_t ops_cap;    /* 4-byte ops the sizing workgroup's LDS store holds */
     uint32_t next_cap;   /* store of the next level (0: none, overflow goes to the arena) */
     uint32_t level;      /* 0: whole batch; 1, 2: walk b_list[level - 1] */
+    uint32_t lvl0_max;   /* records with more than this many cigar bytes / 2 start at level 1 (k_header queued them) */
     DevInfo *info;
     paffy_filter filter; /* thresholds of PAFFY_FILTER stages */
     const uint32_t *emit_order; /* records by descending output size (coarse): the one-wave-per-record writers start the long ones first */

@@ -92,6 +92,8 @@ def lib():
         L.paffy_hip_profile_reset.argtypes = [vp]
         L.paffy_hip_profile_read.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(i64), C.c_int]
         L.paffy_hip_synth.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64)]
+        L.paffy_hip_synth4_setup.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, i64, i64, C.c_int]
+        L.paffy_hip_synth4.argtypes = [vp, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64)]
         L.paffy_hip_device_count.restype = C.c_int
         _lib = L
     return _lib
@@ -253,6 +255,20 @@ class Engine:
         buf = self.torch.zeros(_pad16(nbytes.value), dtype=self.torch.uint8, device=self.device)
         self._check(lib().paffy_hip_synth(self._ctx, seed, mean_ops, r0, n, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(nbytes)),
                     "paffy_hip_synth(fill)")
+        return buf, nbytes.value
+
+    def synth4_setup(self, seed, mean_ops, n_contigs=24, tlen_min=50_000_000, tlen_span=200_000_000, genomes=True):
+        """cfg4 workload: master alignments of n_contigs contig pairs and, with `genomes`, both genomes
+        written into the sequence store of this engine (what set_sequences would hold)."""
+        self._check(lib().paffy_hip_synth4_setup(self._ctx, seed, mean_ops, n_contigs, tlen_min, tlen_span, 1 if genomes else 0),
+                    "paffy_hip_synth4_setup")
+
+    def synth4(self, r0, n):
+        """cfg4 records [r0, r0+n) generated on the device; returns (tensor, nbytes)."""
+        nbytes = C.c_int64()
+        self._check(lib().paffy_hip_synth4(self._ctx, r0, n, None, 0, C.byref(nbytes)), "paffy_hip_synth4(size)")
+        buf = self.torch.zeros(_pad16(nbytes.value), dtype=self.torch.uint8, device=self.device)
+        self._check(lib().paffy_hip_synth4(self._ctx, r0, n, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(nbytes)), "paffy_hip_synth4(fill)")
         return buf, nbytes.value
 
     # ---- per-kernel HIP-event timing ----

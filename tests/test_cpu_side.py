@@ -56,3 +56,24 @@ def test_synth_is_deterministic_and_valid():
     out, err = O.run([O.stage(O.INVERT), O.stage(O.TRIM_IDENTITY), O.stage(O.SHATTER)], a)
     assert err.code == 0 and out.count(b"\n") > 300
     assert hashlib.sha256(a).hexdigest() == open(os.path.join(ROOT, "tests", "golden", "synth_cfg2_300.sha256")).read().strip()
+
+
+def test_synth_cfg4_records_lie_on_homologous_bases():
+    """cfg4 (records + genomes): windows of one master alignment per contig pair, so add_mismatches finds ~98 % identity
+    on both strands; record r does not depend on its batch."""
+    import re
+
+    s = synth_lib.Synth4(0x5EED0004, 512, n_contigs=8, tlen_min=60_000, tlen_span=90_000)
+    a = s.records(0, 300)
+    assert a == s.records(0, 300, threads=1) and s.records(100, 50) in a
+    seqs = s.genomes()
+    assert len(seqs) == 16 and all(set(v) <= set(b"ACGTacgt") for v in seqs.values())
+    out, err = O.run([O.stage(O.ADD_MISMATCHES)], a, seqs)
+    assert err.code == 0
+    for strand in (b"+", b"-"):
+        lines = [l for l in out.splitlines() if l.split(b"\t")[4] == strand]
+        assert lines
+        eq = sum(int(x) for l in lines for x in re.findall(rb"(\d+)=", l))
+        xx = sum(int(x) for l in lines for x in re.findall(rb"(\d+)X", l))
+        assert 0.97 < eq / (eq + xx) < 0.99
+    assert O.run([O.stage(O.ADD_MISMATCHES), O.stage(O.REMOVE_MISMATCHES)], a, seqs)[0] == O.run([O.stage(O.PASS)], a)[0]

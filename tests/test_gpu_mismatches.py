@@ -114,3 +114,35 @@ def test_known_answers_and_errors(eng):
         got, info = eng.run(gs([S(O.ADD_MISMATCHES)]), ok + bad + ok, raise_on_error=False)
         w, e = O.run([S(O.ADD_MISMATCHES)], ok + bad + ok, {"q": "AAAAA", "t": "AAAAA"})
         assert (info.error.code, info.error.record) == (code, 1) == (e.code, e.record) and got == w
+
+
+def test_cfg4_workload_device_equals_host_and_oracle(eng):
+    """cfg4: the device generator writes the same records and genomes as the host build, the records sit on
+    homologous bases (98 % identity on both strands), and add_mismatches over them equals the oracle."""
+    import re
+
+    import synth_lib
+
+    args = dict(n_contigs=8, tlen_min=60_000, tlen_span=90_000)
+    host = synth_lib.Synth4(0x5EED0004, 512, **args)
+    want_recs = host.records(5, 600)
+    seqs = host.genomes()
+    eng.synth4_setup(0x5EED0004, 512, **args)
+    buf, nbytes = eng.synth4(5, 600)
+    assert bytes(buf[:nbytes].cpu().numpy().tobytes()) == want_recs
+    # genomes as the device wrote them: add_mismatches against them must equal the oracle against the host genomes
+    want, werr = O.run([S(O.ADD_MISMATCHES)], want_recs, seqs)
+    assert werr.code == 0
+    got, info = eng.run(gs([S(O.ADD_MISMATCHES)]), want_recs)
+    assert got == want
+    eq = sum(int(x) for x in re.findall(rb"(\d+)=", want))
+    xx = sum(int(x) for x in re.findall(rb"(\d+)X", want))
+    assert 0.975 < eq / (eq + xx) < 0.985
+    assert any(b"\t-\t" in line for line in want_recs.split(b"\n"))
+    # and through the host-loaded store too (same bytes either way)
+    eng.set_sequences(seqs)
+    assert eng.run(gs([S(O.ADD_MISMATCHES)]), want_recs)[0] == want
+    for stages in ([S(O.ADD_MISMATCHES), S(O.SHATTER)], [S(O.INVERT), S(O.ADD_MISMATCHES), S(O.TRIM_IDENTITY)]):
+        w, e = O.run(stages, want_recs, seqs)
+        g, i = eng.run(gs(stages), want_recs, raise_on_error=False)
+        assert i.error.code == e.code and g == w
