@@ -720,6 +720,8 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_slices), hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_LEAN>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_ADD>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds_long<PAFFY_MASK_ADD>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds_long<PAFFY_MASK_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds_long<PAFFY_MASK_LEAN>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emit_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_EMIT_LDS_BYTES);
@@ -823,6 +825,8 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     }
     bool lean = true; /* only stage kinds the lean sizing kernel knows */
     for (int32_t i = 0; i < n_stages; i++) lean = lean && ((PAFFY_MASK_LEAN >> stages[i].kind) & 1u);
+    bool lean_add = !lean; /* the lean kinds and add_mismatches: its own instantiation (the encoder wants the registers) */
+    for (int32_t i = 0; i < n_stages; i++) lean_add = lean_add && ((PAFFY_MASK_ADD >> stages[i].kind) & 1u);
     c->planned = false;
     c->plan_is_tile = false;
     memset(info, 0, sizeof(*info));
@@ -839,9 +843,14 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     const uint8_t *in = static_cast<const uint8_t *>(d_in);
     const uint32_t len = (uint32_t)in_len;
     uint32_t n_lines = 0;
-    /* add_mismatches makes more ops of a cigar (about 1.8 x at 2 % substitutions, 1.45 per two cigar bytes): its records start one
-       store level up at 5/8 of the usual length, so that the rebuilt array usually fits the level the record was parsed at */
-    const uint32_t lvl0_max = need_seqs ? PAFFY_OPS_CAP * 5 / 8 : PAFFY_OPS_CAP;
+    /* add_mismatches makes more ops of a cigar (about 1.8 x at 2 % substitutions, 1.45 per two cigar bytes): when a stage follows it, its
+       records start one store level up at 5/8 of the usual length, so that the rebuilt array usually fits the level the record was parsed at */
+    const bool add_not_last = need_seqs && [&] {
+        for (int32_t i = 0; i + 1 < n_stages; i++)
+            if (stages[i].kind == PAFFY_ADD_MISMATCHES) return true;
+        return false;
+    }();
+    const uint32_t lvl0_max = add_not_last ? PAFFY_OPS_CAP * 5 / 8 : PAFFY_OPS_CAP;
     {
         int rc = index_and_parse(c, in, len, &n_lines, lvl0_max);
         if (rc) return rc;
@@ -906,11 +915,13 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
                 k1.next_cap = PAFFY_OPS_CAP_BIG;
                 k1.level = 1;
                 if (lean) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_LEAN>, dim3(768), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_MID), c->side, k1);
+                else if (lean_add) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_ADD>, dim3(768), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_MID), c->side, k1);
                 else hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_ALL>, dim3(768), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_MID), c->side, k1);
                 k1.ops_cap = PAFFY_OPS_CAP_BIG;
                 k1.next_cap = 0;
                 k1.level = 2;
                 if (lean) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_LEAN>, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), c->side, k1);
+                else if (lean_add) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_ADD>, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), c->side, k1);
                 else hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_ALL>, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), c->side, k1);
                 HIPCHK(c, hipGetLastError());
                 HIPCHK(c, hipEventRecord(c->ev_join, c->side));
@@ -919,6 +930,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             kp.next_cap = 0;
             kp.level = 0;
             if (lean) LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_LEAN>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
+            else if (lean_add) LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_ADD>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             else LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_ALL>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); /* join */
             LAUNCH(c, "k_arena_size", k_arena_size, dim3(2048), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);

@@ -61,6 +61,15 @@ struct OpsGlobal { /* the HBM mirror, read by the emit pass */
         len = (int64_t)(w >> 3);
     }
 };
+struct OpsCoherent { /* 4-byte ops another wave of this workgroup has just written to HBM: read past the L1 */
+    const uint32_t *p;
+    static constexpr bool kNarrow = true;
+    __device__ __forceinline__ void get(uint32_t i, int64_t &len, int &op) const {
+        const uint32_t w = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        op = (int)(w & 7u);
+        len = (int64_t)(w >> 3);
+    }
+};
 struct OpsArena { /* 8-byte ops in HBM: the CigarRecord layout, inc/paf.h:61-64 */
     uint64_t *p;
     static constexpr bool kNarrow = false;
@@ -1091,18 +1100,20 @@ __device__ __forceinline__ int32_t wave_incl_max_i32(int32_t v) {
     return x;
 }
 
-/* One walk over this wave's ops. FILL = false: computes every chunk's match mask (kept in masks[], one 16-bit word per item,
- * for the second walk) and returns the number of ops the wave's range becomes (*bad = first op whose bases lie outside a
- * sequence, INT64_MAX none). FILL = true: writes the ops at blk[out_base ..) from the masks. q0 / t0: bases consumed on the
- * query / target before the wave's first op (below 2^30 for the whole record); masks: the wave's first item. */
-template <bool FILL, class OPS>
-__device__ __forceinline__ uint32_t mismatch_runs_wave(const KParams &P, const RecState &s, const View<OPS> &v, const uint8_t *Q, int64_t qseq_len,
-                                                       const uint8_t *T, int64_t tseq_len, uint32_t wb, uint32_t we, int64_t q0, int64_t t0,
-                                                       uint32_t out_base, uint32_t *blk, uint16_t *masks, int64_t *bad) {
+/*
+ * Walk 1 over this wave's ops [wb, we): every item gets one 32-bit word in items[] (the wave's share of the scratch), in op order:
+ *   chunk of an M op:  OP_M | columns << 3 | match mask << 8 | first chunk << 24 | last chunk << 25
+ *   any other op:      its 4-byte op word (len << 3 | op, op != OP_M)
+ * Returns the number of ops the range becomes; *n_items = words written; *bad = first op whose bases lie outside a sequence
+ * (INT64_MAX: none). q0 / t0: bases consumed on the query / target before the wave's first op (below 2^30 for the whole record).
+ */
+template <class OPS>
+__device__ __forceinline__ uint32_t mismatch_count_wave(const KParams &P, const RecState &s, const View<OPS> &v, const uint8_t *Q, int64_t qseq_len,
+                                                        const uint8_t *T, int64_t tseq_len, uint32_t wb, uint32_t we, int64_t q0, int64_t t0,
+                                                        uint32_t *items, uint32_t *n_items_out, int64_t *bad) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t qpos = (uint32_t)q0, tpos = (uint32_t)t0; /* wave-uniform */
-    uint32_t done = out_base; /* ops written so far; wave-uniform */
-    uint32_t lane_cnt = 0;
+    uint32_t lane_cnt = 0, written = 0;
     int64_t first_bad = INT64_MAX;
     for (uint32_t base = wb; base < we; base += 64) {
         const uint32_t i = base + lane;
@@ -1114,30 +1125,24 @@ __device__ __forceinline__ uint32_t mismatch_runs_wave(const KParams &P, const R
         const uint32_t qrel = qinc - dq, trel = tinc - dt; /* columns in front of this op, from the window's first */
         /* the window's first column on both sequences (wave-uniform); the - strand walks the query downwards from qe - 1 */
         const int64_t tj0 = s.ts + (int64_t)tpos, qoff0 = s.same ? s.qs + (int64_t)qpos : s.qe - 1 - (int64_t)qpos;
-        bool is_m = false;
-        if (!FILL) {
-            is_m = i < we && op == OP_M && len > 0;
-            if (is_m) {
-                const int64_t tj = tj0 + trel, qoff = s.same ? qoff0 + qrel : qoff0 - qrel;
-                const bool in_range = tj >= 0 && tj + len <= tseq_len && (s.same ? (qoff >= 0 && qoff + len <= qseq_len) : (qoff < qseq_len && qoff - (len - 1) >= 0));
-                if (!in_range) {
-                    if (first_bad == INT64_MAX) first_bad = i;
-                    is_m = false;
-                }
+        bool is_m = i < we && op == OP_M && len > 0;
+        if (is_m) {
+            const int64_t tj = tj0 + trel, qoff = s.same ? qoff0 + qrel : qoff0 - qrel;
+            const bool in_range = tj >= 0 && tj + len <= tseq_len && (s.same ? (qoff >= 0 && qoff + len <= qseq_len) : (qoff < qseq_len && qoff - (len - 1) >= 0));
+            if (!in_range) {
+                if (first_bad == INT64_MAX) first_bad = i;
+                is_m = false;
             }
-        } else {
-            is_m = i < we && op == OP_M && len > 0; /* the count walk found every op in range */
         }
         qpos += wave_last_u32(qinc);
         tpos += wave_last_u32(tinc);
         /* items of this op: chunks of an M op; one for any other op; none for an M op of length 0 (impl/paf.c:747-779 writes nothing) */
-        const uint32_t nch = (i < we && op == OP_M) ? (is_m || FILL ? (uint32_t)((len + 15) >> 4) : 0u) : (i < we ? 1u : 0u);
+        const uint32_t nch = is_m ? (uint32_t)((len + 15) >> 4) : ((i < we && op != OP_M) ? 1u : 0u);
         const uint32_t iinc = wave_incl_scan_u32(nch);
         const uint32_t ioff = iinc - nch, n_items = wave_last_u32(iinc);
         const uint32_t opw = ((uint32_t)len << 3) | (uint32_t)op;
         const uint8_t *Tw = T + tj0, *Qw = Q + qoff0;
-        uint32_t carry_m = 0;      /* mask of the last item of the iteration before */
-        int32_t carry_start = 0;   /* column of the last run start seen in the op under way */
+        uint32_t carry_m = 0; /* mask of the last item of the iteration before */
         for (uint32_t c0 = 0; c0 < n_items; c0 += 64) {
             const uint32_t c = c0 + lane;
             const bool act = c < n_items;
@@ -1150,84 +1155,105 @@ __device__ __forceinline__ uint32_t mismatch_runs_wave(const KParams &P, const R
             }
             const uint32_t ow = __shfl(opw, (int)ol);
             const uint32_t o_first = __shfl(ioff, (int)ol);
+            const uint32_t oq = __shfl(qrel, (int)ol), ot = __shfl(trel, (int)ol); /* by every lane: the source lanes must be live */
             const uint32_t olen = ow >> 3;
-            const int oop = (int)(ow & 7u);
-            const bool item_m = act && oop == OP_M;
+            const bool item_m = act && (ow & 7u) == (uint32_t)OP_M;
             const uint32_t k = (c - o_first) << 4;
-            const uint32_t nb = item_m ? (olen - k < 16u ? olen - k : 16u) : 0u;
-            uint32_t m = 0;
-            if (!FILL) {
-                const uint32_t oq = __shfl(qrel, (int)ol), ot = __shfl(trel, (int)ol); /* by every lane: the source lanes must be live */
-                if (item_m) {
-                    m = match_mask16(P.seq_base, s.same ? Qw + (oq + k) : Qw - (oq + k), Tw + (ot + k), s.same) & ((1u << nb) - 1u);
-                    masks[c] = (uint16_t)m;
-                }
-            } else if (item_m) {
-                m = __hip_atomic_load(masks + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* past the L1: a line may predate the stores */
+            uint32_t m = 0, word = ow;
+            if (item_m) {
+                const uint32_t nb = olen - k < 16u ? olen - k : 16u;
+                m = match_mask16(P.seq_base, s.same ? Qw + (oq + k) : Qw - (oq + k), Tw + (ot + k), s.same) & ((1u << nb) - 1u);
+                word = (uint32_t)OP_M | (nb << 3) | (m << 8) | (k == 0 ? 1u << 24 : 0u) | (k + 16u >= olen ? 1u << 25 : 0u);
             }
+            if (act) items[written + c] = word;
             uint32_t pm = __shfl_up(m, 1);
             if (lane == 0) pm = carry_m;
-            const uint32_t prevbit = (pm >> 15) & 1u; /* the chunk before is full when this one is not the first of its op */
-            uint32_t starts = 0;
-            if (item_m) {
-                starts = (m ^ ((m << 1) | prevbit)) & ((1u << nb) - 1u);
+            if (item_m) { /* a column starts a run when its match bit differs from the column before; the chunk before is full */
+                uint32_t starts = m ^ ((m << 1) | ((pm >> 15) & 1u));
+                starts &= (1u << ((word >> 3) & 31u)) - 1u;
                 if (k == 0) starts |= 1u;
-            }
-            const uint32_t cnt = item_m ? (uint32_t)__popc(starts) : (act ? 1u : 0u);
-            if (!FILL) {
-                lane_cnt += cnt;
-            } else {
-                const uint32_t cinc = wave_incl_scan_u32(cnt);
-                uint32_t idx = done + cinc - cnt; /* ops in front of this item's first start */
-                done += wave_last_u32(cinc);
-                /* column of the previous start: the nearest lane before with a start, or the carry */
-                const int32_t my_last = starts ? (int32_t)(k + 31u - (uint32_t)__clz((int)starts)) : 0;
-                const int32_t src_incl = wave_incl_max_i32(starts ? (int32_t)lane : -1);
-                int32_t src = __shfl_up(src_incl, 1);
-                if (lane == 0) src = -1;
-                const int32_t from = __shfl(my_last, src < 0 ? 0 : src);
-                int32_t prev = src < 0 ? carry_start : from;
-                if (item_m) {
-                    uint32_t st = starts;
-                    while (st) {
-                        const uint32_t j = (uint32_t)__ffs((int)st) - 1u;
-                        st &= st - 1u;
-                        const int32_t pos = (int32_t)(k + j);
-                        if (pos != 0) {
-                            const uint32_t before = j ? (m >> (j - 1u)) & 1u : prevbit;
-                            blk[idx - 1u] = ((uint32_t)(pos - prev) << 3) | (before ? (uint32_t)OP_EQ : (uint32_t)OP_X);
-                        }
-                        prev = pos;
-                        idx++;
-                    }
-                    if (k + 16u >= olen) blk[idx - 1u] = ((olen - (uint32_t)prev) << 3) | (((m >> (nb - 1u)) & 1u) ? (uint32_t)OP_EQ : (uint32_t)OP_X);
-                } else if (act) {
-                    blk[idx] = ow;
-                }
-                const int32_t top = __builtin_amdgcn_readlane(src_incl, 63);
-                if (top >= 0) carry_start = __shfl(my_last, top);
+                lane_cnt += (uint32_t)__popc(starts);
+            } else if (act) {
+                lane_cnt++;
             }
             carry_m = __builtin_amdgcn_readlane((int)m, 63);
         }
-        masks += n_items;
+        written += n_items;
     }
-    if (!FILL) {
-        *bad = first_bad;
-        return wave_last_u32(wave_incl_scan_u32(lane_cnt));
-    }
-    return done;
+    *bad = first_bad;
+    *n_items_out = written;
+    return wave_last_u32(wave_incl_scan_u32(lane_cnt));
 }
 
-/*
- * LDS class: returns 0 / PAFFY_ERR_SEQ_RANGE / -1 (does not fit the narrow path: arena class) / -2 (arena full, repeated by
- * the host) / -3 (more than `cap` ops: *n_out says how many). On 0 the new ops are in LDS and in the arena block *blk_off
- * (4-byte ops), which replaces the record's mirror.
- */
+/* Walk 2: the wave's item words, 64 at a time, become the ops blk[out_base ..): no op is looked at again. */
+__device__ __forceinline__ void mismatch_fill_wave(const uint32_t *items, uint32_t n_items, uint32_t out_base, uint32_t *blk) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t done = out_base; /* ops written so far; wave-uniform */
+    uint32_t carry_m = 0;     /* mask of the last item of the iteration before */
+    int32_t carry_start = 0;  /* column (16 * item + bit) of the last run start seen */
+    for (uint32_t c0 = 0; c0 < n_items; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        const bool act = c < n_items;
+        /* past the L1: a line may predate the stores of walk 1 */
+        const uint32_t w = act ? __hip_atomic_load(items + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+        const bool item_m = (w & 7u) == (uint32_t)OP_M;
+        const uint32_t m = item_m ? (w >> 8) & 0xffffu : 0u, nb = (w >> 3) & 31u;
+        uint32_t pm = __shfl_up(m, 1);
+        if (lane == 0) pm = carry_m;
+        const uint32_t prevbit = (pm >> 15) & 1u;
+        uint32_t starts = 0;
+        if (item_m) starts = ((m ^ ((m << 1) | prevbit)) & ((1u << nb) - 1u)) | ((w >> 24) & 1u);
+        const uint32_t cnt = item_m ? (uint32_t)__popc(starts) : (act ? 1u : 0u);
+        const uint32_t cinc = wave_incl_scan_u32(cnt);
+        uint32_t idx = done + cinc - cnt; /* ops in front of this item's first start */
+        done += wave_last_u32(cinc);
+        /* column of the previous start: the nearest lane before with a start (always one of the same op), or the carry */
+        const int32_t col0 = (int32_t)(c << 4);
+        const int32_t my_last = starts ? col0 + 31 - __clz((int)starts) : 0;
+        const int32_t src_incl = wave_incl_max_i32(starts ? (int32_t)lane : -1);
+        int32_t src = __shfl_up(src_incl, 1);
+        if (lane == 0) src = -1;
+        const int32_t from = __shfl(my_last, src < 0 ? 0 : src);
+        int32_t prev = src < 0 ? carry_start : from;
+        if (item_m) {
+            uint32_t st = starts;
+            const bool first = (w >> 24) & 1u;
+            while (st) {
+                const uint32_t j = (uint32_t)__ffs((int)st) - 1u;
+                st &= st - 1u;
+                const int32_t pos = col0 + (int32_t)j;
+                if (!(first && j == 0)) { /* the run in front of this start ends here */
+                    const uint32_t before = j ? (m >> (j - 1u)) & 1u : prevbit;
+                    blk[idx - 1u] = ((uint32_t)(pos - prev) << 3) | (before ? (uint32_t)OP_EQ : (uint32_t)OP_X);
+                }
+                prev = pos;
+                idx++;
+            }
+            if ((w >> 25) & 1u) blk[idx - 1u] = ((uint32_t)(col0 + (int32_t)nb - prev) << 3) | (((m >> (nb - 1u)) & 1u) ? (uint32_t)OP_EQ : (uint32_t)OP_X);
+        } else if (act) {
+            blk[idx] = w;
+        }
+        const int32_t top = __builtin_amdgcn_readlane(src_incl, 63);
+        if (top >= 0) carry_start = __shfl(my_last, top);
+        carry_m = __builtin_amdgcn_readlane((int)m, 63);
+    }
+}
+
+#if defined(PAFFY_ABL) && PAFFY_ABL == 23 /* phase clock of the LDS-class mismatch encoder (device printf per sampled record) */
+#define ABL23_DECL unsigned long long a23_t0 = __builtin_readcyclecounter(), a23[5] = {0, 0, 0, 0, 0};
+#define ABL23_MARK(k) { unsigned long long t1_ = __builtin_readcyclecounter(); a23[k] += t1_ - a23_t0; a23_t0 = t1_; }
+#define ABL23_PRINT if ((blockIdx.x & 8191u) == 77u && (threadIdx.x & 63u) == 0) printf("blk %u wave %u ops %u -> %u items %lld: sweep %llu count %llu alloc %llu fill %llu copy %llu\n", blockIdx.x, threadIdx.x >> 6, v.n, ctot[0], (long long)tot[2], a23[0], a23[1], a23[2], a23[3], a23[4]);
+#else
+#define ABL23_DECL
+#define ABL23_MARK(k)
+#define ABL23_PRINT
+#endif
 __device__ __forceinline__ int encode_mismatch_runs_lds(const KParams &P, const RecState &s, View<OpsLds> &v, OpsLds &ops, uint32_t cap, const uint8_t *Q,
                                                         int64_t qseq_len, const uint8_t *T, int64_t tseq_len, BlockComm &bc, Shared *sh, uint32_t *n_out,
-                                                        uint64_t *blk_off) {
-    uint32_t b, e;
-    sweep_bounds(v.n, b, e);
+                                                        uint64_t *blk_off, bool keep_lds) {
+    ABL23_DECL
+    /* an even split of the ops over the threads, so that the four waves get a quarter each whatever the record's size */
+    const uint32_t b = (uint32_t)((uint64_t)v.n * threadIdx.x / PAFFY_NT), e = (uint32_t)((uint64_t)v.n * (threadIdx.x + 1) / PAFFY_NT);
     int64_t c[3] = {0, 0, 0}, tot[3]; /* query bases, target bases, items (16-column chunks of M ops + the other ops) */
     for (uint32_t i = b; i < e; i++) {
         int64_t len;
@@ -1238,28 +1264,30 @@ __device__ __forceinline__ int encode_mismatch_runs_lds(const KParams &P, const 
         c[2] += op == OP_M ? (len + 15) >> 4 : 1;
     }
     block_excl_scan<3>(c, tot, bc);
+    ABL23_MARK(0)
     if (tot[0] >= (1ll << 30) || tot[1] >= (1ll << 30)) return -1; /* 32-bit columns and op counts below */
-    /* scratch for the match masks: 2 bytes per item, in the arena */
-    const uint64_t mslots = ((uint64_t)tot[2] + 3) >> 2;
+    /* scratch for the item words: 4 bytes per item, in the arena */
+    const uint64_t mslots = ((uint64_t)tot[2] + 1) >> 1;
     if (threadIdx.x == 0) sh->bcast[3] = (int64_t)atomicAdd(&P.info->arena_used, (unsigned long long)mslots);
     __syncthreads();
     const uint64_t moff = (uint64_t)sh->bcast[3];
     __syncthreads();
     if (moff + mslots > P.arena_cap) return -2;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint64_t span = 64ull * (((v.n + PAFFY_NT - 1) / PAFFY_NT) | 1u); /* = sweep_bounds(): the wave's ops are its lanes' chunks */
-    const uint32_t wb = span * wave < v.n ? (uint32_t)(span * wave) : v.n, we = span * (wave + 1) < v.n ? (uint32_t)(span * (wave + 1)) : v.n;
+    const uint32_t wb = (uint32_t)((uint64_t)v.n * (64u * wave) / PAFFY_NT), we = (uint32_t)((uint64_t)v.n * (64u * wave + 64u) / PAFFY_NT);
     const int64_t q0 = wave_first_i64(c[0]), t0 = wave_first_i64(c[1]);
-    uint16_t *masks = reinterpret_cast<uint16_t *>(P.arena + moff) + wave_first_i64(c[2]);
+    uint32_t *items = reinterpret_cast<uint32_t *>(P.arena + moff) + wave_first_i64(c[2]);
     int64_t bad = INT64_MAX;
-    const uint32_t wcnt = mismatch_runs_wave<false>(P, s, v, Q, qseq_len, T, tseq_len, wb, we, q0, t0, 0u, nullptr, masks, &bad);
+    uint32_t n_items = 0;
+    const uint32_t wcnt = mismatch_count_wave(P, s, v, Q, qseq_len, T, tseq_len, wb, we, q0, t0, items, &n_items, &bad);
+    ABL23_MARK(1)
     bad = block_min_i64(wave_min(bad), bc);
     uint32_t cw[1] = {lane == 0 ? wcnt : 0u}, ctot[1];
     block_excl_scan_u32<1>(cw, ctot, bc);
     const uint32_t out_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[0]);
     *n_out = ctot[0];
     if (bad != INT64_MAX) return PAFFY_ERR_SEQ_RANGE;
-    if (ctot[0] > cap) return -3;
+    if (keep_lds && ctot[0] > cap) return -3;
     const uint64_t slots = ((uint64_t)ctot[0] + 1) >> 1; /* 8-byte arena slots holding 4-byte ops */
     if (threadIdx.x == 0) sh->bcast[3] = (int64_t)atomicAdd(&P.info->arena_used, (unsigned long long)slots);
     __syncthreads();
@@ -1267,13 +1295,22 @@ __device__ __forceinline__ int encode_mismatch_runs_lds(const KParams &P, const 
     __syncthreads();
     if (off + slots > P.arena_cap) return -2;
     uint32_t *blk = reinterpret_cast<uint32_t *>(P.arena + off);
-    mismatch_runs_wave<true>(P, s, v, Q, qseq_len, T, tseq_len, wb, we, q0, t0, out_base, blk, masks, &bad);
+    ABL23_MARK(2)
+    mismatch_fill_wave(items, n_items, out_base, blk);
+    ABL23_MARK(3)
     __syncthreads(); /* every op of the old array has been read, every op of the new one written */
+    *blk_off = off;
+    if (!keep_lds) { /* last stage: LDS keeps the old ops (the record check runs on them), the line is sized from the block */
+        ABL23_MARK(4)
+        ABL23_PRINT
+        return 0;
+    }
     for (uint32_t i = threadIdx.x; i < ctot[0]; i += PAFFY_NT) ops.p[i] = __hip_atomic_load(blk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    ABL23_MARK(4)
+    ABL23_PRINT
     ops.g = blk;
     ops.g_cap = ctot[0];
-    *blk_off = off;
     return 0;
 }
 
@@ -2631,6 +2668,7 @@ __device__ __forceinline__ void load_state(const RecMeta &m, RecState &s) {
  */
 #define PAFFY_MASK_ALL 0xffffffffu
 #define PAFFY_MASK_LEAN ((1u << PAFFY_INVERT) | (1u << PAFFY_TRIM_IDENTITY) | (1u << PAFFY_SHATTER) | (1u << PAFFY_PASS))
+#define PAFFY_MASK_ADD (PAFFY_MASK_LEAN | (1u << PAFFY_ADD_MISMATCHES))
 #define STAGE_ON(kind) ((MASK >> (kind)) & 1u)
 template <class OPS, uint32_t MASK = PAFFY_MASK_ALL>
 __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t cap, const RecLds &L, uint32_t klass,
@@ -2676,6 +2714,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
     }
     bool swapped = false, shatter = false;
     bool ops_in_arena = false; /* LDS class whose op array was rebuilt: 4-byte ops in an arena block instead of the mirror */
+    bool ops_block_only = false; /* ... by the last stage: the new ops are in that block only, LDS still holds the old ones */
     uint64_t arena_block = 0;
     bool checked = false; /* a paf_check has passed since the record last changed */
     int32_t si = 0;
@@ -2730,8 +2769,9 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
                 else if (ti < 0) rc = PAFFY_ERR_MISSING_TARGET_SEQ; /* :123-127 */
                 else if (s.has_cigar) {
                     uint32_t n2 = 0;
+                    const bool last = si == P.n_stages - 1; /* nothing reads the new ops but the line writer: they need not fit LDS */
                     const int r = encode_mismatch_runs_lds(P, s, v, ops, cap, P.seq_base + P.seqs[qi].off, P.seqs[qi].len, P.seq_base + P.seqs[ti].off,
-                                                           P.seqs[ti].len, L.bc, L.sh, &n2, &arena_block);
+                                                           P.seqs[ti].len, L.bc, L.sh, &n2, &arena_block, !last);
                     if (r == -1) return false; /* wider than the narrow path: arena class */
                     if (r == -2) return true;  /* arena full: repeated by the host */
                     if (r == -3) {             /* more ops than this store holds */
@@ -2740,11 +2780,15 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
                     }
                     if (r > 0) rc = r;
                     else {
+                        if (last) rc = check_record(s, v, L.bc); /* on the ops still in LDS: the runs of an M op add up to it */
                         v.reset(ops, n2);
                         ops_in_arena = true;
+                        ops_block_only = last;
+                        if (last && !rc) goto add_done;
                     }
                 }
                 if (!rc) rc = check_record(s, v, L.bc);
+            add_done:;
             } else if constexpr (OPS::kNarrow) {
                 return false;
             } else {
@@ -2819,7 +2863,15 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
         direct = lenH > 3 * PAFFY_TMPL_MAX; /* header too long for the LDS staging: built straight in HBM */
         line_kernel = OPS::kNarrow && lenH + 8 <= PAFFY_TMPL_MAX && v.n <= PAFFY_ROWS_MAX_OPS; /* written by k_emit_line */
         bytes = lenH;
-        if (!nl_in_header) bytes += cigar_text_len(v, plan, L.bc) + 1;
+        if (!nl_in_header) {
+            if (ops_block_only) {
+                View<OpsCoherent> gv;
+                gv.reset(OpsCoherent{reinterpret_cast<const uint32_t *>(P.arena + arena_block)}, v.n);
+                bytes += cigar_text_len(gv, plan, L.bc) + 1;
+            } else {
+                bytes += cigar_text_len(v, plan, L.bc) + 1;
+            }
+        }
         rows = 1;
     }
     if (threadIdx.x == 0) {
