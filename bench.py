@@ -31,11 +31,14 @@ WORKLOADS = {
                  desc="10M synthetic PAF records, mean 2k cigar ops, invert | trim | shatter"),
     "cfg2": dict(seed=0x5EED0002, mean_ops=512, total=1_000_000, pipe="shatter",
                  desc="1M synthetic PAF records, mean 512 cigar ops, shatter"),
+    # records on homologous bases of two device-generated genomes (24 + 24 contigs of 50-250 Mb, 2 % substitutions)
+    "cfg4": dict(seed=0x5EED0004, mean_ops=2048, total=10_000_000, pipe="add_mismatches", genomes=True,
+                 desc="10M synthetic PAF records, mean 2k cigar ops + 2x3.6 Gb synthetic genomes resident in HBM, add_mismatches"),
 }
 
 
 def stages_for(pipe, mod):
-    kinds = {"invert": mod.INVERT, "trim": mod.TRIM_IDENTITY, "shatter": mod.SHATTER}
+    kinds = {"invert": mod.INVERT, "trim": mod.TRIM_IDENTITY, "shatter": mod.SHATTER, "add_mismatches": mod.ADD_MISMATCHES}
     return [mod.stage(kinds[k]) for k in pipe.split("|")]
 
 
@@ -85,11 +88,18 @@ def main():
 
     batches = []
     mine = shard.batches_of_rank(rank, world, n_batches * world * args.batch, args.batch)  # rank r: batches r, r+N, ...
+    if wl.get("genomes"):
+        eng.synth4_setup(wl["seed"], wl["mean_ops"])  # both genomes replicated on every GPU
     for _, first, n in mine:
         r0 = first % max(1, wl["total"] - args.batch + 1)  # weak scaling: past the end the stream repeats
-        buf, nbytes = eng.synth(wl["seed"], wl["mean_ops"], r0, n)
+        buf, nbytes = eng.synth4(r0, n) if wl.get("genomes") else eng.synth(wl["seed"], wl["mean_ops"], r0, n)
         batches.append((buf, nbytes, r0))
     torch.cuda.synchronize()
+    aligned_per_record = 0.0
+    if wl.get("genomes"):  # add_mismatches also reads one byte of each genome per aligned base (PAF column 10 here)
+        head = bytes(batches[0][0][: batches[0][1]].cpu().numpy().tobytes())
+        lines = head.split(b"\n")[:-1]
+        aligned_per_record = sum(int(l.split(b"\t", 10)[9]) for l in lines) / max(1, len(lines))
 
     # one untimed plan to size the output slab (reused by every step)
     info0 = eng.plan(stages, batches[0][0], batches[0][1])
@@ -148,7 +158,7 @@ def main():
         # dominant kernel = the one with the largest total time in the timed region; it is priced with the
         # algorithmic bytes of the launch (input + output line bytes of the batch) over its average
         # duration. The other record kernels are listed the same way in `roofline_by_kernel`.
-        per_launch_bytes = (in_bytes + out_bytes) / args.steps
+        per_launch_bytes = (in_bytes + out_bytes) / args.steps + 2.0 * aligned_per_record * args.batch
         by_kernel = {}
         for name, (ms, launches) in kernels.items():
             if launches <= 0 or ms <= 0:
@@ -167,7 +177,7 @@ def main():
                         "algorithmic_bytes_per_launch": int(per_launch_bytes)}
         cpu = None
         if args.cpu_sample > 0 and world == 1:  # the CPU leg runs on rank 0 of the one-GPU run only
-            cpu = cpu_baseline(eng, wl, stages, args.cpu_sample)
+            cpu = cpu_baseline_genomes(wl, stages, min(args.cpu_sample, 16384)) if wl.get("genomes") else cpu_baseline(eng, wl, stages, args.cpu_sample)
         line = {
             "metric": "PAF records/sec (shatter+invert+trim pipe); % HBM roofline at 1/2/4/8 GPU",
             "value": round(records / elapsed, 1),
@@ -186,11 +196,12 @@ def main():
                        "input_bytes_per_record": round(in_bytes / (args.batch * args.steps), 1),
                        "output_bytes_per_record": round(out_bytes / (args.batch * args.steps), 1),
                        "output_rows_per_record": round(rows / (args.batch * args.steps), 2),
+                       "aligned_bases_per_record": round(aligned_per_record, 1),
                        "sharding": "contiguous record batches per rank, no collective"},
-            "whole_path_GBps_per_gpu": round((job_in + job_out) / world / elapsed / 1e9, 1),
+            "whole_path_GBps_per_gpu": round(((job_in + job_out) / world + 2.0 * aligned_per_record * args.batch * args.steps) / elapsed / 1e9, 1),
             "roofline": roofline,
-            "roofline_by_kernel": {k: v for k, v in by_kernel.items() if k in ("k_size_lds", "k_emit_rows", "k_emit_lds", "k_emit_lds<line>")},
-            "whole_path_frac_of_hbm_peak": round((job_in + job_out) / world / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline_by_kernel": {k: v for k, v in by_kernel.items() if k in ("k_size_lds", "k_emit_rows", "k_emit_lds", "k_emit_lds<line>", "k_emit_line")},
+            "whole_path_frac_of_hbm_peak": round(((job_in + job_out) / world + 2.0 * aligned_per_record * args.batch * args.steps) / elapsed / 1e9 / HBM_PEAK_GBS, 4),
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kernels.items()},
         }
@@ -236,6 +247,34 @@ def cpu_baseline(eng, wl, stages, n):
     got, _ = eng.run(stages, data)
     return {"value": round(n / dt, 1), "unit": "records/s", "cores": 1, "kind": "port",
             "sample": f"first {n} records of the same stream ({len(data)} B in, {len(want)} B out), {dt:.1f} s, single thread",
+            "gpu_output_matches": bool(got == want and err.code == 0)}
+
+
+def cpu_baseline_genomes(wl, stages, n):
+    """CPU leg of the add_mismatches workload: the oracle on n records of the same generator with contigs of 0.5-2 Mb
+    (the host build of the 50-250 Mb genomes would take minutes); a second engine runs the same sample on the GPU."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    import synth_lib
+
+    import paffy_amd
+
+    small = dict(n_contigs=24, tlen_min=500_000, tlen_span=1_500_000)
+    host = synth_lib.Synth4(wl["seed"], wl["mean_ops"], **small)
+    data = host.records(0, n)
+    seqs = host.genomes()
+    ost = [O.stage(O.ADD_MISMATCHES)]
+    O.run(ost, data[: data.index(b"\n") + 1], seqs)  # builds the oracle's sequence table outside the timed call
+    t0 = time.perf_counter()
+    want, err = O.run(ost, data, seqs)
+    dt = time.perf_counter() - t0
+    e2 = paffy_amd.Engine()
+    e2.synth4_setup(wl["seed"], wl["mean_ops"], **small)
+    got, _ = e2.run(stages, data)
+    e2.close()
+    return {"value": round(n / dt, 1), "unit": "records/s", "cores": 1, "kind": "port",
+            "sample": f"{n} records of the same generator on 24 + 24 contigs of 0.5-2 Mb ({len(data)} B in, {len(want)} B out), {dt:.1f} s, "
+                      "single thread, sequence table passed per call",
             "gpu_output_matches": bool(got == want and err.code == 0)}
 
 

@@ -519,6 +519,18 @@ __global__ __launch_bounds__(PAFFY_NT) void k_scan_i64(const int64_t *in, uint32
     if (threadIdx.x == 0) *total = carry;
 }
 
+/* Sequences are kept in the form they are compared in (impl/paf.c:752-757: toupper of both bases, the query base complemented
+ * on the - strand): seq upper-cased in place, comp = its complement. 16 bytes per lane. */
+__global__ __launch_bounds__(PAFFY_NT) void k_seq_canon(uint8_t *seq, uint8_t *comp, uint64_t n16) {
+    const uint64_t i = (uint64_t)blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (i >= n16) return;
+    uint4 w = reinterpret_cast<uint4 *>(seq)[i];
+    w.x = upper4(w.x); w.y = upper4(w.y); w.z = upper4(w.z); w.w = upper4(w.w);
+    reinterpret_cast<uint4 *>(seq)[i] = w;
+    w.x = comp4(w.x); w.y = comp4(w.y); w.z = comp4(w.z); w.w = comp4(w.w);
+    reinterpret_cast<uint4 *>(comp)[i] = w;
+}
+
 /* ---- cfg4 workload: master alignments, genomes, records (paf_synth_core.h; host twin in tools/paf_synth.c) ---- */
 
 /* one wave per contig pair walks the master ops 64 at a time: op count, query length, checkpoints */
@@ -617,7 +629,7 @@ struct paffy_hip_ctx {
     hipStream_t side = nullptr; /* sizing launches of the long-cigar records run here, beside the main launch */
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string last_error;
-    DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, b_list, b_list1, arena, info, synth_sizes, rec_plan, ops_mirror, seq_blob, seq_table, seq_names, seq_name_off, rec_qseq, rec_tseq;
+    DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, b_list, b_list1, arena, info, synth_sizes, rec_plan, ops_mirror, seq_blob, seq_table, seq_names, seq_name_off, rec_qseq, rec_tseq, seq_comp;
     int32_t n_seqs = 0;
     DevBuf synth4_contigs, synth4_q, synth4_t; /* cfg4 workload tables (paffy_hip_synth4_setup) */
     psynth4_cfg synth4_cfg = {0, 0, 0, 0, 0};
@@ -737,7 +749,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     if (!c) return;
     prof_collect(c);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
-                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t,
+                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
                       &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts, &c->scan_part, &c->dedupe_keys, &c->emit_order, &c->order_cnt};
     for (DevBuf *b : bufs)
@@ -879,6 +891,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
                static_cast<const uint32_t *>(c->seq_name_off.p), c->n_seqs, static_cast<int32_t *>(c->rec_qseq.p),
                static_cast<int32_t *>(c->rec_tseq.p));
         kp.seq_base = static_cast<const uint8_t *>(c->seq_blob.p);
+        kp.seq_comp = static_cast<const uint8_t *>(c->seq_comp.p);
         kp.seqs = static_cast<const SeqEntry *>(c->seq_table.p);
         kp.rec_qseq = static_cast<const int32_t *>(c->rec_qseq.p);
         kp.rec_tseq = static_cast<const int32_t *>(c->rec_tseq.p);
@@ -1449,6 +1462,19 @@ static int seq_store_layout(paffy_hip_ctx *c, int64_t n, const char *const *name
     return 0;
 }
 
+/* After the bases are in seq_blob: upper-case them and build the complemented copy. */
+static int seq_store_canon(paffy_hip_ctx *c) {
+    const size_t bytes = c->seq_blob.cap & ~(size_t)15; /* the whole allocation, whole 16-byte words */
+    if (ensure(c, c->seq_comp, c->seq_blob.cap)) return PAFFY_E_HIP;
+    const uint64_t n16 = bytes / 16;
+    if (n16) {
+        LAUNCH(c, "k_seq_canon", k_seq_canon, dim3((unsigned)((n16 + PAFFY_NT - 1) / PAFFY_NT)), dim3(PAFFY_NT), 0, static_cast<uint8_t *>(c->seq_blob.p),
+               static_cast<uint8_t *>(c->seq_comp.p), n16);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
 int paffy_hip_set_sequences(paffy_hip_ctx *c, int64_t n, const char *const *names, const char *const *seqs, const int64_t *lens) {
     if (!c || n < 0 || (n > 0 && (!names || !seqs || !lens))) return PAFFY_E_ARG;
     c->n_seqs = 0;
@@ -1459,6 +1485,7 @@ int paffy_hip_set_sequences(paffy_hip_ctx *c, int64_t n, const char *const *name
     for (int64_t i = 0; i < n; i++)
         if (lens[i] > 0)
             HIPCHK(c, hipMemcpy(static_cast<uint8_t *>(c->seq_blob.p) + blob_off[(size_t)i], seqs[i], (size_t)lens[i], hipMemcpyHostToDevice));
+    if (seq_store_canon(c)) return PAFFY_E_HIP;
     c->n_seqs = (int32_t)n;
     return 0;
 }
@@ -1631,6 +1658,7 @@ int paffy_hip_synth4_setup(paffy_hip_ctx *c, uint64_t seed, uint32_t mean_ops, u
         LAUNCH(c, "k_synth4_target", k_synth4_target, dim3(t_blocks), dim3(PAFFY_NT), 0, cfg, k, ct[k].tlen, blob + blob_off[n_contigs + k]);
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (seq_store_canon(c)) return PAFFY_E_HIP;
     c->n_seqs = (int32_t)names.size();
     return 0;
 }

@@ -1052,30 +1052,26 @@ __device__ __forceinline__ uint32_t equal4(uint32_t a, uint32_t b) { /* bit j = 
     const uint32_t r = (~nonzero4(a ^ b) & 0x80808080u) >> 7;
     return (r | (r >> 7) | (r >> 14) | (r >> 21)) & 0xfu;
 }
-/* bit j = toupper(T[tj + j]) == toupper(query base of column j), j < 16; q points at Q[qoff] (+ strand: columns go up; - strand:
- * column j is the complement of Q[qoff - j]). `lowest`: first byte of the sequence store (nothing in front of it is read). */
+/* bit j = T[j] == query base of column j, j < 16, on the canonical copies of the sequences (upper case; for the - strand the
+ * complemented copy): q points at column 0 (+ strand: columns go up; - strand: column j is q[-j]). `lowest`: first byte of the
+ * store q points into (nothing in front of it is read). */
 __device__ __forceinline__ uint32_t match_mask16(const uint8_t *lowest, const uint8_t *q, const uint8_t *t, bool same) {
     const uint64_t t0 = *reinterpret_cast<const u64_unaligned *>(t), t1 = *reinterpret_cast<const u64_unaligned *>(t + 8);
-    const uint32_t tw[4] = {upper4((uint32_t)t0), upper4((uint32_t)(t0 >> 32)), upper4((uint32_t)t1), upper4((uint32_t)(t1 >> 32))};
     uint32_t qw[4];
     if (same) {
         const uint64_t q0 = *reinterpret_cast<const u64_unaligned *>(q), q1 = *reinterpret_cast<const u64_unaligned *>(q + 8);
-        qw[0] = upper4((uint32_t)q0); qw[1] = upper4((uint32_t)(q0 >> 32)); qw[2] = upper4((uint32_t)q1); qw[3] = upper4((uint32_t)(q1 >> 32));
+        qw[0] = (uint32_t)q0; qw[1] = (uint32_t)(q0 >> 32); qw[2] = (uint32_t)q1; qw[3] = (uint32_t)(q1 >> 32);
     } else if (q - 15 >= lowest) {
         const uint64_t q0 = *reinterpret_cast<const u64_unaligned *>(q - 15), q1 = *reinterpret_cast<const u64_unaligned *>(q - 7);
-        /* byte 15 - j of the 16 loaded is Q[qoff - j] */
-        qw[0] = comp4(upper4(__builtin_bswap32((uint32_t)(q1 >> 32)))); qw[1] = comp4(upper4(__builtin_bswap32((uint32_t)q1)));
-        qw[2] = comp4(upper4(__builtin_bswap32((uint32_t)(q0 >> 32)))); qw[3] = comp4(upper4(__builtin_bswap32((uint32_t)q0)));
+        /* byte 15 - j of the 16 loaded is column j */
+        qw[0] = __builtin_bswap32((uint32_t)(q1 >> 32)); qw[1] = __builtin_bswap32((uint32_t)q1);
+        qw[2] = __builtin_bswap32((uint32_t)(q0 >> 32)); qw[3] = __builtin_bswap32((uint32_t)q0);
     } else { /* the chunk would reach in front of the store: single bytes (the caller masks the columns beyond the op) */
         qw[0] = qw[1] = qw[2] = qw[3] = 0;
         for (int j = 0; j < 16; j++)
-            if (q - j >= lowest) qw[j >> 2] |= up_base(rc_base(*(q - j))) << (8 * (j & 3));
+            if (q - j >= lowest) qw[j >> 2] |= (uint32_t)*(q - j) << (8 * (j & 3));
     }
-    return equal4(tw[0], qw[0]) | (equal4(tw[1], qw[1]) << 4) | (equal4(tw[2], qw[2]) << 8) | (equal4(tw[3], qw[3]) << 12);
-}
-__device__ __forceinline__ int64_t shfl_i64(int64_t x, int src) {
-    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)x, src), hi = (uint32_t)__shfl((int)(uint32_t)((uint64_t)x >> 32), src);
-    return (int64_t)(((uint64_t)hi << 32) | lo);
+    return equal4((uint32_t)t0, qw[0]) | (equal4((uint32_t)(t0 >> 32), qw[1]) << 4) | (equal4((uint32_t)t1, qw[2]) << 8) | (equal4((uint32_t)(t1 >> 32), qw[3]) << 12);
 }
 __device__ __forceinline__ int64_t wave_first_i64(int64_t x) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)x >> 32));
@@ -1141,7 +1137,7 @@ __device__ __forceinline__ uint32_t mismatch_count_wave(const KParams &P, const 
         const uint32_t iinc = wave_incl_scan_u32(nch);
         const uint32_t ioff = iinc - nch, n_items = wave_last_u32(iinc);
         const uint32_t opw = ((uint32_t)len << 3) | (uint32_t)op;
-        const uint8_t *Tw = T + tj0, *Qw = Q + qoff0;
+        const uint8_t *Tw = T + tj0, *Qw = (s.same ? Q : P.seq_comp + (Q - P.seq_base)) + qoff0; /* - strand: the complemented copy */
         uint32_t carry_m = 0; /* mask of the last item of the iteration before */
         for (uint32_t c0 = 0; c0 < n_items; c0 += 64) {
             const uint32_t c = c0 + lane;
@@ -1162,7 +1158,7 @@ __device__ __forceinline__ uint32_t mismatch_count_wave(const KParams &P, const 
             uint32_t m = 0, word = ow;
             if (item_m) {
                 const uint32_t nb = olen - k < 16u ? olen - k : 16u;
-                m = match_mask16(P.seq_base, s.same ? Qw + (oq + k) : Qw - (oq + k), Tw + (ot + k), s.same) & ((1u << nb) - 1u);
+                m = match_mask16(P.seq_comp, s.same ? Qw + (oq + k) : Qw - (oq + k), Tw + (ot + k), s.same) & ((1u << nb) - 1u);
                 word = (uint32_t)OP_M | (nb << 3) | (m << 8) | (k == 0 ? 1u << 24 : 0u) | (k + 16u >= olen ? 1u << 25 : 0u);
             }
             if (act) items[written + c] = word;
@@ -1186,8 +1182,9 @@ __device__ __forceinline__ uint32_t mismatch_count_wave(const KParams &P, const 
 }
 
 /* Walk 2: the wave's item words, 64 at a time, become the ops blk[out_base ..): no op is looked at again. */
-__device__ __forceinline__ void mismatch_fill_wave(const uint32_t *items, uint32_t n_items, uint32_t out_base, uint32_t *blk) {
+__device__ __forceinline__ uint32_t mismatch_fill_wave(const uint32_t *items, uint32_t n_items, uint32_t out_base, uint32_t *blk) {
     const uint32_t lane = threadIdx.x & 63u;
+    uint32_t text = 0; /* bytes of cigar text of the ops this lane wrote (digits + letter) */
     uint32_t done = out_base; /* ops written so far; wave-uniform */
     uint32_t carry_m = 0;     /* mask of the last item of the iteration before */
     int32_t carry_start = 0;  /* column (16 * item + bit) of the last run start seen */
@@ -1225,18 +1222,25 @@ __device__ __forceinline__ void mismatch_fill_wave(const uint32_t *items, uint32
                 if (!(first && j == 0)) { /* the run in front of this start ends here */
                     const uint32_t before = j ? (m >> (j - 1u)) & 1u : prevbit;
                     blk[idx - 1u] = ((uint32_t)(pos - prev) << 3) | (before ? (uint32_t)OP_EQ : (uint32_t)OP_X);
+                    text += dec_len_u32((uint32_t)(pos - prev)) + 1u;
                 }
                 prev = pos;
                 idx++;
             }
-            if ((w >> 25) & 1u) blk[idx - 1u] = ((uint32_t)(col0 + (int32_t)nb - prev) << 3) | (((m >> (nb - 1u)) & 1u) ? (uint32_t)OP_EQ : (uint32_t)OP_X);
+            if ((w >> 25) & 1u) {
+                const uint32_t rl = (uint32_t)(col0 + (int32_t)nb - prev);
+                blk[idx - 1u] = (rl << 3) | (((m >> (nb - 1u)) & 1u) ? (uint32_t)OP_EQ : (uint32_t)OP_X);
+                text += dec_len_u32(rl) + 1u;
+            }
         } else if (act) {
             blk[idx] = w;
+            text += dec_len_u32(w >> 3) + 1u;
         }
         const int32_t top = __builtin_amdgcn_readlane(src_incl, 63);
         if (top >= 0) carry_start = __shfl(my_last, top);
         carry_m = __builtin_amdgcn_readlane((int)m, 63);
     }
+    return wave_last_u32(wave_incl_scan_u32(text));
 }
 
 #if defined(PAFFY_ABL) && PAFFY_ABL == 23 /* phase clock of the LDS-class mismatch encoder (device printf per sampled record) */
@@ -1250,7 +1254,7 @@ __device__ __forceinline__ void mismatch_fill_wave(const uint32_t *items, uint32
 #endif
 __device__ __forceinline__ int encode_mismatch_runs_lds(const KParams &P, const RecState &s, View<OpsLds> &v, OpsLds &ops, uint32_t cap, const uint8_t *Q,
                                                         int64_t qseq_len, const uint8_t *T, int64_t tseq_len, BlockComm &bc, Shared *sh, uint32_t *n_out,
-                                                        uint64_t *blk_off, bool keep_lds) {
+                                                        uint64_t *blk_off, bool keep_lds, int64_t *text_out) {
     ABL23_DECL
     /* an even split of the ops over the threads, so that the four waves get a quarter each whatever the record's size */
     const uint32_t b = (uint32_t)((uint64_t)v.n * threadIdx.x / PAFFY_NT), e = (uint32_t)((uint64_t)v.n * (threadIdx.x + 1) / PAFFY_NT);
@@ -1296,11 +1300,14 @@ __device__ __forceinline__ int encode_mismatch_runs_lds(const KParams &P, const 
     if (off + slots > P.arena_cap) return -2;
     uint32_t *blk = reinterpret_cast<uint32_t *>(P.arena + off);
     ABL23_MARK(2)
-    mismatch_fill_wave(items, n_items, out_base, blk);
+    const uint32_t wtext = mismatch_fill_wave(items, n_items, out_base, blk);
     ABL23_MARK(3)
     __syncthreads(); /* every op of the old array has been read, every op of the new one written */
     *blk_off = off;
-    if (!keep_lds) { /* last stage: LDS keeps the old ops (the record check runs on them), the line is sized from the block */
+    if (!keep_lds) { /* last stage: LDS keeps the old ops (the record check runs on them), the line is sized from the walk */
+        uint32_t tw[1] = {lane == 0 ? wtext : 0u}, ttot[1];
+        block_excl_scan_u32<1>(tw, ttot, bc);
+        *text_out = ttot[0];
         ABL23_MARK(4)
         ABL23_PRINT
         return 0;
@@ -2715,6 +2722,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
     bool swapped = false, shatter = false;
     bool ops_in_arena = false; /* LDS class whose op array was rebuilt: 4-byte ops in an arena block instead of the mirror */
     bool ops_block_only = false; /* ... by the last stage: the new ops are in that block only, LDS still holds the old ones */
+    int64_t block_text = 0;      /* ... and their cigar text takes this many bytes */
     uint64_t arena_block = 0;
     bool checked = false; /* a paf_check has passed since the record last changed */
     int32_t si = 0;
@@ -2771,7 +2779,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
                     uint32_t n2 = 0;
                     const bool last = si == P.n_stages - 1; /* nothing reads the new ops but the line writer: they need not fit LDS */
                     const int r = encode_mismatch_runs_lds(P, s, v, ops, cap, P.seq_base + P.seqs[qi].off, P.seqs[qi].len, P.seq_base + P.seqs[ti].off,
-                                                           P.seqs[ti].len, L.bc, L.sh, &n2, &arena_block, !last);
+                                                           P.seqs[ti].len, L.bc, L.sh, &n2, &arena_block, !last, &block_text);
                     if (r == -1) return false; /* wider than the narrow path: arena class */
                     if (r == -2) return true;  /* arena full: repeated by the host */
                     if (r == -3) {             /* more ops than this store holds */
@@ -2864,7 +2872,9 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
         line_kernel = OPS::kNarrow && lenH + 8 <= PAFFY_TMPL_MAX && v.n <= PAFFY_ROWS_MAX_OPS; /* written by k_emit_line */
         bytes = lenH;
         if (!nl_in_header) {
-            if (ops_block_only) {
+            if (ops_block_only && line_kernel) { /* one wave writes the line: no per-wave starts needed */
+                bytes += block_text + 1;
+            } else if (ops_block_only) {
                 View<OpsCoherent> gv;
                 gv.reset(OpsCoherent{reinterpret_cast<const uint32_t *>(P.arena + arena_block)}, v.n);
                 bytes += cigar_text_len(gv, plan, L.bc) + 1;

@@ -69,7 +69,8 @@ struct KParams {
     void *rec_plan; /* RecPlan[n_rec] */
     uint32_t *ops_mirror; /* 4-byte ops of LDS-class records, indexed from cg_off / 2 */
     /* add_mismatches: sequences in HBM and, per record, the index of its query / target sequence (-1: absent) */
-    const uint8_t *seq_base;
+    const uint8_t *seq_base; /* upper-cased when loaded (every comparison is of toupper'ed bases, impl/paf.c:752-757) */
+    const uint8_t *seq_comp; /* the same bytes complemented (A<->T, C<->G): what the - strand compares, read backwards */
     const SeqEntry *seqs;
     const int32_t *rec_qseq;
     const int32_t *rec_tseq;

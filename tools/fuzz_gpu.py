@@ -101,7 +101,7 @@ def fuzz_mismatches(eng, rng, budget):
     while time.time() - t0 < budget:
         seqs = {}
         for i in range(rng.randrange(1, 4)):
-            L = rng.choice([50, 2000, 60000])
+            L = rng.choice([50, 2000, 60000, 250000])
             tseq = "".join(rng.choice("ACGTacgtN" if rng.random() < 0.2 else "ACGT") for _ in range(L))
             seqs[f"t{i}"] = tseq
             q = list(tseq)
@@ -112,7 +112,7 @@ def fuzz_mismatches(eng, rng, budget):
         for _ in range(rng.choice([1, 20, 120])):
             i = rng.randrange(len(seqs) // 2)
             L = len(seqs[f"t{i}"])
-            recs.append(consistent_record(rng, f"q{i}", L, f"t{i}", L, rng.choice([1, 9, 200]), rng.choice([[1, 2], [7, 30], [100, 900]])))
+            recs.append(consistent_record(rng, f"q{i}", L, f"t{i}", L, rng.choice([1, 9, 200, 200, 3000, 9000, 20000]), rng.choice([[1, 2], [7, 30], [100, 900], [1, 17, 40]])))
         data = "".join(recs).encode()
         want, werr = O.run([O.stage(O.ADD_MISMATCHES)], data, seqs)
         eng.set_sequences(seqs)
@@ -123,6 +123,12 @@ def fuzz_mismatches(eng, rng, budget):
             got2 = eng.run([paffy_amd.stage(paffy_amd.ADD_MISMATCHES), paffy_amd.stage(paffy_amd.REMOVE_MISMATCHES), paffy_amd.stage(paffy_amd.SHATTER)], data,
                            raise_on_error=False)[0]
             ok = got2 == want2
+            for pipe in ([O.INVERT, O.ADD_MISMATCHES], [O.ADD_MISMATCHES, O.TRIM_IDENTITY], [O.TRIM_FIXED, O.ADD_MISMATCHES, O.INVERT]):
+                if not ok:
+                    break
+                w3, e3 = O.run([O.stage(k, 0.2, 0.5) for k in pipe], data, seqs)
+                g3, i3 = eng.run([paffy_amd.stage(k, 0.2, 0.5) for k in pipe], data, raise_on_error=False)
+                ok = g3 == w3 and i3.error.code == e3.code
         if not ok:
             with open(os.path.join(ROOT, "gpurun_out", "fuzz_mism_fail.paf"), "wb") as fh:
                 fh.write(data)
