@@ -36,7 +36,9 @@ enum {
     PAFFY_ADD_MISMATCHES = 5,    /* impl/paf_add_mismatches.c:113-131: paf_encode_mismatches          */
     PAFFY_REMOVE_MISMATCHES = 6, /* impl/paf_add_mismatches.c:110-112: paf_remove_mismatches          */
     PAFFY_PASS = 7,              /* paf_read -> paf_write only (normalises tags, impl/paf.c:317-389)  */
-    PAFFY_FILTER = 8             /* impl/paf_filter.c:120-156: records failing the thresholds of paffy_hip_set_filter vanish */
+    PAFFY_FILTER = 8,            /* impl/paf_filter.c:120-156: records failing the thresholds of paffy_hip_set_filter vanish */
+    PAFFY_TRIM_ENDS = 9          /* paf_trim_ends(paf, n), impl/paf.c:575-598: n aligned bases off each end; n = the 64 bits of (p0, p1),
+                                    see paffy_stage_trim_ends(); then paf_check like the other trims */
 };
 #define PAFFY_MAX_STAGES 8
 
@@ -45,6 +47,17 @@ typedef struct {
     float p0; /* trim: trim_by_identity_fraction, a float as in impl/paf_trim.c:16 (default 0.05) */
     float p1; /* trim: trim_end_fraction, a float as in impl/paf_trim.c:14 (default 1.0)          */
 } paffy_stage;
+
+/* PAFFY_TRIM_ENDS carries its int64 argument in the two float slots, bit for bit. */
+static inline paffy_stage paffy_stage_trim_ends(int64_t end_bases) {
+    paffy_stage s;
+    union { int64_t i; float f[2]; } u;
+    u.i = end_bases;
+    s.kind = PAFFY_TRIM_ENDS;
+    s.p0 = u.f[0];
+    s.p1 = u.f[1];
+    return s;
+}
 
 /* Record-level failures: what the reference turns into st_errAbort / assert / a crash. */
 enum {
@@ -148,6 +161,24 @@ int paffy_hip_sync(paffy_hip_ctx *ctx);
 /* Host-buffer convenience used by the CLI drivers: H2D, plan, emit, D2H. *h_out is malloc'ed. */
 int paffy_hip_run_host(paffy_hip_ctx *ctx, const paffy_stage *stages, int32_t n_stages, const char *h_in, int64_t in_len,
                        char **h_out, int64_t *out_len, paffy_plan_info *info);
+
+/*
+ * Records as structs, for hosts that hold `Paf` objects (the per-record API of inc/paf.h:75-269, host/paf_api.c): the text is
+ * parsed on the GPU (paf_parse + cigar_parse, impl/paf.c:70-209) and the fields come back as arrays -- one paffy_record per line,
+ * names and cigar text as slices of h_in, the ops of all records back to back in the CigarRecord layout of inc/paf.h:61-64
+ * (bits 0-55 length, bits 56-63 op). *recs and *ops are malloc'ed. A failing line is reported in info->error and nothing is returned.
+ */
+typedef struct {
+    int64_t query_length, query_start, query_end, target_length, target_start, target_end;
+    int64_t score, mapping_quality, num_matches, num_bases, tile_level, chain_id, chain_score;
+    int64_t ops_first; /* index of this record's first op in *ops */
+    int64_t n_ops;     /* -1: no cigar (Paf.cigar == NULL: no cg tag, or an empty one) */
+    uint32_t query_name_off, query_name_len, target_name_off, target_name_len;
+    uint32_t cigar_off, cigar_len; /* the cg:Z: value in h_in (cigar_len 0: none) */
+    uint8_t same_strand, type, pad[6];
+} paffy_record;
+int paffy_hip_parse_host(paffy_hip_ctx *ctx, const char *h_in, int64_t in_len, paffy_record **recs, uint64_t **ops, int64_t *n_ops_total,
+                         paffy_plan_info *info);
 
 /*
  * Sequences for PAFFY_ADD_MISMATCHES: what the reference loads with fastaReadToFunction into a

@@ -826,7 +826,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     bool need_seqs = false;
     for (int32_t i = 0; i < n_stages; i++) {
         int k = stages[i].kind;
-        bool ok = k == PAFFY_INVERT || k == PAFFY_TRIM_IDENTITY || k == PAFFY_TRIM_FIXED || k == PAFFY_PASS || k == PAFFY_FILTER ||
+        bool ok = k == PAFFY_INVERT || k == PAFFY_TRIM_IDENTITY || k == PAFFY_TRIM_FIXED || k == PAFFY_TRIM_ENDS || k == PAFFY_PASS || k == PAFFY_FILTER ||
                   k == PAFFY_REMOVE_MISMATCHES || (k == PAFFY_ADD_MISMATCHES && c->n_seqs > 0) ||
                   (k == PAFFY_SHATTER && i == n_stages - 1);
         if (k == PAFFY_ADD_MISMATCHES) need_seqs = true;
@@ -1420,6 +1420,74 @@ int paffy_hip_run_host(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_st
     }
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
+int paffy_hip_parse_host(paffy_hip_ctx *c, const char *h_in, int64_t in_len, paffy_record **recs, uint64_t **ops, int64_t *n_ops_total,
+                         paffy_plan_info *info) {
+    if (!c || !recs || !ops || !n_ops_total || !info || in_len < 0 || (in_len > 0 && !h_in)) return PAFFY_E_ARG;
+    *recs = nullptr;
+    *ops = nullptr;
+    *n_ops_total = 0;
+    void *d_in = nullptr;
+    int rc = 0;
+    if (in_len > 0) {
+        HIPCHK(c, hipMalloc(&d_in, (size_t)in_len + 64));
+        if (hipMemcpy(d_in, h_in, (size_t)in_len, hipMemcpyHostToDevice) != hipSuccess) rc = PAFFY_E_HIP;
+    }
+    const paffy_stage pass = {PAFFY_PASS, 0.0f, 0.0f};
+    if (!rc) rc = paffy_hip_plan(c, &pass, 1, d_in, in_len, info); /* index, header parse, cigar parse: the ops are in the mirror / arena */
+    const size_t n = (size_t)info->n_records;
+    if (!rc && info->error.code == 0 && n > 0) {
+        std::vector<RecMeta> meta(n);
+        std::vector<RecPlan> plan(n);
+        std::vector<uint32_t> status(n), mirror((size_t)in_len / 2 + 64);
+        std::vector<uint64_t> arena_off(n), arena((size_t)c->h_info->arena_used);
+        if (hipMemcpy(meta.data(), c->meta.p, sizeof(RecMeta) * n, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(plan.data(), c->rec_plan.p, sizeof(RecPlan) * n, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(status.data(), c->status.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(arena_off.data(), c->arena_off.p, sizeof(uint64_t) * n, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(mirror.data(), c->ops_mirror.p, sizeof(uint32_t) * mirror.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+            (!arena.empty() && hipMemcpy(arena.data(), c->arena.p, sizeof(uint64_t) * arena.size(), hipMemcpyDeviceToHost) != hipSuccess)) {
+            c->last_error = "paffy_hip_parse_host: copy back failed";
+            rc = PAFFY_E_HIP;
+        } else {
+            int64_t total = 0;
+            for (size_t r = 0; r < n; r++)
+                if (plan[r].flags & 8u) total += plan[r].n;
+            paffy_record *out = static_cast<paffy_record *>(calloc(n, sizeof(paffy_record)));
+            uint64_t *oo = static_cast<uint64_t *>(malloc(sizeof(uint64_t) * (size_t)(total > 0 ? total : 1)));
+            int64_t at = 0;
+            for (size_t r = 0; r < n; r++) {
+                const RecMeta &m = meta[r];
+                paffy_record &o = out[r];
+                o.query_length = m.qlen; o.query_start = m.qs; o.query_end = m.qe;
+                o.target_length = m.tlen; o.target_start = m.ts; o.target_end = m.te;
+                o.score = m.score; o.mapping_quality = m.mapq; o.num_matches = m.nmatch; o.num_bases = m.nbases;
+                o.tile_level = m.tile_level; o.chain_id = m.chain_id; o.chain_score = m.chain_score;
+                o.query_name_off = m.qname_off; o.query_name_len = m.qname_len; o.target_name_off = m.tname_off; o.target_name_len = m.tname_len;
+                o.cigar_off = m.has_cg ? m.cg_off : 0; o.cigar_len = m.has_cg ? m.cg_len : 0;
+                o.same_strand = m.same_strand; o.type = m.type;
+                o.ops_first = at;
+                o.n_ops = -1;
+                if (plan[r].flags & 8u) { /* has a cigar: the ops as parsed (a pass stage leaves the view on the whole array) */
+                    o.n_ops = plan[r].n;
+                    if ((status[r] >> 16) == KLASS_ARENA) {
+                        const uint64_t *src = arena.data() + arena_off[r];
+                        for (uint32_t i = 0; i < plan[r].n; i++) oo[at++] = (((uint64_t)((int64_t)src[i] >> 8)) & 0x00ffffffffffffffull) | ((src[i] & 0xffull) << 56);
+                    } else {
+                        const uint32_t *src = mirror.data() + (m.cg_off >> 1);
+                        for (uint32_t i = 0; i < plan[r].n; i++) oo[at++] = (uint64_t)(src[i] >> 3) | ((uint64_t)(src[i] & 7u) << 56);
+                    }
+                }
+            }
+            *recs = out;
+            *ops = oo;
+            *n_ops_total = at;
+        }
+    }
+    c->planned = false; /* the input buffer goes away */
+    if (d_in) (void)hipFree(d_in);
     return rc;
 }
 

@@ -777,8 +777,8 @@ __device__ __forceinline__ void trim_front_fixed(View<OPS> &v, int64_t end, int6
 
 /* paf_trim_end_fraction + paf_trim_ends, impl/paf.c:578-598. */
 template <class OPS>
-__device__ __forceinline__ int trim_fixed(RecState &s, View<OPS> &v, float pct, BlockComm &bc, Shared *sh) {
-    if (!(pct >= 0.0f && pct <= 1.0f)) return PAFFY_ERR_TRIM_FIXED_ASSERT;
+__device__ __forceinline__ int trim_fixed(RecState &s, View<OPS> &v, float pct, BlockComm &bc, Shared *sh, bool by_count = false, int64_t count = 0) {
+    if (!by_count && !(pct >= 0.0f && pct <= 1.0f)) return PAFFY_ERR_TRIM_FIXED_ASSERT;
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
     int64_t a[1] = {0};
@@ -789,7 +789,7 @@ __device__ __forceinline__ int trim_fixed(RecState &s, View<OPS> &v, float pct, 
         if (is_aligned_op(op)) a[0] += len;
     }
     block_sum<1>(a, bc);
-    const int64_t end = __double2ll_rz((double)__fmul_rn(__ll2float_rn(a[0]), pct) / 2.0);
+    const int64_t end = by_count ? count : __double2ll_rz((double)__fmul_rn(__ll2float_rn(a[0]), pct) / 2.0); /* paf_trim_ends / paf_trim_end_fraction */
     if (!s.has_cigar) return PAFFY_ERR_NULL_CIGAR;
     int64_t dq, dt;
     trim_front_fixed(v, end, dq, dt, bc, sh);
@@ -2746,6 +2746,10 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
             PT_MARK(3)
         } else if (STAGE_ON(PAFFY_TRIM_FIXED) && st.kind == PAFFY_TRIM_FIXED) {
             rc = trim_fixed(s, v, st.p1, L.bc, L.sh);
+            if (!rc) rc = check_record(s, v, L.bc);
+        } else if (STAGE_ON(PAFFY_TRIM_ENDS) && st.kind == PAFFY_TRIM_ENDS) {
+            const int64_t count = (int64_t)(((uint64_t)__float_as_uint(st.p1) << 32) | (uint64_t)__float_as_uint(st.p0));
+            rc = trim_fixed(s, v, 0.0f, L.bc, L.sh, true, count);
             if (!rc) rc = check_record(s, v, L.bc);
         } else if (STAGE_ON(PAFFY_REMOVE_MISMATCHES) && st.kind == PAFFY_REMOVE_MISMATCHES) {
             if (s.has_cigar) {

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 _LIB = os.environ.get("PAFFY_HIP_LIB", os.path.join(HERE, "libpaffy_hip.so"))  # override for A/B experiments only
 
-INVERT, TRIM_IDENTITY, TRIM_FIXED, SHATTER, ADD_MISMATCHES, REMOVE_MISMATCHES, PASS, FILTER = 1, 2, 3, 4, 5, 6, 7, 8
+INVERT, TRIM_IDENTITY, TRIM_FIXED, SHATTER, ADD_MISMATCHES, REMOVE_MISMATCHES, PASS, FILTER, TRIM_ENDS = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 
 class Stage(C.Structure):
@@ -46,6 +46,16 @@ class PafError(RuntimeError):
 def stage(kind, trim_identity=0.05, trim_fraction=1.0):
     """One command of a pipe. trim_identity = `paffy trim -r`, trim_fraction = `-t` (impl/paf_trim.c:14-16)."""
     return Stage(kind, trim_identity, trim_fraction)
+
+
+def stage_trim_ends(end_bases):
+    """paf_trim_ends(paf, end_bases) (impl/paf.c:575-598): the int64 argument travels in the two float slots, bit for bit."""
+    import struct
+
+    p0, p1 = struct.unpack("<ff", struct.pack("<q", end_bases))
+    st = Stage(TRIM_ENDS, 0.0, 0.0)
+    C.memmove(C.addressof(st) + Stage.p0.offset, struct.pack("<ff", p0, p1), 8)  # no float round trip: NaN payloads must survive
+    return st
 
 
 def library_path():

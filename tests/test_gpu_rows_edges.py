@@ -140,3 +140,33 @@ def test_fuzz_regressions(eng):
         with open(path, "rb") as fh:
             data = fh.read()
         run_both(eng, data, ([O.SHATTER], [O.PASS], [O.INVERT, O.SHATTER]))
+
+
+def test_trim_ends_stage_equals_paf_trim_ends():
+    """PAFFY_TRIM_ENDS (the stage behind paf_trim_ends of the per-record API) against the oracle's paf_trim_ends on the
+    reference's known answers (tests/paf_unit_test.c:413-457) and on fixture records, both strands, several counts."""
+    import os
+
+    import paffy_amd
+
+    eng = paffy_amd.Engine()
+    lines = [b"q\t100\t5\t15\t+\tt\t100\t5\t15\t10\t10\t60\tcg:Z:10M\n", b"q\t100\t0\t10\t+\tt\t100\t0\t10\t10\t10\t60\tcg:Z:10M\n",
+             b"q\t100\t0\t8\t+\tt\t100\t0\t7\t7\t8\t60\tcg:Z:2M1I5M\n", b"q\t100\t0\t8\t-\tt\t100\t0\t7\t7\t8\t60\tcg:Z:2M1I5M\n",
+             b"q\t100\t0\t13\t-\tt\t100\t0\t12\t10\t15\t60\tcg:Z:5M3I2D4=1X\n"]
+    with open(os.path.join(os.path.dirname(__file__), "golden", "human_chimp.paf"), "rb") as fh:
+        lines += fh.read().splitlines(keepends=True)[:60]
+    checked = 0
+    for count in (0, 1, 2, 3, 7, 40, 1000):
+        want = []
+        for ln in lines:
+            rc, out = O.trim_ends_line(ln, count)
+            want.append(out if rc == 0 else None)
+        keep = [ln for ln, w in zip(lines, want) if w is not None]
+        got, info = eng.run([paffy_amd.stage_trim_ends(count)], b"".join(keep), raise_on_error=False)
+        # the stage also runs paf_check like the command loops: compare the records the oracle's check accepts too
+        ok = [w for w in want if w is not None]
+        if info.error.code == 0:
+            assert got == b"".join(ok), count
+            checked += len(ok)
+    assert checked > 200
+    eng.close()
