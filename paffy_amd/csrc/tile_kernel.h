@@ -48,11 +48,13 @@ struct TileParams {
 };
 
 #define TILE_SLICE_SHIFT 20 /* 1 Mi bases per slice */
-#define TILE_PAIRS 16       /* distinct levels a (record, slice) partial histogram can hold */
+#define TILE_PAIRS 128      /* distinct levels a (record, slice) partial histogram can hold: at coverage c the new counts of one
+                               record spread over about 8 sqrt(c) levels, so 128 serves coverage in the hundreds */
 
-struct TilePartial {
+struct TilePartial { /* pairs in increasing level order */
     uint32_t n, overflow;
-    uint32_t level[TILE_PAIRS], count[TILE_PAIRS];
+    uint16_t level[TILE_PAIRS]; /* < TILE_HIST in sliced mode */
+    uint32_t count[TILE_PAIRS];
 };
 
 /* first / last slice a record's query range touches (host and device use the same arithmetic) */
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_tile_slices(TileParams P) {
             const uint32_t h = hist[base + i];
             if (h) {
                 if (o < TILE_PAIRS) {
-                    part->level[o] = base + i;
+                    part->level[o] = (uint16_t)(base + i);
                     part->count[o] = h;
                 }
                 o++;
@@ -438,24 +440,41 @@ __global__ __launch_bounds__(PAFFY_NT) void k_tile_merge(TileParams P, uint32_t 
         for (uint32_t i = 0; i < part[s].n; i++) aligned += part[s].count[i];
     int64_t level = 32767; /* no aligned base */
     if (aligned > 0) {
-        /* walk the levels in increasing order: repeatedly take the smallest level above the last one */
+        /* the partial histograms are sorted by level: merge them, smallest level first, until half the bases are covered */
+        const uint32_t ns = s1 - s0 + 1;
         uint64_t acc = 0;
-        int64_t last = -1;
         level = -1;
-        for (;;) {
-            uint32_t best = 0xffffffffu;
-            for (uint32_t s = 0; s <= s1 - s0; s++)
-                for (uint32_t i = 0; i < part[s].n; i++)
-                    if ((int64_t)part[s].level[i] > last && part[s].level[i] < best) best = part[s].level[i];
-            if (best == 0xffffffffu) break;
-            for (uint32_t s = 0; s <= s1 - s0; s++)
-                for (uint32_t i = 0; i < part[s].n; i++)
-                    if (part[s].level[i] == best) acc += part[s].count[i];
-            if (2 * acc >= aligned) {
-                level = best;
-                break;
+        if (ns <= 8) {
+            uint32_t cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (;;) {
+                uint32_t best = 0xffffffffu;
+                for (uint32_t s = 0; s < ns; s++)
+                    if (cur[s] < part[s].n && part[s].level[cur[s]] < best) best = part[s].level[cur[s]];
+                if (best == 0xffffffffu) break;
+                for (uint32_t s = 0; s < ns; s++)
+                    if (cur[s] < part[s].n && part[s].level[cur[s]] == best) acc += part[s].count[cur[s]++];
+                if (2 * acc >= aligned) {
+                    level = best;
+                    break;
+                }
             }
-            last = best;
+        } else { /* a record over more than eight slices: no cursors, repeatedly take the smallest level above the last one */
+            int64_t last = -1;
+            for (;;) {
+                uint32_t best = 0xffffffffu;
+                for (uint32_t s = 0; s < ns; s++)
+                    for (uint32_t i = 0; i < part[s].n; i++)
+                        if ((int64_t)part[s].level[i] > last && part[s].level[i] < best) best = part[s].level[i];
+                if (best == 0xffffffffu) break;
+                for (uint32_t s = 0; s < ns; s++)
+                    for (uint32_t i = 0; i < part[s].n; i++)
+                        if (part[s].level[i] == best) acc += part[s].count[i];
+                if (2 * acc >= aligned) {
+                    level = best;
+                    break;
+                }
+                last = best;
+            }
         }
         if (level <= 0) { /* assert(i > 0) / assert(0) */
             P.err_aux[rec] = 3;

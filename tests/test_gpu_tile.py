@@ -104,7 +104,7 @@ def test_errors_and_edges(eng):
 def kernels_used(eng, data):
     eng.profile(True)
     check(eng, data)
-    names = set(eng.profile_read())
+    names = {k for k, (ms, launches) in eng.profile_read().items() if launches > 0}
     eng.profile(False)
     return names
 
@@ -126,9 +126,16 @@ def test_sliced_path_and_fallback(eng):
     data = "".join(lines[:12]).encode()
     used = kernels_used(eng, data)
     assert "k_tile_slices" in used and "k_tile" not in used
-    data = "".join(lines).encode()      # deep, ragged pile: more than 16 distinct levels in a slice
+    data = "".join(lines).encode()      # deep, ragged pile: dozens of distinct levels in one (record, slice) histogram
     used = kernels_used(eng, data)
-    assert "k_tile_slices" in used
+    assert "k_tile_slices" in used and "k_tile" not in used
+    # a staircase: record k covers [100 k, 100 k + 20000), the last record spans them all and meets 150 distinct levels
+    stairs = [f"st\t100000\t{100 * k}\t{100 * k + 20000}\t+\tt\t9000000\t0\t20000\t20000\t20000\t60\tAS:i:{1000 - k}\tcg:Z:20000M\n" for k in range(150)]
+    stairs.append("st\t100000\t0\t40000\t-\tt\t9000000\t0\t40000\t40000\t40000\t60\tAS:i:1\tcg:Z:40000M\n")
+    used = kernels_used(eng, "".join(stairs).encode())  # more than 128 distinct levels: the exact fallback takes over
+    assert "k_tile" in used
+    used = kernels_used(eng, "".join(stairs[:100] + stairs[-1:]).encode())  # 100 levels: still sliced
+    assert "k_tile_slices" in used and "k_tile" not in used
     # levels beyond the 4096-level window
     one = b"deep\t10\t2\t3\t+\tt\t10\t0\t1\t1\t1\t60\tcg:Z:1M\n"
     used = kernels_used(eng, one * 4200)
