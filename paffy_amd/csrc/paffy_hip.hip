@@ -916,7 +916,11 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
                    static_cast<uint32_t *>(c->emit_order.p));
             kp.size_order = static_cast<const uint32_t *>(c->emit_order.p); /* any permutation serves a repeated sizing pass too */
         }
-        for (int attempt = 0; attempt < 3; attempt++) {
+        /* add_mismatches keeps one word per 16 columns and the new 4-byte ops of every record in the arena: about eight times
+           the text for 2 %-divergent sequences; start there instead of finding out through repeated passes */
+        if (need_seqs && ensure(c, c->arena, (size_t)len * 8 + ((size_t)8 << 20))) return PAFFY_E_HIP;
+        const int max_attempts = 6;
+        for (int attempt = 0; attempt < max_attempts; attempt++) {
             kp.arena = static_cast<uint64_t *>(c->arena.p);
             kp.arena_cap = c->arena.cap / 8;
             /* fork: levels 1 and 2 (long cigars, queued by k_header) on the side stream, level 0 on the main one */
@@ -970,7 +974,9 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             if (fetch_info(c)) return PAFFY_E_HIP;
             if (c->h_info->arena_used <= kp.arena_cap) break;
             /* arena too small: grow to the demand seen so far and redo the sizing pass */
+            /* a record that found no room stopped asking, so the demand seen is a lower bound: at least double what there was */
             size_t need = (size_t)c->h_info->arena_used * 8 * 2;
+            if (need < c->arena.cap * 2) need = c->arena.cap * 2;
             if (ensure(c, c->arena, need)) return PAFFY_E_HIP;
             DevInfo z = *c->h_info;
             z.arena_used = 0;
@@ -981,7 +987,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             z.out_bytes = z.out_rows = 0;
             HIPCHK(c, hipMemcpyAsync(c->info.p, &z, sizeof(z), hipMemcpyHostToDevice, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (attempt == 2) {
+            if (attempt == max_attempts - 1) {
                 c->last_error = "arena demand kept growing";
                 return PAFFY_E_HIP;
             }

@@ -146,3 +146,25 @@ def test_cfg4_workload_device_equals_host_and_oracle(eng):
         w, e = O.run(stages, want_recs, seqs)
         g, i = eng.run(gs(stages), want_recs, raise_on_error=False)
         assert i.error.code == e.code and g == w
+
+
+def test_alternating_columns_grow_the_arena(eng):
+    """Every column differs from the one before: sixteen ops per 16-column chunk, far more than the arena was sized for --
+    the sizing pass must be repeated with a bigger arena, and records whose new ops outgrow every LDS store (a stage follows)
+    take the arena class. Equal to the oracle either way."""
+    n = 200_000
+    seqs = {"t": "AC" * (n // 2), "q": "A" * n}
+    recs = []
+    for k in range(40):
+        span = [50, 3000, 20_000, 70_000][k % 4]
+        qs = 17 * k
+        recs.append(f"q\t{n}\t{qs}\t{qs + span}\t+\tt\t{n}\t{qs + 1}\t{qs + 1 + span}\t{span}\t{span}\t60\tcg:Z:{span}M\n")
+    data = "".join(recs).encode()
+    e2 = type(eng)()  # a fresh context: its arena starts small
+    e2.set_sequences(seqs)
+    for stages in ([S(O.ADD_MISMATCHES)], [S(O.ADD_MISMATCHES), S(O.INVERT)]):
+        want, werr = O.run(stages, data, seqs)
+        got, info = e2.run(gs(stages), data, raise_on_error=False)
+        assert werr.code == 0 and info.error.code == 0 and got == want
+    assert want.count(b"1X") > 100_000
+    e2.close()
