@@ -200,7 +200,9 @@ def main():
                        "sharding": "contiguous record batches per rank, no collective"},
             "whole_path_GBps_per_gpu": round(((job_in + job_out) / world + 2.0 * aligned_per_record * args.batch * args.steps) / elapsed / 1e9, 1),
             "roofline": roofline,
-            "roofline_by_kernel": {k: v for k, v in by_kernel.items() if k in ("k_size_lds", "k_emit_rows", "k_emit_lds", "k_emit_lds<line>", "k_emit_line")},
+            # the record kernels that take at least a tenth of the dominant kernel's time (a small kernel priced with the whole batch's bytes says nothing)
+            "roofline_by_kernel": {k: v for k, v in by_kernel.items()
+                                   if k in ("k_size_lds", "k_emit_rows", "k_emit_lds", "k_emit_lds<line>", "k_emit_line") and kernels[k][0] >= 0.1 * max(x[0] for x in kernels.values())},
             "whole_path_frac_of_hbm_peak": round(((job_in + job_out) / world + 2.0 * aligned_per_record * args.batch * args.steps) / elapsed / 1e9 / HBM_PEAK_GBS, 4),
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kernels.items()},

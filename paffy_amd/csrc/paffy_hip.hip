@@ -1027,6 +1027,30 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
  * bytes per record; the per-base coverage walk runs on the GPU, one workgroup per query sequence.
  * Any failing record means nothing is written (the reference writes only after the last record).
  */
+/* Stable LSD radix sort of record indices by a 64-bit key per record (ascending), 16 bits per pass; passes whose digit is the
+ * same for every record are skipped. The host-side orderings of `paffy tile` (a million records) take milliseconds this way. */
+static void radix_sort_by(std::vector<uint32_t> &idx, const std::vector<uint64_t> &key) {
+    const size_t n = idx.size();
+    if (n < 2) return;
+    uint64_t all_or = 0, all_and = ~0ull;
+    for (size_t i = 0; i < n; i++) {
+        all_or |= key[idx[i]];
+        all_and &= key[idx[i]];
+    }
+    std::vector<uint32_t> tmp(n);
+    std::vector<uint32_t> cnt(65537);
+    for (int pass = 0; pass < 4; pass++) {
+        const int sh = 16 * pass;
+        if ((((all_or ^ all_and) >> sh) & 0xffffu) == 0) continue; /* every record has the same digit */
+        std::fill(cnt.begin(), cnt.end(), 0u);
+        for (size_t i = 0; i < n; i++) cnt[((key[idx[i]] >> sh) & 0xffffu) + 1]++;
+        for (size_t d = 0; d < 65536; d++) cnt[d + 1] += cnt[d];
+        for (size_t i = 0; i < n; i++) tmp[cnt[(key[idx[i]] >> sh) & 0xffffu]++] = idx[i];
+        idx.swap(tmp);
+    }
+}
+static inline uint64_t descending_key(int64_t x) { return ~((uint64_t)x ^ 0x8000000000000000ull); } /* ascending in this = descending in x */
+
 int paffy_hip_tile_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, paffy_plan_info *info) {
     if (!c || !info) return PAFFY_E_ARG;
     if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
@@ -1078,10 +1102,11 @@ int paffy_hip_tile_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, paff
     /* visiting order: paf_cmp_by_descending_score, impl/paf_tile.c:28-34, ties in input order (stable) */
     std::vector<uint32_t> order(n);
     for (uint32_t i = 0; i < n; i++) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-        if (keys[a].chain_score != keys[b].chain_score) return keys[a].chain_score > keys[b].chain_score;
-        return keys[a].score > keys[b].score;
-    });
+    std::vector<uint64_t> sort_key(n);
+    for (uint32_t i = 0; i < n; i++) sort_key[i] = descending_key(keys[i].score);
+    radix_sort_by(order, sort_key); /* least significant key first: score, then chain_score; both passes are stable */
+    for (uint32_t i = 0; i < n; i++) sort_key[i] = descending_key(keys[i].chain_score);
+    radix_sort_by(order, sort_key);
     std::vector<uint32_t> rank_of(n);
     for (uint32_t k = 0; k < n; k++) rank_of[order[k]] = k;
     /* query sequences: keyed by (hash, length) of the name; counters are allocated on first sight (impl/paf.c:675-688) */
@@ -1090,10 +1115,10 @@ int paffy_hip_tile_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, paff
     std::vector<std::pair<std::pair<uint64_t, uint32_t>, uint32_t>> index; /* sorted lookup */
     {
         std::vector<uint32_t> by_name(order);
-        std::stable_sort(by_name.begin(), by_name.end(), [&](uint32_t a, uint32_t b) {
-            if (keys[a].name_hash != keys[b].name_hash) return keys[a].name_hash < keys[b].name_hash;
-            return keys[a].name_len < keys[b].name_len;
-        });
+        for (uint32_t i = 0; i < n; i++) sort_key[i] = keys[i].name_len;
+        radix_sort_by(by_name, sort_key);
+        for (uint32_t i = 0; i < n; i++) sort_key[i] = keys[i].name_hash;
+        radix_sort_by(by_name, sort_key);
         for (uint32_t k = 0; k < n; k++) { /* by_name keeps visiting order inside a group (stable) */
             uint32_t r = by_name[k];
             if (contigs.empty() || contigs.back().hash != keys[r].name_hash || contigs.back().name_len != keys[r].name_len)
@@ -1165,8 +1190,33 @@ int paffy_hip_tile_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, paff
             item_off.push_back(0);
             for (size_t ci = 0; ci < contigs.size(); ci++) {
                 /* bucket this sequence's records (already in visiting order) by slice */
-                std::vector<std::pair<uint32_t, uint32_t>> pairs; /* (slice, position in recs) */
                 const auto &recs = contigs[ci].recs;
+                uint32_t top_slice = 0;
+                for (uint32_t r : recs) {
+                    const uint32_t l = tile_last_slice(keys[r].qs, keys[r].qe, keys[r].qlen);
+                    if (l > top_slice) top_slice = l;
+                }
+                if (top_slice < (1u << 22)) { /* the usual case: a counting sort over the sequence's slices */
+                    std::vector<uint32_t> at(top_slice + 2, 0u);
+                    for (uint32_t r : recs)
+                        for (uint32_t sl = tile_first_slice(keys[r].qs, keys[r].qe, keys[r].qlen); sl <= tile_last_slice(keys[r].qs, keys[r].qe, keys[r].qlen); sl++)
+                            at[sl + 1]++;
+                    const size_t base = item_recs.size();
+                    for (uint32_t sl = 0; sl <= top_slice; sl++) {
+                        if (at[sl + 1]) {
+                            item_contig.push_back((uint32_t)ci);
+                            item_slice.push_back(sl);
+                            item_off.push_back((uint32_t)(base + at[sl] + at[sl + 1])); /* end of this item = start of the next */
+                        }
+                        at[sl + 1] += at[sl];
+                    }
+                    item_recs.resize(base + at[top_slice + 1]);
+                    for (uint32_t r : recs)
+                        for (uint32_t sl = tile_first_slice(keys[r].qs, keys[r].qe, keys[r].qlen); sl <= tile_last_slice(keys[r].qs, keys[r].qe, keys[r].qlen); sl++)
+                            item_recs[base + at[sl]++] = r;
+                    continue;
+                }
+                std::vector<std::pair<uint32_t, uint32_t>> pairs; /* (slice, position in recs) */
                 for (uint32_t k = 0; k < recs.size(); k++) {
                     const TileKey &key = keys[recs[k]];
                     for (uint32_t sl = tile_first_slice(key.qs, key.qe, key.qlen); sl <= tile_last_slice(key.qs, key.qe, key.qlen); sl++)
