@@ -6,6 +6,7 @@
  */
 #define _GNU_SOURCE
 #include <getopt.h>
+#include <inttypes.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -353,4 +354,92 @@ int paffy_tile_main(int argc, char *argv[]) {
     if (o.in_path) fclose(in);
     if (o.out_path) fclose(out);
     return rc;
+}
+
+/*
+ * impl/paf_view.c:42-213 restricted to the aggregate line (`-s -t`): every record is encoded against the sequences
+ * (paf_encode_mismatches) and its paf_stats_calc sums are added up; the per-alignment pretty print is outside this build.
+ */
+int paffy_view_main(int argc, char *argv[]) {
+    static struct option opts[] = {{"logLevel", required_argument, 0, 'l'}, {"inputFile", required_argument, 0, 'i'},
+                                   {"outputFile", required_argument, 0, 'o'}, {"includeAlignment", no_argument, 0, 'a'},
+                                   {"printAggregateStats", no_argument, 0, 's'}, {"noPerAlignmentStats", no_argument, 0, 't'},
+                                   {"errorIfIdentityLowerThanX", required_argument, 0, 'u'}, {"errorIfAlignedBasesLowerThanX", required_argument, 0, 'v'},
+                                   {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+    cmd_opts o;
+    memset(&o, 0, sizeof(o));
+    int include_alignment = 0, aggregate = 0, per_alignment = 1;
+    float min_identity = 0.0f;          /* impl/paf_view.c:67: a float set by atof */
+    int64_t min_aligned = 0;            /* :68: set by atoi */
+    optind = 1;
+    for (;;) {
+        int idx = 0;
+        int key = getopt_long(argc, argv, "l:i:o:hastu:v:", opts, &idx);
+        if (key == -1) break;
+        switch (key) {
+            case 'l': o.log_level = optarg; break;
+            case 'i': o.in_path = optarg; break;
+            case 'o': o.out_path = optarg; break;
+            case 'a': include_alignment = 1; break;
+            case 's': aggregate = 1; break;
+            case 't': per_alignment = 0; break;
+            case 'u': min_identity = (float)atof(optarg); break;
+            case 'v': min_aligned = atoi(optarg); break;
+            case 'h':
+            default:
+                fprintf(stderr, "paffy view [fasta_files]xN [options], MI355X build\nAggregate alignment stats (-s -t); the per-alignment view is not in this build\n");
+                fprintf(stderr, "-i --inputFile : PAF file to read (default: stdin)\n-o --outputFile : file to write (default: stdout)\n");
+                fprintf(stderr, "-s --printAggregateStats : print overall stats at the end\n-t --noPerAlignmentStats : no stats per alignment\n");
+                fprintf(stderr, "-u --errorIfIdentityLowerThanX : assert the average identity is >= X\n-v --errorIfAlignedBasesLowerThanX : assert the aligned bases are >= X\n");
+                usage_tail();
+                return key == 'h' ? 0 : 1;
+        }
+    }
+    if (optind >= argc) { /* impl/paf_view.c:108-111 */
+        fprintf(stderr, "Expected at least one sequence file\n");
+        exit(1);
+    }
+    if (per_alignment) {
+        (void)include_alignment;
+        fprintf(stderr, "paffy view without -t (the per-alignment pretty print) is outside the scope of this build (hot path only)\n");
+        return 1;
+    }
+    host_set_log_level(o.log_level);
+    fasta_set f;
+    memset(&f, 0, sizeof(f));
+    for (int i = optind; i < argc; i++) {
+        host_log_info("Parsing sequence file : %s\n", argv[i]);
+        if (fasta_read(argv[i], &f) != 0) {
+            fprintf(stderr, "paffy view: cannot open %s\n", argv[i]);
+            return 1;
+        }
+    }
+    host_set_sequences((const char *const *)f.names, (const char *const *)f.seqs, f.lens, f.n);
+    const paffy_stage st[2] = {{PAFFY_ADD_MISMATCHES, 0.05f, 1.0f}, {PAFFY_STATS, 0.0f, 0.0f}};
+    host_set_stats(1);
+    FILE *in = o.in_path ? fopen(o.in_path, "r") : stdin;
+    FILE *out = o.out_path ? fopen(o.out_path, "w") : stdout;
+    if (!in || !out) {
+        fprintf(stderr, "paffy view: cannot open %s\n", !in ? o.in_path : o.out_path);
+        return 1;
+    }
+    int rc = host_stream(st, 2, in, out);
+    int64_t t[6], n_alignments = 0; /* matches, mismatches, inserts, deletes, insert bases, delete bases */
+    host_get_stats(t, &n_alignments);
+    host_set_stats(0);
+    if (rc) return rc;
+    if (!aggregate) memset(t, 0, sizeof(t)); /* the reference only adds the records up under -s (impl/paf_view.c:163-168) */
+    if (aggregate) /* impl/paf_view.c:176-184, same float arithmetic and format */
+        fprintf(out, "Total-alignments:%" PRIi64 "\tAvg-Identity:%f\tAvg-Identity-with-gaps:%f\tAligned-bases:%" PRIi64 "\tAligned-bases-with-gaps:%" PRIi64
+                     "\tQuery-inserts:%" PRIi64 "\tQuery-deletes:%" PRIi64 "\n",
+                n_alignments, (float)t[0] / (t[0] + t[1]), (float)t[0] / (t[0] + t[1] + t[4] + t[5]), t[0] + t[1], t[0] + t[1] + t[4] + t[5], t[2], t[3]);
+    fflush(out);
+    /* the two sanity asserts, impl/paf_view.c:187-188 (NaN >= x is false: an empty input fails the first one there too) */
+    if (!((float)t[0] / (t[0] + t[1]) >= min_identity) || !(t[0] + t[1] >= min_aligned)) {
+        fprintf(stderr, "paffy view: Assertion failed (average identity or aligned bases below the requested minimum)\n");
+        abort();
+    }
+    if (o.in_path) fclose(in);
+    if (o.out_path) fclose(out);
+    return 0;
 }

@@ -21,6 +21,7 @@ int paffy_split_file_main(int argc, char *argv[]);
 int paffy_trim_main(int argc, char *argv[]);
 int paffy_add_mismatches_main(int argc, char *argv[]);
 int paffy_tile_main(int argc, char *argv[]);
+int paffy_view_main(int argc, char *argv[]);
 
 /* Log level shared by the drivers: 0 off, 1 info, 2 debug (set from -l/--logLevel). */
 void host_set_log_level(const char *s);
@@ -37,6 +38,10 @@ int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out);
 void host_set_filter(const paffy_filter *f);
 /* paffy dedupe: host_stream runs paffy_hip_dedupe_plan per chunk on one context (which remembers the records written). */
 void host_set_dedupe(int check_inverse);
+
+/* paffy view -s -t: host_stream adds up the PAFFY_STATS sums of the chunks instead of writing lines */
+void host_set_stats(int on);
+void host_get_stats(int64_t sums[6], int64_t *n_records);
 
 /* `paffy tile`: reads all of `in`, one tile_plan + emit, writes `out`. */
 int host_tile(FILE *in, FILE *out);

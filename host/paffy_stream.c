@@ -93,6 +93,33 @@ static int dedupe_chunk(paffy_hip_ctx *ctx, const char *h_in, int64_t in_len, ch
     return rc;
 }
 
+/* paffy view -s -t: nothing is written per record; the PAFFY_STATS sums of every chunk are added up */
+static int g_stats_mode = 0;
+static int64_t g_stats[6], g_stats_records;
+void host_set_stats(int on) {
+    g_stats_mode = on;
+    memset(g_stats, 0, sizeof(g_stats));
+    g_stats_records = 0;
+}
+void host_get_stats(int64_t sums[6], int64_t *n_records) {
+    memcpy(sums, g_stats, sizeof(g_stats));
+    *n_records = g_stats_records;
+}
+static int stats_chunk(paffy_hip_ctx *ctx, const paffy_stage *stages, int n_stages, const char *buf, int64_t len, paffy_plan_info *info) {
+    void *d_in = NULL;
+    if (paffy_hip_malloc(&d_in, len + 64) != 0) return PAFFY_E_HIP;
+    int rc = paffy_hip_memcpy_h2d(d_in, buf, len);
+    if (!rc) rc = paffy_hip_plan(ctx, stages, n_stages, d_in, len, info);
+    int64_t sums[6];
+    if (!rc) rc = paffy_hip_plan_stats(ctx, sums);
+    if (!rc && info->error.code == 0) {
+        for (int k = 0; k < 6; k++) g_stats[k] += sums[k];
+        g_stats_records += info->n_records;
+    }
+    paffy_hip_free(d_in);
+    return rc;
+}
+
 int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out) {
     paffy_hip_ctx *ctx = NULL;
     if (paffy_hip_create(&ctx, -1) != 0) {
@@ -130,7 +157,8 @@ int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out) {
         int64_t out_len = 0;
         paffy_plan_info info;
         int r = g_dedupe_mode ? dedupe_chunk(ctx, buf, (int64_t)use, &h_out, &out_len, &info)
-                              : paffy_hip_run_host(ctx, stages, n_stages, buf, (int64_t)use, &h_out, &out_len, &info);
+                : g_stats_mode ? stats_chunk(ctx, stages, n_stages, buf, (int64_t)use, &info)
+                               : paffy_hip_run_host(ctx, stages, n_stages, buf, (int64_t)use, &h_out, &out_len, &info);
         if (r != 0) {
             fprintf(stderr, "paffy: GPU call failed (%d): %s\n", r, paffy_hip_last_error(ctx));
             rc = 1;

@@ -37,6 +37,8 @@ enum {
     PAFFY_REMOVE_MISMATCHES = 6, /* impl/paf_add_mismatches.c:110-112: paf_remove_mismatches          */
     PAFFY_PASS = 7,              /* paf_read -> paf_write only (normalises tags, impl/paf.c:317-389)  */
     PAFFY_FILTER = 8,            /* impl/paf_filter.c:120-156: records failing the thresholds of paffy_hip_set_filter vanish */
+    PAFFY_STATS = 10,            /* paf_stats_calc(.., zero_counts = 0) of every record into the plan's running sums (the aggregate of
+                                    `paffy view -s`, impl/paf_view.c:163-168); the record passes on unchanged. See paffy_hip_plan_stats() */
     PAFFY_TRIM_ENDS = 9          /* paf_trim_ends(paf, n), impl/paf.c:575-598: n aligned bases off each end; n = the 64 bits of (p0, p1),
                                     see paffy_stage_trim_ends(); then paf_check like the other trims */
 };
@@ -161,6 +163,13 @@ int paffy_hip_sync(paffy_hip_ctx *ctx);
 /* Host-buffer convenience used by the CLI drivers: H2D, plan, emit, D2H. *h_out is malloc'ed. */
 int paffy_hip_run_host(paffy_hip_ctx *ctx, const paffy_stage *stages, int32_t n_stages, const char *h_in, int64_t in_len,
                        char **h_out, int64_t *out_len, paffy_plan_info *info);
+
+/*
+ * Sums of the PAFFY_STATS stages of the last plan, in the argument order of paf_stats_calc (impl/paf.c:236-260): matches (M and =
+ * bases), mismatches (X bases), query inserts, query deletes, query insert bases, query delete bases -- over the whole batch;
+ * meaningful when no record failed (a failing record ends the reference process before it prints anything).
+ */
+int paffy_hip_plan_stats(paffy_hip_ctx *ctx, int64_t sums[6]);
 
 /*
  * Records as structs, for hosts that hold `Paf` objects (the per-record API of inc/paf.h:75-269, host/paf_api.c): the text is

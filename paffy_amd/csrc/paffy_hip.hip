@@ -826,7 +826,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     bool need_seqs = false;
     for (int32_t i = 0; i < n_stages; i++) {
         int k = stages[i].kind;
-        bool ok = k == PAFFY_INVERT || k == PAFFY_TRIM_IDENTITY || k == PAFFY_TRIM_FIXED || k == PAFFY_TRIM_ENDS || k == PAFFY_PASS || k == PAFFY_FILTER ||
+        bool ok = k == PAFFY_INVERT || k == PAFFY_TRIM_IDENTITY || k == PAFFY_TRIM_FIXED || k == PAFFY_TRIM_ENDS || k == PAFFY_PASS || k == PAFFY_FILTER || k == PAFFY_STATS ||
                   k == PAFFY_REMOVE_MISMATCHES || (k == PAFFY_ADD_MISMATCHES && c->n_seqs > 0) ||
                   (k == PAFFY_SHATTER && i == n_stages - 1);
         if (k == PAFFY_ADD_MISMATCHES) need_seqs = true;
@@ -983,6 +983,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             z.w_count = 0;
             z.g_count = 0;
             z.b_count[1] = 0; /* b_count[0] was filled by k_header and stays */
+            for (int k = 0; k < 6; k++) z.stats[k] = 0;
             z.first_err_key = ~0ull;
             z.out_bytes = z.out_rows = 0;
             HIPCHK(c, hipMemcpyAsync(c->info.p, &z, sizeof(z), hipMemcpyHostToDevice, c->stream));
@@ -1477,6 +1478,13 @@ int paffy_hip_run_host(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_st
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
     return rc;
+}
+
+int paffy_hip_plan_stats(paffy_hip_ctx *c, int64_t sums[6]) {
+    if (!c || !sums) return PAFFY_E_ARG;
+    if (!c->planned || c->plan_is_tile) return PAFFY_E_STATE;
+    for (int k = 0; k < 6; k++) sums[k] = c->plan.in_bytes > 0 ? (int64_t)c->h_info->stats[k] : 0;
+    return 0;
 }
 
 int paffy_hip_parse_host(paffy_hip_ctx *c, const char *h_in, int64_t in_len, paffy_record **recs, uint64_t **ops, int64_t *n_ops_total,

@@ -2820,6 +2820,32 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
                 }
                 if (!rc) rc = check_record(s, v, L.bc);
             }
+        } else if (STAGE_ON(PAFFY_STATS) && st.kind == PAFFY_STATS) {
+            /* paf_stats_calc(.., zero_counts = 0), impl/paf.c:236-260, into the batch's sums (`paffy view -s`, impl/paf_view.c:163-168) */
+            if (s.has_cigar) {
+                uint32_t b, e;
+                sweep_bounds(v.n, b, e);
+                int64_t a[3] = {0, 0, 0}, c2[3] = {0, 0, 0}; /* matches, mismatches, insert bases | delete bases, inserts, deletes */
+                for (uint32_t i = b; i < e; i++) {
+                    int64_t len;
+                    int op;
+                    v.get(i, len, op);
+                    if (op == OP_M || op == OP_EQ) a[0] += len;
+                    else if (op == OP_X) a[1] += len;
+                    else if (op == OP_I) { a[2] += len; c2[1]++; }
+                    else { c2[0] += len; c2[2]++; }
+                }
+                block_sum<3>(a, L.bc);
+                block_sum<3>(c2, L.bc);
+                if (threadIdx.x == 0) {
+                    atomicAdd(&P.info->stats[0], (unsigned long long)a[0]);
+                    atomicAdd(&P.info->stats[1], (unsigned long long)a[1]);
+                    atomicAdd(&P.info->stats[2], (unsigned long long)c2[1]);
+                    atomicAdd(&P.info->stats[3], (unsigned long long)c2[2]);
+                    atomicAdd(&P.info->stats[4], (unsigned long long)a[2]);
+                    atomicAdd(&P.info->stats[5], (unsigned long long)c2[0]);
+                }
+            }
         } else if (STAGE_ON(PAFFY_FILTER) && st.kind == PAFFY_FILTER) {
             /* paffy filter, impl/paf_filter.c:120-156: paf_stats_calc sums from the view's running totals
                (matches = M and =; tx = X + I + D, I = all - tt, D = all - tq) */
@@ -2852,7 +2878,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
             report(P, rec, rc, si, 0, klass);
             return true;
         }
-        checked = st.kind != PAFFY_PASS && st.kind != PAFFY_FILTER; /* every other stage ends with a passed paf_check */
+        if (st.kind != PAFFY_STATS) checked = st.kind != PAFFY_PASS && st.kind != PAFFY_FILTER; /* every other stage ends with a passed paf_check */
     }
     RecPlan *plan = static_cast<RecPlan *>(P.rec_plan) + rec;
     int64_t bytes, rows;

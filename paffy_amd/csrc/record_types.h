@@ -50,6 +50,7 @@ struct DevInfo {
     uint32_t b_count[2]; /* records routed to the next (bigger LDS store) sizing launch, per level */
     uint32_t internal;  /* internal-limit flags (must stay 0) */
     uint32_t g_count;   /* LDS-class shatter records left to the general row kernel (not eligible for k_emit_rows) */
+    unsigned long long stats[6]; /* PAFFY_STATS: matches, mismatches, inserts, deletes, insert bases, delete bases */
 };
 
 struct KParams {

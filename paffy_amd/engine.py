@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 _LIB = os.environ.get("PAFFY_HIP_LIB", os.path.join(HERE, "libpaffy_hip.so"))  # override for A/B experiments only
 
-INVERT, TRIM_IDENTITY, TRIM_FIXED, SHATTER, ADD_MISMATCHES, REMOVE_MISMATCHES, PASS, FILTER, TRIM_ENDS = 1, 2, 3, 4, 5, 6, 7, 8, 9
+INVERT, TRIM_IDENTITY, TRIM_FIXED, SHATTER, ADD_MISMATCHES, REMOVE_MISMATCHES, PASS, FILTER, TRIM_ENDS, STATS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 
 class Stage(C.Structure):
@@ -102,6 +102,7 @@ def lib():
         L.paffy_hip_profile_reset.argtypes = [vp]
         L.paffy_hip_profile_read.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(i64), C.c_int]
         L.paffy_hip_synth.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64)]
+        L.paffy_hip_plan_stats.argtypes = [vp, C.POINTER(i64)]
         L.paffy_hip_synth4_setup.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, i64, i64, C.c_int]
         L.paffy_hip_synth4.argtypes = [vp, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64)]
         L.paffy_hip_device_count.restype = C.c_int
@@ -266,6 +267,12 @@ class Engine:
         self._check(lib().paffy_hip_synth(self._ctx, seed, mean_ops, r0, n, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(nbytes)),
                     "paffy_hip_synth(fill)")
         return buf, nbytes.value
+
+    def plan_stats(self):
+        """Sums of the STATS stages of the last plan: (matches, mismatches, inserts, deletes, insert bases, delete bases)."""
+        out = (C.c_int64 * 6)()
+        self._check(lib().paffy_hip_plan_stats(self._ctx, out), "paffy_hip_plan_stats")
+        return tuple(out)
 
     def synth4_setup(self, seed, mean_ops, n_contigs=24, tlen_min=50_000_000, tlen_span=200_000_000, genomes=True):
         """cfg4 workload: master alignments of n_contigs contig pairs and, with `genomes`, both genomes
