@@ -443,3 +443,101 @@ int paffy_view_main(int argc, char *argv[]) {
     if (o.out_path) fclose(out);
     return 0;
 }
+
+/*
+ * impl/paf_to_bed.c:69-213: coverage of the query sequences (with -n of the target sequences too) as BED runs. -q adds, under -f,
+ * the sequences of a FASTA file that no alignment names (write_missing_fasta_seqs, impl/paf_to_bed.c:63-67: "name 0 length\t0").
+ */
+int paffy_to_bed_main(int argc, char *argv[]) {
+    static struct option opts[] = {{"logLevel", required_argument, 0, 'l'}, {"inputFile", required_argument, 0, 'i'},
+                                   {"outputFile", required_argument, 0, 'o'}, {"binary", no_argument, 0, 'b'},
+                                   {"excludeUnaligned", no_argument, 0, 'e'}, {"excludeAligned", no_argument, 0, 'f'},
+                                   {"minSize", required_argument, 0, 'm'}, {"includeInverted", no_argument, 0, 'n'},
+                                   {"queryFastaFile", required_argument, 0, 'q'}, {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+    cmd_opts o;
+    memset(&o, 0, sizeof(o));
+    paffy_bed_opts b;
+    memset(&b, 0, sizeof(b));
+    b.min_size = 1;
+    const char *query_fasta = NULL;
+    optind = 1;
+    for (;;) {
+        int idx = 0;
+        int key = getopt_long(argc, argv, "l:i:o:hbefm:nq:", opts, &idx);
+        if (key == -1) break;
+        switch (key) {
+            case 'l': o.log_level = optarg; break;
+            case 'i': o.in_path = optarg; break;
+            case 'o': o.out_path = optarg; break;
+            case 'b': b.binary = 1; break;
+            case 'e': b.exclude_unaligned = 1; break;
+            case 'f': b.exclude_aligned = 1; break;
+            case 'm': b.min_size = atoi(optarg); break; /* impl/paf_to_bed.c: atoi */
+            case 'n': b.include_inverted = 1; break;
+            case 'q': query_fasta = optarg; break;
+            case 'h':
+            default:
+                fprintf(stderr, "paffy to_bed [options], MI355X build\nBED file of the alignment coverage of the query sequences\n");
+                fprintf(stderr, "-i --inputFile : PAF file to read (default: stdin)\n-o --outputFile : BED file to write (default: stdout)\n");
+                fprintf(stderr, "-b --binary : 0 / 1 instead of the number of alignments\n-e --excludeUnaligned : no intervals without alignments\n");
+                fprintf(stderr, "-f --excludeAligned : no intervals with alignments\n-m --minSize : no intervals shorter than this\n");
+                fprintf(stderr, "-n --includeInverted : count the target sequences too\n-q --queryFastaFile : with -f, also list sequences no alignment names\n");
+                usage_tail();
+                return key == 'h' ? 0 : 1;
+        }
+    }
+    host_set_log_level(o.log_level);
+    FILE *in = o.in_path ? fopen(o.in_path, "r") : stdin;
+    FILE *out = o.out_path ? fopen(o.out_path, "w") : stdout;
+    if (!in || !out) {
+        fprintf(stderr, "paffy to_bed: cannot open %s\n", !in ? o.in_path : o.out_path);
+        return 1;
+    }
+    int rc;
+    if (b.exclude_aligned && query_fasta) {
+        /* the names the alignments use are needed afterwards: keep the text */
+        size_t cap = 1 << 20, have = 0;
+        char *buf = (char *)malloc(cap);
+        for (;;) {
+            if (have == cap) buf = (char *)realloc(buf, cap *= 2);
+            size_t got = fread(buf + have, 1, cap - have, in);
+            if (got == 0) break;
+            have += got;
+        }
+        FILE *mem = fmemopen(buf, have ? have : 1, "r");
+        if (have == 0) fgetc(mem);
+        rc = host_to_bed(mem, out, &b);
+        fclose(mem);
+        fasta_set f;
+        memset(&f, 0, sizeof(f));
+        if (rc == 0 && fasta_read(query_fasta, &f) == 0) {
+            for (int64_t k = 0; k < f.n; k++) {
+                const size_t nl = strlen(f.names[k]);
+                int seen = 0;
+                for (const char *p = buf, *end = buf + have; p < end && !seen;) { /* a sequence is known if a line names it as query (or, with -n, as target) */
+                    const char *le = memchr(p, '\n', (size_t)(end - p));
+                    if (!le) le = end;
+                    const char *t1 = memchr(p, '\t', (size_t)(le - p));
+                    if (t1 && (size_t)(t1 - p) == nl && memcmp(p, f.names[k], nl) == 0) seen = 1;
+                    if (!seen && b.include_inverted && t1) {
+                        const char *q = t1;
+                        for (int col = 1; col < 5 && q; col++) q = memchr(q + 1, '\t', (size_t)(le - q - 1));
+                        if (q) {
+                            const char *t6 = memchr(q + 1, '\t', (size_t)(le - q - 1));
+                            if (t6 && (size_t)(t6 - q - 1) == nl && memcmp(q + 1, f.names[k], nl) == 0) seen = 1;
+                        }
+                    }
+                    p = le + 1;
+                }
+                if (!seen) fprintf(out, "%s 0 %" PRIi64 "\t0\n", f.names[k], f.lens[k]);
+            }
+        }
+        free(buf);
+    } else {
+        rc = host_to_bed(in, out, &b);
+    }
+    if (o.in_path) fclose(in);
+    if (o.out_path) fclose(out);
+    else fflush(out);
+    return rc;
+}

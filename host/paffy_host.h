@@ -22,6 +22,7 @@ int paffy_trim_main(int argc, char *argv[]);
 int paffy_add_mismatches_main(int argc, char *argv[]);
 int paffy_tile_main(int argc, char *argv[]);
 int paffy_view_main(int argc, char *argv[]);
+int paffy_to_bed_main(int argc, char *argv[]);
 
 /* Log level shared by the drivers: 0 off, 1 info, 2 debug (set from -l/--logLevel). */
 void host_set_log_level(const char *s);
@@ -45,6 +46,8 @@ void host_get_stats(int64_t sums[6], int64_t *n_records);
 
 /* `paffy tile`: reads all of `in`, one tile_plan + emit, writes `out`. */
 int host_tile(FILE *in, FILE *out);
+/* `paffy to_bed`: reads all of `in`, one bed_plan + emit, writes `out` */
+int host_to_bed(FILE *in, FILE *out, const paffy_bed_opts *opts);
 /* paffy split_file: normalised lines (cigar text verbatim) routed to "<prefix><contig>.paf" / "<prefix>small_<k>.paf" */
 int host_split_file(FILE *in, const char *prefix, int by_query, int64_t min_length);
 

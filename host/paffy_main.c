@@ -24,7 +24,7 @@ static const struct {
     {"invert", paffy_invert_main, "Switch query and target coordinates"},
     {"shatter", paffy_shatter_main, "Break alignments into gapless blocks"},
     {"tile", paffy_tile_main, "Give alignments tile levels along the query"},
-    {"to_bed", NULL, "Coverage map in BED format (not in this build)"},
+    {"to_bed", paffy_to_bed_main, "Coverage of the query sequences in BED format"},
     {"trim", paffy_trim_main, "Slice off lower identity tails"},
     {"upconvert", NULL, "Convert coordinates to extracted subsequences (not in this build)"},
     {"split_file", paffy_split_file_main, "Split a PAF file per contig"},

@@ -356,7 +356,12 @@ int host_split_file(FILE *in, const char *prefix, int by_query, int64_t min_leng
     return rc;
 }
 
-int host_tile(FILE *in, FILE *out) {
+static int whole_file(FILE *in, FILE *out, const paffy_bed_opts *bed);
+int host_tile(FILE *in, FILE *out) { return whole_file(in, out, NULL); }
+/* paffy to_bed: the whole file is one batch, like tile */
+int host_to_bed(FILE *in, FILE *out, const paffy_bed_opts *opts) { return whole_file(in, out, opts); }
+
+static int whole_file(FILE *in, FILE *out, const paffy_bed_opts *bed) {
     size_t cap = 1 << 20, have = 0;
     char *buf = (char *)malloc(cap);
     for (;;) {
@@ -377,7 +382,7 @@ int host_tile(FILE *in, FILE *out) {
     paffy_plan_info info;
     int rc = 1;
     if (paffy_hip_malloc(&d_in, (int64_t)have + 64) == 0 && paffy_hip_memcpy_h2d(d_in, buf, (int64_t)have) == 0 &&
-        paffy_hip_tile_plan(ctx, d_in, (int64_t)have, &info) == 0) {
+        (bed ? paffy_hip_bed_plan(ctx, d_in, (int64_t)have, bed, &info) : paffy_hip_tile_plan(ctx, d_in, (int64_t)have, &info)) == 0) {
         if (info.error.code) die_like_reference(&info.error, 0);
         rc = 0;
         if (info.out_bytes > 0) {
@@ -390,7 +395,7 @@ int host_tile(FILE *in, FILE *out) {
             free(h);
         }
     } else {
-        fprintf(stderr, "paffy tile: GPU call failed: %s\n", paffy_hip_last_error(ctx));
+        fprintf(stderr, "paffy %s: GPU call failed: %s\n", bed ? "to_bed" : "tile", paffy_hip_last_error(ctx));
     }
     if (d_in) paffy_hip_free(d_in);
     if (d_out) paffy_hip_free(d_out);

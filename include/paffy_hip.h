@@ -147,6 +147,19 @@ int paffy_hip_dedupe_reset(paffy_hip_ctx *ctx);
 #define PAFFY_DEDUPE_KEEP_ALL 2
 
 /*
+ * bed_plan: `paffy to_bed` (impl/paf_to_bed.c:33-55, 166-190) over the whole batch: per-base coverage counters of every query
+ * sequence (with include_inverted also of every target sequence, as the inverted record would count), written as maximal runs
+ * "name start end value\n"; binary / exclude_unaligned / exclude_aligned / min_size are the reference's -b -e -f -m. Sequences come
+ * in order of first appearance (the reference walks a hash table: no order defined). A failing record means no output at all.
+ * Followed by paffy_hip_emit().
+ */
+typedef struct {
+    int32_t binary, exclude_unaligned, exclude_aligned, include_inverted;
+    int64_t min_size; /* default 1 */
+} paffy_bed_opts;
+int paffy_hip_bed_plan(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len, const paffy_bed_opts *opts, paffy_plan_info *info);
+
+/*
  * After a tile or dedupe plan: the lines emit will write, in output order -- record[k] = zero-based input record of line k,
  * out_off[k] = its first output byte, out_off[n] = the total (cap >= n + 1 entries each). Returns n, or a negative error.
  * This is what a router such as `paffy split_file` needs to send every written line to the file of its contig.

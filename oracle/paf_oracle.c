@@ -1056,6 +1056,92 @@ int po_tile(const char *in, int64_t in_len, char **out, int64_t *out_len, po_err
     return rc;
 }
 
+/*
+ * paffy to_bed, impl/paf_to_bed.c:166-190 (the loop) and :33-55 (write_bed): every record, parsed with its cigar, bumps the
+ * counters of its query range (get_alignment_count_array + increase_alignment_level_counts, impl/paf.c:675-709) and, with
+ * include_inverted, once more after paf_invert; then the runs of every sequence. The reference iterates a sonLib hash, whose
+ * order is not defined: sequences are written in order of first appearance here (tests compare the lines as a set).
+ */
+static int bed_count(run_ctx *c, rec *r, count_array **arrs, int64_t *narr, int64_t *acap) {
+    count_array *ca = NULL;
+    for (int64_t a = 0; a < *narr; a++)
+        if ((*arrs)[a].name_len == r->qname_len && memcmp((*arrs)[a].name, r->qname, (size_t)r->qname_len) == 0) { ca = &(*arrs)[a]; break; }
+    if (!ca) {
+        if (*narr == *acap) { *acap = *acap ? *acap * 2 : 64; *arrs = (count_array *)realloc(*arrs, sizeof(count_array) * (size_t)*acap); }
+        ca = &(*arrs)[(*narr)++];
+        ca->name = r->qname; ca->name_len = r->qname_len; ca->length = r->qlen;
+        ca->counts = (uint16_t *)calloc((size_t)(r->qlen > 0 ? r->qlen : 1), sizeof(uint16_t));
+    } else if (ca->length != r->qlen) return fail(c, PO_ERR_TILE_ASSERT, 0, 1);
+    int64_t i = r->qs;
+    if (r->has_cigar)
+        for (int64_t o = 0; o < r->n; o++) {
+            const oop *op = &r->ops[r->lo + o];
+            if (op->op == OP_D) continue;
+            if (op->op != OP_I)
+                for (int64_t j = 0; j < op->len; j++) {
+                    int64_t pos = i + j;
+                    if (!(pos < r->qe && pos >= 0 && pos < r->qlen)) return fail(c, PO_ERR_TILE_ASSERT, 0, 2);
+                    if (ca->counts[pos] < 32767 - 1) ca->counts[pos]++;
+                }
+            i += op->len;
+        }
+    if (i != r->qe) return fail(c, PO_ERR_TILE_ASSERT, 0, 2);
+    return PO_OK;
+}
+
+int po_to_bed(const char *in, int64_t in_len, int binary, int exclude_unaligned, int exclude_aligned, int64_t min_size, int include_inverted,
+              char **out, int64_t *out_len, po_error *err) {
+    run_ctx c;
+    memset(&c, 0, sizeof(c));
+    c.err = err;
+    if (err) memset(err, 0, sizeof(*err));
+    int rc = PO_OK;
+    count_array *arrs = NULL;
+    int64_t narr = 0, acap = 0, nrec = 0;
+    /* names point into the input text, which outlives the records */
+    const char *p = in, *end = in + in_len;
+    while (p < end && !rc) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        rec r;
+        int64_t aux = 0;
+        c.record = nrec;
+        rc = parse_line(p, le, 1, &r, &aux);
+        if (rc) {
+            fail(&c, rc, -1, aux);
+            break;
+        }
+        rc = bed_count(&c, &r, &arrs, &narr, &acap);
+        if (!rc && include_inverted) {
+            invert_rec(&r);
+            rc = bed_count(&c, &r, &arrs, &narr, &acap);
+        }
+        rec_free(&r);
+        nrec++;
+        p = nl ? nl + 1 : end;
+    }
+    if (!rc)
+        for (int64_t a = 0; a < narr; a++) { /* write_bed */
+            const count_array *ca = &arrs[a];
+            for (int64_t i = 0; i < ca->length;) {
+                int64_t j = i + 1;
+                while (j < ca->length && !(binary ? (ca->counts[i] > 0) != (ca->counts[j] > 0) : ca->counts[i] != ca->counts[j])) j++;
+                if (j - i >= min_size && (ca->counts[i] == 0 ? !exclude_unaligned : !exclude_aligned)) {
+                    char tmp[96];
+                    ob_bytes(&c.out, ca->name, ca->name_len);
+                    int k = snprintf(tmp, sizeof(tmp), " %lld %lld %i\n", (long long)i, (long long)j, binary ? ca->counts[i] > 0 : ca->counts[i]);
+                    ob_bytes(&c.out, tmp, k);
+                }
+                i = j;
+            }
+        }
+    for (int64_t a = 0; a < narr; a++) free(arrs[a].counts);
+    free(arrs);
+    *out = c.out.p;
+    *out_len = c.out.n;
+    return rc;
+}
+
 void po_free(void *p) { free(p); }
 
 int po_error_exit_status(int32_t code) {

@@ -106,6 +106,9 @@ int po_run(const po_stage *stages, int32_t n_stages, const char *in, int64_t in_
 
 /* `paffy tile` over a whole buffer (impl/paf_tile.c:156-178). */
 int po_tile(const char *in, int64_t in_len, char **out, int64_t *out_len, po_error *err);
+/* paffy to_bed [-b -e -f -m min_size -n] (impl/paf_to_bed.c); sequences in order of first appearance */
+int po_to_bed(const char *in, int64_t in_len, int binary, int exclude_unaligned, int exclude_aligned, int64_t min_size, int include_inverted,
+              char **out, int64_t *out_len, po_error *err);
 
 /*
  * `paffy dedupe [-a]` over a whole buffer (impl/paf_dedupe.c:117-143): records are read without parsing the cigar; a

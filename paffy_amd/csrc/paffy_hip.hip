@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -404,6 +405,36 @@ __global__ __launch_bounds__(PAFFY_NT) void k_tile_keys(const uint8_t *in, const
     keys[r] = k;
 }
 
+/* to_bed: both sequences of a record (name hash, length, range), whether it has a cigar, its parse error */
+struct BedKey {
+    uint64_t hash[2];
+    int64_t len[2], lo[2], hi[2];
+    uint32_t name_off[2], name_len[2];
+    int32_t err, has_cg, minus, pad;
+};
+__global__ __launch_bounds__(PAFFY_NT) void k_bed_keys(const uint8_t *in, const RecMeta *meta, uint32_t n, BedKey *keys) {
+    uint32_t r = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (r >= n) return;
+    const RecMeta &m = meta[r];
+    BedKey k;
+    for (int s = 0; s < 2; s++) {
+        const uint32_t off = s ? m.tname_off : m.qname_off, len = s ? m.tname_len : m.qname_len;
+        uint64_t h = 0xcbf29ce484222325ull; /* FNV-1a over the name */
+        for (uint32_t i = 0; i < len; i++) h = (h ^ in[off + i]) * 0x100000001b3ull;
+        k.hash[s] = h;
+        k.name_off[s] = off;
+        k.name_len[s] = len;
+        k.len[s] = s ? m.tlen : m.qlen;
+        k.lo[s] = s ? m.ts : m.qs;
+        k.hi[s] = s ? m.te : m.qe;
+    }
+    k.err = m.err;
+    k.has_cg = m.has_cg && m.cg_len > 0;
+    k.minus = !m.same_strand;
+    k.pad = 0;
+    keys[r] = k;
+}
+
 /* dedupe: 128-bit key of (query name, target name, strand, four coordinates), the same for the swapped record, the
  * coordinate part of paf_check (impl/paf.c:427-438; the cigar is not parsed here) and the record's own tile level */
 struct DedupeKey {
@@ -638,6 +669,10 @@ struct paffy_hip_ctx {
     std::unordered_set<std::string> dedupe_seen; /* 16-byte keys of the records written so far */
     DevBuf scan_part, emit_order, order_cnt, tile_keys, tile_order, tile_rank, tile_coff, tile_cbase, tile_cov, tile_level, tile_len, tile_items, tile_slots, tile_parts;
     bool plan_is_tile = false;
+    bool plan_is_bed = false; /* paffy to_bed: emit writes the run lines */
+    DevBuf bed_keys, bed_tab, bed_starts, bed_len, bed_off, bed_tiles;
+    struct BedParams *bed_params = nullptr; /* host copy */
+    uint64_t bed_runs = 0;
     uint32_t tile_n = 0;
     const uint8_t *tile_in = nullptr;
     DevInfo *h_info = nullptr; /* pinned */
@@ -749,11 +784,12 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     if (!c) return;
     prof_collect(c);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
-                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp,
+                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
                       &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts, &c->scan_part, &c->dedupe_keys, &c->emit_order, &c->order_cnt};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    delete c->bed_params;
     if (c->h_info) (void)hipHostFree(c->h_info);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -841,6 +877,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     for (int32_t i = 0; i < n_stages; i++) lean_add = lean_add && ((PAFFY_MASK_ADD >> stages[i].kind) & 1u);
     c->planned = false;
     c->plan_is_tile = false;
+    c->plan_is_bed = false;
     memset(info, 0, sizeof(*info));
     info->in_bytes = in_len;
     memset(&c->plan, 0, sizeof(c->plan));
@@ -1057,6 +1094,7 @@ int paffy_hip_tile_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, paff
     if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
     c->planned = false;
     c->plan_is_tile = true;
+    c->plan_is_bed = false;
     memset(info, 0, sizeof(*info));
     memset(&c->plan, 0, sizeof(c->plan));
     info->in_bytes = c->plan.in_bytes = in_len;
@@ -1422,9 +1460,16 @@ int64_t paffy_hip_plan_rows(paffy_hip_ctx *c, int64_t cap, uint32_t *record, int
 int paffy_hip_emit(paffy_hip_ctx *c, void *d_out, int64_t out_cap) {
     if (!c) return PAFFY_E_ARG;
     if (!c->planned) return PAFFY_E_STATE;
-    if (c->plan.out_bytes == 0 || (!c->plan_is_tile && c->kp.n_rec == 0)) return 0;
+    if (c->plan.out_bytes == 0 || (!c->plan_is_tile && !c->plan_is_bed && c->kp.n_rec == 0)) return 0;
     if (!d_out || (reinterpret_cast<uintptr_t>(d_out) & 15)) return PAFFY_E_ARG;
     if (out_cap < c->plan.out_bytes) return PAFFY_E_CAPACITY;
+    if (c->plan_is_bed) {
+        const uint64_t n_runs = c->bed_runs;
+        LAUNCH(c, "k_bed_lines", k_bed_lines, dim3((unsigned)((n_runs + PAFFY_NT - 1) / PAFFY_NT)), dim3(PAFFY_NT), 0, *c->bed_params,
+               static_cast<const uint64_t *>(c->bed_starts.p), n_runs, static_cast<int64_t *>(c->bed_len.p), static_cast<const int64_t *>(c->bed_off.p),
+               static_cast<uint8_t *>(d_out));
+        return 0;
+    }
     if (c->plan_is_tile) {
         LAUNCH(c, "k_tile_emit", k_tile_emit, dim3(c->tile_n), dim3(PAFFY_NT), 0, c->tile_in, static_cast<const RecMeta *>(c->meta.p),
                static_cast<const uint32_t *>(c->tile_order.p), static_cast<const int64_t *>(c->tile_level.p),
@@ -1478,6 +1523,266 @@ int paffy_hip_run_host(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_st
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
     return rc;
+}
+
+/* exclusive scan of n int64 values on the device (two levels); *total on the host */
+static int scan64(paffy_hip_ctx *c, const int64_t *in, uint64_t n, int64_t *out, int64_t *total) {
+    const uint64_t tiles = (n + PAFFY_NT * 16 - 1) / (PAFFY_NT * 16);
+    if (ensure(c, c->bed_tiles, sizeof(int64_t) * (size_t)(2 * tiles + 2))) return PAFFY_E_HIP;
+    int64_t *sums = static_cast<int64_t *>(c->bed_tiles.p), *offs = sums + tiles, *tot = offs + tiles;
+    LAUNCH(c, "k_scan64_tiles", k_scan64_tiles, dim3((unsigned)tiles), dim3(PAFFY_NT), 0, in, n, sums);
+    LAUNCH(c, "k_scan_i64", k_scan_i64, dim3(1), dim3(PAFFY_NT), 0, sums, (uint32_t)tiles, offs, tot);
+    LAUNCH(c, "k_scan64_fix", k_scan64_fix, dim3((unsigned)tiles), dim3(PAFFY_NT), 0, in, n, static_cast<const int64_t *>(offs), out);
+    HIPCHK(c, hipMemcpyAsync(total, tot, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+/*
+ * `paffy to_bed` over a whole batch (impl/paf_to_bed.c:166-190): coverage counters per sequence as in `paffy tile` (every record
+ * bumps the counters of its query range; with include_inverted also those of its target range, as the inverted record would),
+ * then each sequence's counters as maximal runs. Sequences are written in order of first appearance (the reference iterates a
+ * sonLib hash: its order is not defined). Any failing record means no output.
+ */
+int paffy_hip_bed_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, const paffy_bed_opts *opts, paffy_plan_info *info) {
+    if (!c || !info || !opts) return PAFFY_E_ARG;
+    if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
+    c->planned = false;
+    c->plan_is_tile = false;
+    c->plan_is_bed = true;
+    memset(info, 0, sizeof(*info));
+    memset(&c->plan, 0, sizeof(c->plan));
+    info->in_bytes = c->plan.in_bytes = in_len;
+    memset(&c->kp, 0, sizeof(c->kp));
+    c->bed_runs = 0;
+    if (in_len == 0) {
+        c->planned = true;
+        return 0;
+    }
+    const uint8_t *in = static_cast<const uint8_t *>(d_in);
+    uint32_t n = 0;
+    {
+        int rc = index_and_parse(c, in, (uint32_t)in_len, &n);
+        if (rc) return rc;
+    }
+    c->plan.n_records = n;
+    if (n == 0 || n >= (1u << 30)) {
+        *info = c->plan;
+        c->planned = n == 0;
+        return n == 0 ? 0 : PAFFY_E_UNSUPPORTED;
+    }
+    const uint32_t grid = (n + PAFFY_NT - 1) / PAFFY_NT;
+    if (ensure(c, c->bed_keys, sizeof(BedKey) * (size_t)n)) return PAFFY_E_HIP;
+    LAUNCH(c, "k_bed_keys", k_bed_keys, dim3(grid), dim3(PAFFY_NT), 0, in, static_cast<const RecMeta *>(c->meta.p), n, static_cast<BedKey *>(c->bed_keys.p));
+    std::vector<BedKey> keys(n);
+    HIPCHK(c, hipMemcpyAsync(keys.data(), c->bed_keys.p, sizeof(BedKey) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int sides = opts->include_inverted ? 2 : 1;
+    /* the records one by one, as the reference's loop meets them: parse error, sequence length assert (impl/paf.c:685), and for a
+       record without cigar the end assert (impl/paf.c:708: nothing is walked, so start must equal end) */
+    struct Seq { uint64_t hash; uint32_t name_off, name_len; int64_t len; std::vector<uint32_t> entries; };
+    std::vector<Seq> seqs;
+    std::unordered_map<uint64_t, std::vector<uint32_t>> by_hash; /* hash -> indices into seqs (names of equal hash differ in length here) */
+    int64_t bad_rec = -1;
+    int bad_code = 0, bad_aux = 0;
+    for (uint32_t r = 0; r < n && bad_rec < 0; r++) {
+        const BedKey &k = keys[r];
+        if (k.err) {
+            bad_rec = r;
+            bad_code = k.err;
+            RecMeta m;
+            HIPCHK(c, hipMemcpy(&m, static_cast<RecMeta *>(c->meta.p) + r, sizeof(m), hipMemcpyDeviceToHost));
+            bad_aux = m.err_aux;
+            break;
+        }
+        for (int sd = 0; sd < sides; sd++) {
+            std::vector<uint32_t> &cands = by_hash[k.hash[sd]];
+            int64_t si = -1;
+            for (uint32_t ci : cands)
+                if (seqs[ci].name_len == k.name_len[sd]) si = ci;
+            if (si < 0) {
+                si = (int64_t)seqs.size();
+                seqs.push_back(Seq{k.hash[sd], k.name_off[sd], k.name_len[sd], k.len[sd], {}});
+                cands.push_back((uint32_t)si);
+            } else if (seqs[(size_t)si].len != k.len[sd]) {
+                bad_rec = r;
+                bad_code = PAFFY_ERR_TILE_ASSERT;
+                bad_aux = 1;
+                break;
+            }
+            if (!k.has_cg && k.lo[sd] != k.hi[sd]) {
+                bad_rec = r;
+                bad_code = PAFFY_ERR_TILE_ASSERT;
+                bad_aux = 2;
+                break;
+            }
+            const uint32_t side = sd == 0 ? 0u : (k.minus ? 2u : 1u);
+            if (k.has_cg) seqs[(size_t)si].entries.push_back(r | (side << 30));
+        }
+    }
+    auto fail_with = [&](int64_t rec, int code, int aux) {
+        c->plan.error.code = code;
+        c->plan.error.stage = code == PAFFY_ERR_TILE_ASSERT ? 0 : -1;
+        c->plan.error.record = rec;
+        c->plan.error.aux = aux;
+        *info = c->plan;
+        c->planned = true;
+        return 0;
+    };
+    /* counters: every sequence followed by 64 counters of padding */
+    const size_t ns = seqs.size();
+    std::vector<uint64_t> cbase(ns + 1);
+    std::vector<int64_t> clen(ns);
+    std::vector<uint32_t> name_off(ns), name_len(ns);
+    uint64_t cov_total = 0;
+    for (size_t i = 0; i < ns; i++) {
+        cbase[i] = cov_total;
+        clen[i] = seqs[i].len;
+        name_off[i] = seqs[i].name_off;
+        name_len[i] = seqs[i].name_len;
+        if (seqs[i].len > (1ll << 40)) return PAFFY_E_UNSUPPORTED;
+        cov_total += (uint64_t)(seqs[i].len > 0 ? seqs[i].len : 0) + 64;
+    }
+    cbase[ns] = cov_total;
+    if (ensure(c, c->tile_cov, sizeof(uint16_t) * (size_t)(cov_total + 64))) return PAFFY_E_HIP;
+    HIPCHK(c, hipMemsetAsync(c->tile_cov.p, 0, sizeof(uint16_t) * (size_t)cov_total, c->stream));
+    /* work items: (sequence, slice) with the entries that touch the slice, in input order */
+    std::vector<uint32_t> item_off, item_contig, item_slice, item_recs;
+    item_off.push_back(0);
+    for (size_t ci = 0; ci < ns; ci++) {
+        const auto &ent = seqs[ci].entries;
+        auto range = [&](uint32_t e, uint32_t &f, uint32_t &l) {
+            const BedKey &k = keys[e & 0x3fffffffu];
+            const int sd = (e >> 30) ? 1 : 0;
+            f = tile_first_slice(k.lo[sd], k.hi[sd], k.len[sd]);
+            l = tile_last_slice(k.lo[sd], k.hi[sd], k.len[sd]);
+        };
+        uint32_t top = 0;
+        for (uint32_t e : ent) {
+            uint32_t f, l;
+            range(e, f, l);
+            if (l > top) top = l;
+        }
+        if (ent.empty()) continue;
+        if (top >= (1u << 22)) return PAFFY_E_UNSUPPORTED; /* coordinates far beyond any sequence this build holds counters for */
+        std::vector<uint32_t> at(top + 2, 0u);
+        for (uint32_t e : ent) {
+            uint32_t f, l;
+            range(e, f, l);
+            for (uint32_t sl = f; sl <= l; sl++) at[sl + 1]++;
+        }
+        const size_t base = item_recs.size();
+        for (uint32_t sl = 0; sl <= top; sl++) {
+            if (at[sl + 1]) {
+                item_contig.push_back((uint32_t)ci);
+                item_slice.push_back(sl);
+                item_off.push_back((uint32_t)(base + at[sl] + at[sl + 1]));
+            }
+            at[sl + 1] += at[sl];
+        }
+        item_recs.resize(base + at[top + 1]);
+        for (uint32_t e : ent) {
+            uint32_t f, l;
+            range(e, f, l);
+            for (uint32_t sl = f; sl <= l; sl++) item_recs[base + at[sl]++] = e;
+        }
+    }
+    if (bad_rec >= 0) { /* the device may still find an earlier record failing inside its cigar; later ones do not matter */
+        unsigned long long key = ((unsigned long long)bad_rec << 16) | (1ull << 8) | (unsigned long long)(bad_code & 0xff);
+        HIPCHK(c, hipMemcpyAsync(&static_cast<DevInfo *>(c->info.p)->first_err_key, &key, sizeof(key), hipMemcpyHostToDevice, c->stream));
+    }
+    const uint32_t n_items = (uint32_t)item_contig.size();
+    /* device tables: contig_base[ns + 1] | contig_len[ns] (8-byte words), then name_off | name_len | rank | items (4-byte words) */
+    const size_t w64 = (ns + 1) + ns, w32 = 2 * ns + n + item_off.size() + 2 * (size_t)n_items + item_recs.size();
+    if (ensure(c, c->bed_tab, 8 * w64 + 4 * w32 + 64)) return PAFFY_E_HIP;
+    uint64_t *d_cbase = static_cast<uint64_t *>(c->bed_tab.p);
+    int64_t *d_clen = reinterpret_cast<int64_t *>(d_cbase + ns + 1);
+    uint32_t *d_noff = reinterpret_cast<uint32_t *>(d_clen + ns), *d_nlen = d_noff + ns, *d_rank = d_nlen + ns, *d_ioff = d_rank + n;
+    uint32_t *d_icontig = d_ioff + item_off.size(), *d_islice = d_icontig + n_items, *d_irecs = d_islice + n_items;
+    std::vector<uint32_t> rank(n);
+    for (uint32_t r = 0; r < n; r++) rank[r] = r; /* first failure = smallest record index */
+    HIPCHK(c, hipMemcpyAsync(d_cbase, cbase.data(), 8 * (ns + 1), hipMemcpyHostToDevice, c->stream));
+    if (ns) {
+        HIPCHK(c, hipMemcpyAsync(d_clen, clen.data(), 8 * ns, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_noff, name_off.data(), 4 * ns, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_nlen, name_len.data(), 4 * ns, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(d_rank, rank.data(), 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_ioff, item_off.data(), 4 * item_off.size(), hipMemcpyHostToDevice, c->stream));
+    if (n_items) {
+        HIPCHK(c, hipMemcpyAsync(d_icontig, item_contig.data(), 4 * (size_t)n_items, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_islice, item_slice.data(), 4 * (size_t)n_items, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_irecs, item_recs.data(), 4 * item_recs.size(), hipMemcpyHostToDevice, c->stream));
+    }
+    TileParams tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.in = in;
+    tp.meta = static_cast<const RecMeta *>(c->meta.p);
+    tp.contig_base = d_cbase;
+    tp.rank_of = d_rank;
+    tp.counts = static_cast<uint16_t *>(c->tile_cov.p);
+    tp.n_contigs = (uint32_t)ns;
+    tp.info = static_cast<DevInfo *>(c->info.p);
+    tp.err_aux = static_cast<int32_t *>(c->err_aux.p);
+    tp.order = d_irecs;
+    tp.item_off = d_ioff;
+    tp.item_contig = d_icontig;
+    tp.item_slice = d_islice;
+    tp.n_items = n_items;
+    if (n_items > 0) LAUNCH(c, "k_bed_cover", k_bed_cover, dim3(n_items), dim3(PAFFY_NT), TILE_LDS_BYTES, tp);
+    if (fetch_info(c)) return PAFFY_E_HIP; /* also keeps the host vectors alive until the copies are done */
+    if (c->h_info->first_err_key != ~0ull) {
+        const unsigned long long k = c->h_info->first_err_key;
+        const int64_t rec = (int64_t)(k >> 16);
+        int32_t aux = bad_aux;
+        if (rec != bad_rec) HIPCHK(c, hipMemcpy(&aux, static_cast<int32_t *>(c->err_aux.p) + rec, sizeof(aux), hipMemcpyDeviceToHost));
+        if (c->profile) prof_collect(c);
+        return fail_with(rec, (int)(k & 0xff), aux);
+    }
+    /* the runs */
+    if (!c->bed_params) c->bed_params = new BedParams;
+    BedParams &B = *c->bed_params;
+    memset(&B, 0, sizeof(B));
+    B.counts = static_cast<const uint16_t *>(c->tile_cov.p);
+    B.n_counts = cov_total;
+    B.contig_base = d_cbase;
+    B.contig_len = d_clen;
+    B.name_off = d_noff;
+    B.name_len = d_nlen;
+    B.n_contigs = (uint32_t)ns;
+    B.in = in;
+    B.binary = opts->binary;
+    B.exclude_unaligned = opts->exclude_unaligned;
+    B.exclude_aligned = opts->exclude_aligned;
+    B.min_size = opts->min_size;
+    if (ns == 0 || cov_total == 0) {
+        *info = c->plan;
+        c->planned = true;
+        return 0;
+    }
+    const uint64_t rtiles = (cov_total + (uint64_t)PAFFY_NT * BED_PER - 1) / ((uint64_t)PAFFY_NT * BED_PER);
+    if (ensure(c, c->bed_len, sizeof(int64_t) * (size_t)(2 * rtiles + 2))) return PAFFY_E_HIP;
+    int64_t *tile_cnt = static_cast<int64_t *>(c->bed_len.p), *tile_off = tile_cnt + rtiles;
+    LAUNCH(c, "k_bed_runs", k_bed_runs, dim3((unsigned)rtiles), dim3(PAFFY_NT), 0, B, static_cast<const int64_t *>(nullptr), tile_cnt, static_cast<uint64_t *>(nullptr));
+    int64_t n_runs = 0;
+    if (scan64(c, tile_cnt, rtiles, tile_off, &n_runs)) return PAFFY_E_HIP;
+    if (ensure(c, c->bed_starts, sizeof(uint64_t) * (size_t)(n_runs + 1))) return PAFFY_E_HIP;
+    LAUNCH(c, "k_bed_runs", k_bed_runs, dim3((unsigned)rtiles), dim3(PAFFY_NT), 0, B, static_cast<const int64_t *>(tile_off), tile_cnt, static_cast<uint64_t *>(c->bed_starts.p));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); /* bed_len is reused below */
+    if (ensure(c, c->bed_len, sizeof(int64_t) * (size_t)(n_runs + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->bed_off, sizeof(int64_t) * (size_t)(n_runs + 1))) return PAFFY_E_HIP;
+    const unsigned lgrid = (unsigned)(((uint64_t)n_runs + PAFFY_NT - 1) / PAFFY_NT);
+    LAUNCH(c, "k_bed_lines", k_bed_lines, dim3(lgrid), dim3(PAFFY_NT), 0, B, static_cast<const uint64_t *>(c->bed_starts.p), (uint64_t)n_runs,
+           static_cast<int64_t *>(c->bed_len.p), static_cast<const int64_t *>(nullptr), static_cast<uint8_t *>(nullptr));
+    int64_t total = 0;
+    if (scan64(c, static_cast<const int64_t *>(c->bed_len.p), (uint64_t)n_runs, static_cast<int64_t *>(c->bed_off.p), &total)) return PAFFY_E_HIP;
+    if (c->profile) prof_collect(c);
+    c->bed_runs = (uint64_t)n_runs;
+    c->plan.out_bytes = total;
+    c->plan.n_rows = 0; /* lines: counted by the caller if wanted */
+    *info = c->plan;
+    c->planned = true;
+    return 0;
 }
 
 int paffy_hip_plan_stats(paffy_hip_ctx *c, int64_t sums[6]) {

@@ -91,6 +91,13 @@ __device__ __forceinline__ void tile_fail(const TileParams &P, uint32_t rec, int
  * only read them. Levels in [win, win + TILE_HIST) are histogrammed into hist[]; levels below win
  * are counted in *below. Returns 0, or an error code (bad cigar character / position assert).
  */
+/*
+ * SIDE 0: the query sequence, as `paffy tile` and `paffy to_bed` walk it. SIDE 1 / 2: the TARGET sequence of the record, what
+ * `paffy to_bed -n` walks after paf_invert (impl/paf_to_bed.c:176-180): the inverted record's query is the target, its I ops are
+ * the D ops, and on the - strand its cigar is reversed (impl/paf.c:463-490) -- walking the reversed ops upward from target_start
+ * covers the mirror image of what the forward ops cover, so SIDE 2 walks forward and mirrors every position in [ts, te).
+ */
+template <int SIDE = 0>
 __device__ int tile_walk(const TileParams &P, uint32_t rec, const RecMeta &m, uint16_t *counts, bool bump, uint32_t win, uint32_t *hist,
                          TileOp *list, uint8_t *txt, BlockComm &bc, Shared *sh, int64_t *aligned_out, int64_t *below_out,
                          uint64_t clip_lo = 0, uint64_t clip_hi = ~0ull) {
@@ -103,7 +110,9 @@ __device__ int tile_walk(const TileParams &P, uint32_t rec, const RecMeta &m, ui
         sh->flags = 0;
     }
     __syncthreads();
-    int64_t qcur = m.qs;      /* query position of the next op (wave-uniform carry) */
+    const int64_t w_start = SIDE ? m.ts : m.qs, w_end = SIDE ? m.te : m.qe, w_len = SIDE ? m.tlen : m.qlen;
+    const int skip_op = SIDE ? OP_I : OP_D; /* the op that does not advance along the walked sequence */
+    int64_t qcur = w_start;   /* position of the next op on the walked sequence (wave-uniform carry) */
     int64_t aligned = 0, below = 0;
     for (uint32_t tb = a0; tb < end; tb += TILE_TEXT) {
         /* stage the tile; 32 bytes of halo carry digit runs across tiles */
@@ -158,7 +167,7 @@ __device__ int tile_walk(const TileParams &P, uint32_t rec, const RecMeta &m, ui
                 int64_t l56 = (int64_t)(len << 8) >> 8;
                 lens[j] = l56;
                 codes[j] = code;
-                if (code != OP_D) sums[0] += l56;
+                if (code != skip_op) sums[0] += l56;
                 if (code == OP_M || code == OP_EQ || code == OP_X) {
                     sums[1] += l56;
                     sums[2] += 1;
@@ -175,7 +184,7 @@ __device__ int tile_walk(const TileParams &P, uint32_t rec, const RecMeta &m, ui
                 if (codes[j] < 0) continue;
                 if (codes[j] == OP_M || codes[j] == OP_EQ || codes[j] == OP_X) {
                     /* assert(i + j < query_end && i + j >= 0 && i + j < query_length), impl/paf.c:698 */
-                    if (lens[j] > 0 && (q < 0 || q + lens[j] > m.qe || q + lens[j] > m.qlen)) atomicOr(&sh->flags, 2u);
+                    if (lens[j] > 0 && (q < 0 || q + lens[j] > w_end || q + lens[j] > w_len)) atomicOr(&sh->flags, 2u);
                     TileOp o;
                     o.qpos = (uint64_t)q;
                     o.len = lens[j] < 0 ? 0u : (lens[j] > 0xffffffffll ? 0xffffffffu : (uint32_t)lens[j]);
@@ -183,7 +192,7 @@ __device__ int tile_walk(const TileParams &P, uint32_t rec, const RecMeta &m, ui
                     list[li++] = o;
                     a += lens[j];
                 }
-                if (codes[j] != OP_D) q += lens[j];
+                if (codes[j] != skip_op) q += lens[j];
             }
         }
         __syncthreads();
@@ -222,8 +231,9 @@ __device__ int tile_walk(const TileParams &P, uint32_t rec, const RecMeta &m, ui
                             while (oi + 1 < n_al && (uint64_t)list[oi + 1].apos <= au) oi++;
                             const TileOp o = list[oi];
                             const uint64_t rel = au - o.apos;
-                            if (rel < o.len && o.qpos + rel >= clip_lo && o.qpos + rel < clip_hi) { /* inside the op and inside this slice */
-                                cp[u] = counts + o.qpos + rel;
+                            const uint64_t at = SIDE == 2 ? (uint64_t)(w_start + w_end - 1) - (o.qpos + rel) : o.qpos + rel;
+                            if (rel < o.len && at >= clip_lo && at < clip_hi) { /* inside the op and inside this slice */
+                                cp[u] = counts + at;
                                 cv[u] = *cp[u];
                             }
                         }
@@ -269,7 +279,7 @@ __device__ int tile_walk(const TileParams &P, uint32_t rec, const RecMeta &m, ui
         if (bump) tile_fail(P, rec, PAFFY_ERR_CIGAR_CHAR, ep < end ? P.in[ep] : 0);
         return PAFFY_ERR_CIGAR_CHAR;
     }
-    if ((fl & 0xffffu) || qcur != m.qe) { /* position asserts / assert(i == query_end), impl/paf.c:708 */
+    if ((fl & 0xffffu) || qcur != w_end) { /* position asserts / assert(i == query_end), impl/paf.c:708 */
         if (bump) tile_fail(P, rec, PAFFY_ERR_TILE_ASSERT, (int)fl);
         return PAFFY_ERR_TILE_ASSERT;
     }
@@ -483,6 +493,178 @@ __global__ __launch_bounds__(PAFFY_NT) void k_tile_merge(TileParams P, uint32_t 
         }
     }
     P.tile_level[rec] = level;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * `paffy to_bed` (impl/paf_to_bed.c:33-55, 166-190): the coverage counters of `paffy tile` without the levels, then every
+ * sequence's counters as maximal runs "name start end value". Work items are (sequence, slice) like the sliced tile mode; an
+ * entry of the item's list is a record index, with bits 30-31 = the SIDE of tile_walk (-n adds the target side of every record).
+ * ---------------------------------------------------------------------------------------------- */
+__global__ __launch_bounds__(PAFFY_NT) void k_bed_cover(TileParams P) {
+    extern __shared__ uint4 smem4[];
+    uint8_t *smem = reinterpret_cast<uint8_t *>(smem4);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem);
+    TileOp *list = reinterpret_cast<TileOp *>(smem + TILE_HIST * 4);
+    uint8_t *txt = smem + TILE_HIST * 4 + (PAFFY_NT * 8) * 16;
+    BlockComm bc;
+    bc.scratch = reinterpret_cast<int64_t *>(txt + PAFFY_HALO + TILE_TEXT);
+    bc.flip = 0;
+    Shared *sh = reinterpret_cast<Shared *>(reinterpret_cast<uint8_t *>(bc.scratch) + 64 * 8);
+    const uint32_t item = blockIdx.x;
+    const uint32_t c = P.item_contig[item], slice = P.item_slice[item];
+    uint16_t *counts = P.counts + P.contig_base[c];
+    const uint64_t lo = (uint64_t)slice << TILE_SLICE_SHIFT, hi = lo + (1ull << TILE_SLICE_SHIFT);
+    for (uint32_t k = P.item_off[item]; k < P.item_off[item + 1]; k++) {
+        const uint32_t rec = P.order[k] & 0x3fffffffu, side = P.order[k] >> 30;
+        const RecMeta m = P.meta[rec];
+        int64_t aligned = 0, below = 0;
+        if (!m.has_cg) continue; /* no cigar: nothing to count (cigar_count(NULL) == 0, inc/paf.h:75) -- only the end assert can fail */
+        /* the level window is of no interest here: counts beyond it only raise a flag that nobody reads */
+        if (side == 0) tile_walk<0>(P, rec, m, counts, true, 0, hist, list, txt, bc, sh, &aligned, &below, lo, hi);
+        else if (side == 1) tile_walk<1>(P, rec, m, counts, true, 0, hist, list, txt, bc, sh, &aligned, &below, lo, hi);
+        else tile_walk<2>(P, rec, m, counts, true, 0, hist, list, txt, bc, sh, &aligned, &below, lo, hi);
+        __syncthreads();
+    }
+}
+
+struct BedParams {
+    const uint16_t *counts;
+    uint64_t n_counts;           /* all sequences back to back, each followed by a little padding */
+    const uint64_t *contig_base; /* [n_contigs + 1] */
+    const int64_t *contig_len;   /* [n_contigs] */
+    const uint32_t *name_off, *name_len; /* [n_contigs] slices of the input text */
+    uint32_t n_contigs;
+    const uint8_t *in;
+    int32_t binary, exclude_unaligned, exclude_aligned;
+    int64_t min_size;
+};
+
+#define BED_PER 16u /* counters per lane per step */
+/* which sequence a global counter position belongs to */
+__device__ __forceinline__ uint32_t bed_contig_of(const BedParams &B, uint64_t g) {
+    uint32_t lo = 0, hi = B.n_contigs - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (B.contig_base[mid] <= g) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+/* a run starts at g: the first counter of a sequence, the first position behind one, or a value that differs from the one before */
+__device__ __forceinline__ bool bed_starts_run(const BedParams &B, uint64_t g, uint32_t v, uint32_t before, uint32_t c) {
+    const uint64_t rel = g - B.contig_base[c];
+    if (rel == 0 || rel == (uint64_t)B.contig_len[c]) return true;
+    if (rel > (uint64_t)B.contig_len[c]) return false; /* padding */
+    return B.binary ? (v > 0) != (before > 0) : v != before;
+}
+/* pass 1 (starts == nullptr): run starts per workgroup tile; pass 2: their positions, at tile_off[tile] + rank inside the tile */
+__global__ __launch_bounds__(PAFFY_NT) void k_bed_runs(BedParams B, const int64_t *tile_off, int64_t *tile_cnt, uint64_t *starts) {
+    __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
+    BlockComm bc{scratch_mem, 0};
+    const uint64_t g0 = ((uint64_t)blockIdx.x * PAFFY_NT + threadIdx.x) * BED_PER;
+    uint32_t flags = 0;
+    if (g0 < B.n_counts) {
+        uint32_t c = bed_contig_of(B, g0);
+        uint32_t before = g0 ? B.counts[g0 - 1] : 0;
+        for (uint32_t j = 0; j < BED_PER && g0 + j < B.n_counts; j++) {
+            const uint64_t g = g0 + j;
+            while (c + 1 < B.n_contigs && B.contig_base[c + 1] <= g) c++;
+            const uint32_t v = B.counts[g];
+            if (bed_starts_run(B, g, v, before, c)) flags |= 1u << j;
+            before = v;
+        }
+    }
+    int64_t n[1] = {(int64_t)__popc(flags)}, tot[1];
+    block_excl_scan<1>(n, tot, bc);
+    if (!starts) {
+        if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot[0];
+        return;
+    }
+    uint64_t o = (uint64_t)tile_off[blockIdx.x] + (uint64_t)n[0];
+    while (flags) {
+        const uint32_t j = (uint32_t)__ffs((int)flags) - 1u;
+        flags &= flags - 1u;
+        starts[o++] = g0 + j;
+    }
+}
+__device__ __forceinline__ uint32_t bed_digits(uint64_t v) {
+    uint32_t d = 1;
+    while (v >= 10) {
+        v /= 10;
+        d++;
+    }
+    return d;
+}
+__device__ __forceinline__ uint8_t *bed_put(uint8_t *p, uint64_t v) {
+    const uint32_t d = bed_digits(v);
+    for (uint32_t i = 0; i < d; i++) {
+        p[d - 1 - i] = (uint8_t)('0' + (uint32_t)(v % 10));
+        v /= 10;
+    }
+    return p + d;
+}
+/* one lane per run: its line "name start end value\n" (impl/paf_to_bed.c:44-47) -- out == nullptr: the length only */
+__global__ __launch_bounds__(PAFFY_NT) void k_bed_lines(BedParams B, const uint64_t *starts, uint64_t n_runs, int64_t *len, const int64_t *off, uint8_t *out) {
+    const uint64_t k = (uint64_t)blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (k >= n_runs) return;
+    const uint64_t g = starts[k];
+    const uint32_t c = bed_contig_of(B, g);
+    const uint64_t i = g - B.contig_base[c], L = (uint64_t)(B.contig_len[c] > 0 ? B.contig_len[c] : 0);
+    int64_t bytes = 0;
+    if (i < L) { /* not the padding behind a sequence */
+        uint64_t j = k + 1 < n_runs ? starts[k + 1] - B.contig_base[c] : L;
+        if (j > L) j = L;
+        const uint32_t v = B.counts[g];
+        const bool keep = (int64_t)(j - i) >= B.min_size && (v == 0 ? !B.exclude_unaligned : !B.exclude_aligned);
+        if (keep) {
+            const uint64_t shown = B.binary ? (v > 0 ? 1u : 0u) : v;
+            bytes = (int64_t)B.name_len[c] + 1 + bed_digits(i) + 1 + bed_digits(j) + 1 + bed_digits(shown) + 1;
+            if (out) {
+                uint8_t *p = out + off[k];
+                for (uint32_t t = 0; t < B.name_len[c]; t++) p[t] = B.in[B.name_off[c] + t];
+                p += B.name_len[c];
+                *p++ = ' ';
+                p = bed_put(p, i);
+                *p++ = ' ';
+                p = bed_put(p, j);
+                *p++ = ' ';
+                p = bed_put(p, shown);
+                *p++ = '\n';
+            }
+        }
+    }
+    if (!out) len[k] = bytes;
+}
+/* exclusive scan of n int64 values in two levels: sums per 4096-value tile, a one-workgroup scan of those, then the tiles */
+__global__ __launch_bounds__(PAFFY_NT) void k_scan64_tiles(const int64_t *in, uint64_t n, int64_t *tile_sum) {
+    __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
+    BlockComm bc{scratch_mem, 0};
+    const uint64_t base = (uint64_t)blockIdx.x * (PAFFY_NT * 16);
+    int64_t v[1] = {0};
+    for (uint32_t j = 0; j < 16; j++) {
+        const uint64_t i = base + (uint64_t)threadIdx.x * 16 + j;
+        if (i < n) v[0] += in[i];
+    }
+    block_sum<1>(v, bc);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = v[0];
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_scan64_fix(const int64_t *in, uint64_t n, const int64_t *tile_off, int64_t *out) {
+    __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
+    BlockComm bc{scratch_mem, 0};
+    const uint64_t base = (uint64_t)blockIdx.x * (PAFFY_NT * 16);
+    int64_t mine[16], v[1] = {0}, tot[1];
+    for (uint32_t j = 0; j < 16; j++) {
+        const uint64_t i = base + (uint64_t)threadIdx.x * 16 + j;
+        mine[j] = i < n ? in[i] : 0;
+        v[0] += mine[j];
+    }
+    block_excl_scan<1>(v, tot, bc);
+    int64_t run = tile_off[blockIdx.x] + v[0];
+    for (uint32_t j = 0; j < 16; j++) {
+        const uint64_t i = base + (uint64_t)threadIdx.x * 16 + j;
+        if (i < n) out[i] = run;
+        run += mine[j];
+    }
 }
 
 #endif

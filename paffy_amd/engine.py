@@ -15,6 +15,11 @@ _LIB = os.environ.get("PAFFY_HIP_LIB", os.path.join(HERE, "libpaffy_hip.so"))  #
 INVERT, TRIM_IDENTITY, TRIM_FIXED, SHATTER, ADD_MISMATCHES, REMOVE_MISMATCHES, PASS, FILTER, TRIM_ENDS, STATS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 
+class BedOpts(C.Structure):
+    _fields_ = [("binary", C.c_int32), ("exclude_unaligned", C.c_int32), ("exclude_aligned", C.c_int32), ("include_inverted", C.c_int32),
+                ("min_size", C.c_int64)]
+
+
 class Stage(C.Structure):
     _fields_ = [("kind", C.c_int32), ("p0", C.c_float), ("p1", C.c_float)]
 
@@ -103,6 +108,7 @@ def lib():
         L.paffy_hip_profile_read.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(i64), C.c_int]
         L.paffy_hip_synth.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64)]
         L.paffy_hip_plan_stats.argtypes = [vp, C.POINTER(i64)]
+        L.paffy_hip_bed_plan.argtypes = [vp, vp, i64, C.POINTER(BedOpts), C.POINTER(PlanInfo)]
         L.paffy_hip_synth4_setup.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, i64, i64, C.c_int]
         L.paffy_hip_synth4.argtypes = [vp, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64)]
         L.paffy_hip_device_count.restype = C.c_int
@@ -267,6 +273,24 @@ class Engine:
         self._check(lib().paffy_hip_synth(self._ctx, seed, mean_ops, r0, n, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(nbytes)),
                     "paffy_hip_synth(fill)")
         return buf, nbytes.value
+
+    def to_bed(self, data, binary=False, exclude_unaligned=False, exclude_aligned=False, min_size=1, include_inverted=False, raise_on_error=True):
+        """paffy to_bed [-b -e -f -m -n] (impl/paf_to_bed.c) over PAF text; returns (BED bytes, PlanInfo)."""
+        d_in = self.to_device(data)
+        info = PlanInfo()
+        opts = BedOpts(int(binary), int(exclude_unaligned), int(exclude_aligned), int(include_inverted), min_size)
+        self._check(lib().paffy_hip_bed_plan(self._ctx, C.c_void_p(d_in.data_ptr()), len(data), C.byref(opts), C.byref(info)), "paffy_hip_bed_plan")
+        out = b""
+        if info.out_bytes:
+            d_out = self.alloc_out(info.out_bytes)
+            self.emit(d_out)
+            self.sync()
+            out = bytes(d_out[: info.out_bytes].cpu().numpy().tobytes())
+        if info.error.code and raise_on_error:
+            L = lib()
+            raise PafError(f"record {info.error.record}: {L.paffy_hip_error_string(info.error.code).decode()}", info,
+                           L.paffy_hip_error_exit_status(info.error.code))
+        return out, info
 
     def plan_stats(self):
         """Sums of the STATS stages of the last plan: (matches, mismatches, inserts, deletes, insert bases, delete bases)."""

@@ -50,6 +50,8 @@ def lib():
                              C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(Error)]
         L.po_tile.restype = C.c_int
         L.po_tile.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(Error)]
+        L.po_to_bed.restype = C.c_int
+        L.po_to_bed.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(Error)]
         L.po_free.argtypes = [C.c_void_p]
         L.po_split_file.restype = C.c_int
         L.po_split_file.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int, C.c_int64, C.POINTER(Error)]
@@ -117,6 +119,12 @@ def tile(data):
     L = lib()
     out, n, err = C.c_void_p(), C.c_int64(), Error()
     L.po_tile(data, len(data), C.byref(out), C.byref(n), C.byref(err))
+    return _take(out, n), err
+
+
+def to_bed(data, binary=False, exclude_unaligned=False, exclude_aligned=False, min_size=1, include_inverted=False):
+    out, n, err = C.c_void_p(), C.c_int64(), Error()
+    lib().po_to_bed(data, len(data), int(binary), int(exclude_unaligned), int(exclude_aligned), min_size, int(include_inverted), C.byref(out), C.byref(n), C.byref(err))
     return _take(out, n), err
 
 
