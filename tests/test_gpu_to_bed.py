@@ -83,6 +83,11 @@ def test_cli(tmp_path, human_chimp):
         assert r.stdout == O.to_bed(human_chimp, **kw)[0], args
     r = subprocess.run([PAFFY, "to_bed", "-o", str(tmp_path / "o.bed")], input=human_chimp, capture_output=True)
     assert r.returncode == 0 and (tmp_path / "o.bed").read_bytes() == O.to_bed(human_chimp)[0]
+    # -f -q: sequences of the FASTA that no alignment names are listed as wholly unaligned ("name 0 length<TAB>0", impl/paf_to_bed.c:63-67)
+    fa = tmp_path / "q.fa"
+    fa.write_bytes(b">chr10\nACGT\n>nowhere\nACGTACGTAC\nACG\n")
+    r = subprocess.run([PAFFY, "to_bed", "-i", str(src), "-f", "-q", str(fa)], capture_output=True)
+    assert r.returncode == 0 and r.stdout == O.to_bed(human_chimp, exclude_aligned=True)[0] + b"nowhere 0 13\t0\n"
     bad = human_chimp + b"q\t30\t2\t13\t+\tt\t40\t5\t15\t10\t10\t60\tcg:Z:10M\n"
     r = subprocess.run([PAFFY, "to_bed"], input=bad, capture_output=True)
     assert r.returncode == -6 and r.stdout == b""  # assert -> SIGABRT, nothing written

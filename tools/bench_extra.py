@@ -15,7 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--records", type=int, default=200000)
     ap.add_argument("--mean-ops", type=int, default=2048)
-    ap.add_argument("--cmd", default="tile", choices=["tile", "invert", "trim", "shatter", "remove", "filter", "add", "dedupe"])
+    ap.add_argument("--cmd", default="tile", choices=["tile", "invert", "trim", "shatter", "remove", "filter", "add", "dedupe", "bed", "stats"])
     a = ap.parse_args()
     import torch
 
@@ -34,11 +34,17 @@ def main():
     kinds = {"invert": paffy_amd.INVERT, "trim": paffy_amd.TRIM_IDENTITY, "shatter": paffy_amd.SHATTER, "remove": paffy_amd.REMOVE_MISMATCHES, "filter": paffy_amd.FILTER}
     eng.set_filter(min_identity=0.9)
     kinds["add"] = paffy_amd.ADD_MISMATCHES
+    kinds["stats"] = paffy_amd.STATS
     res = []
     eng.profile(True)
     for rep in range(3):
         t0 = time.perf_counter()
-        if a.cmd == "dedupe":
+        if a.cmd == "bed":
+            opts = paffy_amd.engine.BedOpts(0, 0, 0, 1, 1)  # -n: both sides of every record
+            info = paffy_amd.engine.PlanInfo()
+            rc = paffy_amd.engine.lib().paffy_hip_bed_plan(eng._ctx, buf.data_ptr(), nbytes, opts, info)
+            assert rc == 0, rc
+        elif a.cmd == "dedupe":
             paffy_amd.engine.lib().paffy_hip_dedupe_reset(eng._ctx)
             info = eng.dedupe_plan(buf, nbytes, True)
         else:
