@@ -345,33 +345,40 @@ void paf_encode_mismatches(Paf *paf, char *query_seq, char *target_seq) { /* imp
     transform(paf, &st, 1, "Q", "T");
 }
 
-/* Sums over the caller's own op array: accessors, nothing to launch (impl/paf.c:507-517, 236-260). */
-int64_t paf_get_number_of_aligned_bases(Paf *paf) {
-    int64_t n = 0;
-    for (int64_t i = 0; i < cigar_count(paf->cigar); i++) {
-        CigarRecord *c = cigar_get(paf->cigar, i);
-        if (c->op != query_insert && c->op != query_delete) n += c->length;
-    }
-    return n;
+/* paf_stats_calc (impl/paf.c:236-260) of one record: a PAFFY_STATS plan, the six sums read back */
+static void stats_of(Paf *paf, int64_t sums[6]) {
+    for (int k = 0; k < 6; k++) sums[k] = 0;
+    if (!paf->cigar) return; /* cigar_count(NULL) == 0 */
+    Buf b = {0};
+    hand_over(&b, paf, NULL, NULL);
+    const paffy_stage st = {PAFFY_STATS, 0.0f, 0.0f};
+    void *d_in = NULL;
+    paffy_plan_info info;
+    if (paffy_hip_malloc(&d_in, (int64_t)b.n + 64) || paffy_hip_memcpy_h2d(d_in, b.p, (int64_t)b.n) || paffy_hip_plan(ctx(), &st, 1, d_in, (int64_t)b.n, &info) ||
+        paffy_hip_plan_stats(ctx(), sums))
+        die("paf_stats_calc on MI355X", paffy_hip_last_error(ctx()));
+    if (info.error.code) record_failure(&info);
+    paffy_hip_free(d_in);
+    free(b.p);
+}
+
+int64_t paf_get_number_of_aligned_bases(Paf *paf) { /* impl/paf.c:507-517: the bases of M, = and X ops */
+    int64_t t[6];
+    stats_of(paf, t);
+    return t[0] + t[1];
 }
 
 void paf_stats_calc(Paf *paf, int64_t *matches, int64_t *mismatches, int64_t *query_inserts, int64_t *query_deletes,
                     int64_t *query_insert_bases, int64_t *query_delete_bases, bool zero_counts) {
+    int64_t t[6];
+    stats_of(paf, t);
     if (zero_counts) *matches = *mismatches = *query_inserts = *query_deletes = *query_insert_bases = *query_delete_bases = 0;
-    for (int64_t i = 0; i < cigar_count(paf->cigar); i++) {
-        CigarRecord *c = cigar_get(paf->cigar, i);
-        if (c->op == match || c->op == sequence_match) {
-            *matches += c->length;
-        } else if (c->op == sequence_mismatch) {
-            *mismatches += c->length;
-        } else if (c->op == query_insert) {
-            *query_inserts += 1;
-            *query_insert_bases += c->length;
-        } else {
-            *query_deletes += 1;
-            *query_delete_bases += c->length;
-        }
-    }
+    *matches += t[0];
+    *mismatches += t[1];
+    *query_inserts += t[2];
+    *query_deletes += t[3];
+    *query_insert_bases += t[4];
+    *query_delete_bases += t[5];
 }
 
 /* ---- whole files and lists: one batch per call ---- */

@@ -118,6 +118,14 @@ static void trimming(void) {
     paf_stats_calc(p, &mat, &mis, &qi, &qd, &qib, &qdb, true);
     CHECK(mat == 9 && mis == 1 && qi == 1 && qib == 3 && qd == 1 && qdb == 2);
     paf_destruct(p);
+    p = make_paf("q", 100, 0, 5, true, "t", 100, 0, 5, 5, 5, 60, "5M"); /* zero_counts = false accumulates, true resets first */
+    mat = mis = qi = qd = qib = qdb = 0;
+    paf_stats_calc(p, &mat, &mis, &qi, &qd, &qib, &qdb, false);
+    paf_stats_calc(p, &mat, &mis, &qi, &qd, &qib, &qdb, false);
+    CHECK(mat == 10);
+    paf_stats_calc(p, &mat, &mis, &qi, &qd, &qib, &qdb, true);
+    CHECK(mat == 5 && mis == 0 && qi == 0 && qd == 0);
+    paf_destruct(p);
     p = make_paf("q", 100, 5, 15, true, "t", 100, 5, 15, 10, 10, 60, "10M");
     paf_trim_ends(p, 0);
     CHECK(p->query_start == 5 && p->query_end == 15 && p->target_start == 5 && p->target_end == 15 && cigar_count(p->cigar) == 1 && op_is(p, 0, match, 10));
