@@ -64,6 +64,24 @@ static void cigars(void) {
     CHECK(c && cigar_count(c) == 1 && cigar_get(c, 0)->length == 1000000);
     cigar_destruct(c);
     CHECK(cigar_count(NULL) == 0);
+    /* ops that do not fit the 4-byte stores of the fast path (length >= 2^29) and more ops than any LDS store holds: the arena class */
+    char s4[] = "600000000M3I72057594037927935D";
+    c = cigar_parse(s4);
+    CHECK(c && cigar_count(c) == 3 && cigar_get(c, 0)->length == 600000000 && cigar_get(c, 1)->op == query_insert && cigar_get(c, 2)->op == query_delete);
+    CHECK(c && cigar_get(c, 2)->length == -1); /* 2^56 - 1 in the signed 56-bit field, as the reference's bitfield stores it */
+    cigar_destruct(c);
+    const int n_ops = 50001;
+    char *big = malloc((size_t)n_ops * 2 + 1);
+    for (int i = 0; i < n_ops; i++) {
+        big[2 * i] = (char)('1' + i % 9);
+        big[2 * i + 1] = "MID"[i % 3];
+    }
+    big[2 * n_ops] = '\0';
+    c = cigar_parse(big);
+    CHECK(c && cigar_count(c) == n_ops && cigar_get(c, 50000)->length == 1 + 50000 % 9 && cigar_get(c, 50000)->op == (int64_t)(50000 % 3));
+    CHECK(c && cigar_get(c, 12345)->length == 1 + 12345 % 9 && cigar_get(c, 12345)->op == (int64_t)(12345 % 3));
+    cigar_destruct(c);
+    free(big);
 }
 
 static void parsing(void) {
