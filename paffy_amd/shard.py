@@ -5,7 +5,8 @@ reference loop touches one Paf, impl/paf_invert.c:84-89), so the N-GPU path is a
 the record stream with no data-path collective: rank r owns batches r, r+N, r+2N, ... of
 `batch` records each. Output order is restored by concatenating per-batch outputs in batch
 order; the only exchange is an all-gather of per-batch output byte counts (8 bytes per batch) so
-that every rank knows where its bytes go in the ordered output (pwrite / gather-to-writer).
+that every rank knows where its bytes go in the ordered output: each rank pwrites its ranges, or the batches travel to one
+writer in order (gather_to_writer: point-to-point sends over xGMI with the nccl backend).
 `tile` shards by query contig instead (its state is keyed by query name, impl/paf.c:675-688).
 """
 
@@ -42,6 +43,44 @@ def gather_batch_sizes(dist, local, n_batches, device="cpu"):
         t[b] = s
     dist.all_reduce(t, op=dist.ReduceOp.SUM)  # disjoint ownership: a sum is a gather
     return [int(x) for x in t.tolist()]
+
+
+def gather_to_writer(dist, rank, world, local, sizes_by_batch, write, device="cpu", writer=0):
+    """The ordered write: batch outputs travel to the writer rank in batch order (a gatherv with per-batch sizes).
+
+    `local` maps the batch indices this rank owns to uint8 tensors (on `device`; with the nccl backend they stay on the GPU and
+    move over xGMI as point-to-point sends, RCCL send/recv); `sizes_by_batch` is the table from gather_batch_sizes. The writer
+    calls `write(batch_index, tensor)` for batch 0, 1, 2, ... -- receives are posted a few batches ahead so that the links stay
+    busy while the writer drains. Other ranks return once their sends are done.
+    """
+    import torch
+
+    n_batches = len(sizes_by_batch)
+    owner = [b % world for b in range(n_batches)]  # = batches_of_rank's round robin
+    if rank != writer:
+        reqs = [dist.isend(local[b].contiguous(), dst=writer, tag=b) for b in range(n_batches) if owner[b] == rank and sizes_by_batch[b] > 0]
+        for r in reqs:
+            r.wait()
+        return
+    ahead, pending = 4, {}
+
+    def post(b):
+        if b < n_batches and owner[b] != writer and sizes_by_batch[b] > 0:
+            buf = torch.empty(sizes_by_batch[b], dtype=torch.uint8, device=device)
+            pending[b] = (dist.irecv(buf, src=owner[b], tag=b), buf)
+
+    for b in range(min(ahead, n_batches)):
+        post(b)
+    for b in range(n_batches):
+        post(b + ahead)
+        if sizes_by_batch[b] == 0:
+            continue
+        if owner[b] == writer:
+            write(b, local[b])
+        else:
+            req, buf = pending.pop(b)
+            req.wait()
+            write(b, buf)
 
 
 def contig_partition(weights, world):

@@ -47,6 +47,14 @@ def _worker(rank, world, port, tmpdir):
     for b, o in local.items():
         os.pwrite(fd, o, offs[b])
     os.close(fd)
+    # the other way to the ordered output: the batches travel to rank 0 in order (gatherv with per-batch sizes)
+    chunks = []
+    tens = {b: torch.frombuffer(bytearray(o), dtype=torch.uint8) for b, o in local.items()}
+    shard.gather_to_writer(dist, rank, world, tens, sizes, lambda b, t: chunks.append((b, bytes(t.numpy().tobytes()))))
+    if rank == 0:
+        assert [b for b, _ in chunks] == [b for b in range(n_batches) if sizes[b] > 0]
+        with open(os.path.join(tmpdir, "gathered.paf"), "wb") as fh:
+            fh.write(b"".join(c for _, c in chunks))
     # the bench's timing reduction: max over ranks
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -61,6 +69,7 @@ def test_two_rank_sharding_is_order_preserving(tmp_path):
     want, err = O.run([O.stage(*s) for s in STAGES], synth_lib.generate(0x5EED0003, 300, 0, TOTAL, threads=1))
     assert err.code == 0
     assert (tmp_path / "out.paf").read_bytes() == want
+    assert (tmp_path / "gathered.paf").read_bytes() == want
 
 
 def test_batch_partition_covers_stream_once():
