@@ -34,6 +34,9 @@ WORKLOADS = {
     # records on homologous bases of two device-generated genomes (24 + 24 contigs of 50-250 Mb, 2 % substitutions)
     "cfg4": dict(seed=0x5EED0004, mean_ops=2048, total=10_000_000, pipe="add_mismatches", genomes=True,
                  desc="10M synthetic PAF records, mean 2k cigar ops + 2x3.6 Gb synthetic genomes resident in HBM, add_mismatches"),
+    # `paffy tile` over one GPU's share of the records (cfg5 shards the query contigs over 8 GPUs; here every step tiles one batch)
+    "cfg5": dict(seed=0x5EED0005, mean_ops=2048, total=10_000_000, pipe="tile", tile=True,
+                 desc="synthetic PAF records, mean 2k cigar ops, tile (one GPU's share per step)"),
 }
 
 
@@ -80,7 +83,7 @@ def main():
     if args.pipe:
         wl["pipe"] = args.pipe
     eng = paffy_amd.Engine()
-    stages = stages_for(wl["pipe"], paffy_amd)
+    stages = [] if wl.get("tile") else stages_for(wl["pipe"], paffy_amd)
     n_batches = args.warmup + args.steps
 
     # ---- synthetic input, generated on the device, resident before the timed region ----
@@ -96,20 +99,24 @@ def main():
         batches.append((buf, nbytes, r0))
     torch.cuda.synchronize()
     aligned_per_record = 0.0
-    if wl.get("genomes"):  # add_mismatches also reads one byte of each genome per aligned base (PAF column 10 here)
+    extra_per_base = 4.0 if wl.get("tile") else 2.0  # tile: 2 B read + 2 B write of the counter of every aligned base
+    if wl.get("genomes") or wl.get("tile"):  # add_mismatches also reads one byte of each genome per aligned base (PAF column 10 here)
         head = bytes(batches[0][0][: batches[0][1]].cpu().numpy().tobytes())
         lines = head.split(b"\n")[:-1]
         aligned_per_record = sum(int(l.split(b"\t", 10)[9]) for l in lines) / max(1, len(lines))
 
+    def plan(buf, nbytes):
+        return eng.tile_plan(buf, nbytes) if wl.get("tile") else eng.plan(stages, buf, nbytes)
+
     # one untimed plan to size the output slab (reused by every step)
-    info0 = eng.plan(stages, batches[0][0], batches[0][1])
+    info0 = plan(batches[0][0], batches[0][1])
     out_cap = int(info0.out_bytes * 1.25) + (1 << 20)
     d_out = eng.alloc_out(out_cap)
 
     def step(i):
         nonlocal d_out, out_cap
         buf, nbytes, _ = batches[i]
-        info = eng.plan(stages, buf, nbytes)
+        info = plan(buf, nbytes)
         if info.error.code:
             raise RuntimeError(f"synthetic record failed: code {info.error.code} record {info.error.record}")
         if info.out_bytes > out_cap:
@@ -158,7 +165,7 @@ def main():
         # dominant kernel = the one with the largest total time in the timed region; it is priced with the
         # algorithmic bytes of the launch (input + output line bytes of the batch) over its average
         # duration. The other record kernels are listed the same way in `roofline_by_kernel`.
-        per_launch_bytes = (in_bytes + out_bytes) / args.steps + 2.0 * aligned_per_record * args.batch
+        per_launch_bytes = (in_bytes + out_bytes) / args.steps + extra_per_base * aligned_per_record * args.batch
         by_kernel = {}
         for name, (ms, launches) in kernels.items():
             if launches <= 0 or ms <= 0:
@@ -177,7 +184,12 @@ def main():
                         "algorithmic_bytes_per_launch": int(per_launch_bytes)}
         cpu = None
         if args.cpu_sample > 0 and world == 1:  # the CPU leg runs on rank 0 of the one-GPU run only
-            cpu = cpu_baseline_genomes(wl, stages, min(args.cpu_sample, 16384)) if wl.get("genomes") else cpu_baseline(eng, wl, stages, args.cpu_sample)
+            if wl.get("genomes"):
+                cpu = cpu_baseline_genomes(wl, stages, min(args.cpu_sample, 16384))
+            elif wl.get("tile"):
+                cpu = cpu_baseline_tile(eng, wl, min(args.cpu_sample, 8192))
+            else:
+                cpu = cpu_baseline(eng, wl, stages, args.cpu_sample)
         line = {
             "metric": "PAF records/sec (shatter+invert+trim pipe); % HBM roofline at 1/2/4/8 GPU",
             "value": round(records / elapsed, 1),
@@ -198,12 +210,12 @@ def main():
                        "output_rows_per_record": round(rows / (args.batch * args.steps), 2),
                        "aligned_bases_per_record": round(aligned_per_record, 1),
                        "sharding": "contiguous record batches per rank, no collective"},
-            "whole_path_GBps_per_gpu": round(((job_in + job_out) / world + 2.0 * aligned_per_record * args.batch * args.steps) / elapsed / 1e9, 1),
+            "whole_path_GBps_per_gpu": round(((job_in + job_out) / world + extra_per_base * aligned_per_record * args.batch * args.steps) / elapsed / 1e9, 1),
             "roofline": roofline,
             # the record kernels that take at least a tenth of the dominant kernel's time (a small kernel priced with the whole batch's bytes says nothing)
             "roofline_by_kernel": {k: v for k, v in by_kernel.items()
-                                   if k in ("k_size_lds", "k_emit_rows", "k_emit_lds", "k_emit_lds<line>", "k_emit_line") and kernels[k][0] >= 0.1 * max(x[0] for x in kernels.values())},
-            "whole_path_frac_of_hbm_peak": round(((job_in + job_out) / world + 2.0 * aligned_per_record * args.batch * args.steps) / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+                                   if k in ("k_size_lds", "k_emit_rows", "k_emit_lds", "k_emit_lds<line>", "k_emit_line", "k_tile_slices", "k_tile_emit") and kernels[k][0] >= 0.1 * max(x[0] for x in kernels.values())},
+            "whole_path_frac_of_hbm_peak": round(((job_in + job_out) / world + extra_per_base * aligned_per_record * args.batch * args.steps) / elapsed / 1e9 / HBM_PEAK_GBS, 4),
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kernels.items()},
         }
@@ -247,6 +259,23 @@ def cpu_baseline(eng, wl, stages, n):
     want = bytes((C.c_char * on.value).from_address(out.value)) if on.value else b""
     L.po_free(out)
     got, _ = eng.run(stages, data)
+    return {"value": round(n / dt, 1), "unit": "records/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} records of the same stream ({len(data)} B in, {len(want)} B out), {dt:.1f} s, single thread",
+            "gpu_output_matches": bool(got == want and err.code == 0)}
+
+
+def cpu_baseline_tile(eng, wl, n):
+    """CPU leg of the tile workload: the oracle's `paffy tile` on the first n records (one thread; it allocates the same per-base
+    counters); the same sample runs on the GPU for the equality check."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    buf, nbytes = eng.synth(wl["seed"], wl["mean_ops"], 0, n)
+    data = bytes(buf[:nbytes].cpu().numpy().tobytes())
+    t0 = time.perf_counter()
+    want, err = O.tile(data)
+    dt = time.perf_counter() - t0
+    got, _ = eng.tile(data)
     return {"value": round(n / dt, 1), "unit": "records/s", "cores": 1, "kind": "port",
             "sample": f"first {n} records of the same stream ({len(data)} B in, {len(want)} B out), {dt:.1f} s, single thread",
             "gpu_output_matches": bool(got == want and err.code == 0)}
