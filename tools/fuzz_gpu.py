@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak test (GPU box): random records through random pipes, HIP path vs the CPU oracle, for a time budget.
-usage: python tools/fuzz_gpu.py [seconds] [seed]   -- prints the first mismatch (and saves it under gpurun_out/) or a summary."""
+usage: python tools/fuzz_gpu.py [seconds] [seed] [pipe|tile|mism|bed]   -- prints the first mismatch (and saves it under gpurun_out/) or a summary."""
 import hashlib
 import os
 import random
@@ -95,6 +95,34 @@ def fuzz_tile(eng, rng, budget):
     print(f"tile fuzz ok: {rounds} rounds")
 
 
+def fuzz_bed(eng, rng, budget):
+    """to_bed with random options; -n walks the target side too (both strands, sequences in both roles)."""
+    t0, rounds = time.time(), 0
+    while time.time() - t0 < budget:
+        contigs = [(f"ctg{i}", rng.choice([300, 5000, 70000, 1200000, 2500000])) for i in range(rng.randrange(1, 5))]
+        recs = []
+        for _ in range(rng.choice([1, 10, 200, 1200])):
+            qn, qlen = rng.choice(contigs)
+            tn, tlen = rng.choice(contigs) if rng.random() < 0.3 else ("t", 4000000)
+            recs.append(consistent_record(rng, qn, qlen, tn, tlen, rng.choice([1, 5, 60, 900]), rng.choice([[1, 3], [5, 50, 300], [1000, 20000]])))
+        if rng.random() < 0.1:  # a record that breaks an assert somewhere in the middle
+            f = recs[len(recs) // 2].split("\t")
+            f[3] = str(int(f[3]) + 1)
+            recs[len(recs) // 2] = "\t".join(f)
+        data = "".join(recs).encode()
+        kw = dict(binary=rng.random() < 0.3, exclude_unaligned=rng.random() < 0.3, exclude_aligned=rng.random() < 0.2, min_size=rng.choice([1, 1, 2, 40, 5000]),
+                  include_inverted=rng.random() < 0.5)
+        want, werr = O.to_bed(data, **kw)
+        got, info = eng.to_bed(data, raise_on_error=False, **kw)
+        if got != want or info.error.code != werr.code or (werr.code and info.error.record != werr.record):
+            with open(os.path.join(ROOT, "gpurun_out", "fuzz_bed_fail.paf"), "wb") as fh:
+                fh.write(data)
+            print("BED MISMATCH", kw, info.error.code, werr.code, info.error.record, werr.record, len(got), len(want))
+            sys.exit(1)
+        rounds += 1
+    print(f"to_bed fuzz ok: {rounds} rounds")
+
+
 def fuzz_mismatches(eng, rng, budget):
     t0, rounds = time.time(), 0
     comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
@@ -147,6 +175,8 @@ def main():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     if mode == "tile":
         return fuzz_tile(eng, rng, budget)
+    if mode == "bed":
+        return fuzz_bed(eng, rng, budget)
     if mode == "mism":
         return fuzz_mismatches(eng, rng, budget)
     kinds = [O.INVERT, O.TRIM_IDENTITY, O.TRIM_FIXED, O.REMOVE_MISMATCHES, O.PASS, O.FILTER]
