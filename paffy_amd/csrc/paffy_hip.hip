@@ -768,6 +768,8 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_LEAN>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_ADD>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds_long<PAFFY_MASK_PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds_long<PAFFY_MASK_ADD>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds_long<PAFFY_MASK_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds_long<PAFFY_MASK_LEAN>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
@@ -875,6 +877,8 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     for (int32_t i = 0; i < n_stages; i++) lean = lean && ((PAFFY_MASK_LEAN >> stages[i].kind) & 1u);
     bool lean_add = !lean; /* the lean kinds and add_mismatches: its own instantiation (the encoder wants the registers) */
     for (int32_t i = 0; i < n_stages; i++) lean_add = lean_add && ((PAFFY_MASK_ADD >> stages[i].kind) & 1u);
+    bool plain = !lean; /* no stage of the kinds that came with the encoder: the instantiation without them */
+    for (int32_t i = 0; i < n_stages; i++) plain = plain && ((PAFFY_MASK_PLAIN >> stages[i].kind) & 1u);
     c->planned = false;
     c->plan_is_tile = false;
     c->plan_is_bed = false;
@@ -970,12 +974,14 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
                 k1.level = 1;
                 if (lean) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_LEAN>, dim3(768), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_MID), c->side, k1);
                 else if (lean_add) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_ADD>, dim3(768), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_MID), c->side, k1);
+                else if (plain) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_PLAIN>, dim3(768), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_MID), c->side, k1);
                 else hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_ALL>, dim3(768), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_MID), c->side, k1);
                 k1.ops_cap = PAFFY_OPS_CAP_BIG;
                 k1.next_cap = 0;
                 k1.level = 2;
                 if (lean) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_LEAN>, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), c->side, k1);
                 else if (lean_add) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_ADD>, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), c->side, k1);
+                else if (plain) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_PLAIN>, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), c->side, k1);
                 else hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_ALL>, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), c->side, k1);
                 HIPCHK(c, hipGetLastError());
                 HIPCHK(c, hipEventRecord(c->ev_join, c->side));
@@ -985,6 +991,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             kp.level = 0;
             if (lean) LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_LEAN>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             else if (lean_add) LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_ADD>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
+            else if (plain) LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_PLAIN>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             else LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_ALL>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); /* join */
             LAUNCH(c, "k_arena_size", k_arena_size, dim3(2048), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);

@@ -2676,6 +2676,8 @@ __device__ __forceinline__ void load_state(const RecMeta &m, RecState &s) {
 #define PAFFY_MASK_ALL 0xffffffffu
 #define PAFFY_MASK_LEAN ((1u << PAFFY_INVERT) | (1u << PAFFY_TRIM_IDENTITY) | (1u << PAFFY_SHATTER) | (1u << PAFFY_PASS))
 #define PAFFY_MASK_ADD (PAFFY_MASK_LEAN | (1u << PAFFY_ADD_MISMATCHES))
+/* everything but the mismatch encoder, the stats sums and the trim by count: the pipes of filter, fixed trim, add_mismatches -a */
+#define PAFFY_MASK_PLAIN (PAFFY_MASK_ALL & ~((1u << PAFFY_ADD_MISMATCHES) | (1u << PAFFY_STATS) | (1u << PAFFY_TRIM_ENDS)))
 #define STAGE_ON(kind) ((MASK >> (kind)) & 1u)
 template <class OPS, uint32_t MASK = PAFFY_MASK_ALL>
 __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t cap, const RecLds &L, uint32_t klass,
