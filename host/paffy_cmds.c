@@ -387,7 +387,7 @@ int paffy_view_main(int argc, char *argv[]) {
             case 'v': min_aligned = atoi(optarg); break;
             case 'h':
             default:
-                fprintf(stderr, "paffy view [fasta_files]xN [options], MI355X build\nAggregate alignment stats (-s -t); the per-alignment view is not in this build\n");
+                fprintf(stderr, "paffy view [fasta_files]xN [options], MI355X build\nAlignment stats per record and overall (-s); the base-level print (-a) is not in this build\n");
                 fprintf(stderr, "-i --inputFile : PAF file to read (default: stdin)\n-o --outputFile : file to write (default: stdout)\n");
                 fprintf(stderr, "-s --printAggregateStats : print overall stats at the end\n-t --noPerAlignmentStats : no stats per alignment\n");
                 fprintf(stderr, "-u --errorIfIdentityLowerThanX : assert the average identity is >= X\n-v --errorIfAlignedBasesLowerThanX : assert the aligned bases are >= X\n");
@@ -399,9 +399,8 @@ int paffy_view_main(int argc, char *argv[]) {
         fprintf(stderr, "Expected at least one sequence file\n");
         exit(1);
     }
-    if (per_alignment) {
-        (void)include_alignment;
-        fprintf(stderr, "paffy view without -t (the per-alignment pretty print) is outside the scope of this build (hot path only)\n");
+    if (include_alignment) {
+        fprintf(stderr, "paffy view -a (the base-level alignment print) is outside the scope of this build (hot path only)\n");
         return 1;
     }
     host_set_log_level(o.log_level);
@@ -423,7 +422,9 @@ int paffy_view_main(int argc, char *argv[]) {
         fprintf(stderr, "paffy view: cannot open %s\n", !in ? o.in_path : o.out_path);
         return 1;
     }
+    if (per_alignment) host_set_stats_lines(out); /* paf_pretty_print's stats line per record, impl/paf_view.c:158-160 */
     int rc = host_stream(st, 2, in, out);
+    host_set_stats_lines(NULL);
     int64_t t[6], n_alignments = 0; /* matches, mismatches, inserts, deletes, insert bases, delete bases */
     host_get_stats(t, &n_alignments);
     host_set_stats(0);

@@ -43,6 +43,8 @@ void host_set_dedupe(int check_inverse);
 /* paffy view -s -t: host_stream adds up the PAFFY_STATS sums of the chunks instead of writing lines */
 void host_set_stats(int on);
 void host_get_stats(int64_t sums[6], int64_t *n_records);
+/* paffy view without -t: every record's paf_pretty_print stats line is written to fh as the chunks go by (NULL: off) */
+void host_set_stats_lines(FILE *fh);
 
 /* `paffy tile`: reads all of `in`, one tile_plan + emit, writes `out`. */
 int host_tile(FILE *in, FILE *out);

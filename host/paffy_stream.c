@@ -4,6 +4,7 @@
  * impl/paf_invert.c:84-89 and friends).
  */
 #define _GNU_SOURCE
+#include <inttypes.h>
 #include <signal.h>
 #include <stdarg.h>
 #include <stdlib.h>
@@ -105,6 +106,38 @@ void host_get_stats(int64_t sums[6], int64_t *n_records) {
     memcpy(sums, g_stats, sizeof(g_stats));
     *n_records = g_stats_records;
 }
+static FILE *g_stats_lines = NULL; /* paffy view without -t: one paf_pretty_print stats line per record goes here */
+void host_set_stats_lines(FILE *fh) { g_stats_lines = fh; }
+
+/* the per-alignment line of paf_pretty_print (impl/paf.c:269-281): the six sums come from the GPU, the fields from the GPU's parse */
+static int stats_lines(paffy_hip_ctx *ctx, const char *buf, int64_t len, int64_t n_records) {
+    int64_t *t = (int64_t *)malloc(sizeof(int64_t) * 6 * (size_t)(n_records > 0 ? n_records : 1));
+    int64_t got = paffy_hip_plan_record_stats(ctx, n_records, t);
+    paffy_record *recs = NULL;
+    uint64_t *ops = NULL;
+    int64_t n_ops = 0;
+    paffy_plan_info pi;
+    int rc = got == n_records ? paffy_hip_parse_host(ctx, buf, len, &recs, &ops, &n_ops, &pi) : PAFFY_E_STATE;
+    if (!rc && pi.error.code == 0 && pi.n_records == n_records) {
+        for (int64_t r = 0; r < n_records; r++) {
+            const paffy_record *p = &recs[r];
+            const int64_t *s = t + 6 * r; /* matches, mismatches, inserts, deletes, insert bases, delete bases */
+            fprintf(g_stats_lines, "Query:%.*s\tQ-start:%" PRIi64 "\tQ-length:%" PRIi64 "\tTarget:%.*s\tT-start:%" PRIi64 "\tT-length:%" PRIi64
+                    "\tSame-strand:%i\tScore:%" PRIi64 "\tIdentity:%f\tIdentity-with-gaps%f\tAligned-bases:%" PRIi64 "\tQuery-inserts:%" PRIi64
+                    "\tQuery-deletes:%" PRIi64 "\n",
+                    (int)p->query_name_len, buf + p->query_name_off, p->query_start, p->query_end - p->query_start, (int)p->target_name_len,
+                    buf + p->target_name_off, p->target_start, p->target_end - p->target_start, (int)p->same_strand, p->score,
+                    (float)s[0] / (s[0] + s[1]), (float)s[0] / (s[0] + s[1] + s[4] + s[5]), s[0] + s[1], s[2], s[3]);
+        }
+    } else if (!rc) {
+        rc = PAFFY_E_STATE;
+    }
+    free(recs);
+    free(ops);
+    free(t);
+    return rc;
+}
+
 static int stats_chunk(paffy_hip_ctx *ctx, const paffy_stage *stages, int n_stages, const char *buf, int64_t len, paffy_plan_info *info) {
     void *d_in = NULL;
     if (paffy_hip_malloc(&d_in, len + 64) != 0) return PAFFY_E_HIP;
@@ -115,6 +148,7 @@ static int stats_chunk(paffy_hip_ctx *ctx, const paffy_stage *stages, int n_stag
     if (!rc && info->error.code == 0) {
         for (int k = 0; k < 6; k++) g_stats[k] += sums[k];
         g_stats_records += info->n_records;
+        if (g_stats_lines) rc = stats_lines(ctx, buf, len, info->n_records);
     }
     paffy_hip_free(d_in);
     return rc;

@@ -183,6 +183,9 @@ int paffy_hip_run_host(paffy_hip_ctx *ctx, const paffy_stage *stages, int32_t n_
  * meaningful when no record failed (a failing record ends the reference process before it prints anything).
  */
 int paffy_hip_plan_stats(paffy_hip_ctx *ctx, int64_t sums[6]);
+/* The same six sums for every record of the batch (6 * n_records values, record by record): the numbers of the per-alignment line of
+ * `paffy view` (paf_pretty_print, impl/paf.c:269-281). Returns n_records or a negative error. */
+int64_t paffy_hip_plan_record_stats(paffy_hip_ctx *ctx, int64_t cap_records, int64_t *sums);
 
 /*
  * Records as structs, for hosts that hold `Paf` objects (the per-record API of inc/paf.h:75-269, host/paf_api.c): the text is

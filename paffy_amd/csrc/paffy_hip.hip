@@ -670,6 +670,7 @@ struct paffy_hip_ctx {
     DevBuf scan_part, emit_order, order_cnt, tile_keys, tile_order, tile_rank, tile_coff, tile_cbase, tile_cov, tile_level, tile_len, tile_items, tile_slots, tile_parts;
     bool plan_is_tile = false;
     bool plan_is_bed = false; /* paffy to_bed: emit writes the run lines */
+    DevBuf rec_stats; /* six sums per record of the PAFFY_STATS stage */
     DevBuf bed_keys, bed_tab, bed_starts, bed_len, bed_off, bed_tiles;
     struct BedParams *bed_params = nullptr; /* host copy */
     uint64_t bed_runs = 0;
@@ -786,7 +787,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     if (!c) return;
     prof_collect(c);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
-                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
+                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->rec_stats, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
                       &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts, &c->scan_part, &c->dedupe_keys, &c->emit_order, &c->order_cnt};
     for (DevBuf *b : bufs)
@@ -943,6 +944,12 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     kp.b_list[1] = static_cast<uint32_t *>(c->b_list1.p);
     kp.info = static_cast<DevInfo *>(c->info.p);
     kp.filter = c->filter;
+    for (int32_t i = 0; i < n_stages; i++)
+        if (stages[i].kind == PAFFY_STATS && n_lines > 0) {
+            if (ensure(c, c->rec_stats, sizeof(int64_t) * 6 * (size_t)n_lines)) return PAFFY_E_HIP;
+            kp.rec_stats = static_cast<int64_t *>(c->rec_stats.p);
+            HIPCHK(c, hipMemsetAsync(c->rec_stats.p, 0, sizeof(int64_t) * 6 * (size_t)n_lines, c->stream)); /* records that stop before the stage */
+        }
 
     if (n_lines > 0) {
         { /* launch order of the sizing workgroups: long cigars first (out_len is scratch until the sizing pass fills it) */
@@ -1797,6 +1804,17 @@ int paffy_hip_plan_stats(paffy_hip_ctx *c, int64_t sums[6]) {
     if (!c->planned || c->plan_is_tile) return PAFFY_E_STATE;
     for (int k = 0; k < 6; k++) sums[k] = c->plan.in_bytes > 0 ? (int64_t)c->h_info->stats[k] : 0;
     return 0;
+}
+
+int64_t paffy_hip_plan_record_stats(paffy_hip_ctx *c, int64_t cap_records, int64_t *sums) {
+    if (!c || !sums || cap_records < 0) return PAFFY_E_ARG;
+    if (!c->planned || c->plan_is_tile || c->plan_is_bed) return PAFFY_E_STATE;
+    const int64_t n = c->plan.n_records;
+    if (n == 0) return 0;
+    if (!c->kp.rec_stats) return PAFFY_E_STATE; /* no PAFFY_STATS stage in the plan */
+    if (cap_records < n) return PAFFY_E_CAPACITY;
+    HIPCHK(c, hipMemcpy(sums, c->kp.rec_stats, sizeof(int64_t) * 6 * (size_t)n, hipMemcpyDeviceToHost));
+    return n;
 }
 
 int paffy_hip_parse_host(paffy_hip_ctx *c, const char *h_in, int64_t in_len, paffy_record **recs, uint64_t **ops, int64_t *n_ops_total,

@@ -2846,7 +2846,13 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
                     atomicAdd(&P.info->stats[3], (unsigned long long)c2[2]);
                     atomicAdd(&P.info->stats[4], (unsigned long long)a[2]);
                     atomicAdd(&P.info->stats[5], (unsigned long long)c2[0]);
+                    if (P.rec_stats) {
+                        int64_t *o = P.rec_stats + 6ull * rec;
+                        o[0] = a[0]; o[1] = a[1]; o[2] = c2[1]; o[3] = c2[2]; o[4] = a[2]; o[5] = c2[0];
+                    }
                 }
+            } else if (threadIdx.x == 0 && P.rec_stats) {
+                for (int k = 0; k < 6; k++) P.rec_stats[6ull * rec + k] = 0; /* cigar_count(NULL) == 0 */
             }
         } else if (STAGE_ON(PAFFY_FILTER) && st.kind == PAFFY_FILTER) {
             /* paffy filter, impl/paf_filter.c:120-156: paf_stats_calc sums from the view's running totals

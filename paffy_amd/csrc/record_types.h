@@ -91,6 +91,7 @@ struct KParams {
     paffy_filter filter; /* thresholds of PAFFY_FILTER stages */
     const uint32_t *emit_order; /* records by descending output size (coarse): the one-wave-per-record writers start the long ones first */
     const uint32_t *size_order; /* records by descending cigar length (coarse), for the sizing launch */
+    int64_t *rec_stats;         /* PAFFY_STATS: six sums per record (the order of paf_stats_calc's arguments), or NULL */
 };
 
 #endif

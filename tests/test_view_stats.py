@@ -62,4 +62,18 @@ def test_stats_stage_and_cli(tmp_path, human_chimp):
     r = subprocess.run([PAFFY, "view", "-s", "-t", "-u", "0.995", "-i", str(paf), str(fa)], capture_output=True)
     assert r.returncode == -6 and r.stdout.decode() == line
     assert subprocess.run([PAFFY, "view", "-s", "-t", "-i", str(paf)], capture_output=True).returncode == 1
-    assert subprocess.run([PAFFY, "view", "-s", "-i", str(paf), str(fa)], capture_output=True).returncode == 1
+    # without -t: paf_pretty_print's stats line for every record (impl/paf.c:269-281), then the aggregate
+    r = subprocess.run([PAFFY, "view", "-s", "-i", str(paf), str(fa)], capture_output=True, env=dict(os.environ, PAFFY_CHUNK_MB="1"))
+    assert r.returncode == 0, r.stderr[-500:]
+    got = r.stdout.decode().splitlines(keepends=True)
+    assert len(got) == 1501 and got[-1] == line
+    enc = O.run([O.stage(O.ADD_MISMATCHES)], data, seqs)[0].splitlines()
+    for k in (0, 1, 700, 1499):
+        f = enc[k].split(b"\t")
+        m1, x1, i1, d1, ib1, db1 = O.cigar_stats(enc[k].split(b"cg:Z:")[1].decode())
+        want_line = ("Query:%s\tQ-start:%d\tQ-length:%d\tTarget:%s\tT-start:%d\tT-length:%d\tSame-strand:%d\tScore:%d\tIdentity:%f\tIdentity-with-gaps%f"
+                     "\tAligned-bases:%d\tQuery-inserts:%d\tQuery-deletes:%d\n"
+                     % (f[0].decode(), int(f[2]), int(f[3]) - int(f[2]), f[5].decode(), int(f[7]), int(f[8]) - int(f[7]), 1 if f[4] == b"+" else 0,
+                        int([t for t in f if t.startswith(b"AS:i:")][0][5:]), f32(f32(m1) / f32(m1 + x1)), f32(f32(m1) / f32(m1 + x1 + ib1 + db1)), m1 + x1, i1, d1))
+        assert got[k] == want_line, k
+    assert subprocess.run([PAFFY, "view", "-a", "-i", str(paf), str(fa)], capture_output=True).returncode == 1  # base-level print: not in this build
