@@ -6,12 +6,14 @@ PAF text that is already resident in HBM. Workloads follow BASELINE.json / SURVE
   cfg3 (default): 10M-record stream, mean 2048 cigar ops, `invert | trim | shatter`
   cfg2          :  1M-record stream, mean  512 cigar ops, `shatter`
 Every step takes the next `--batch` records of the stream (rank r of N takes every N-th batch),
-so K steps process K*batch distinct records per GPU (weak scaling, no data-path collective).
+so K steps process K*batch distinct records per GPU (weak scaling). `--gpus N` starts the N ranks itself
+when no launcher did (one process per GPU, RCCL); the ordered write across ranks -- an all-gather of
+every step's output sizes, from which each rank knows its byte range -- runs inside the timed region.
 
 Prints ONE JSON line on rank 0 (see the driver contract): value = records/s over all GPUs;
-`roofline` prices the dominant kernel (largest total time: the sizing kernel k_size_lds
-or the row writer k_emit_rows) with algorithmic bytes = input line bytes + output line bytes of
-the batch over its HIP-event duration; `cpu_baseline`
+`roofline` prices one pass of the hot path over one batch: algorithmic bytes = input line bytes +
+output line bytes of the batch (SURVEY 8d) over the summed HIP-event durations of the step's kernels;
+`roofline_by_kernel` prices every record kernel with the bytes it moves itself; `cpu_baseline`
 times the CPU oracle (a port of the reference algorithm; the reference cannot be built here)
 single-threaded on a bounded sample of the same records.
 """
@@ -57,7 +59,15 @@ def main():
     ap.add_argument("--pipe", default=None, help="override the workload's command pipe, e.g. 'shatter' (experiments only)")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="records of the stream timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="plumbing rehearsal without a GPU: ranks, rendezvous, the per-step size exchange and the reductions run, the hot path does not (value is null)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` outside a launcher: start the N ranks here, before anything touches the GPU
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
+    if args.rehearse:
+        return rehearse(args)
 
     import torch
 
@@ -130,12 +140,19 @@ def main():
     eng.sync()
 
     eng.profile(not args.no_kernel_events)
+    # the ordered write across ranks: every step's output sizes are exchanged (RCCL all-gather) inside the timed region, and each
+    # rank's bytes stay in its own HBM at a known offset of the ordered output (per-rank ranges, no gather of the bytes)
+    exch = SizeExchange(dist, world, args.steps, dev if (dist is None or args.dist_backend == "nccl") else "cpu")
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    infos = [step(args.warmup + i) for i in range(args.steps)]
+    infos = []
+    for i in range(args.steps):
+        infos.append(step(args.warmup + i))
+        exch.post(i, infos[-1].out_bytes)
     eng.sync()
+    my_offsets, ordered_total = exch.finish(rank)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -162,25 +179,35 @@ def main():
         job_in, job_out, job_rows = float(in_bytes), float(out_bytes), float(rows)
 
     if rank == 0:
-        # dominant kernel = the one with the largest total time in the timed region; it is priced with the
-        # algorithmic bytes of the launch (input + output line bytes of the batch) over its average
-        # duration. The other record kernels are listed the same way in `roofline_by_kernel`.
-        per_launch_bytes = (in_bytes + out_bytes) / args.steps + extra_per_base * aligned_per_record * args.batch
+        # One launch of the hot path = one pass over one batch = every kernel of a step. The headline `roofline` prices that pass:
+        # the batch's algorithmic bytes (input + output line bytes, + the per-base bytes of add_mismatches / tile) over
+        # the summed HIP-event time of the step's kernels. No single kernel moves all of those bytes -- the sizing kernel reads
+        # the text, the writers write the lines -- so `roofline_by_kernel` prices each kernel with the algorithmic bytes that
+        # kernel itself moves, and carries its measured HBM traffic where a PMC pass of this workload is committed.
+        per_step_in, per_step_out = in_bytes / args.steps, out_bytes / args.steps
+        per_step_extra = extra_per_base * aligned_per_record * args.batch
+        per_launch_bytes = per_step_in + per_step_out + per_step_extra
+        readers = ("k_size_lds", "k_tile_walk", "k_tile_slices", "k_bed_cover")
+        writers = ("k_emit_rows", "k_emit_lds", "k_emit_lds<line>", "k_emit_line", "k_tile_emit", "k_arena_emit", "k_arena_emit<line>")
         by_kernel = {}
         for name, (ms, launches) in kernels.items():
-            if launches <= 0 or ms <= 0:
+            if launches <= 0 or ms <= 0 or name not in readers + writers:
                 continue
-            ach = per_launch_bytes / (ms / launches * 1e-3) / 1e9
-            by_kernel[name] = {"avg_kernel_ms": round(ms / launches, 4), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
-                               "traffic": measured_traffic(args, name)}
+            own = per_step_in + per_step_extra if name in readers else per_step_out
+            ach = own / (ms / launches * 1e-3) / 1e9
+            by_kernel[name] = {"avg_kernel_ms": round(ms / launches, 4), "own_algorithmic_bytes": int(own), "achieved": round(ach, 1),
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args, name)}
         roofline = None
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k][0])
-            ms, launches = kernels[dom]
-            achieved = per_launch_bytes / (ms / launches * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args, dom),
-                        "avg_kernel_ms": round(ms / launches, 4),
+            step_ms = sum(ms for ms, _ in kernels.values()) / args.steps  # all kernels of one step, HIP events on the launch stream
+            achieved = per_launch_bytes / (step_ms * 1e-3) / 1e9
+            traffic = [measured_traffic(args, k) for k in kernels]
+            roofline = {"bound": "hbm", "kernel": f"all kernels of one step (dominant: {dom})", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": int(sum(t for t in traffic if t)) if any(traffic) else None,
+                        "step_kernels_ms": round(step_ms, 4), "dominant_kernel": dom,
+                        "dominant_avg_kernel_ms": round(kernels[dom][0] / max(1, kernels[dom][1]), 4),
                         "algorithmic_bytes_per_launch": int(per_launch_bytes)}
         cpu = None
         if args.cpu_sample > 0 and world == 1:  # the CPU leg runs on rank 0 of the one-GPU run only
@@ -209,12 +236,13 @@ def main():
                        "output_bytes_per_record": round(out_bytes / (args.batch * args.steps), 1),
                        "output_rows_per_record": round(rows / (args.batch * args.steps), 2),
                        "aligned_bases_per_record": round(aligned_per_record, 1),
-                       "sharding": "contiguous record batches per rank, no collective"},
+                       "sharding": "batch b of the stream on rank b % N; per step one all-gather of the output sizes (8 B per rank) inside the timed "
+                                   "region gives every rank the offset of its bytes in the ordered output; the bytes themselves stay on their GPU"},
+            "ordered_write": {"mode": "per-rank offsets from an all-gather of the step's output sizes", "total_bytes": ordered_total,
+                              "rank0_first_offsets": [int(x) for x in my_offsets[:4].tolist()]},
             "whole_path_GBps_per_gpu": round(((job_in + job_out) / world + extra_per_base * aligned_per_record * args.batch * args.steps) / elapsed / 1e9, 1),
             "roofline": roofline,
-            # the record kernels that take at least a tenth of the dominant kernel's time (a small kernel priced with the whole batch's bytes says nothing)
-            "roofline_by_kernel": {k: v for k, v in by_kernel.items()
-                                   if k in ("k_size_lds", "k_emit_rows", "k_emit_lds", "k_emit_lds<line>", "k_emit_line", "k_tile_slices", "k_tile_emit") and kernels[k][0] >= 0.1 * max(x[0] for x in kernels.values())},
+            "roofline_by_kernel": {k: v for k, v in by_kernel.items() if kernels[k][0] >= 0.05 * max(x[0] for x in kernels.values())},
             "whole_path_frac_of_hbm_peak": round(((job_in + job_out) / world + extra_per_base * aligned_per_record * args.batch * args.steps) / elapsed / 1e9 / HBM_PEAK_GBS, 4),
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kernels.items()},
@@ -222,6 +250,124 @@ def main():
         print(json.dumps(line), flush=True)
     if dist:
         dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """Start one process per GPU (rank r -> cuda:r, or cuda:0 with --one-device) with the torch.distributed environment set, as
+    `python -m torch.distributed.run --nproc-per-node N` would; rank 0 prints the JSON line. Nothing in this process has touched
+    the GPU (no exec of a GPU-initialised process). Returns the exit status: non-zero when any rank failed."""
+    import subprocess
+
+    n = args.gpus
+    if not args.rehearse and not args.one_device:
+        import torch
+
+        have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+        if have < n:
+            print(f"bench.py: --gpus {n} but {have} device(s) visible (use --one-device for a one-GPU rehearsal)", file=sys.stderr)
+            return 2
+    env0 = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for r, p in enumerate(procs):
+            code = p.wait()
+            if code != 0:
+                print(f"bench.py: rank {r} exited with status {code}", file=sys.stderr)
+                rc = rc or (code if code > 0 else 1)
+                for q in procs:  # a rank that lost its peer would wait for the rendezvous timeout: end exactly the ones we started
+                    if q.poll() is None:
+                        q.terminate()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    return rc
+
+
+class SizeExchange:
+    """The ordered write of the stream commands across ranks: batch b of the stream belongs to rank b % N; after every
+    step all ranks exchange the step's output byte counts (one all-gather of 8 bytes per rank: RCCL with the nccl backend), so that
+    every rank knows the byte offset of each of its batches in the ordered output and writes its own range there. The collectives
+    are issued inside the timed region, one per step, and waited for at its end."""
+
+    def __init__(self, dist, world, steps, device):
+        import torch
+
+        self.dist, self.world, self.steps = dist, world, steps
+        self.mine = torch.zeros(steps, dtype=torch.int64, device=device)
+        self.table = torch.zeros(steps, world, dtype=torch.int64, device=device)
+        self.work = []
+
+    def post(self, step, out_bytes):
+        self.mine[step] = out_bytes
+        if self.dist is None:
+            self.table[step, 0] = out_bytes
+            return
+        self.work.append(self.dist.all_gather_into_tensor(self.table[step], self.mine[step:step + 1], async_op=True))
+
+    def finish(self, rank):
+        """-> (offset of each of this rank's batches in the ordered output, total bytes); batch order = step-major, rank-minor"""
+        import torch
+
+        for w in self.work:
+            w.wait()
+        flat = self.table.reshape(-1)
+        ends = torch.cumsum(flat, 0)
+        offs = (ends - flat).reshape(self.steps, self.world)[:, rank]
+        return offs, int(ends[-1].item()) if flat.numel() else 0
+
+
+def rehearse(args):
+    """`--rehearse`: everything of the N-rank run but the hot path -- rendezvous, barriers, the per-step size exchange, the
+    max-over-ranks reduction and the JSON line -- on CPU tensors over gloo. The hot path has no CPU implementation, so nothing is
+    measured: value is null. tests/test_bench_ranks.py runs this with --gpus 2."""
+    import torch
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo")
+    ex = SizeExchange(dist, world, args.steps, "cpu")
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ex.post(i, 1000 * (i + 1) + rank)  # stand-in sizes: batch (step i, rank r) is 1000 (i + 1) + r bytes long
+    offs, total = ex.finish(rank)
+    if dist:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    want = [sum(1000 * (j + 1) * world + world * (world - 1) // 2 for j in range(i)) + sum(1000 * (i + 1) + r for r in range(rank))
+            for i in range(args.steps)]
+    ok = [int(x) for x in offs.tolist()] == want
+    if rank == 0:
+        print(json.dumps({"metric": "PAF records/sec (shatter+invert+trim pipe); % HBM roofline at 1/2/4/8 GPU", "value": None, "unit": "records/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(t.item()) / max(1, args.steps) * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "none", "rehearsal": True,
+                          "ordered_write": {"mode": "per-rank offsets from an all-gather of the step's output sizes", "offsets_ok": ok,
+                                            "total_bytes": total}}), flush=True)
+    if dist:
+        dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def measured_traffic(args, kernel):
