@@ -309,16 +309,32 @@ class SizeExchange:
         import torch
 
         self.dist, self.world, self.steps = dist, world, steps
-        self.mine = torch.zeros(steps, dtype=torch.int64, device=device)
-        self.table = torch.zeros(steps, world, dtype=torch.int64, device=device)
+        self.sizes = [[0] * world for _ in range(steps)]  # single rank: nothing leaves the host
         self.work = []
+        self.on_gpu = dist is not None and str(device) != "cpu"
+        if dist is not None:
+            self.table = torch.zeros(steps, world, dtype=torch.int64, device=device)
+            self.mine = torch.zeros(steps, dtype=torch.int64, device=device)
+        if self.on_gpu:
+            # the size is known on the host right after the plan: it travels on a side stream (pinned staging, no host wait), so
+            # neither the copy nor the collective queues behind the step's emit kernel
+            self.stage = torch.zeros(steps, dtype=torch.int64).pin_memory()
+            self.side = torch.cuda.Stream(device=device)
 
     def post(self, step, out_bytes):
-        self.mine[step] = out_bytes
+        import torch
+
         if self.dist is None:
-            self.table[step, 0] = out_bytes
+            self.sizes[step][0] = int(out_bytes)
             return
-        self.work.append(self.dist.all_gather_into_tensor(self.table[step], self.mine[step:step + 1], async_op=True))
+        if self.on_gpu:
+            self.stage[step] = int(out_bytes)
+            with torch.cuda.stream(self.side):
+                self.mine[step:step + 1].copy_(self.stage[step:step + 1], non_blocking=True)
+                self.work.append(self.dist.all_gather_into_tensor(self.table[step], self.mine[step:step + 1], async_op=True))
+        else:
+            self.mine[step] = int(out_bytes)
+            self.work.append(self.dist.all_gather_into_tensor(self.table[step], self.mine[step:step + 1], async_op=True))
 
     def finish(self, rank):
         """-> (offset of each of this rank's batches in the ordered output, total bytes); batch order = step-major, rank-minor"""
@@ -326,7 +342,13 @@ class SizeExchange:
 
         for w in self.work:
             w.wait()
-        flat = self.table.reshape(-1)
+        if self.dist is None:
+            table = torch.tensor(self.sizes, dtype=torch.int64)
+        else:
+            if self.on_gpu:
+                self.side.synchronize()
+            table = self.table.cpu()
+        flat = table.reshape(-1)
         ends = torch.cumsum(flat, 0)
         offs = (ends - flat).reshape(self.steps, self.world)[:, rank]
         return offs, int(ends[-1].item()) if flat.numel() else 0

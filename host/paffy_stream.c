@@ -392,49 +392,125 @@ int host_split_file(FILE *in, const char *prefix, int by_query, int64_t min_leng
 
 static int whole_file(FILE *in, FILE *out, const paffy_bed_opts *bed);
 int host_tile(FILE *in, FILE *out) { return whole_file(in, out, NULL); }
-/* paffy to_bed: the whole file is one batch, like tile */
+/* paffy to_bed: every record counts before anything is written, like tile */
 int host_to_bed(FILE *in, FILE *out, const paffy_bed_opts *opts) { return whole_file(in, out, opts); }
 
+/*
+ * tile / to_bed read the whole input before they write (read_pafs, impl/paf.c:492-499; the loop of impl/paf_to_bed.c:166-190).
+ * The text goes to the GPU in batches of whole lines (at most PAFFY_CHUNK_MB each, below the 2 GiB a batch may hold) and stays
+ * there; the output comes back through a bounded staging buffer. Inputs are limited by the GPU's memory, not by a batch.
+ */
 static int whole_file(FILE *in, FILE *out, const paffy_bed_opts *bed) {
-    size_t cap = 1 << 20, have = 0;
-    char *buf = (char *)malloc(cap);
-    for (;;) {
-        if (have == cap) {
-            cap *= 2;
-            buf = (char *)realloc(buf, cap);
-        }
-        size_t got = fread(buf + have, 1, cap - have, in);
-        if (got == 0) break;
-        have += got;
-    }
     paffy_hip_ctx *ctx = NULL;
     if (paffy_hip_create(&ctx, -1) != 0) {
         fprintf(stderr, "paffy: no usable GPU (this build has no CPU path)\n");
         return 1;
     }
-    void *d_in = NULL, *d_out = NULL;
+    const char *what = bed ? "to_bed" : "tile";
+    const size_t cap = chunk_bytes();
+    size_t buf_cap = cap + (1 << 20), have = 0;
+    char *buf = (char *)malloc(buf_cap);
+    void **d_batches = NULL;
+    size_t n_batches = 0;
+    int eof = 0, rc = 0;
+    if (!buf) {
+        fprintf(stderr, "paffy %s: out of memory\n", what);
+        return 1;
+    }
+    if ((bed ? paffy_hip_bed_begin(ctx, bed) : paffy_hip_tile_begin(ctx)) != 0) rc = 1;
+    while (!rc && (!eof || have > 0)) {
+        if (!eof) {
+            if (have == buf_cap) { /* a single line longer than the chunk: grow */
+                char *nb = (char *)realloc(buf, buf_cap * 2);
+                if (!nb) {
+                    fprintf(stderr, "paffy %s: out of memory\n", what);
+                    rc = 1;
+                    break;
+                }
+                buf = nb;
+                buf_cap *= 2;
+            }
+            size_t want = (have < cap ? cap : buf_cap) - have;
+            size_t got = fread(buf + have, 1, want, in);
+            have += got;
+            if (got < want) eof = 1;
+        }
+        size_t use = have;
+        if (!eof) {
+            while (use > 0 && buf[use - 1] != '\n') use--;
+            if (use == 0) continue;
+        }
+        if (use == 0) break;
+        if (use >= ((size_t)1 << 31) - 64) {
+            fprintf(stderr, "paffy %s: a single line of 2 GiB or more\n", what);
+            rc = 1;
+            break;
+        }
+        void *d = NULL;
+        if (paffy_hip_malloc(&d, (int64_t)use + 64) != 0 || paffy_hip_memcpy_h2d(d, buf, (int64_t)use) != 0 ||
+            (bed ? paffy_hip_bed_add(ctx, d, (int64_t)use) : paffy_hip_tile_add(ctx, d, (int64_t)use)) != 0) {
+            fprintf(stderr, "paffy %s: GPU call failed: %s (the input must fit the GPU's memory)\n", what, paffy_hip_last_error(ctx));
+            if (d) paffy_hip_free(d);
+            rc = 1;
+            break;
+        }
+        d_batches = (void **)realloc(d_batches, sizeof(void *) * (n_batches + 1));
+        d_batches[n_batches++] = d;
+        memmove(buf, buf + use, have - use);
+        have -= use;
+    }
+    free(buf);
     paffy_plan_info info;
-    int rc = 1;
-    if (paffy_hip_malloc(&d_in, (int64_t)have + 64) == 0 && paffy_hip_memcpy_h2d(d_in, buf, (int64_t)have) == 0 &&
-        (bed ? paffy_hip_bed_plan(ctx, d_in, (int64_t)have, bed, &info) : paffy_hip_tile_plan(ctx, d_in, (int64_t)have, &info)) == 0) {
-        if (info.error.code) die_like_reference(&info.error, 0);
-        rc = 0;
-        if (info.out_bytes > 0) {
+    memset(&info, 0, sizeof(info));
+    if (!rc && (bed ? paffy_hip_bed_run(ctx, bed, &info) : paffy_hip_tile_run(ctx, &info)) != 0) {
+        fprintf(stderr, "paffy %s: GPU call failed: %s\n", what, paffy_hip_last_error(ctx));
+        rc = 1;
+    }
+    if (!rc && info.error.code) die_like_reference(&info.error, 0);
+    if (!rc && info.out_bytes > 0) {
+        if (bed) { /* the runs: one buffer */
+            void *d_out = NULL;
             char *h = (char *)malloc((size_t)info.out_bytes);
-            if (paffy_hip_malloc(&d_out, info.out_bytes + 64) == 0 && paffy_hip_emit(ctx, d_out, info.out_bytes + 64) == 0 &&
-                paffy_hip_sync(ctx) == 0 && paffy_hip_memcpy_d2h(h, d_out, info.out_bytes) == 0)
+            if (h && paffy_hip_malloc(&d_out, info.out_bytes + 64) == 0 && paffy_hip_emit(ctx, d_out, info.out_bytes + 64) == 0 && paffy_hip_sync(ctx) == 0 &&
+                paffy_hip_memcpy_d2h(h, d_out, info.out_bytes) == 0)
                 fwrite(h, 1, (size_t)info.out_bytes, out);
             else
                 rc = 1;
             free(h);
+            if (d_out) paffy_hip_free(d_out);
+        } else { /* the lines, as many at a time as fit the staging buffer */
+            const int64_t n = info.n_rows;
+            uint32_t *rows = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1));
+            int64_t *offs = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
+            int64_t stage = (int64_t)256 << 20;
+            if (!rows || !offs || paffy_hip_plan_rows(ctx, n + 1, rows, offs) != n) rc = 1;
+            for (int64_t k = 0; !rc && k < n; k++)
+                if (offs[k + 1] - offs[k] > stage) stage = offs[k + 1] - offs[k];
+            void *d_stage = NULL;
+            char *h = rc ? NULL : (char *)malloc((size_t)stage);
+            if (!rc && (!h || paffy_hip_malloc(&d_stage, stage + 64) != 0)) rc = 1;
+            int64_t first = 0;
+            while (!rc && first < n) {
+                int64_t last = first + 1;
+                while (last < n && offs[last + 1] - offs[first] <= stage) last++;
+                int64_t bytes = 0;
+                if (paffy_hip_emit_lines(ctx, first, last - first, d_stage, stage + 64, &bytes) != 0 || paffy_hip_sync(ctx) != 0 ||
+                    paffy_hip_memcpy_d2h(h, d_stage, bytes) != 0)
+                    rc = 1;
+                else
+                    fwrite(h, 1, (size_t)bytes, out);
+                first = last;
+            }
+            free(rows);
+            free(offs);
+            free(h);
+            if (d_stage) paffy_hip_free(d_stage);
         }
-    } else {
-        fprintf(stderr, "paffy %s: GPU call failed: %s\n", bed ? "to_bed" : "tile", paffy_hip_last_error(ctx));
+        if (rc) fprintf(stderr, "paffy %s: GPU call failed: %s\n", what, paffy_hip_last_error(ctx));
     }
-    if (d_in) paffy_hip_free(d_in);
-    if (d_out) paffy_hip_free(d_out);
+    for (size_t i = 0; i < n_batches; i++) paffy_hip_free(d_batches[i]);
+    free(d_batches);
     paffy_hip_destroy(ctx);
-    free(buf);
     fflush(out);
     return rc;
 }

@@ -89,7 +89,7 @@ enum {
 /* Call-level failures (negative return values). */
 enum {
     PAFFY_E_HIP = -1,         /* a HIP runtime call failed; see paffy_hip_last_error()         */
-    PAFFY_E_ARG = -2,         /* bad argument (NULL, misaligned pointer, in_len >= 4 GiB - 64) */
+    PAFFY_E_ARG = -2,         /* bad argument (NULL, misaligned pointer, a batch of 2 GiB - 64 bytes or more) */
     PAFFY_E_UNSUPPORTED = -3, /* stage list this build cannot fuse (run the stages one by one)  */
     PAFFY_E_CAPACITY = -4,    /* output buffer smaller than the planned size                   */
     PAFFY_E_STATE = -5        /* emit without a successful plan                                */
@@ -118,7 +118,9 @@ int paffy_hip_set_stream(paffy_hip_ctx *ctx, void *hip_stream);
 
 /*
  * plan: index the lines of d_in[0, in_len) (16-byte aligned device pointer; the allocation
- * must be readable up to the next multiple of 16), parse every record, run the stage list,
+ * must be readable up to the next multiple of 16; in_len < 2 GiB - 64: offsets inside a batch are 32 bits --
+ * a stream command takes any input as a sequence of batches, tile / to_bed through the begin / add / run calls below),
+ * parse every record, run the stage list,
  * and compute each record's exact output size. Blocks until the numbers are known.
  * A final line without '\n' is a record (impl/paf.c:213).
  */
@@ -132,6 +134,26 @@ int paffy_hip_plan(paffy_hip_ctx *ctx, const paffy_stage *stages, int32_t n_stag
  * unchanged. A failing record means no output at all. Followed by paffy_hip_emit().
  */
 int paffy_hip_tile_plan(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len, paffy_plan_info *info);
+/*
+ * The same over an input of any size (the reference reads the whole file, read_pafs, impl/paf.c:492-499): begin, add every batch
+ * of text (each a whole number of lines, < 2 GiB - 64 bytes, 16-byte aligned; it must stay where it is until the output has been
+ * emitted: the lines are written from it), run. Records are ordered and grouped across all batches; info->error.record counts
+ * records from the first batch on. Followed by paffy_hip_emit() or paffy_hip_emit_lines().
+ */
+int paffy_hip_tile_begin(paffy_hip_ctx *ctx);
+int paffy_hip_tile_add(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len);
+int paffy_hip_tile_run(paffy_hip_ctx *ctx, paffy_plan_info *info);
+/*
+ * After a tile run: five int64 per output line, in output order, into device memory -- chain_score, score, input record, bytes of
+ * the line, tile level. This is what the ranks of a `paffy tile` sharded by query sequence exchange (an all-gather of 40 bytes per
+ * record) to find the place of their lines in the ordered output. Returns the number of lines or a negative error.
+ */
+int64_t paffy_hip_tile_keys(paffy_hip_ctx *ctx, int64_t cap_lines, void *d_keys);
+/*
+ * Lines [first, first + n) of a tile / dedupe plan into d_out, the first of them at d_out[0] (16-byte aligned): for hosts that
+ * drain an output larger than their staging buffer. *bytes = what was written.
+ */
+int paffy_hip_emit_lines(paffy_hip_ctx *ctx, int64_t first, int64_t n, void *d_out, int64_t out_cap, int64_t *bytes);
 
 /*
  * dedupe_plan: `paffy dedupe [-a]` (impl/paf_dedupe.c:117-143). A record is kept unless a record kept earlier -- in this
@@ -158,6 +180,10 @@ typedef struct {
     int64_t min_size; /* default 1 */
 } paffy_bed_opts;
 int paffy_hip_bed_plan(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len, const paffy_bed_opts *opts, paffy_plan_info *info);
+/* to_bed over an input of any size, as a sequence of batches (see paffy_hip_tile_begin); the same opts for begin and run */
+int paffy_hip_bed_begin(paffy_hip_ctx *ctx, const paffy_bed_opts *opts);
+int paffy_hip_bed_add(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len);
+int paffy_hip_bed_run(paffy_hip_ctx *ctx, const paffy_bed_opts *opts, paffy_plan_info *info);
 
 /*
  * After a tile or dedupe plan: the lines emit will write, in output order -- record[k] = zero-based input record of line k,
@@ -254,6 +280,9 @@ int paffy_hip_device_count(void);
  */
 int paffy_hip_synth(paffy_hip_ctx *ctx, uint64_t seed, uint32_t mean_ops, uint64_t r0, uint64_t n, void *d_out,
                     int64_t out_cap, int64_t *bytes);
+/* the same with n_contigs contigs per genome instead of 24 (fewer contigs = deeper coverage for a given record count) */
+int paffy_hip_synth_contigs(paffy_hip_ctx *ctx, uint64_t seed, uint32_t mean_ops, uint32_t n_contigs, uint64_t r0, uint64_t n, void *d_out,
+                            int64_t out_cap, int64_t *bytes);
 
 /*
  * cfg4 workload (records + two genomes for PAFFY_ADD_MISMATCHES), generated on the device: every

@@ -952,6 +952,52 @@ int po_split_file(const char *in, int64_t in_len, const char *prefix, int by_que
     return rc;
 }
 
+/*
+ * The coverage counters of `paffy tile` and `paffy to_bed` -- ONE restatement of each reference function, used by po_tile,
+ * po_to_bed and the known-answer probe po_coverage_counts alike, so that the reference's own test of them
+ * (tests/paf_unit_test.c:576-603) pins what tile and to_bed run.
+ */
+/* get_alignment_count_array, impl/paf.c:675-688: the array of the record's query name, zeroed on first sight; NULL (and *mismatch
+ * set) when the name is known with another length (the assert of :685) */
+static count_array *counts_for(count_array **arrs, int64_t *narr, int64_t *acap, const char *name, int64_t name_len, int64_t qlen, int *mismatch) {
+    *mismatch = 0;
+    for (int64_t a = 0; a < *narr; a++)
+        if ((*arrs)[a].name_len == name_len && memcmp((*arrs)[a].name, name, (size_t)name_len) == 0) {
+            if ((*arrs)[a].length != qlen) {
+                *mismatch = 1;
+                return NULL;
+            }
+            return &(*arrs)[a];
+        }
+    if (*narr == *acap) {
+        *acap = *acap ? *acap * 2 : 64;
+        *arrs = (count_array *)realloc(*arrs, sizeof(count_array) * (size_t)*acap);
+    }
+    count_array *ca = &(*arrs)[(*narr)++];
+    ca->name = name;
+    ca->name_len = name_len;
+    ca->length = qlen;
+    ca->counts = (uint16_t *)calloc((size_t)(qlen > 0 ? qlen : 1), sizeof(uint16_t));
+    return ca;
+}
+/* increase_alignment_level_counts, impl/paf.c:690-709: walks upward from query_start in cigar order whatever the strand; M, = and X
+ * bases bump their counter unless it has reached INT16_MAX - 1; I skips its bases, D none. Returns 0, or 1 when one of the
+ * reference's asserts (:698 position, :708 end) would fire. */
+static int bump_counts(uint16_t *counts, const oop *ops, int64_t n, int64_t qs, int64_t qe, int64_t qlen) {
+    int64_t i = qs;
+    for (int64_t o = 0; o < n; o++) {
+        if (ops[o].op == OP_D) continue;
+        if (ops[o].op != OP_I)
+            for (int64_t j = 0; j < ops[o].len; j++) {
+                const int64_t pos = i + j;
+                if (!(pos < qe && pos >= 0 && pos < qlen)) return 1;
+                if (counts[pos] < 32767 - 1) counts[pos]++;
+            }
+        i += ops[o].len;
+    }
+    return i != qe;
+}
+
 int po_tile(const char *in, int64_t in_len, char **out, int64_t *out_len, po_error *err) {
     run_ctx c;
     memset(&c, 0, sizeof(c));
@@ -993,32 +1039,11 @@ int po_tile(const char *in, int64_t in_len, char **out, int64_t *out_len, po_err
             oop *ops; int64_t n; int present; int64_t aux = 0;
             rc = cigar_from_text(r->cg_str, r->cg_str + r->cg_str_len, &ops, &n, &present, &aux);
             if (rc) { fail(&c, rc, 0, aux); break; }
-            /* get_alignment_count_array, impl/paf.c:675-688 */
-            count_array *ca = NULL;
-            for (int64_t a = 0; a < narr; a++)
-                if (arrs[a].name_len == r->qname_len && memcmp(arrs[a].name, r->qname, (size_t)r->qname_len) == 0) { ca = &arrs[a]; break; }
-            if (!ca) {
-                if (narr == acap) { acap = acap ? acap * 2 : 64; arrs = (count_array *)realloc(arrs, sizeof(count_array) * (size_t)acap); }
-                ca = &arrs[narr++];
-                ca->name = r->qname; ca->name_len = r->qname_len; ca->length = r->qlen;
-                ca->counts = (uint16_t *)calloc((size_t)(r->qlen > 0 ? r->qlen : 1), sizeof(uint16_t));
-            } else if (ca->length != r->qlen) { free(ops); rc = fail(&c, PO_ERR_TILE_ASSERT, 0, 1); break; }
-            /* increase_alignment_level_counts, impl/paf.c:690-709: walks upward from query_start
-             * in cigar order whatever the strand; saturates at INT16_MAX-1 */
-            int64_t i = r->qs;
-            int bad = 0;
-            for (int64_t o = 0; o < n && !bad; o++) {
-                if (ops[o].op == OP_D) continue;
-                if (ops[o].op != OP_I) {
-                    for (int64_t j = 0; j < ops[o].len; j++) {
-                        int64_t pos = i + j;
-                        if (!(pos < r->qe && pos >= 0 && pos < r->qlen)) { bad = 1; break; }
-                        if (ca->counts[pos] < 32767 - 1) ca->counts[pos]++;
-                    }
-                }
-                i += ops[o].len;
-            }
-            if (bad || i != r->qe) { free(ops); rc = fail(&c, PO_ERR_TILE_ASSERT, 0, 2); break; }
+            int mismatch = 0;
+            count_array *ca = counts_for(&arrs, &narr, &acap, r->qname, r->qname_len, r->qlen, &mismatch);
+            if (mismatch) { free(ops); rc = fail(&c, PO_ERR_TILE_ASSERT, 0, 1); break; }
+            if (bump_counts(ca->counts, ops, n, r->qs, r->qe, r->qlen)) { free(ops); rc = fail(&c, PO_ERR_TILE_ASSERT, 0, 2); break; }
+            int64_t i;
             /* get_median_alignment_level, impl/paf_tile.c:36-93 */
             int64_t maxlev = 0, matches = 0;
             for (int64_t q = r->qs; q < r->qe; q++) if (ca->counts[q] > maxlev) maxlev = ca->counts[q];
@@ -1063,29 +1088,11 @@ int po_tile(const char *in, int64_t in_len, char **out, int64_t *out_len, po_err
  * order is not defined: sequences are written in order of first appearance here (tests compare the lines as a set).
  */
 static int bed_count(run_ctx *c, rec *r, count_array **arrs, int64_t *narr, int64_t *acap) {
-    count_array *ca = NULL;
-    for (int64_t a = 0; a < *narr; a++)
-        if ((*arrs)[a].name_len == r->qname_len && memcmp((*arrs)[a].name, r->qname, (size_t)r->qname_len) == 0) { ca = &(*arrs)[a]; break; }
-    if (!ca) {
-        if (*narr == *acap) { *acap = *acap ? *acap * 2 : 64; *arrs = (count_array *)realloc(*arrs, sizeof(count_array) * (size_t)*acap); }
-        ca = &(*arrs)[(*narr)++];
-        ca->name = r->qname; ca->name_len = r->qname_len; ca->length = r->qlen;
-        ca->counts = (uint16_t *)calloc((size_t)(r->qlen > 0 ? r->qlen : 1), sizeof(uint16_t));
-    } else if (ca->length != r->qlen) return fail(c, PO_ERR_TILE_ASSERT, 0, 1);
-    int64_t i = r->qs;
-    if (r->has_cigar)
-        for (int64_t o = 0; o < r->n; o++) {
-            const oop *op = &r->ops[r->lo + o];
-            if (op->op == OP_D) continue;
-            if (op->op != OP_I)
-                for (int64_t j = 0; j < op->len; j++) {
-                    int64_t pos = i + j;
-                    if (!(pos < r->qe && pos >= 0 && pos < r->qlen)) return fail(c, PO_ERR_TILE_ASSERT, 0, 2);
-                    if (ca->counts[pos] < 32767 - 1) ca->counts[pos]++;
-                }
-            i += op->len;
-        }
-    if (i != r->qe) return fail(c, PO_ERR_TILE_ASSERT, 0, 2);
+    int mismatch = 0;
+    count_array *ca = counts_for(arrs, narr, acap, r->qname, r->qname_len, r->qlen, &mismatch);
+    if (mismatch) return fail(c, PO_ERR_TILE_ASSERT, 0, 1);
+    /* a record without cigar walks nothing (cigar_count(NULL) == 0, inc/paf.h:75): only the end assert can fire */
+    if (bump_counts(ca->counts, r->has_cigar ? r->ops + r->lo : NULL, r->has_cigar ? r->n : 0, r->qs, r->qe, r->qlen)) return fail(c, PO_ERR_TILE_ASSERT, 0, 2);
     return PO_OK;
 }
 
@@ -1213,27 +1220,36 @@ int po_trim_ends_line(const char *line, int64_t line_len, int64_t end_bases, cha
 }
 
 int64_t po_coverage_counts(const char *in, int64_t in_len, const char *name, uint16_t *counts, int64_t len) {
+    /* the records of `in` through counts_for + bump_counts, the functions po_tile and po_to_bed use; the counters of sequence `name`
+     * are copied out. Returns the number of records applied to it, or -1 - k when record k would trip an assert. */
     const char *p = in, *end = in + in_len;
-    int64_t applied = 0, nl_name = (int64_t)strlen(name);
-    while (p < end) {
+    int64_t applied = 0, nl_name = (int64_t)strlen(name), rec_no = 0, rc = 0;
+    count_array *arrs = NULL;
+    int64_t narr = 0, acap = 0;
+    rec *kept = NULL; /* the names point into the parsed records: keep them until the end */
+    int64_t nkept = 0, kcap = 0;
+    while (p < end && rc == 0) {
         const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
         const char *le = nl ? nl : end;
         rec r; int64_t aux = 0;
-        if (parse_line(p, le, 1, &r, &aux) == PO_OK && r.qname_len == nl_name && memcmp(r.qname, name, (size_t)nl_name) == 0 &&
-            r.qlen == len) {
-            int64_t i = r.qs;
-            for (int64_t o = 0; o < r.n; o++) {
-                const oop *op = &r.ops[r.lo + o];
-                if (op->op == OP_D) continue;
-                if (op->op != OP_I)
-                    for (int64_t j = 0; j < op->len; j++)
-                        if (i + j >= 0 && i + j < len && counts[i + j] < 32767 - 1) counts[i + j]++;
-                i += op->len;
-            }
-            applied++;
+        if (parse_line(p, le, 1, &r, &aux) == PO_OK) {
+            int mismatch = 0;
+            count_array *ca = counts_for(&arrs, &narr, &acap, r.qname, r.qname_len, r.qlen, &mismatch);
+            if (mismatch || bump_counts(ca->counts, r.has_cigar ? r.ops + r.lo : NULL, r.has_cigar ? r.n : 0, r.qs, r.qe, r.qlen)) rc = -1 - rec_no;
+            else if (r.qname_len == nl_name && memcmp(r.qname, name, (size_t)nl_name) == 0) applied++;
+            if (nkept == kcap) { kcap = kcap ? kcap * 2 : 16; kept = (rec *)realloc(kept, sizeof(rec) * (size_t)kcap); }
+            kept[nkept++] = r;
         }
-        rec_free(&r);
+        rec_no++;
         p = nl ? nl + 1 : end;
     }
-    return applied;
+    for (int64_t a = 0; a < narr; a++) {
+        if (rc == 0 && arrs[a].name_len == nl_name && memcmp(arrs[a].name, name, (size_t)nl_name) == 0)
+            for (int64_t i = 0; i < len && i < arrs[a].length; i++) counts[i] = arrs[a].counts[i];
+        free(arrs[a].counts);
+    }
+    free(arrs);
+    for (int64_t k = 0; k < nkept; k++) rec_free(&kept[k]);
+    free(kept);
+    return rc ? rc : applied;
 }

@@ -26,7 +26,8 @@
 #include "../../include/paffy_hip.h"
 #include "paf_synth_core.h"
 #include "record_kernel.h"
-#include "tile_kernel.h"
+#include "coverage_kernel.h"
+#include "bed_kernel.h"
 
 #define SEP_TILE 65536u /* bytes per workgroup in the separator passes */
 
@@ -380,61 +381,6 @@ __global__ __launch_bounds__(PAFFY_NT) void k_order_scatter(const int64_t *out_l
 /* tile: keys for the host ordering, sizes and the verbatim writer       */
 /* ------------------------------------------------------------------ */
 
-struct TileKey {
-    int64_t chain_score, score, qlen, qs, qe;
-    uint64_t name_hash;
-    uint32_t name_len;
-    int32_t err;
-};
-
-__global__ __launch_bounds__(PAFFY_NT) void k_tile_keys(const uint8_t *in, const RecMeta *meta, uint32_t n, TileKey *keys) {
-    uint32_t r = blockIdx.x * PAFFY_NT + threadIdx.x;
-    if (r >= n) return;
-    const RecMeta &m = meta[r];
-    TileKey k;
-    k.chain_score = m.chain_score;
-    k.score = m.score;
-    k.qlen = m.qlen;
-    k.qs = m.qs;
-    k.qe = m.qe;
-    k.name_len = m.qname_len;
-    k.err = m.err;
-    uint64_t h = 0xcbf29ce484222325ull; /* FNV-1a over the query name */
-    for (uint32_t i = 0; i < m.qname_len; i++) h = (h ^ in[m.qname_off + i]) * 0x100000001b3ull;
-    k.name_hash = h;
-    keys[r] = k;
-}
-
-/* to_bed: both sequences of a record (name hash, length, range), whether it has a cigar, its parse error */
-struct BedKey {
-    uint64_t hash[2];
-    int64_t len[2], lo[2], hi[2];
-    uint32_t name_off[2], name_len[2];
-    int32_t err, has_cg, minus, pad;
-};
-__global__ __launch_bounds__(PAFFY_NT) void k_bed_keys(const uint8_t *in, const RecMeta *meta, uint32_t n, BedKey *keys) {
-    uint32_t r = blockIdx.x * PAFFY_NT + threadIdx.x;
-    if (r >= n) return;
-    const RecMeta &m = meta[r];
-    BedKey k;
-    for (int s = 0; s < 2; s++) {
-        const uint32_t off = s ? m.tname_off : m.qname_off, len = s ? m.tname_len : m.qname_len;
-        uint64_t h = 0xcbf29ce484222325ull; /* FNV-1a over the name */
-        for (uint32_t i = 0; i < len; i++) h = (h ^ in[off + i]) * 0x100000001b3ull;
-        k.hash[s] = h;
-        k.name_off[s] = off;
-        k.name_len[s] = len;
-        k.len[s] = s ? m.tlen : m.qlen;
-        k.lo[s] = s ? m.ts : m.qs;
-        k.hi[s] = s ? m.te : m.qe;
-    }
-    k.err = m.err;
-    k.has_cg = m.has_cg && m.cg_len > 0;
-    k.minus = !m.same_strand;
-    k.pad = 0;
-    keys[r] = k;
-}
-
 /* dedupe: 128-bit key of (query name, target name, strand, four coordinates), the same for the swapped record, the
  * coordinate part of paf_check (impl/paf.c:427-438; the cigar is not parsed here) and the record's own tile level */
 struct DedupeKey {
@@ -489,39 +435,6 @@ __device__ __forceinline__ void tile_state(const RecMeta &m, int64_t level, RecS
     load_state(m, s);
     s.has_cigar = false; /* the cigar is written verbatim from the text, impl/paf.c:381-385 */
     s.tile_level = level;
-}
-
-/* out_len[k] for the record at visiting position k */
-__global__ __launch_bounds__(PAFFY_NT) void k_tile_size(const RecMeta *meta, const uint32_t *order, const int64_t *level, uint32_t n,
-                                                         int64_t *out_len) {
-    uint32_t k = blockIdx.x * PAFFY_NT + threadIdx.x;
-    if (k >= n) return;
-    const RecMeta &m = meta[order[k]];
-    RecState s;
-    tile_state(m, level[order[k]], s);
-    out_len[k] = header_len(s, false) + (m.has_cg ? 6 + (int64_t)m.cg_len : 0) + 1;
-}
-
-/* one workgroup per output line: header from LDS, then "\tcg:Z:" + the cigar text as it was read */
-__global__ __launch_bounds__(PAFFY_NT) void k_tile_emit(const uint8_t *in, const RecMeta *meta, const uint32_t *order, const int64_t *level,
-                                                         const int64_t *out_off, uint8_t *out) {
-    __shared__ uint8_t hdr[3 * PAFFY_TMPL_MAX + 8];
-    const RecMeta m = meta[order[blockIdx.x]];
-    uint8_t *o = out + out_off[blockIdx.x];
-    RecState s;
-    tile_state(m, level[order[blockIdx.x]], s);
-    const uint32_t hl = header_len(s, false) + (m.has_cg ? 6u : 0u), cl = m.has_cg ? m.cg_len : 0;
-    const bool direct = hl > 3 * PAFFY_TMPL_MAX; /* header longer than the LDS staging: built in place */
-    if (threadIdx.x < 64) {
-        Piece w{direct ? o : hdr, 0, direct ? hl : 3 * PAFFY_TMPL_MAX, false};
-        build_header(w, s, in, false);
-        if (m.has_cg) w.str("\tcg:Z:", 6);
-    }
-    __syncthreads();
-    if (!direct)
-        for (uint32_t i = threadIdx.x; i < hl; i += PAFFY_NT) o[i] = hdr[i];
-    for (uint32_t i = threadIdx.x; i < cl; i += PAFFY_NT) o[hl + i] = in[m.cg_off + i];
-    if (threadIdx.x == 0) o[hl + cl] = '\n';
 }
 
 /* ------------------------------------------------------------------ */
@@ -676,6 +589,15 @@ struct paffy_hip_ctx {
     uint64_t bed_runs = 0;
     uint32_t tile_n = 0;
     const uint8_t *tile_in = nullptr;
+    struct CovState *cov = nullptr; /* `paffy tile` / `paffy to_bed` over any number of batches (coverage_host.h) */
+    DevBuf one_batch;               /* table with the single text pointer of a one-batch plan (dedupe / split_file lines) */
+    /* what emit writes for a line plan (tile, dedupe): record order, levels, offsets */
+    const uint8_t *const *line_batches = nullptr;
+    const RecMeta *line_meta = nullptr;
+    const uint32_t *line_order = nullptr;
+    const int64_t *line_level = nullptr;
+    const uint64_t *line_off = nullptr;
+    uint64_t line_n = 0;
     DevInfo *h_info = nullptr; /* pinned */
     /* plan state */
     bool planned = false;
@@ -764,8 +686,8 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
     (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     /* the record kernels use more than the default 64 KiB of LDS */
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile), hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_slices), hipFuncAttributeMaxDynamicSharedMemorySize, TILE_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_walk<true>), hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(CovWalkLds));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_walk<false>), hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(CovWalkLds));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_LEAN>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_ADD>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
@@ -783,9 +705,13 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
     return 0;
 }
 
+static void cov_free(paffy_hip_ctx *c); /* coverage_host.h state */
+
 void paffy_hip_destroy(paffy_hip_ctx *c) {
     if (!c) return;
     prof_collect(c);
+    cov_free(c);
+    if (c->one_batch.p) (void)hipFree(c->one_batch.p);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
                       &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->rec_stats, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
@@ -1073,291 +999,117 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
 }
 
 
+} /* extern "C" */
+
+#include "coverage_host.h"
+
+static CovState &cov_state(paffy_hip_ctx *c) {
+    if (!c->cov) c->cov = new CovState();
+    return *c->cov;
+}
+static void cov_free(paffy_hip_ctx *c) {
+    if (!c->cov) return;
+    CovState &S = *c->cov;
+    DevBuf *bufs[] = {&S.meta, &S.batch_ptrs, &S.key_score, &S.key_chain, &S.idx, &S.info, &S.tmp, &S.k64a, &S.k64b, &S.v32a, &S.v32b, &S.order, &S.entries, &S.name_hash,
+                      &S.seq_len, &S.flags, &S.scan32, &S.first_entry, &S.contig_len, &S.contig_cov, &S.contig_slice0, &S.bm_words, &S.n_pairs, &S.bm_off, &S.pair_off,
+                      &S.aligned, &S.bitmap, &S.pairs, &S.pairs2, &S.item_start, &S.item_key, &S.item_idx, &S.item_key2, &S.item_order, &S.slots, &S.arena, &S.arena_used,
+                      &S.cov, &S.backup, &S.level, &S.err_aux, &S.out_len, &S.out_off, &S.names, &S.name_tab};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    delete c->cov;
+    c->cov = nullptr;
+}
+
+extern "C" {
+
 /*
- * `paffy tile` over a whole batch (impl/paf_tile.c:156-178). The visiting order (stable sort by
- * chain_score desc, score desc) and the grouping by query name are computed on the host from 40
- * bytes per record; the per-base coverage walk runs on the GPU, one workgroup per query sequence.
+ * `paffy tile` (impl/paf_tile.c:156-178) over any number of text batches: begin, add every batch (the text stays where it is until
+ * the output has been emitted), run. The visiting order (chain_score desc, score desc, input order) and the grouping by query name
+ * are radix sorts on the device; the per-base walk keeps the counters of a 32 Ki-base slice in LDS (coverage_kernel.h).
  * Any failing record means nothing is written (the reference writes only after the last record).
  */
-/* Stable LSD radix sort of record indices by a 64-bit key per record (ascending), 16 bits per pass; passes whose digit is the
- * same for every record are skipped. The host-side orderings of `paffy tile` (a million records) take milliseconds this way. */
-static void radix_sort_by(std::vector<uint32_t> &idx, const std::vector<uint64_t> &key) {
-    const size_t n = idx.size();
-    if (n < 2) return;
-    uint64_t all_or = 0, all_and = ~0ull;
-    for (size_t i = 0; i < n; i++) {
-        all_or |= key[idx[i]];
-        all_and &= key[idx[i]];
-    }
-    std::vector<uint32_t> tmp(n);
-    std::vector<uint32_t> cnt(65537);
-    for (int pass = 0; pass < 4; pass++) {
-        const int sh = 16 * pass;
-        if ((((all_or ^ all_and) >> sh) & 0xffffu) == 0) continue; /* every record has the same digit */
-        std::fill(cnt.begin(), cnt.end(), 0u);
-        for (size_t i = 0; i < n; i++) cnt[((key[idx[i]] >> sh) & 0xffffu) + 1]++;
-        for (size_t d = 0; d < 65536; d++) cnt[d + 1] += cnt[d];
-        for (size_t i = 0; i < n; i++) tmp[cnt[(key[idx[i]] >> sh) & 0xffffu]++] = idx[i];
-        idx.swap(tmp);
-    }
+int paffy_hip_tile_begin(paffy_hip_ctx *c) {
+    if (!c) return PAFFY_E_ARG;
+    c->planned = false;
+    return cov_begin(c, 1);
 }
-static inline uint64_t descending_key(int64_t x) { return ~((uint64_t)x ^ 0x8000000000000000ull); } /* ascending in this = descending in x */
-
-int paffy_hip_tile_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, paffy_plan_info *info) {
+int paffy_hip_tile_add(paffy_hip_ctx *c, const void *d_in, int64_t in_len) {
+    if (!c) return PAFFY_E_ARG;
+    return cov_add(c, d_in, in_len, true);
+}
+int paffy_hip_tile_run(paffy_hip_ctx *c, paffy_plan_info *info) {
     if (!c || !info) return PAFFY_E_ARG;
-    if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
+    CovState &S = cov_state(c);
     c->planned = false;
     c->plan_is_tile = true;
     c->plan_is_bed = false;
     memset(info, 0, sizeof(*info));
     memset(&c->plan, 0, sizeof(c->plan));
-    info->in_bytes = c->plan.in_bytes = in_len;
     memset(&c->kp, 0, sizeof(c->kp));
-    c->tile_n = 0;
-    if (in_len == 0) {
-        c->planned = true;
-        return 0;
-    }
-    const uint8_t *in = static_cast<const uint8_t *>(d_in);
-    uint32_t n = 0;
-    {
-        int rc = index_and_parse(c, in, (uint32_t)in_len, &n);
+    c->line_n = 0;
+    for (const CovBatch &b : S.batches) c->plan.in_bytes += b.len;
+    c->plan.n_records = (int64_t)S.n_rec;
+    const uint64_t n = S.n_rec;
+    if (n > 0) {
+        int rc = cov_run(c, 0, &c->plan.error);
         if (rc) return rc;
-    }
-    c->plan.n_records = n;
-    if (n == 0) {
-        *info = c->plan;
-        c->planned = true;
-        return 0;
-    }
-    const uint32_t grid = (n + PAFFY_NT - 1) / PAFFY_NT;
-    if (ensure(c, c->tile_keys, sizeof(TileKey) * (size_t)n)) return PAFFY_E_HIP;
-    LAUNCH(c, "k_tile_keys", k_tile_keys, dim3(grid), dim3(PAFFY_NT), 0, in, static_cast<const RecMeta *>(c->meta.p), n,
-           static_cast<TileKey *>(c->tile_keys.p));
-    std::vector<TileKey> keys(n);
-    HIPCHK(c, hipMemcpyAsync(keys.data(), c->tile_keys.p, sizeof(TileKey) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    /* read_pafs parses every line before anything else happens: the first bad line in input order wins */
-    for (uint32_t i = 0; i < n; i++)
-        if (keys[i].err) {
-            c->plan.error.code = keys[i].err;
-            c->plan.error.stage = -1;
-            c->plan.error.record = i;
-            int32_t aux = 0;
-            RecMeta m;
-            HIPCHK(c, hipMemcpy(&m, static_cast<RecMeta *>(c->meta.p) + i, sizeof(m), hipMemcpyDeviceToHost));
-            aux = m.err_aux;
-            c->plan.error.aux = aux;
-            *info = c->plan;
-            c->planned = true;
-            return 0;
+        if (c->plan.error.code == 0) {
+            /* sizes and offsets in visiting order */
+            if (ensure(c, S.out_len, sizeof(uint64_t) * (size_t)(n + 1))) return PAFFY_E_HIP;
+            if (ensure(c, S.out_off, sizeof(uint64_t) * (size_t)(n + 1))) return PAFFY_E_HIP;
+            LAUNCH(c, "k_line_size", k_line_size, dim3((unsigned)((n + 1 + PAFFY_NT - 1) / PAFFY_NT)), dim3(PAFFY_NT), 0, static_cast<const RecMeta *>(S.meta.p),
+                   static_cast<const uint32_t *>(S.order.p), static_cast<const int64_t *>(S.level.p), n, static_cast<uint64_t *>(S.out_len.p));
+            if (cov_excl_scan64(c, S, static_cast<uint64_t *>(S.out_len.p), static_cast<uint64_t *>(S.out_off.p), (size_t)n)) return PAFFY_E_HIP;
+            uint64_t total = 0;
+            if (cov_fetch(c, &total, static_cast<uint64_t *>(S.out_off.p) + n, sizeof(total))) return PAFFY_E_HIP;
+            c->plan.out_bytes = (int64_t)total;
+            c->plan.n_rows = (int64_t)n;
+            c->line_batches = static_cast<const uint8_t *const *>(S.batch_ptrs.p);
+            c->line_meta = static_cast<const RecMeta *>(S.meta.p);
+            c->line_order = static_cast<const uint32_t *>(S.order.p);
+            c->line_level = static_cast<const int64_t *>(S.level.p);
+            c->line_off = static_cast<const uint64_t *>(S.out_off.p);
+            c->line_n = n;
         }
-    /* visiting order: paf_cmp_by_descending_score, impl/paf_tile.c:28-34, ties in input order (stable) */
-    std::vector<uint32_t> order(n);
-    for (uint32_t i = 0; i < n; i++) order[i] = i;
-    std::vector<uint64_t> sort_key(n);
-    for (uint32_t i = 0; i < n; i++) sort_key[i] = descending_key(keys[i].score);
-    radix_sort_by(order, sort_key); /* least significant key first: score, then chain_score; both passes are stable */
-    for (uint32_t i = 0; i < n; i++) sort_key[i] = descending_key(keys[i].chain_score);
-    radix_sort_by(order, sort_key);
-    std::vector<uint32_t> rank_of(n);
-    for (uint32_t k = 0; k < n; k++) rank_of[order[k]] = k;
-    /* query sequences: keyed by (hash, length) of the name; counters are allocated on first sight (impl/paf.c:675-688) */
-    struct Contig { uint64_t hash; uint32_t name_len; int64_t qlen; std::vector<uint32_t> recs; };
-    std::vector<Contig> contigs;
-    std::vector<std::pair<std::pair<uint64_t, uint32_t>, uint32_t>> index; /* sorted lookup */
-    {
-        std::vector<uint32_t> by_name(order);
-        for (uint32_t i = 0; i < n; i++) sort_key[i] = keys[i].name_len;
-        radix_sort_by(by_name, sort_key);
-        for (uint32_t i = 0; i < n; i++) sort_key[i] = keys[i].name_hash;
-        radix_sort_by(by_name, sort_key);
-        for (uint32_t k = 0; k < n; k++) { /* by_name keeps visiting order inside a group (stable) */
-            uint32_t r = by_name[k];
-            if (contigs.empty() || contigs.back().hash != keys[r].name_hash || contigs.back().name_len != keys[r].name_len)
-                contigs.push_back(Contig{keys[r].name_hash, keys[r].name_len, keys[r].qlen, {}});
-            contigs.back().recs.push_back(r);
-        }
+        if (c->profile) prof_collect(c);
     }
-    /* assert(seq_count_array->length == paf->query_length), impl/paf.c:685: first offender in visiting order */
-    uint32_t bad_rank = 0xffffffffu;
-    for (auto &cg : contigs) {
-        cg.qlen = keys[cg.recs[0]].qlen; /* length seen first, in visiting order */
-        for (uint32_t r : cg.recs)
-            if (keys[r].qlen != cg.qlen && rank_of[r] < bad_rank) bad_rank = rank_of[r];
-    }
-    std::vector<uint32_t> flat;
-    std::vector<uint32_t> coff(contigs.size() + 1);
-    std::vector<uint64_t> cbase(contigs.size());
-    uint64_t cov_total = 0;
-    flat.reserve(n);
-    for (size_t ci = 0; ci < contigs.size(); ci++) {
-        coff[ci] = (uint32_t)flat.size();
-        cbase[ci] = cov_total;
-        cov_total += (uint64_t)(contigs[ci].qlen > 0 ? contigs[ci].qlen : 0) + 64;
-        for (uint32_t r : contigs[ci].recs) flat.push_back(r);
-    }
-    coff[contigs.size()] = (uint32_t)flat.size();
-    if (ensure(c, c->tile_order, sizeof(uint32_t) * (size_t)n)) return PAFFY_E_HIP;
-    if (ensure(c, c->tile_rank, sizeof(uint32_t) * (size_t)n)) return PAFFY_E_HIP;
-    if (ensure(c, c->tile_coff, sizeof(uint32_t) * coff.size())) return PAFFY_E_HIP;
-    if (ensure(c, c->tile_cbase, sizeof(uint64_t) * cbase.size())) return PAFFY_E_HIP;
-    if (ensure(c, c->tile_cov, sizeof(uint16_t) * (size_t)cov_total)) return PAFFY_E_HIP;
-    if (ensure(c, c->tile_level, sizeof(int64_t) * (size_t)n)) return PAFFY_E_HIP;
-    if (ensure(c, c->tile_len, sizeof(int64_t) * (size_t)(n + 2))) return PAFFY_E_HIP;
-    HIPCHK(c, hipMemcpyAsync(c->tile_rank.p, rank_of.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->tile_coff.p, coff.data(), sizeof(uint32_t) * coff.size(), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->tile_cbase.p, cbase.data(), sizeof(uint64_t) * cbase.size(), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->tile_cov.p, 0, sizeof(uint16_t) * (size_t)cov_total, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->tile_level.p, 0xff, sizeof(int64_t) * (size_t)n, c->stream));
-    if (bad_rank != 0xffffffffu) { /* seed the first-error key with the length assert */
-        unsigned long long key = ((unsigned long long)bad_rank << 16) | (1ull << 8) | (unsigned long long)PAFFY_ERR_TILE_ASSERT;
-        HIPCHK(c, hipMemcpyAsync(&static_cast<DevInfo *>(c->info.p)->first_err_key, &key, sizeof(key), hipMemcpyHostToDevice, c->stream));
-    }
-    TileParams tp;
-    memset(&tp, 0, sizeof(tp));
-    tp.in = in;
-    tp.meta = static_cast<const RecMeta *>(c->meta.p);
-    tp.contig_off = static_cast<const uint32_t *>(c->tile_coff.p);
-    tp.contig_base = static_cast<const uint64_t *>(c->tile_cbase.p);
-    tp.rank_of = static_cast<const uint32_t *>(c->tile_rank.p);
-    tp.counts = static_cast<uint16_t *>(c->tile_cov.p);
-    tp.n_contigs = (uint32_t)contigs.size();
-    tp.tile_level = static_cast<int64_t *>(c->tile_level.p);
-    tp.info = static_cast<DevInfo *>(c->info.p);
-    tp.err_aux = static_cast<int32_t *>(c->err_aux.p);
-    /*
-     * Sliced mode: work items = (sequence, 1 Mi-base slice) with at least one record; every item lists,
-     * in visiting order, the records whose query range touches the slice.
-     */
-    bool sliced_ok = false;
-    {
-        std::vector<uint32_t> slot_base(n + 1);
-        uint64_t n_slots = 0;
-        for (uint32_t r = 0; r < n; r++) {
-            slot_base[r] = (uint32_t)n_slots;
-            n_slots += tile_last_slice(keys[r].qs, keys[r].qe, keys[r].qlen) - tile_first_slice(keys[r].qs, keys[r].qe, keys[r].qlen) + 1;
-        }
-        if (n_slots < (1ull << 31)) {
-            std::vector<uint32_t> item_off, item_contig, item_slice, item_recs;
-            item_off.push_back(0);
-            for (size_t ci = 0; ci < contigs.size(); ci++) {
-                /* bucket this sequence's records (already in visiting order) by slice */
-                const auto &recs = contigs[ci].recs;
-                uint32_t top_slice = 0;
-                for (uint32_t r : recs) {
-                    const uint32_t l = tile_last_slice(keys[r].qs, keys[r].qe, keys[r].qlen);
-                    if (l > top_slice) top_slice = l;
-                }
-                if (top_slice < (1u << 22)) { /* the usual case: a counting sort over the sequence's slices */
-                    std::vector<uint32_t> at(top_slice + 2, 0u);
-                    for (uint32_t r : recs)
-                        for (uint32_t sl = tile_first_slice(keys[r].qs, keys[r].qe, keys[r].qlen); sl <= tile_last_slice(keys[r].qs, keys[r].qe, keys[r].qlen); sl++)
-                            at[sl + 1]++;
-                    const size_t base = item_recs.size();
-                    for (uint32_t sl = 0; sl <= top_slice; sl++) {
-                        if (at[sl + 1]) {
-                            item_contig.push_back((uint32_t)ci);
-                            item_slice.push_back(sl);
-                            item_off.push_back((uint32_t)(base + at[sl] + at[sl + 1])); /* end of this item = start of the next */
-                        }
-                        at[sl + 1] += at[sl];
-                    }
-                    item_recs.resize(base + at[top_slice + 1]);
-                    for (uint32_t r : recs)
-                        for (uint32_t sl = tile_first_slice(keys[r].qs, keys[r].qe, keys[r].qlen); sl <= tile_last_slice(keys[r].qs, keys[r].qe, keys[r].qlen); sl++)
-                            item_recs[base + at[sl]++] = r;
-                    continue;
-                }
-                std::vector<std::pair<uint32_t, uint32_t>> pairs; /* (slice, position in recs) */
-                for (uint32_t k = 0; k < recs.size(); k++) {
-                    const TileKey &key = keys[recs[k]];
-                    for (uint32_t sl = tile_first_slice(key.qs, key.qe, key.qlen); sl <= tile_last_slice(key.qs, key.qe, key.qlen); sl++)
-                        pairs.push_back({sl, k});
-                }
-                std::stable_sort(pairs.begin(), pairs.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) { return a.first < b.first; });
-                for (size_t i = 0; i < pairs.size(); i++) {
-                    if (i == 0 || pairs[i].first != pairs[i - 1].first) {
-                        if (i) item_off.push_back((uint32_t)item_recs.size());
-                        item_contig.push_back((uint32_t)ci);
-                        item_slice.push_back(pairs[i].first);
-                    }
-                    item_recs.push_back(recs[pairs[i].second]);
-                }
-                if (!pairs.empty()) item_off.push_back((uint32_t)item_recs.size());
-            }
-            const uint32_t n_items = (uint32_t)item_contig.size();
-            const size_t words = item_off.size() + 2 * (size_t)n_items + item_recs.size();
-            if (ensure(c, c->tile_items, sizeof(uint32_t) * (words + 4))) return PAFFY_E_HIP;
-            if (ensure(c, c->tile_slots, sizeof(uint32_t) * (size_t)(n + 1))) return PAFFY_E_HIP;
-            if (ensure(c, c->tile_parts, sizeof(TilePartial) * (size_t)(n_slots + 1))) return PAFFY_E_HIP;
-            uint32_t *d_items = static_cast<uint32_t *>(c->tile_items.p);
-            uint32_t *d_off = d_items, *d_contig = d_off + item_off.size(), *d_slice = d_contig + n_items, *d_recs = d_slice + n_items;
-            HIPCHK(c, hipMemcpyAsync(d_off, item_off.data(), sizeof(uint32_t) * item_off.size(), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(d_contig, item_contig.data(), sizeof(uint32_t) * n_items, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(d_slice, item_slice.data(), sizeof(uint32_t) * n_items, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(d_recs, item_recs.data(), sizeof(uint32_t) * item_recs.size(), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->tile_slots.p, slot_base.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipMemsetAsync(c->tile_parts.p, 0, sizeof(TilePartial) * (size_t)n_slots, c->stream));
-            TileParams ts = tp;
-            ts.order = d_recs;
-            ts.item_off = d_off;
-            ts.item_contig = d_contig;
-            ts.item_slice = d_slice;
-            ts.slot_base = static_cast<const uint32_t *>(c->tile_slots.p);
-            ts.partials = static_cast<TilePartial *>(c->tile_parts.p);
-            ts.n_items = n_items;
-            if (n_items > 0) LAUNCH(c, "k_tile_slices", k_tile_slices, dim3(n_items), dim3(PAFFY_NT), TILE_LDS_BYTES, ts);
-            LAUNCH(c, "k_tile_merge", k_tile_merge, dim3(grid), dim3(PAFFY_NT), 0, ts, n);
-            if (fetch_info(c)) return PAFFY_E_HIP; /* the vectors above must outlive the copies: synchronised here */
-            sliced_ok = (c->h_info->internal & 0x100u) == 0;
-        }
-    }
-    if (!sliced_ok) {
-        /* exact fallback: one workgroup per sequence (levels beyond the LDS window, too many distinct levels) */
-        DevInfo z = *c->h_info;
-        z.internal = 0;
-        z.first_err_key = ~0ull;
-        if (bad_rank != 0xffffffffu)
-            z.first_err_key = ((unsigned long long)bad_rank << 16) | (1ull << 8) | (unsigned long long)PAFFY_ERR_TILE_ASSERT;
-        HIPCHK(c, hipMemcpyAsync(c->info.p, &z, sizeof(z), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->tile_cov.p, 0, sizeof(uint16_t) * (size_t)cov_total, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->tile_level.p, 0xff, sizeof(int64_t) * (size_t)n, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->tile_order.p, flat.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-        tp.order = static_cast<const uint32_t *>(c->tile_order.p);
-        const uint32_t tgrid = tp.n_contigs < 2048 ? tp.n_contigs : 2048;
-        LAUNCH(c, "k_tile", k_tile, dim3(tgrid), dim3(PAFFY_NT), TILE_LDS_BYTES, tp);
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    /* sizes and offsets in visiting order (= the order array sorted by rank) */
-    HIPCHK(c, hipMemcpyAsync(c->tile_order.p, order.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    int64_t *lens = static_cast<int64_t *>(c->tile_len.p);
-    LAUNCH(c, "k_tile_size", k_tile_size, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const RecMeta *>(c->meta.p),
-           static_cast<const uint32_t *>(c->tile_order.p), static_cast<const int64_t *>(c->tile_level.p), n, lens);
-    LAUNCH(c, "k_scan_i64", k_scan_i64, dim3(1), dim3(PAFFY_NT), 0, lens, n, static_cast<int64_t *>(c->out_off.p), lens + n);
-    int64_t total = 0;
-    HIPCHK(c, hipMemcpyAsync(&total, lens + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    if (fetch_info(c)) return PAFFY_E_HIP;
-    if (c->profile) prof_collect(c);
-    if (c->h_info->first_err_key != ~0ull) {
-        unsigned long long k = c->h_info->first_err_key;
-        uint32_t rk = (uint32_t)(k >> 16);
-        c->plan.error.code = (int32_t)(k & 0xff);
-        c->plan.error.stage = 0;
-        c->plan.error.record = order[rk];
-        int32_t aux = 0;
-        HIPCHK(c, hipMemcpy(&aux, static_cast<int32_t *>(c->err_aux.p) + order[rk], sizeof(aux), hipMemcpyDeviceToHost));
-        c->plan.error.aux = c->plan.error.code == PAFFY_ERR_CIGAR_CHAR ? aux : 0;
-        c->plan.out_bytes = 0; /* write_pafs never runs */
-    } else {
-        c->plan.out_bytes = total;
-        c->plan.n_rows = n;
-    }
-    c->tile_n = c->plan.out_bytes ? n : 0;
-    c->tile_in = in;
     *info = c->plan;
     c->planned = true;
     return 0;
+}
+/* the one-batch form */
+int paffy_hip_tile_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, paffy_plan_info *info) {
+    if (!c || !info) return PAFFY_E_ARG;
+    if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
+    int rc = paffy_hip_tile_begin(c);
+    if (!rc) rc = paffy_hip_tile_add(c, d_in, in_len);
+    if (!rc) rc = paffy_hip_tile_run(c, info);
+    return rc;
+}
+
+/* After a tile run: (chain_score, score, input record, line bytes, tile level) of the lines emit writes, in output order -- what ranks
+ * exchange to merge their shares of a `paffy tile` sharded by query sequence. Returns the line count. */
+__global__ __launch_bounds__(PAFFY_NT) void k_tile_keys_out(const RecMeta *meta, const uint32_t *order, const int64_t *level, const uint64_t *out_len, uint64_t n,
+                                                             int64_t *keys) {
+    const uint64_t k = (uint64_t)blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (k >= n) return;
+    const RecMeta &m = meta[order[k]];
+    keys[5 * k + 0] = m.chain_score;
+    keys[5 * k + 1] = m.score;
+    keys[5 * k + 2] = order[k];
+    keys[5 * k + 3] = (int64_t)out_len[k];
+    keys[5 * k + 4] = level[order[k]];
+}
+int64_t paffy_hip_tile_keys(paffy_hip_ctx *c, int64_t cap_lines, void *d_keys) {
+    if (!c || !d_keys) return PAFFY_E_ARG;
+    if (!c->planned || !c->plan_is_tile || !c->cov) return PAFFY_E_STATE;
+    CovState &S = cov_state(c);
+    const uint64_t n = c->line_n;
+    if (c->line_meta != static_cast<const RecMeta *>(S.meta.p)) return PAFFY_E_STATE; /* a dedupe plan */
+    if ((uint64_t)cap_lines < n) return PAFFY_E_CAPACITY;
+    if (n) LAUNCH(c, "k_tile_keys_out", k_tile_keys_out, dim3((unsigned)((n + PAFFY_NT - 1) / PAFFY_NT)), dim3(PAFFY_NT), 0, c->line_meta, c->line_order, c->line_level,
+                  static_cast<const uint64_t *>(S.out_len.p), n, static_cast<int64_t *>(d_keys));
+    return (int64_t)n;
 }
 
 int paffy_hip_dedupe_reset(paffy_hip_ctx *c) {
@@ -1441,17 +1193,24 @@ int paffy_hip_dedupe_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, in
     if (nk > 0) {
         HIPCHK(c, hipMemcpyAsync(c->tile_order.p, kept.data(), sizeof(uint32_t) * (size_t)nk, hipMemcpyHostToDevice, c->stream));
         int64_t *lens = static_cast<int64_t *>(c->tile_len.p);
-        LAUNCH(c, "k_tile_size", k_tile_size, dim3((nk + PAFFY_NT - 1) / PAFFY_NT), dim3(PAFFY_NT), 0, static_cast<const RecMeta *>(c->meta.p),
-               static_cast<const uint32_t *>(c->tile_order.p), static_cast<const int64_t *>(c->tile_level.p), nk, lens);
+        LAUNCH(c, "k_line_size", k_line_size, dim3((nk + 1 + PAFFY_NT - 1) / PAFFY_NT), dim3(PAFFY_NT), 0, static_cast<const RecMeta *>(c->meta.p),
+               static_cast<const uint32_t *>(c->tile_order.p), static_cast<const int64_t *>(c->tile_level.p), (uint64_t)nk, reinterpret_cast<uint64_t *>(lens));
         LAUNCH(c, "k_scan_i64", k_scan_i64, dim3(1), dim3(PAFFY_NT), 0, lens, nk, static_cast<int64_t *>(c->out_off.p), lens + nk);
         HIPCHK(c, hipMemcpyAsync(&total, lens + nk, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        if (ensure(c, c->one_batch, sizeof(void *))) return PAFFY_E_HIP;
+        HIPCHK(c, hipMemcpyAsync(c->one_batch.p, &in, sizeof(void *), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream)); /* `kept` must outlive the copy */
     }
     if (c->profile) prof_collect(c);
     c->plan.out_bytes = total;
     c->plan.n_rows = nk;
     c->tile_n = total ? nk : 0;
-    c->tile_in = in;
+    c->line_batches = static_cast<const uint8_t *const *>(c->one_batch.p);
+    c->line_meta = static_cast<const RecMeta *>(c->meta.p);
+    c->line_order = static_cast<const uint32_t *>(c->tile_order.p);
+    c->line_level = static_cast<const int64_t *>(c->tile_level.p);
+    c->line_off = static_cast<const uint64_t *>(c->out_off.p);
+    c->line_n = c->tile_n;
     *info = c->plan;
     c->planned = true;
     return 0;
@@ -1460,11 +1219,11 @@ int paffy_hip_dedupe_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, in
 int64_t paffy_hip_plan_rows(paffy_hip_ctx *c, int64_t cap, uint32_t *record, int64_t *out_off) {
     if (!c || !record || !out_off) return PAFFY_E_ARG;
     if (!c->planned || !c->plan_is_tile) return PAFFY_E_STATE;
-    const int64_t n = c->tile_n;
+    const int64_t n = (int64_t)c->line_n;
     if (cap < n + 1) return PAFFY_E_CAPACITY;
     if (n > 0) {
-        HIPCHK(c, hipMemcpyAsync(record, c->tile_order.p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(out_off, c->out_off.p, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(record, c->line_order, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out_off, c->line_off, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     out_off[n] = c->plan.out_bytes;
@@ -1485,9 +1244,8 @@ int paffy_hip_emit(paffy_hip_ctx *c, void *d_out, int64_t out_cap) {
         return 0;
     }
     if (c->plan_is_tile) {
-        LAUNCH(c, "k_tile_emit", k_tile_emit, dim3(c->tile_n), dim3(PAFFY_NT), 0, c->tile_in, static_cast<const RecMeta *>(c->meta.p),
-               static_cast<const uint32_t *>(c->tile_order.p), static_cast<const int64_t *>(c->tile_level.p),
-               static_cast<const int64_t *>(c->out_off.p), static_cast<uint8_t *>(d_out));
+        if (c->line_n) LAUNCH(c, "k_tile_emit", k_line_emit, dim3((unsigned)c->line_n), dim3(PAFFY_NT), 0, c->line_batches, c->line_meta, c->line_order, c->line_level,
+                              c->line_off, (uint64_t)0, (uint64_t)0, static_cast<uint8_t *>(d_out));
         return 0;
     }
     KParams kp = c->kp;
@@ -1502,6 +1260,26 @@ int paffy_hip_emit(paffy_hip_ctx *c, void *d_out, int64_t out_cap) {
         if (c->h_info->g_count > 0) LAUNCH(c, "k_emit_lds<line>", k_emit_lds<false>, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
         if (c->h_info->w_count > 0) LAUNCH(c, "k_arena_emit<line>", k_arena_emit<false>, dim3(2048), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
     }
+    return 0;
+}
+
+/* lines [first, first + n) of a line plan (tile, dedupe) into d_out, the first of them at d_out[0]: for hosts that drain a
+ * large output through a bounded staging buffer. *bytes = what was written. */
+int paffy_hip_emit_lines(paffy_hip_ctx *c, int64_t first, int64_t n, void *d_out, int64_t out_cap, int64_t *bytes) {
+    if (!c || !bytes || first < 0 || n < 0) return PAFFY_E_ARG;
+    if (!c->planned || !c->plan_is_tile) return PAFFY_E_STATE;
+    *bytes = 0;
+    if ((uint64_t)(first + n) > c->line_n) return PAFFY_E_ARG;
+    if (n == 0) return 0;
+    if (!d_out || (reinterpret_cast<uintptr_t>(d_out) & 15)) return PAFFY_E_ARG;
+    uint64_t lo = 0, hi = (uint64_t)c->plan.out_bytes;
+    HIPCHK(c, hipMemcpyAsync(&lo, c->line_off + first, sizeof(lo), hipMemcpyDeviceToHost, c->stream));
+    if ((uint64_t)(first + n) < c->line_n) HIPCHK(c, hipMemcpyAsync(&hi, c->line_off + first + n, sizeof(hi), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((int64_t)(hi - lo) > out_cap) return PAFFY_E_CAPACITY;
+    LAUNCH(c, "k_tile_emit", k_line_emit, dim3((unsigned)n), dim3(PAFFY_NT), 0, c->line_batches, c->line_meta, c->line_order, c->line_level, c->line_off, (uint64_t)first,
+           lo, static_cast<uint8_t *>(d_out));
+    *bytes = (int64_t)(hi - lo);
     return 0;
 }
 
@@ -1553,218 +1331,90 @@ static int scan64(paffy_hip_ctx *c, const int64_t *in, uint64_t n, int64_t *out,
 }
 
 /*
- * `paffy to_bed` over a whole batch (impl/paf_to_bed.c:166-190): coverage counters per sequence as in `paffy tile` (every record
- * bumps the counters of its query range; with include_inverted also those of its target range, as the inverted record would),
- * then each sequence's counters as maximal runs. Sequences are written in order of first appearance (the reference iterates a
- * sonLib hash: its order is not defined). Any failing record means no output.
+ * `paffy to_bed` (impl/paf_to_bed.c:166-190) over any number of text batches: coverage counters per sequence as in `paffy tile`
+ * (every record bumps the counters of its query range; with include_inverted also those of its target range, as the inverted
+ * record would), then each sequence's counters as maximal runs. Sequences are written in order of first appearance (the
+ * reference iterates a sonLib hash: its order is not defined). Any failing record means no output.
  */
-int paffy_hip_bed_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, const paffy_bed_opts *opts, paffy_plan_info *info) {
+int paffy_hip_bed_begin(paffy_hip_ctx *c, const paffy_bed_opts *opts) {
+    if (!c || !opts) return PAFFY_E_ARG;
+    c->planned = false;
+    return cov_begin(c, opts->include_inverted ? 2 : 1);
+}
+int paffy_hip_bed_add(paffy_hip_ctx *c, const void *d_in, int64_t in_len) {
+    if (!c) return PAFFY_E_ARG;
+    return cov_add(c, d_in, in_len, false);
+}
+int paffy_hip_bed_run(paffy_hip_ctx *c, const paffy_bed_opts *opts, paffy_plan_info *info) {
     if (!c || !info || !opts) return PAFFY_E_ARG;
-    if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
+    CovState &S = cov_state(c);
+    if (S.sides != (opts->include_inverted ? 2u : 1u)) return PAFFY_E_STATE;
     c->planned = false;
     c->plan_is_tile = false;
     c->plan_is_bed = true;
     memset(info, 0, sizeof(*info));
     memset(&c->plan, 0, sizeof(c->plan));
-    info->in_bytes = c->plan.in_bytes = in_len;
     memset(&c->kp, 0, sizeof(c->kp));
     c->bed_runs = 0;
-    if (in_len == 0) {
-        c->planned = true;
-        return 0;
-    }
-    const uint8_t *in = static_cast<const uint8_t *>(d_in);
-    uint32_t n = 0;
-    {
-        int rc = index_and_parse(c, in, (uint32_t)in_len, &n);
-        if (rc) return rc;
-    }
-    c->plan.n_records = n;
-    if (n == 0 || n >= (1u << 30)) {
-        *info = c->plan;
-        c->planned = n == 0;
-        return n == 0 ? 0 : PAFFY_E_UNSUPPORTED;
-    }
-    const uint32_t grid = (n + PAFFY_NT - 1) / PAFFY_NT;
-    if (ensure(c, c->bed_keys, sizeof(BedKey) * (size_t)n)) return PAFFY_E_HIP;
-    LAUNCH(c, "k_bed_keys", k_bed_keys, dim3(grid), dim3(PAFFY_NT), 0, in, static_cast<const RecMeta *>(c->meta.p), n, static_cast<BedKey *>(c->bed_keys.p));
-    std::vector<BedKey> keys(n);
-    HIPCHK(c, hipMemcpyAsync(keys.data(), c->bed_keys.p, sizeof(BedKey) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const int sides = opts->include_inverted ? 2 : 1;
-    /* the records one by one, as the reference's loop meets them: parse error, sequence length assert (impl/paf.c:685), and for a
-       record without cigar the end assert (impl/paf.c:708: nothing is walked, so start must equal end) */
-    struct Seq { uint64_t hash; uint32_t name_off, name_len; int64_t len; std::vector<uint32_t> entries; };
-    std::vector<Seq> seqs;
-    std::unordered_map<uint64_t, std::vector<uint32_t>> by_hash; /* hash -> indices into seqs (names of equal hash differ in length here) */
-    int64_t bad_rec = -1;
-    int bad_code = 0, bad_aux = 0;
-    for (uint32_t r = 0; r < n && bad_rec < 0; r++) {
-        const BedKey &k = keys[r];
-        if (k.err) {
-            bad_rec = r;
-            bad_code = k.err;
-            RecMeta m;
-            HIPCHK(c, hipMemcpy(&m, static_cast<RecMeta *>(c->meta.p) + r, sizeof(m), hipMemcpyDeviceToHost));
-            bad_aux = m.err_aux;
-            break;
-        }
-        for (int sd = 0; sd < sides; sd++) {
-            std::vector<uint32_t> &cands = by_hash[k.hash[sd]];
-            int64_t si = -1;
-            for (uint32_t ci : cands)
-                if (seqs[ci].name_len == k.name_len[sd]) si = ci;
-            if (si < 0) {
-                si = (int64_t)seqs.size();
-                seqs.push_back(Seq{k.hash[sd], k.name_off[sd], k.name_len[sd], k.len[sd], {}});
-                cands.push_back((uint32_t)si);
-            } else if (seqs[(size_t)si].len != k.len[sd]) {
-                bad_rec = r;
-                bad_code = PAFFY_ERR_TILE_ASSERT;
-                bad_aux = 1;
-                break;
-            }
-            if (!k.has_cg && k.lo[sd] != k.hi[sd]) {
-                bad_rec = r;
-                bad_code = PAFFY_ERR_TILE_ASSERT;
-                bad_aux = 2;
-                break;
-            }
-            const uint32_t side = sd == 0 ? 0u : (k.minus ? 2u : 1u);
-            if (k.has_cg) seqs[(size_t)si].entries.push_back(r | (side << 30));
-        }
-    }
-    auto fail_with = [&](int64_t rec, int code, int aux) {
-        c->plan.error.code = code;
-        c->plan.error.stage = code == PAFFY_ERR_TILE_ASSERT ? 0 : -1;
-        c->plan.error.record = rec;
-        c->plan.error.aux = aux;
+    for (const CovBatch &b : S.batches) c->plan.in_bytes += b.len;
+    c->plan.n_records = (int64_t)S.n_rec;
+    if (S.n_rec == 0) {
         *info = c->plan;
         c->planned = true;
         return 0;
-    };
-    /* counters: every sequence followed by 64 counters of padding */
-    const size_t ns = seqs.size();
+    }
+    int rc = cov_run(c, 1, &c->plan.error);
+    if (rc) return rc;
+    if (c->plan.error.code) {
+        if (c->plan.error.code == PAFFY_ERR_CIGAR_CHAR) c->plan.error.stage = -1; /* the read loop parses the cigar (paf_read(.., 1)) */
+        *info = c->plan;
+        c->planned = true;
+        return 0;
+    }
+    /* the runs: sequences in order of first appearance = ascending counter bases */
+    const size_t ns = S.n_contigs;
     std::vector<uint64_t> cbase(ns + 1);
     std::vector<int64_t> clen(ns);
     std::vector<uint32_t> name_off(ns), name_len(ns);
-    uint64_t cov_total = 0;
-    for (size_t i = 0; i < ns; i++) {
-        cbase[i] = cov_total;
-        clen[i] = seqs[i].len;
-        name_off[i] = seqs[i].name_off;
-        name_len[i] = seqs[i].name_len;
-        if (seqs[i].len > (1ll << 40)) return PAFFY_E_UNSUPPORTED;
-        cov_total += (uint64_t)(seqs[i].len > 0 ? seqs[i].len : 0) + 64;
+    {
+        std::vector<CovName> cname(ns);
+        if (cov_fetch(c, cname.data(), S.name_tab.p, sizeof(CovName) * ns)) return PAFFY_E_HIP;
+        std::vector<uint32_t> boff(ns + 1);
+        uint32_t at = 0;
+        for (size_t ci = 0; ci < ns; ci++) {
+            boff[ci] = at;
+            at += cname[ci].len;
+        }
+        for (size_t k = 0; k < ns; k++) {
+            const uint32_t ci = S.appearance[k];
+            cbase[k] = S.h_contig_cov[ci];
+            clen[k] = S.h_contig_len[ci];
+            name_off[k] = boff[ci];
+            name_len[k] = cname[ci].len;
+        }
+        cbase[ns] = S.cov_total;
     }
-    cbase[ns] = cov_total;
-    if (ensure(c, c->tile_cov, sizeof(uint16_t) * (size_t)(cov_total + 64))) return PAFFY_E_HIP;
-    HIPCHK(c, hipMemsetAsync(c->tile_cov.p, 0, sizeof(uint16_t) * (size_t)cov_total, c->stream));
-    /* work items: (sequence, slice) with the entries that touch the slice, in input order */
-    std::vector<uint32_t> item_off, item_contig, item_slice, item_recs;
-    item_off.push_back(0);
-    for (size_t ci = 0; ci < ns; ci++) {
-        const auto &ent = seqs[ci].entries;
-        auto range = [&](uint32_t e, uint32_t &f, uint32_t &l) {
-            const BedKey &k = keys[e & 0x3fffffffu];
-            const int sd = (e >> 30) ? 1 : 0;
-            f = tile_first_slice(k.lo[sd], k.hi[sd], k.len[sd]);
-            l = tile_last_slice(k.lo[sd], k.hi[sd], k.len[sd]);
-        };
-        uint32_t top = 0;
-        for (uint32_t e : ent) {
-            uint32_t f, l;
-            range(e, f, l);
-            if (l > top) top = l;
-        }
-        if (ent.empty()) continue;
-        if (top >= (1u << 22)) return PAFFY_E_UNSUPPORTED; /* coordinates far beyond any sequence this build holds counters for */
-        std::vector<uint32_t> at(top + 2, 0u);
-        for (uint32_t e : ent) {
-            uint32_t f, l;
-            range(e, f, l);
-            for (uint32_t sl = f; sl <= l; sl++) at[sl + 1]++;
-        }
-        const size_t base = item_recs.size();
-        for (uint32_t sl = 0; sl <= top; sl++) {
-            if (at[sl + 1]) {
-                item_contig.push_back((uint32_t)ci);
-                item_slice.push_back(sl);
-                item_off.push_back((uint32_t)(base + at[sl] + at[sl + 1]));
-            }
-            at[sl + 1] += at[sl];
-        }
-        item_recs.resize(base + at[top + 1]);
-        for (uint32_t e : ent) {
-            uint32_t f, l;
-            range(e, f, l);
-            for (uint32_t sl = f; sl <= l; sl++) item_recs[base + at[sl]++] = e;
-        }
-    }
-    if (bad_rec >= 0) { /* the device may still find an earlier record failing inside its cigar; later ones do not matter */
-        unsigned long long key = ((unsigned long long)bad_rec << 16) | (1ull << 8) | (unsigned long long)(bad_code & 0xff);
-        HIPCHK(c, hipMemcpyAsync(&static_cast<DevInfo *>(c->info.p)->first_err_key, &key, sizeof(key), hipMemcpyHostToDevice, c->stream));
-    }
-    const uint32_t n_items = (uint32_t)item_contig.size();
-    /* device tables: contig_base[ns + 1] | contig_len[ns] (8-byte words), then name_off | name_len | rank | items (4-byte words) */
-    const size_t w64 = (ns + 1) + ns, w32 = 2 * ns + n + item_off.size() + 2 * (size_t)n_items + item_recs.size();
-    if (ensure(c, c->bed_tab, 8 * w64 + 4 * w32 + 64)) return PAFFY_E_HIP;
+    if (ensure(c, c->bed_tab, 8 * (2 * ns + 1) + 4 * 2 * ns + 64)) return PAFFY_E_HIP;
     uint64_t *d_cbase = static_cast<uint64_t *>(c->bed_tab.p);
     int64_t *d_clen = reinterpret_cast<int64_t *>(d_cbase + ns + 1);
-    uint32_t *d_noff = reinterpret_cast<uint32_t *>(d_clen + ns), *d_nlen = d_noff + ns, *d_rank = d_nlen + ns, *d_ioff = d_rank + n;
-    uint32_t *d_icontig = d_ioff + item_off.size(), *d_islice = d_icontig + n_items, *d_irecs = d_islice + n_items;
-    std::vector<uint32_t> rank(n);
-    for (uint32_t r = 0; r < n; r++) rank[r] = r; /* first failure = smallest record index */
+    uint32_t *d_noff = reinterpret_cast<uint32_t *>(d_clen + ns), *d_nlen = d_noff + ns;
     HIPCHK(c, hipMemcpyAsync(d_cbase, cbase.data(), 8 * (ns + 1), hipMemcpyHostToDevice, c->stream));
-    if (ns) {
-        HIPCHK(c, hipMemcpyAsync(d_clen, clen.data(), 8 * ns, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(d_noff, name_off.data(), 4 * ns, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(d_nlen, name_len.data(), 4 * ns, hipMemcpyHostToDevice, c->stream));
-    }
-    HIPCHK(c, hipMemcpyAsync(d_rank, rank.data(), 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_ioff, item_off.data(), 4 * item_off.size(), hipMemcpyHostToDevice, c->stream));
-    if (n_items) {
-        HIPCHK(c, hipMemcpyAsync(d_icontig, item_contig.data(), 4 * (size_t)n_items, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(d_islice, item_slice.data(), 4 * (size_t)n_items, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(d_irecs, item_recs.data(), 4 * item_recs.size(), hipMemcpyHostToDevice, c->stream));
-    }
-    TileParams tp;
-    memset(&tp, 0, sizeof(tp));
-    tp.in = in;
-    tp.meta = static_cast<const RecMeta *>(c->meta.p);
-    tp.contig_base = d_cbase;
-    tp.rank_of = d_rank;
-    tp.counts = static_cast<uint16_t *>(c->tile_cov.p);
-    tp.n_contigs = (uint32_t)ns;
-    tp.info = static_cast<DevInfo *>(c->info.p);
-    tp.err_aux = static_cast<int32_t *>(c->err_aux.p);
-    tp.order = d_irecs;
-    tp.item_off = d_ioff;
-    tp.item_contig = d_icontig;
-    tp.item_slice = d_islice;
-    tp.n_items = n_items;
-    if (n_items > 0) LAUNCH(c, "k_bed_cover", k_bed_cover, dim3(n_items), dim3(PAFFY_NT), TILE_LDS_BYTES, tp);
-    if (fetch_info(c)) return PAFFY_E_HIP; /* also keeps the host vectors alive until the copies are done */
-    if (c->h_info->first_err_key != ~0ull) {
-        const unsigned long long k = c->h_info->first_err_key;
-        const int64_t rec = (int64_t)(k >> 16);
-        int32_t aux = bad_aux;
-        if (rec != bad_rec) HIPCHK(c, hipMemcpy(&aux, static_cast<int32_t *>(c->err_aux.p) + rec, sizeof(aux), hipMemcpyDeviceToHost));
-        if (c->profile) prof_collect(c);
-        return fail_with(rec, (int)(k & 0xff), aux);
-    }
-    /* the runs */
+    HIPCHK(c, hipMemcpyAsync(d_clen, clen.data(), 8 * ns, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_noff, name_off.data(), 4 * ns, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_nlen, name_len.data(), 4 * ns, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint64_t cov_total = S.cov_total;
     if (!c->bed_params) c->bed_params = new BedParams;
     BedParams &B = *c->bed_params;
     memset(&B, 0, sizeof(B));
-    B.counts = static_cast<const uint16_t *>(c->tile_cov.p);
+    B.counts = static_cast<const uint16_t *>(S.cov.p);
     B.n_counts = cov_total;
     B.contig_base = d_cbase;
     B.contig_len = d_clen;
     B.name_off = d_noff;
     B.name_len = d_nlen;
     B.n_contigs = (uint32_t)ns;
-    B.in = in;
+    B.in = static_cast<const uint8_t *>(S.names.p);
     B.binary = opts->binary;
     B.exclude_unaligned = opts->exclude_unaligned;
     B.exclude_aligned = opts->exclude_aligned;
@@ -1797,6 +1447,14 @@ int paffy_hip_bed_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, const
     *info = c->plan;
     c->planned = true;
     return 0;
+}
+int paffy_hip_bed_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, const paffy_bed_opts *opts, paffy_plan_info *info) {
+    if (!c || !info || !opts) return PAFFY_E_ARG;
+    if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
+    int rc = paffy_hip_bed_begin(c, opts);
+    if (!rc) rc = paffy_hip_bed_add(c, d_in, in_len);
+    if (!rc) rc = paffy_hip_bed_run(c, opts, info);
+    return rc;
 }
 
 int paffy_hip_plan_stats(paffy_hip_ctx *c, int64_t sums[6]) {
@@ -2037,15 +1695,21 @@ int paffy_hip_device_count(void) {
     return n;
 }
 
+int paffy_hip_synth_contigs(paffy_hip_ctx *c, uint64_t seed, uint32_t mean_ops, uint32_t n_contigs, uint64_t r0, uint64_t n, void *d_out, int64_t out_cap,
+                            int64_t *bytes);
 int paffy_hip_synth(paffy_hip_ctx *c, uint64_t seed, uint32_t mean_ops, uint64_t r0, uint64_t n, void *d_out, int64_t out_cap,
                     int64_t *bytes) {
-    if (!c || !bytes || n >= (1ull << 31)) return PAFFY_E_ARG;
+    return paffy_hip_synth_contigs(c, seed, mean_ops, 24, r0, n, d_out, out_cap, bytes);
+}
+int paffy_hip_synth_contigs(paffy_hip_ctx *c, uint64_t seed, uint32_t mean_ops, uint32_t n_contigs, uint64_t r0, uint64_t n, void *d_out, int64_t out_cap,
+                            int64_t *bytes) {
+    if (!c || !bytes || n >= (1ull << 31) || n_contigs < 1) return PAFFY_E_ARG;
     *bytes = 0;
     if (n == 0) return 0;
     psynth_cfg cfg;
     cfg.seed = seed;
     cfg.mean_ops = mean_ops;
-    cfg.n_contigs = 24;
+    cfg.n_contigs = n_contigs;
     if (ensure(c, c->synth_sizes, sizeof(int64_t) * (size_t)(2 * n + 2))) return PAFFY_E_HIP;
     int64_t *sizes = static_cast<int64_t *>(c->synth_sizes.p), *offs = sizes + n, *total = offs + n;
     const uint32_t nn = (uint32_t)n, grid = (nn + PAFFY_NT - 1) / PAFFY_NT;

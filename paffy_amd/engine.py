@@ -93,6 +93,15 @@ def lib():
         L.paffy_hip_plan.argtypes = [vp, C.POINTER(Stage), i32, vp, i64, C.POINTER(PlanInfo)]
         L.paffy_hip_emit.argtypes = [vp, vp, i64]
         L.paffy_hip_tile_plan.argtypes = [vp, vp, i64, C.POINTER(PlanInfo)]
+        L.paffy_hip_tile_begin.argtypes = [vp]
+        L.paffy_hip_tile_add.argtypes = [vp, vp, i64]
+        L.paffy_hip_tile_run.argtypes = [vp, C.POINTER(PlanInfo)]
+        L.paffy_hip_tile_keys.restype = i64
+        L.paffy_hip_tile_keys.argtypes = [vp, i64, vp]
+        L.paffy_hip_emit_lines.argtypes = [vp, i64, i64, vp, i64, C.POINTER(i64)]
+        L.paffy_hip_bed_begin.argtypes = [vp, C.POINTER(BedOpts)]
+        L.paffy_hip_bed_add.argtypes = [vp, vp, i64]
+        L.paffy_hip_bed_run.argtypes = [vp, C.POINTER(BedOpts), C.POINTER(PlanInfo)]
         L.paffy_hip_sync.argtypes = [vp]
         L.paffy_hip_dedupe_plan.argtypes = [vp, vp, i64, C.c_int, C.POINTER(PlanInfo)]
         L.paffy_hip_dedupe_reset.argtypes = [vp]
@@ -107,6 +116,7 @@ def lib():
         L.paffy_hip_profile_reset.argtypes = [vp]
         L.paffy_hip_profile_read.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(i64), C.c_int]
         L.paffy_hip_synth.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64)]
+        L.paffy_hip_synth_contigs.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64)]
         L.paffy_hip_plan_stats.argtypes = [vp, C.POINTER(i64)]
         L.paffy_hip_bed_plan.argtypes = [vp, vp, i64, C.POINTER(BedOpts), C.POINTER(PlanInfo)]
         L.paffy_hip_synth4_setup.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, i64, i64, C.c_int]
@@ -182,10 +192,52 @@ class Engine:
         self._check(lib().paffy_hip_tile_plan(self._ctx, C.c_void_p(d_in.data_ptr()), in_len, C.byref(info)), "paffy_hip_tile_plan")
         return info
 
-    def tile(self, data, raise_on_error=True):
-        """paffy tile (impl/paf_tile.c) over PAF text; returns (output bytes, PlanInfo)."""
-        d_in = self.to_device(data)
-        info = self.tile_plan(d_in, len(data))
+    def tile_batches(self, bufs):
+        """paffy tile over an input held as several device batches [(uint8 tensor, nbytes)], each a whole number of lines and
+        below 2 GiB; they must stay alive until the output has been emitted. Returns the PlanInfo."""
+        self._check(lib().paffy_hip_tile_begin(self._ctx), "paffy_hip_tile_begin")
+        for buf, nbytes in bufs:
+            self._check(lib().paffy_hip_tile_add(self._ctx, C.c_void_p(buf.data_ptr()), nbytes), "paffy_hip_tile_add")
+        info = PlanInfo()
+        self._check(lib().paffy_hip_tile_run(self._ctx, C.byref(info)), "paffy_hip_tile_run")
+        return info
+
+    def tile_keys(self, n_lines):
+        """After a tile plan: int64 tensor [n_lines, 5] on the device -- chain_score, score, input record, line bytes, tile level
+        of every output line, in output order (what the ranks of a sharded tile exchange)."""
+        keys = self.torch.empty((max(1, n_lines), 5), dtype=self.torch.int64, device=self.device)
+        n = lib().paffy_hip_tile_keys(self._ctx, n_lines, C.c_void_p(keys.data_ptr()))
+        if n < 0:
+            raise RuntimeError(f"paffy_hip_tile_keys failed ({n})")
+        return keys[:n]
+
+    def emit_lines(self, first, n, d_out):
+        """Lines [first, first + n) of a tile / dedupe plan into d_out (from its first byte); returns the bytes written."""
+        nbytes = C.c_int64()
+        self._check(lib().paffy_hip_emit_lines(self._ctx, first, n, C.c_void_p(d_out.data_ptr()), d_out.numel(), C.byref(nbytes)), "paffy_hip_emit_lines")
+        return nbytes.value
+
+    def split_lines(self, data, max_bytes):
+        """Cut PAF text into pieces of at most max_bytes that end on line boundaries (one line may exceed it)."""
+        out, at = [], 0
+        while at < len(data):
+            end = min(len(data), at + max_bytes)
+            if end < len(data):
+                nl = data.rfind(b"\n", at, end)
+                end = nl + 1 if nl >= at else (data.find(b"\n", end) + 1 or len(data))
+            out.append(data[at:end])
+            at = end
+        return out
+
+    def tile(self, data, raise_on_error=True, batch_bytes=None):
+        """paffy tile (impl/paf_tile.c) over PAF text; returns (output bytes, PlanInfo). With batch_bytes the text goes to the
+        device in pieces of at most that size (inputs of 2 GiB and more must)."""
+        if batch_bytes:
+            bufs = [(self.to_device(p), len(p)) for p in self.split_lines(data, batch_bytes)]
+            info = self.tile_batches(bufs)
+        else:
+            d_in = self.to_device(data)
+            info = self.tile_plan(d_in, len(data))
         out = b""
         if info.out_bytes:
             d_out = self.alloc_out(info.out_bytes)
@@ -265,21 +317,30 @@ class Engine:
             data, _ = self.run([st], data)
         return data
 
-    def synth(self, seed, mean_ops, r0, n):
+    def synth(self, seed, mean_ops, r0, n, n_contigs=24):
         """Synthetic PAF records [r0, r0+n) generated on the device; returns (tensor, nbytes)."""
         nbytes = C.c_int64()
-        self._check(lib().paffy_hip_synth(self._ctx, seed, mean_ops, r0, n, None, 0, C.byref(nbytes)), "paffy_hip_synth(size)")
+        self._check(lib().paffy_hip_synth_contigs(self._ctx, seed, mean_ops, n_contigs, r0, n, None, 0, C.byref(nbytes)), "paffy_hip_synth(size)")
         buf = self.torch.zeros(_pad16(nbytes.value), dtype=self.torch.uint8, device=self.device)
-        self._check(lib().paffy_hip_synth(self._ctx, seed, mean_ops, r0, n, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(nbytes)),
+        self._check(lib().paffy_hip_synth_contigs(self._ctx, seed, mean_ops, n_contigs, r0, n, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(nbytes)),
                     "paffy_hip_synth(fill)")
         return buf, nbytes.value
 
-    def to_bed(self, data, binary=False, exclude_unaligned=False, exclude_aligned=False, min_size=1, include_inverted=False, raise_on_error=True):
-        """paffy to_bed [-b -e -f -m -n] (impl/paf_to_bed.c) over PAF text; returns (BED bytes, PlanInfo)."""
-        d_in = self.to_device(data)
+    def to_bed(self, data, binary=False, exclude_unaligned=False, exclude_aligned=False, min_size=1, include_inverted=False, raise_on_error=True,
+               batch_bytes=None):
+        """paffy to_bed [-b -e -f -m -n] (impl/paf_to_bed.c) over PAF text; returns (BED bytes, PlanInfo). With batch_bytes the text
+        goes to the device in pieces of at most that size."""
         info = PlanInfo()
         opts = BedOpts(int(binary), int(exclude_unaligned), int(exclude_aligned), int(include_inverted), min_size)
-        self._check(lib().paffy_hip_bed_plan(self._ctx, C.c_void_p(d_in.data_ptr()), len(data), C.byref(opts), C.byref(info)), "paffy_hip_bed_plan")
+        if batch_bytes:
+            bufs = [(self.to_device(p), len(p)) for p in self.split_lines(data, batch_bytes)]
+            self._check(lib().paffy_hip_bed_begin(self._ctx, C.byref(opts)), "paffy_hip_bed_begin")
+            for buf, nbytes in bufs:
+                self._check(lib().paffy_hip_bed_add(self._ctx, C.c_void_p(buf.data_ptr()), nbytes), "paffy_hip_bed_add")
+            self._check(lib().paffy_hip_bed_run(self._ctx, C.byref(opts), C.byref(info)), "paffy_hip_bed_run")
+        else:
+            d_in = self.to_device(data)
+            self._check(lib().paffy_hip_bed_plan(self._ctx, C.c_void_p(d_in.data_ptr()), len(data), C.byref(opts), C.byref(info)), "paffy_hip_bed_plan")
         out = b""
         if info.out_bytes:
             d_out = self.alloc_out(info.out_bytes)

@@ -26,8 +26,8 @@ def lib():
     return _lib
 
 
-def generate(seed, mean_ops, r0, n, threads=4):
-    cfg = Cfg(seed, mean_ops, 24)
+def generate(seed, mean_ops, r0, n, threads=4, n_contigs=24):
+    cfg = Cfg(seed, mean_ops, n_contigs)
     total = lib().psynth_generate(cfg, r0, n, None, 0, None, threads)
     buf = C.create_string_buffer(total)
     lib().psynth_generate(cfg, r0, n, buf, total, None, threads)

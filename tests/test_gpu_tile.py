@@ -22,9 +22,9 @@ def eng():
     e.close()
 
 
-def check(eng, data):
+def check(eng, data, **kw):
     want, werr = O.tile(data)
-    got, info = eng.tile(data, raise_on_error=False)
+    got, info = eng.tile(data, raise_on_error=False, **kw)
     assert info.error.code == werr.code, (info.error.code, werr.code, info.error.record, werr.record)
     if werr.code:
         assert info.error.record == werr.record
@@ -101,17 +101,17 @@ def test_errors_and_edges(eng):
     check(eng, b"q\t100\t3\t5\t+\tt\t100\t0\t0\t0\t0\t60\tcg:Z:2I\n")
 
 
-def kernels_used(eng, data):
+def kernels_used(eng, data, **kw):
     eng.profile(True)
-    check(eng, data)
+    check(eng, data, **kw)
     names = {k for k, (ms, launches) in eng.profile_read().items() if launches > 0}
     eng.profile(False)
     return names
 
 
-def test_sliced_path_and_fallback(eng):
-    """Records spanning several 1 Mi-base slices stay on the sliced path; many distinct levels inside one
-    slice or levels beyond the LDS window repeat the batch on the one-workgroup-per-sequence kernel."""
+def test_slices_piles_and_wide_level_spreads(eng):
+    """Records spanning many 32 Ki-base slices, deep ragged piles, a staircase whose last record meets more distinct levels than
+    the LDS histogram tells apart (the exact window-by-window path), levels in the thousands: always the slice walk, always exact."""
     rng = random.Random(5)
     qlen = 5_000_000
     lines = []
@@ -123,20 +123,100 @@ def test_sliced_path_and_fallback(eng):
         tspan = span - 5 + 7 if a > 5 else span
         lines.append(f"big{r % 2}\t{qlen}\t{qs}\t{qs + span}\t{rng.choice('+-')}\tt\t9000000\t10\t{10 + tspan}\t{span}\t{span}\t60\t"
                      f"AS:i:{rng.randrange(50)}\tcg:Z:{cig}\n")
-    data = "".join(lines[:12]).encode()
-    used = kernels_used(eng, data)
-    assert "k_tile_slices" in used and "k_tile" not in used
-    data = "".join(lines).encode()      # deep, ragged pile: dozens of distinct levels in one (record, slice) histogram
-    used = kernels_used(eng, data)
-    assert "k_tile_slices" in used and "k_tile" not in used
-    # a staircase: record k covers [100 k, 100 k + 20000), the last record spans them all and meets 150 distinct levels
-    stairs = [f"st\t100000\t{100 * k}\t{100 * k + 20000}\t+\tt\t9000000\t0\t20000\t20000\t20000\t60\tAS:i:{1000 - k}\tcg:Z:20000M\n" for k in range(150)]
+    used = kernels_used(eng, "".join(lines[:12]).encode())
+    assert "k_cov_walk" in used and "k_cov_bitmap" in used and "k_cov_merge" in used
+    check(eng, "".join(lines).encode())  # deep, ragged pile: dozens of distinct levels in one (record, slice) histogram
+    # a staircase: record k covers [10 k, 10 k + 20000), the last record spans them all and meets 1500 distinct levels (> 1024)
+    stairs = [f"st\t100000\t{10 * k}\t{10 * k + 20000}\t+\tt\t9000000\t0\t20000\t20000\t20000\t60\tAS:i:{5000 - k}\tcg:Z:20000M\n" for k in range(1500)]
     stairs.append("st\t100000\t0\t40000\t-\tt\t9000000\t0\t40000\t40000\t40000\t60\tAS:i:1\tcg:Z:40000M\n")
-    used = kernels_used(eng, "".join(stairs).encode())  # more than 128 distinct levels: the exact fallback takes over
-    assert "k_tile" in used
-    used = kernels_used(eng, "".join(stairs[:100] + stairs[-1:]).encode())  # 100 levels: still sliced
-    assert "k_tile_slices" in used and "k_tile" not in used
-    # levels beyond the 4096-level window
+    got, _ = check(eng, "".join(stairs).encode())
+    assert got.splitlines()[-1].split(b"\ttl:i:")[1].split(b"\t")[0] == b"751"  # the oracle's value: the last record meets levels 2 .. 1501
+    check(eng, "".join(stairs[:100] + stairs[-1:]).encode())
+    # a pile 4200 deep on one base
     one = b"deep\t10\t2\t3\t+\tt\t10\t0\t1\t1\t1\t60\tcg:Z:1M\n"
-    used = kernels_used(eng, one * 4200)
-    assert "k_tile" in used
+    got, _ = check(eng, one * 4200)
+    assert got.splitlines()[-1].split(b"\ttl:i:")[1].split(b"\t")[0] == b"4200"
+
+
+def test_counters_saturate_at_32766(eng):
+    """impl/paf.c:700: a counter stops at INT16_MAX - 1, and so do the levels."""
+    one = b"deep\t10\t2\t4\t+\tt\t10\t0\t2\t2\t2\t60\tcg:Z:2M\n"
+    got, _ = check(eng, one * 32800)
+    levels = [int(l.split(b"\ttl:i:")[1].split(b"\t")[0]) for l in got.splitlines()]
+    assert levels[0] == 1 and levels[32765] == 32766 and levels[-1] == 32766
+
+
+def test_batches_and_chunks_give_the_same_bytes(eng, human_chimp):
+    """An input held as several text batches, and a walk cut into chunks of entries (bitmap budget), equal the one-batch run."""
+    data = human_chimp + synth_lib.generate(0x5EED0005, 300, 0, 500) + overlapping_records(random.Random(3), 800)
+    want, _ = check(eng, data)
+    for batch_bytes in (1 << 20, 200_000, 70_000):
+        got, info = eng.tile(data, batch_bytes=batch_bytes)
+        assert got == want and info.n_records == data.count(b"\n")
+    os.environ["PAFFY_COV_BITMAP_MB"] = "1"
+    try:
+        assert eng.tile(data)[0] == want
+        assert eng.tile(data, batch_bytes=300_000)[0] == want
+        check(eng, overlapping_records(random.Random(4), 3000, contigs=2, qlen=70_000))
+    finally:
+        del os.environ["PAFFY_COV_BITMAP_MB"]
+    # an error in a later batch is reported with its record number over all batches
+    bad = data + b"q\t100\t0\t5\t*\tt\t100\t0\t5\t5\t5\t60\tcg:Z:5M\n"
+    got, info = eng.tile(bad, raise_on_error=False, batch_bytes=200_000)
+    assert got == b"" and info.error.code == 2 and info.error.record == data.count(b"\n")
+
+
+def test_emit_in_pieces(eng, human_chimp):
+    """paffy_hip_emit_lines: the output drained through a small staging buffer equals the one-shot emit."""
+    want, _ = O.tile(human_chimp)
+    bufs = [(eng.to_device(p), len(p)) for p in eng.split_lines(human_chimp, 400_000)]  # must outlive the emits: the lines are written from them
+    info = eng.tile_batches(bufs)
+    assert info.error.code == 0 and info.out_bytes == len(want)
+    stage = eng.alloc_out(200_000)
+    got, first = b"", 0
+    while first < info.n_rows:
+        n = min(7, info.n_rows - first)
+        while True:  # as many lines as fit
+            try:
+                nbytes = eng.emit_lines(first, n, stage)
+                break
+            except RuntimeError:
+                n -= 1
+                assert n >= 1
+        eng.sync()
+        got += bytes(stage[:nbytes].cpu().numpy().tobytes())
+        first += n
+    assert got == want
+    keys = eng.tile_keys(info.n_rows).cpu().numpy()
+    assert keys.shape == (207, 5) and int(keys[:, 3].sum()) == len(want)
+    assert [int(x) for x in keys[:, 4]] == [int(l.split(b"\ttl:i:")[1].split(b"\t")[0]) for l in want.splitlines()]
+
+
+def test_more_than_2_gib_at_depth(eng):
+    """`paffy tile` on an input beyond the 2 GiB a single batch can hold -- 500 000 records of mean 2k ops on ONE
+    query contig (~150x coverage) in four text batches -- byte-equal to the oracle."""
+    import hashlib
+
+    import torch
+
+    bufs, host = [], []
+    for b in range(4):
+        buf, nbytes = eng.synth(0x5EED0005, 2048, b * 125_000, 125_000, n_contigs=1)
+        bufs.append((buf, nbytes))
+        host.append(bytes(buf[:nbytes].cpu().numpy().tobytes()))
+    data = b"".join(host)
+    del host
+    assert len(data) > (1 << 31)
+    info = eng.tile_batches(bufs)
+    assert info.error.code == 0 and info.n_records == 500_000
+    d_out = eng.alloc_out(info.out_bytes)
+    eng.emit(d_out)
+    eng.sync()
+    got = hashlib.sha256(d_out[: info.out_bytes].cpu().numpy().tobytes()).hexdigest()
+    levels = eng.tile_keys(info.n_rows)[:, 4]
+    assert int(levels.max()) > 50  # deep: the median level of the last records is in the hundreds
+    del d_out, bufs
+    torch.cuda.empty_cache()
+    want, err = O.tile(data)
+    assert err.code == 0 and len(want) == info.out_bytes
+    assert hashlib.sha256(want).hexdigest() == got

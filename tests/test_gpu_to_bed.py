@@ -54,6 +54,21 @@ def test_synthetic_piles_both_strands(eng):
     check(eng, b"".join(lines[:700]), include_inverted=True)
 
 
+def test_batches_give_the_same_bytes(eng, human_chimp):
+    """to_bed over an input held as several text batches (any size: the counters are per sequence, not per batch)."""
+    host = synth_lib.Synth4(0x5EED0004, 512, n_contigs=4, tlen_min=200_000, tlen_span=300_000)
+    data = host.records(0, 2500)
+    for kw in (dict(), dict(include_inverted=True), dict(binary=True, min_size=20)):
+        want, err = O.to_bed(data, **kw)
+        assert err.code == 0
+        for batch_bytes in (1 << 20, 150_000):
+            got, info = eng.to_bed(data, batch_bytes=batch_bytes, **kw)
+            assert got == want and info.n_records == data.count(b"\n")
+    bad = data + b"q\t30\t2\t13\t+\tt\t40\t5\t15\t10\t10\t60\tcg:Z:10M\n"
+    got, info = eng.to_bed(bad, batch_bytes=150_000, raise_on_error=False)
+    assert got == b"" and info.error.code == 19 and info.error.record == data.count(b"\n")
+
+
 def test_edges_and_errors(eng):
     ok = b"q\t30\t2\t12\t+\tt\t40\t5\t15\t10\t10\t60\tcg:Z:10M\n"
     check(eng, b"")

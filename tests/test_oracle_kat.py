@@ -142,9 +142,50 @@ def test_encode_and_remove_mismatches():
 
 
 # ---- 12. coverage counters, paf_unit_test.c:576-603 ----
+# O.coverage_counts drives counts_for() + bump_counts() of oracle/paf_oracle.c: the very functions po_tile and po_to_bed call
+# (one restatement of get_alignment_count_array / increase_alignment_level_counts, impl/paf.c:675-709), so this reference test
+# pins what `tile` and `to_bed` run.
 def test_coverage_counts():
-    applied, counts = O.coverage_counts(line("seq1", 10, 2, 5, "+", "t", 100, 0, 3, 3, 3, 60, "3M"), "seq1", 10)
+    rec = line("seq1", 10, 2, 5, "+", "t", 100, 0, 3, 3, 3, 60, "3M")
+    applied, counts = O.coverage_counts(rec, "seq1", 10)
     assert applied == 1 and counts == [0, 0, 1, 1, 1, 0, 0, 0, 0, 0]
+    # "second call with same query name returns the same array" (:589-591): two records of one name share the counters
+    applied, counts = O.coverage_counts(rec + rec, "seq1", 10)
+    assert applied == 2 and counts == [0, 0, 2, 2, 2, 0, 0, 0, 0, 0]
+    # ... and the tile / to_bed entry points show the same counters: to_bed prints them as runs, tile's level 1 then 2
+    bed, err = O.to_bed(rec + rec)
+    assert err.code == 0 and bed == b"seq1 0 2 0\nseq1 2 5 2\nseq1 5 10 0\n"
+    tiled, err = O.tile(rec + rec)
+    assert err.code == 0 and [l.split(b"\ttl:i:")[1][:1] for l in tiled.splitlines()] == [b"1", b"2"]
+    # the length assert of impl/paf.c:685 and the end assert of :708
+    assert O.coverage_counts(rec + line("seq1", 11, 2, 5, "+", "t", 100, 0, 3, 3, 3, 60, "3M"), "seq1", 10)[0] == -2
+    assert O.coverage_counts(line("seq1", 10, 2, 6, "+", "t", 100, 0, 3, 3, 3, 60, "3M"), "seq1", 10)[0] == -1
+
+
+# ---- 3b. cigar kept as a string (paf_parse(.., false)), paf_unit_test.c:148-160: tile and dedupe read records this way and write the
+# cigar text back verbatim (impl/paf.c:381-385) -- even text cigar_parse would reject or normalise
+def test_parse_cigar_string_mode():
+    src = line("q1", 100, 0, 8, "+", "t1", 200, 0, 7, 8, 10, 60, "5M3I2D")
+    out, err = O.dedupe(src)
+    assert err.code == 0 and out == out_line("q1", 100, 0, 8, "+", "t1", 200, 0, 7, 8, 10, 60, "5M3I2D")
+    odd = line("q1", 100, 0, 8, "+", "t1", 200, 0, 7, 8, 10, 60, "005M3I2D")
+    out, err = O.dedupe(odd)
+    assert err.code == 0 and out == out_line("q1", 100, 0, 8, "+", "t1", 200, 0, 7, 8, 10, 60, "005M3I2D")
+
+
+# ---- 5b. read_pafs / write_pafs list round trip, paf_unit_test.c:269-291: three records in, the same three out, in order
+def test_read_write_pafs_list():
+    src = (line("q1", 100, 0, 50, "+", "t1", 200, 0, 50, 50, 50, 60) + line("q2", 200, 10, 60, "-", "t2", 300, 20, 70, 50, 50, 30) +
+           line("q3", 150, 5, 55, "+", "t3", 250, 15, 65, 50, 50, 40))
+    out, err = O.dedupe(src)  # read_pafs(.., 0)-style parse of every line, write in input order
+    assert err.code == 0 and [l.split(b"\t")[0] for l in out.splitlines()] == [b"q1", b"q2", b"q3"]
+
+
+# Reference tests of paf_unit_test.c:735-778 NOT restated here, and why:
+#   test_decode_fasta_header (:607-616), test_cmp_intervals (:618-632)  -- FASTA-header helpers of dechunk/upconvert, outside SURVEY 8
+#       (cmp_intervals is restated for the C API in tests/c/paf_api_kat.c)
+#   test_paf_pretty_print_basic (:691-701) -- only asserts "output is non-empty"; the stats line is checked in tests/test_view_stats.py
+# Every other test of the suite has its restatement above (numbers 1-12, 14, 16).
 
 
 # ---- 14. paf_trim_unreliable_tails, paf_unit_test.c:634-687 ----
