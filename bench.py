@@ -36,9 +36,10 @@ WORKLOADS = {
     # records on homologous bases of two device-generated genomes (24 + 24 contigs of 50-250 Mb, 2 % substitutions)
     "cfg4": dict(seed=0x5EED0004, mean_ops=2048, total=10_000_000, pipe="add_mismatches", genomes=True,
                  desc="10M synthetic PAF records, mean 2k cigar ops + 2x3.6 Gb synthetic genomes resident in HBM, add_mismatches"),
-    # `paffy tile` over one GPU's share of the records (cfg5 shards the query contigs over 8 GPUs; here every step tiles one batch)
-    "cfg5": dict(seed=0x5EED0005, mean_ops=2048, total=10_000_000, pipe="tile", tile=True,
-                 desc="synthetic PAF records, mean 2k cigar ops, tile (one GPU's share per step)"),
+    # `paffy tile` over ONE record set per step, --batch records per GPU, partitioned by query contig across the GPUs (all-to-all of the
+    # lines), tiled, and ordered by an all-gather of 32-byte keys; BASELINE's cfg5 is --gpus 8 --batch 10000000 --steps 1
+    "cfg5": dict(seed=0x5EED0005, mean_ops=2048, total=80_000_000, pipe="tile", tile=True,
+                 desc="synthetic PAF records, mean 2k cigar ops, partitioned by query contig across the GPUs, tile + ordered write"),
 }
 
 
@@ -59,6 +60,7 @@ def main():
     ap.add_argument("--pipe", default=None, help="override the workload's command pipe, e.g. 'shatter' (experiments only)")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="records of the stream timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    ap.add_argument("--verify", action="store_true", help="cfg5: gather the ordered output of the last step on rank 0 and compare it with a one-process tile of the same records (small --batch only)")
     ap.add_argument("--rehearse", action="store_true",
                     help="plumbing rehearsal without a GPU: ranks, rendezvous, the per-step size exchange and the reductions run, the hot path does not (value is null)")
     args = ap.parse_args()
@@ -92,6 +94,8 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.pipe:
         wl["pipe"] = args.pipe
+    if wl.get("tile"):
+        return bench_tile(args, wl, rank, world, dist, dev)
     eng = paffy_amd.Engine()
     stages = [] if wl.get("tile") else stages_for(wl["pipe"], paffy_amd)
     n_batches = args.warmup + args.steps
@@ -248,6 +252,120 @@ def main():
             "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kernels.items()},
         }
         print(json.dumps(line), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+def bench_tile(args, wl, rank, world, dist, dev):
+    """cfg5: a step is `paffy tile` over one set of world x --batch records. Every rank generates a contiguous share of the set on
+    its GPU (untimed); timed: the partition by query contig (hash + regroup on the device, one all-to-all of the lines), the tile of
+    what the rank owns (bitmaps, slice walk, merge), the all-gather of the 32-byte keys that places every line in the ordered output,
+    and the local write of the lines."""
+    import torch
+
+    import paffy_amd
+    from paffy_amd import shard
+
+    eng = paffy_amd.Engine()
+    worker = shard.GpuTileWorker(eng)
+    comm = dev if (dist is None or args.dist_backend == "nccl") else "cpu"
+    per_batch = 200_000  # records per text batch: about 1.1 GB of text, below the 2 GiB of a batch
+
+    def share(step_no):
+        first, n = shard.share_of_rank(rank, world, world * args.batch)
+        first += step_no * world * args.batch
+        out = []
+        for r0 in range(first, first + n, per_batch):
+            buf, nbytes = eng.synth(wl["seed"], wl["mean_ops"], r0 % wl["total"], min(per_batch, first + n - r0))
+            out.append((buf, nbytes))
+        return out, first
+
+    n_steps = args.warmup + args.steps
+    in_bytes = out_bytes = rows = 0
+    aligned_per_record = 0.0
+    eng.profile(False)
+    elapsed, last, kernels = 0.0, None, {}
+    for i in range(n_steps):
+        batches, first = share(i)
+        if i == 0:
+            head = bytes(batches[0][0][: min(batches[0][1], 4 << 20)].cpu().numpy().tobytes())
+            lines = head.split(b"\n")[:-1]
+            aligned_per_record = sum(int(l.split(b"\t", 10)[9]) for l in lines) / max(1, len(lines))
+        timed = i >= args.warmup
+        if i == args.warmup:
+            eng.profile(not args.no_kernel_events)
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = shard.tile_sharded(worker, dist, rank, world, batches, first, comm)
+        out = worker.emit()
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if timed:
+            elapsed += dt
+            in_bytes += sum(n for _, n in worker.keep)
+            out_bytes += int(out.numel())
+            rows += int(res["keys"].shape[0])
+        last = (res, out, batches, first)
+    kernels = eng.profile_read()
+    eng.profile(False)
+    red = dev if (dist is not None and args.dist_backend == "nccl") else "cpu"
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    verified = None
+    if args.verify:
+        res, out, batches, first = last
+        whole = shard.gather_ordered_output(worker, dist, rank, world, out, res["keys"][:, 3].contiguous(), res["offsets"], res["total"], comm)
+        if rank == 0:
+            e2 = paffy_amd.Engine()
+            allb = []
+            base = (n_steps - 1) * world * args.batch
+            for r0 in range(base, base + world * args.batch, per_batch):
+                allb.append(e2.synth(wl["seed"], wl["mean_ops"], r0 % wl["total"], min(per_batch, base + world * args.batch - r0)))
+            info = e2.tile_batches(allb)
+            ref = e2.alloc_out(info.out_bytes)
+            e2.emit(ref)
+            e2.sync()
+            verified = bool(info.error.code == 0 and info.out_bytes == res["total"] and torch.equal(ref[: info.out_bytes].cpu(), whole.cpu()))
+            e2.close()
+    if rank == 0:
+        records = world * args.batch * args.steps
+        per_step = (in_bytes + out_bytes) / max(1, args.steps) + 4.0 * aligned_per_record * (rows / max(1, args.steps))  # this rank's share of a step
+        step_ms = sum(ms for ms, _ in kernels.values()) / max(1, args.steps)
+        roofline, by_kernel = None, {}
+        if kernels and step_ms > 0:
+            dom = max(kernels, key=lambda k: kernels[k][0])
+            ach = per_step / (step_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": f"all kernels of one step on one rank (dominant: {dom})", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "step_kernels_ms": round(step_ms, 4), "dominant_kernel": dom,
+                        "dominant_avg_kernel_ms": round(kernels[dom][0] / max(1, kernels[dom][1]), 4), "algorithmic_bytes_per_launch": int(per_step),
+                        "note": "algorithmic bytes = input lines + output lines + 4 B per aligned base (SURVEY 8d counts the counter of every aligned base as 2 B read + 2 B "
+                                "written in HBM; here a slice's counters live in LDS while its records are walked, so the walk itself moves one bit per base)"}
+            for name, (ms, launches) in kernels.items():
+                if launches > 0 and ms >= 0.05 * kernels[dom][0]:
+                    by_kernel[name] = {"avg_kernel_ms": round(ms / launches, 4), "launches_per_step": round(launches / max(1, args.steps), 2)}
+        cpu = cpu_baseline_tile(eng, wl, min(args.cpu_sample, 8192)) if (args.cpu_sample > 0 and world == 1) else None
+        print(json.dumps({
+            "metric": "PAF records/sec (shatter+invert+trim pipe); % HBM roofline at 1/2/4/8 GPU", "value": round(records / elapsed, 1), "unit": "records/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u16 counters / int64 keys", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {wl['desc']}", "pipe": "tile", "records_per_step_per_gpu": args.batch, "records_timed": records,
+                       "mean_cigar_ops": wl["mean_ops"], "aligned_bases_per_record": round(aligned_per_record, 1),
+                       "input_bytes_per_record": round(in_bytes / max(1, rows), 1), "output_bytes_per_record": round(out_bytes / max(1, rows), 1),
+                       "sharding": "records partitioned by query contig (heaviest contig to the lightest rank): one all-to-all of the lines + 8 B per record, "
+                                   "then an all-gather of 32 B per record places every line in the ordered output; all inside the timed region"},
+            "ordered_write": {"mode": "per-line offsets from the all-gathered keys; lines written by their owner", "total_bytes": int(last[0]["total"]),
+                              "verified_against_one_process": verified},
+            "roofline": roofline, "roofline_by_kernel": by_kernel, "cpu_baseline": cpu,
+            "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kernels.items()},
+        }), flush=True)
+    eng.close()
     if dist:
         dist.destroy_process_group()
 

@@ -150,6 +150,24 @@ int paffy_hip_tile_run(paffy_hip_ctx *ctx, paffy_plan_info *info);
  */
 int64_t paffy_hip_tile_keys(paffy_hip_ctx *ctx, int64_t cap_lines, void *d_keys);
 /*
+ * Sharding `paffy tile` by query sequence across GPUs (what `paffy split_file -q` does with files in the reference
+ * pipeline, tests/paf_pipeline_test.sh:42, impl/paf_split_file.c:142-173). Names travel as 64-bit hashes.
+ *   query_names:    the distinct query names of a batch (hashes[], host) and the bytes of their lines (weights[], host): what a
+ *                   partitioner balances. Returns their number (<= cap) or a negative error.
+ *   split_by_owner: the lines of the batch regrouped by part -- part = table_owner[i] for a query name with hash table_hash[i]
+ *                   (ascending hashes; a name the table lacks goes to hash % n_parts) -- input order kept inside a part, every line
+ *                   newline-terminated, into d_out (out_cap >= in_len + 1). part_bytes / part_records (host, n_parts each) say where
+ *                   the parts end; d_rec_index (device, rec_index_cap int64, may be NULL) gets the batch index of every output line.
+ *                   This is the send buffer of the all-to-all that gives every rank the records of its sequences.
+ *   scatter_lines:  line k = d_src[src_off[k], src_off[k + 1]) goes to d_dst + dst_off[k] (int64 offsets in device memory; n_lines + 1
+ *                   source offsets): the ordered write once every line's place in the global output is known.
+ */
+int64_t paffy_hip_query_names(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len, int64_t cap, uint64_t *hashes, int64_t *weights);
+int paffy_hip_split_by_owner(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len, int32_t n_parts, const uint64_t *table_hash, const uint32_t *table_owner,
+                             int64_t n_table, void *d_out, int64_t out_cap, int64_t *part_bytes, int64_t *part_records, void *d_rec_index, int64_t rec_index_cap,
+                             int64_t *n_records);
+int paffy_hip_scatter_lines(paffy_hip_ctx *ctx, const void *d_src, const void *d_src_off, const void *d_dst_off, int64_t n_lines, void *d_dst);
+/*
  * Lines [first, first + n) of a tile / dedupe plan into d_out, the first of them at d_out[0] (16-byte aligned): for hosts that
  * drain an output larger than their staging buffer. *bytes = what was written.
  */

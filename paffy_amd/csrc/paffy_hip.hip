@@ -1087,6 +1087,185 @@ int paffy_hip_tile_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, paff
     return rc;
 }
 
+/*
+ * Sharding `paffy tile` by query sequence (the reference pipeline's `split_file -q`, tests/paf_pipeline_test.sh:42):
+ *   paffy_hip_query_names    the distinct query names of a batch as 64-bit hashes with the bytes of their lines (the weights a
+ *                            partitioner balances)
+ *   paffy_hip_split_by_owner the lines of a batch regrouped by the owner of their query name (owner table: hash -> part), input order
+ *                            kept inside a part: what an all-to-all over the ranks sends
+ *   paffy_hip_scatter_lines  lines to given offsets of an output (the ordered write once every line's place is known)
+ */
+__global__ __launch_bounds__(PAFFY_NT) void k_query_hash(const uint8_t *in, const RecMeta *meta, const uint32_t *sep_pos, const uint32_t *nl_idx, uint32_t n, uint32_t in_len,
+                                                          uint64_t *hash, uint64_t *line_len, uint32_t *idx) {
+    const uint32_t r = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (r >= n) return;
+    const RecMeta &m = meta[r];
+    hash[r] = cov_name_hash(in, m.qname_off, m.qname_len);
+    const uint32_t start = r == 0 ? 0u : sep_pos[nl_idx[r - 1]] + 1u, end = sep_pos[nl_idx[r]];
+    (void)in_len;
+    line_len[r] = (uint64_t)(end - start) + 1u; /* with its newline (a last line without one gets one) */
+    idx[r] = r;
+}
+/* sorted by hash: weight of every run of equal hashes, at its head */
+__global__ __launch_bounds__(PAFFY_NT) void k_run_weights(const uint64_t *sorted_hash, const uint32_t *sorted_idx, const uint64_t *line_len, const uint32_t *flag,
+                                                           const uint32_t *scan, uint32_t n, uint64_t *out_hash, unsigned long long *out_weight) {
+    const uint32_t i = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = scan[i] - 1u;
+    if (flag[i]) out_hash[c] = sorted_hash[i];
+    atomicAdd(&out_weight[c], (unsigned long long)line_len[sorted_idx[i]]);
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_owner_keys(const uint64_t *hash, uint32_t n, const uint64_t *tab_hash, const uint32_t *tab_owner, uint32_t n_tab, uint32_t n_parts,
+                                                          uint64_t *key) {
+    const uint32_t r = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (r >= n) return;
+    uint32_t lo = 0, hi = n_tab; /* first entry >= hash */
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tab_hash[mid] < hash[r]) lo = mid + 1;
+        else hi = mid;
+    }
+    uint32_t owner = (lo < n_tab && tab_hash[lo] == hash[r]) ? tab_owner[lo] : (uint32_t)(hash[r] % n_parts); /* a name the table does not know */
+    if (owner >= n_parts) owner = n_parts - 1;
+    key[r] = ((uint64_t)owner << 32) | r;
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_gather_len(const uint64_t *sorted_key, const uint64_t *line_len, uint32_t n, uint64_t *out) {
+    const uint32_t i = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (i < n) out[i] = line_len[(uint32_t)sorted_key[i]];
+    if (i == 0) out[n] = 0;
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_part_totals(const uint64_t *sorted_key, const uint64_t *off, uint32_t n, uint32_t n_parts, int64_t *part_bytes, int64_t *part_records,
+                                                           int64_t *rec_index) {
+    const uint32_t i = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = (uint32_t)(sorted_key[i] >> 32);
+    rec_index[i] = (int64_t)(uint32_t)sorted_key[i];
+    atomicAdd(reinterpret_cast<unsigned long long *>(&part_records[p]), 1ull);
+    atomicAdd(reinterpret_cast<unsigned long long *>(&part_bytes[p]), (unsigned long long)(off[i + 1] - off[i]));
+    (void)n_parts;
+}
+/* one workgroup per line: bytes [src_off, src_off + len) of src to dst + dst_off; a source line that ends without newline gets one */
+__device__ __forceinline__ void copy_line(const uint8_t *src, uint64_t len, uint8_t *dst, bool add_nl) {
+    const uint64_t body = add_nl ? len - 1 : len;
+    const uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+    if (head >= body) {
+        for (uint64_t x = threadIdx.x; x < body; x += PAFFY_NT) dst[x] = src[x];
+    } else {
+        for (uint32_t x = threadIdx.x; x < head; x += PAFFY_NT) dst[x] = src[x];
+        const uint64_t n_ch = (body - head) >> 4;
+        for (uint64_t ch = threadIdx.x; ch < n_ch; ch += PAFFY_NT)
+            *reinterpret_cast<u32x4 *>(dst + head + 16 * ch) = *reinterpret_cast<const u32x4_unaligned *>(src + head + 16 * ch);
+        for (uint64_t x = head + 16 * n_ch + threadIdx.x; x < body; x += PAFFY_NT) dst[x] = src[x];
+    }
+    if (add_nl && threadIdx.x == 0) dst[body] = '\n';
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_split_copy(const uint8_t *in, uint32_t in_len, const uint32_t *sep_pos, const uint32_t *nl_idx, const uint64_t *sorted_key,
+                                                          const uint64_t *off, uint8_t *out) {
+    const uint32_t r = (uint32_t)sorted_key[blockIdx.x];
+    const uint32_t start = r == 0 ? 0u : sep_pos[nl_idx[r - 1]] + 1u, end = sep_pos[nl_idx[r]];
+    copy_line(in + start, (uint64_t)(end - start) + 1u, out + off[blockIdx.x], end >= in_len);
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_scatter_lines(const uint8_t *src, const int64_t *src_off, const int64_t *dst_off, uint8_t *dst) {
+    const uint64_t k = blockIdx.x;
+    copy_line(src + src_off[k], (uint64_t)(src_off[k + 1] - src_off[k]), dst + dst_off[k], false);
+}
+
+int64_t paffy_hip_query_names(paffy_hip_ctx *c, const void *d_in, int64_t in_len, int64_t cap, uint64_t *hashes, int64_t *weights) {
+    if (!c || !hashes || !weights || cap < 0) return PAFFY_E_ARG;
+    if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
+    if (in_len == 0) return 0;
+    CovState &S = cov_state(c);
+    uint32_t n = 0;
+    const uint8_t *in = static_cast<const uint8_t *>(d_in);
+    int rc = index_and_parse(c, in, (uint32_t)in_len, &n);
+    if (rc) return rc;
+    if (n == 0) return 0;
+    const uint32_t g = (n + PAFFY_NT - 1) / PAFFY_NT;
+    if (ensure(c, S.k64a, sizeof(uint64_t) * ((size_t)n + 1)) || ensure(c, S.k64b, sizeof(uint64_t) * ((size_t)n + 1)) || ensure(c, S.name_hash, sizeof(uint64_t) * ((size_t)n + 1)) ||
+        ensure(c, S.v32a, sizeof(uint32_t) * ((size_t)n + 1)) || ensure(c, S.v32b, sizeof(uint32_t) * ((size_t)n + 1)) || ensure(c, S.flags, sizeof(uint32_t) * ((size_t)n + 1)) ||
+        ensure(c, S.scan32, sizeof(uint32_t) * ((size_t)n + 1)))
+        return PAFFY_E_HIP;
+    uint64_t *hash = static_cast<uint64_t *>(S.name_hash.p), *len = static_cast<uint64_t *>(S.k64b.p), *sorted = static_cast<uint64_t *>(S.k64a.p);
+    uint32_t *idx = static_cast<uint32_t *>(S.v32a.p), *sidx = static_cast<uint32_t *>(S.v32b.p), *flags = static_cast<uint32_t *>(S.flags.p), *scan = static_cast<uint32_t *>(S.scan32.p);
+    LAUNCH(c, "k_query_hash", k_query_hash, dim3(g), dim3(PAFFY_NT), 0, in, static_cast<const RecMeta *>(c->meta.p), static_cast<const uint32_t *>(c->sep_pos.p),
+           static_cast<const uint32_t *>(c->nl_idx.p), n, (uint32_t)in_len, hash, len, idx);
+    if (cov_sort_pairs(c, S, hash, sorted, idx, sidx, n)) return PAFFY_E_HIP;
+    LAUNCH(c, "k_cov_run_heads", k_cov_run_heads, dim3(g), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(sorted), n, flags);
+    if (cov_incl_scan32(c, S, flags, scan, n)) return PAFFY_E_HIP;
+    uint32_t n_names = 0;
+    if (cov_fetch(c, &n_names, scan + (n - 1), sizeof(uint32_t))) return PAFFY_E_HIP;
+    if ((int64_t)n_names > cap) return PAFFY_E_CAPACITY;
+    if (ensure(c, S.pairs, sizeof(uint64_t) * (size_t)n_names) || ensure(c, S.pairs2, sizeof(uint64_t) * (size_t)n_names)) return PAFFY_E_HIP;
+    HIPCHK(c, hipMemsetAsync(S.pairs2.p, 0, sizeof(uint64_t) * (size_t)n_names, c->stream));
+    LAUNCH(c, "k_run_weights", k_run_weights, dim3(g), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(sorted), static_cast<const uint32_t *>(sidx), static_cast<const uint64_t *>(len),
+           static_cast<const uint32_t *>(flags), static_cast<const uint32_t *>(scan), n, static_cast<uint64_t *>(S.pairs.p), static_cast<unsigned long long *>(S.pairs2.p));
+    HIPCHK(c, hipMemcpyAsync(hashes, S.pairs.p, sizeof(uint64_t) * (size_t)n_names, hipMemcpyDeviceToHost, c->stream));
+    if (cov_fetch(c, weights, S.pairs2.p, sizeof(int64_t) * (size_t)n_names)) return PAFFY_E_HIP;
+    return (int64_t)n_names;
+}
+
+int paffy_hip_split_by_owner(paffy_hip_ctx *c, const void *d_in, int64_t in_len, int32_t n_parts, const uint64_t *table_hash, const uint32_t *table_owner, int64_t n_table,
+                             void *d_out, int64_t out_cap, int64_t *part_bytes, int64_t *part_records, void *d_rec_index, int64_t rec_index_cap, int64_t *n_records) {
+    if (!c || n_parts < 1 || n_table < 0 || (n_table > 0 && (!table_hash || !table_owner)) || !part_bytes || !part_records || !n_records) return PAFFY_E_ARG;
+    if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
+    for (int32_t p = 0; p < n_parts; p++) part_bytes[p] = part_records[p] = 0;
+    *n_records = 0;
+    if (in_len == 0) return 0;
+    if (!d_out || out_cap < in_len + 1) return PAFFY_E_CAPACITY;
+    CovState &S = cov_state(c);
+    uint32_t n = 0;
+    const uint8_t *in = static_cast<const uint8_t *>(d_in);
+    int rc = index_and_parse(c, in, (uint32_t)in_len, &n);
+    if (rc) return rc;
+    *n_records = n;
+    if (n == 0) return 0;
+    if (d_rec_index && rec_index_cap < (int64_t)n) return PAFFY_E_CAPACITY;
+    const uint32_t g = (n + PAFFY_NT - 1) / PAFFY_NT;
+    if (ensure(c, S.k64a, sizeof(uint64_t) * ((size_t)n + 1)) || ensure(c, S.k64b, sizeof(uint64_t) * ((size_t)n + 1)) || ensure(c, S.name_hash, sizeof(uint64_t) * ((size_t)n + 1)) ||
+        ensure(c, S.v32a, sizeof(uint32_t) * ((size_t)n + 1)) || ensure(c, S.bm_words, sizeof(uint64_t) * ((size_t)n + 1)) || ensure(c, S.bm_off, sizeof(uint64_t) * ((size_t)n + 2)) ||
+        ensure(c, S.pairs, (sizeof(uint64_t) + sizeof(uint32_t)) * ((size_t)n_table + 1)) || ensure(c, S.pairs2, sizeof(int64_t) * 2 * (size_t)n_parts))
+        return PAFFY_E_HIP;
+    uint64_t *hash = static_cast<uint64_t *>(S.name_hash.p), *len = static_cast<uint64_t *>(S.k64b.p), *key = static_cast<uint64_t *>(S.k64a.p), *skey = static_cast<uint64_t *>(S.bm_words.p);
+    uint64_t *off = static_cast<uint64_t *>(S.bm_off.p);
+    uint64_t *d_th = static_cast<uint64_t *>(S.pairs.p);
+    uint32_t *d_to = reinterpret_cast<uint32_t *>(d_th + n_table + 1);
+    if (n_table) {
+        HIPCHK(c, hipMemcpyAsync(d_th, table_hash, sizeof(uint64_t) * (size_t)n_table, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_to, table_owner, sizeof(uint32_t) * (size_t)n_table, hipMemcpyHostToDevice, c->stream));
+    }
+    LAUNCH(c, "k_query_hash", k_query_hash, dim3(g), dim3(PAFFY_NT), 0, in, static_cast<const RecMeta *>(c->meta.p), static_cast<const uint32_t *>(c->sep_pos.p),
+           static_cast<const uint32_t *>(c->nl_idx.p), n, (uint32_t)in_len, hash, len, static_cast<uint32_t *>(S.v32a.p));
+    LAUNCH(c, "k_owner_keys", k_owner_keys, dim3(g), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(hash), n, static_cast<const uint64_t *>(d_th), static_cast<const uint32_t *>(d_to),
+           (uint32_t)n_table, (uint32_t)n_parts, key);
+    if (cov_sort_keys(c, S, key, skey, n)) return PAFFY_E_HIP; /* (owner, input index): input order inside a part */
+    LAUNCH(c, "k_gather_len", k_gather_len, dim3(g), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(skey), static_cast<const uint64_t *>(len), n, key);
+    if (cov_excl_scan64(c, S, key, off, n)) return PAFFY_E_HIP;
+    int64_t *d_tot = static_cast<int64_t *>(S.pairs2.p);
+    HIPCHK(c, hipMemsetAsync(d_tot, 0, sizeof(int64_t) * 2 * (size_t)n_parts, c->stream));
+    if (ensure(c, S.out_len, sizeof(int64_t) * ((size_t)n + 1))) return PAFFY_E_HIP;
+    int64_t *d_idx = d_rec_index ? static_cast<int64_t *>(d_rec_index) : static_cast<int64_t *>(S.out_len.p);
+    LAUNCH(c, "k_part_totals", k_part_totals, dim3(g), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(skey), static_cast<const uint64_t *>(off), n, (uint32_t)n_parts, d_tot,
+           d_tot + n_parts, d_idx);
+    LAUNCH(c, "k_split_copy", k_split_copy, dim3(n), dim3(PAFFY_NT), 0, in, (uint32_t)in_len, static_cast<const uint32_t *>(c->sep_pos.p), static_cast<const uint32_t *>(c->nl_idx.p),
+           static_cast<const uint64_t *>(skey), static_cast<const uint64_t *>(off), static_cast<uint8_t *>(d_out));
+    std::vector<int64_t> tot(2 * (size_t)n_parts);
+    if (cov_fetch(c, tot.data(), d_tot, sizeof(int64_t) * 2 * (size_t)n_parts)) return PAFFY_E_HIP;
+    for (int32_t p = 0; p < n_parts; p++) {
+        part_bytes[p] = tot[(size_t)p];
+        part_records[p] = tot[(size_t)n_parts + p];
+    }
+    return 0;
+}
+
+int paffy_hip_scatter_lines(paffy_hip_ctx *c, const void *d_src, const void *d_src_off, const void *d_dst_off, int64_t n_lines, void *d_dst) {
+    if (!c || n_lines < 0 || n_lines >= (1ll << 31)) return PAFFY_E_ARG;
+    if (n_lines == 0) return 0;
+    if (!d_src || !d_src_off || !d_dst_off || !d_dst) return PAFFY_E_ARG;
+    LAUNCH(c, "k_scatter_lines", k_scatter_lines, dim3((unsigned)n_lines), dim3(PAFFY_NT), 0, static_cast<const uint8_t *>(d_src), static_cast<const int64_t *>(d_src_off),
+           static_cast<const int64_t *>(d_dst_off), static_cast<uint8_t *>(d_dst));
+    return 0;
+}
+
 /* After a tile run: (chain_score, score, input record, line bytes, tile level) of the lines emit writes, in output order -- what ranks
  * exchange to merge their shares of a `paffy tile` sharded by query sequence. Returns the line count. */
 __global__ __launch_bounds__(PAFFY_NT) void k_tile_keys_out(const RecMeta *meta, const uint32_t *order, const int64_t *level, const uint64_t *out_len, uint64_t n,

@@ -102,6 +102,11 @@ def lib():
         L.paffy_hip_bed_begin.argtypes = [vp, C.POINTER(BedOpts)]
         L.paffy_hip_bed_add.argtypes = [vp, vp, i64]
         L.paffy_hip_bed_run.argtypes = [vp, C.POINTER(BedOpts), C.POINTER(PlanInfo)]
+        L.paffy_hip_query_names.restype = i64
+        L.paffy_hip_query_names.argtypes = [vp, vp, i64, i64, C.POINTER(C.c_uint64), C.POINTER(i64)]
+        L.paffy_hip_split_by_owner.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), i64, vp, i64, C.POINTER(i64), C.POINTER(i64), vp, i64,
+                                               C.POINTER(i64)]
+        L.paffy_hip_scatter_lines.argtypes = [vp, vp, vp, vp, i64, vp]
         L.paffy_hip_sync.argtypes = [vp]
         L.paffy_hip_dedupe_plan.argtypes = [vp, vp, i64, C.c_int, C.POINTER(PlanInfo)]
         L.paffy_hip_dedupe_reset.argtypes = [vp]
@@ -210,6 +215,36 @@ class Engine:
         if n < 0:
             raise RuntimeError(f"paffy_hip_tile_keys failed ({n})")
         return keys[:n]
+
+    # ---- `paffy tile` sharded by query sequence: the device side of the partition and of the ordered write ----
+    def query_names(self, d_in, in_len, cap=1 << 20):
+        """Distinct query names of a device batch as ({hash: bytes of its lines}): what the partitioner balances."""
+        h, w = (C.c_uint64 * cap)(), (C.c_int64 * cap)()
+        n = lib().paffy_hip_query_names(self._ctx, C.c_void_p(d_in.data_ptr()), in_len, cap, h, w)
+        if n < 0:
+            raise RuntimeError(f"paffy_hip_query_names failed ({n}): {lib().paffy_hip_last_error(self._ctx).decode()}")
+        return {int(h[i]): int(w[i]) for i in range(n)}
+
+    def split_by_owner(self, d_in, in_len, n_parts, owner_of):
+        """Lines of a device batch regrouped by owner_of[hash of the query name] (input order inside a part). Returns (uint8 tensor,
+        bytes per part, records per part, int64 tensor: batch index of every output line)."""
+        t = self.torch
+        items = sorted(owner_of.items())
+        nt = len(items)
+        th = (C.c_uint64 * max(1, nt))(*[k for k, _ in items])
+        to = (C.c_uint32 * max(1, nt))(*[v for _, v in items])
+        out = t.empty(_pad16(in_len + 1), dtype=t.uint8, device=self.device)
+        pb, pr, nrec = (C.c_int64 * n_parts)(), (C.c_int64 * n_parts)(), C.c_int64()
+        idx = t.empty(max(1, in_len // 24 + 16), dtype=t.int64, device=self.device)  # a PAF line that parses has at least 24 bytes (the call checks the capacity)
+        self._check(lib().paffy_hip_split_by_owner(self._ctx, C.c_void_p(d_in.data_ptr()), in_len, n_parts, th, to, nt, C.c_void_p(out.data_ptr()), out.numel(), pb, pr,
+                                                   C.c_void_p(idx.data_ptr()), idx.numel(), C.byref(nrec)), "paffy_hip_split_by_owner")
+        return out, list(pb), list(pr), idx[: nrec.value]
+
+    def scatter_lines(self, d_src, src_off, dst_off, d_dst):
+        """Line k = d_src[src_off[k] : src_off[k + 1]] to d_dst[dst_off[k]:] (int64 device tensors)."""
+        n = dst_off.numel()
+        self._check(lib().paffy_hip_scatter_lines(self._ctx, C.c_void_p(d_src.data_ptr()), C.c_void_p(src_off.data_ptr()), C.c_void_p(dst_off.data_ptr()), n,
+                                                  C.c_void_p(d_dst.data_ptr())), "paffy_hip_scatter_lines")
 
     def emit_lines(self, first, n, d_out):
         """Lines [first, first + n) of a tile / dedupe plan into d_out (from its first byte); returns the bytes written."""

@@ -90,47 +90,118 @@ def test_contig_partition_is_balanced_and_total():
     assert max(loads) - min(loads) <= max(w.values())
 
 
-def _tile_worker(rank, world, port, tmpdir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    data = open(os.path.join(tmpdir, "in.paf"), "rb").read()
-    lines = data.splitlines(keepends=True)
-    weights = {}
-    for ln in lines:
-        weights[shard.query_name(ln)] = weights.get(shard.query_name(ln), 0) + len(ln)
-    owner = shard.contig_partition(weights, world)
-    mine = shard.split_by_owner(lines, owner).get(rank, [])
-    # this rank tiles only its contigs (the oracle stands in for the GPU worker); order of equal keys = input order
-    out, err = O.tile(b"".join(ln for _, ln in mine))
-    assert err.code == 0
-    out_lines = out.splitlines(keepends=True)
-    # keys of my output lines: my inputs sorted by key give the global indices in output order
-    order = sorted(range(len(mine)), key=lambda k: shard.tile_key(mine[k][1], mine[k][0]))
-    keyed = [(shard.tile_key(mine[k][1], mine[k][0]), out_lines[pos]) for pos, k in enumerate(order)]
-    gathered = [None] * world
-    dist.all_gather_object(gathered, keyed)
-    if rank == 0:
-        with open(os.path.join(tmpdir, "tiled.paf"), "wb") as fh:
-            fh.write(b"".join(shard.merge_tiled(gathered)))
-    dist.barrier()
-    dist.destroy_process_group()
+class OracleTileWorker:
+    """CPU stand-in for shard.GpuTileWorker in the gloo tests: the same interface, numpy for the regrouping and the CPU oracle for
+    the tiling itself. The exchange code under test (shard.tile_sharded and everything it calls) is the code the GPU ranks run."""
+
+    def __init__(self):
+        self.out = b""
+
+    @staticmethod
+    def _lines(batches):
+        return [ln for buf, n in batches for ln in bytes(buf[:n].numpy().tobytes()).splitlines(keepends=True)]
+
+    def query_names(self, batches):
+        w = {}
+        for ln in self._lines(batches):
+            h = shard.name_hash(shard.query_name(ln))
+            w[h] = w.get(h, 0) + len(ln)
+        return w
+
+    def split(self, batches, owner_of, world, first_record):
+        parts = [[] for _ in range(world)]
+        for i, ln in enumerate(self._lines(batches)):
+            parts[owner_of[shard.name_hash(shard.query_name(ln))]].append((first_record + i, ln))
+        send = b"".join(ln for p in parts for _, ln in p)
+        gidx = torch.tensor([g for p in parts for g, _ in p], dtype=torch.int64)
+        return (torch.frombuffer(bytearray(send), dtype=torch.uint8) if send else torch.empty(0, dtype=torch.uint8),
+                [sum(len(ln) for _, ln in p) for p in parts], gidx, [len(p) for p in parts])
+
+    def tile(self, recv_buf):
+        data = bytes(recv_buf.numpy().tobytes())
+        self.out, err = O.tile(data)
+        assert err.code == 0
+        lines = data.splitlines(keepends=True)
+
+        def tag(ln, name, default):
+            i = ln.find(b"\t" + name + b":i:")
+            return default if i < 0 else int(ln[i + 6:].split(b"\t")[0])
+
+        order = sorted(range(len(lines)), key=lambda k: (-tag(lines[k], b"s1", -1), -tag(lines[k], b"AS", 0), k))
+        out_lines = self.out.splitlines(keepends=True)
+        rows = [[tag(lines[k], b"s1", -1), tag(lines[k], b"AS", 0), k, len(out_lines[pos]), int(out_lines[pos].split(b"\ttl:i:")[1].split(b"\t")[0])]
+                for pos, k in enumerate(order)]
+        return torch.tensor(rows, dtype=torch.int64).reshape(-1, 5)
+
+    def emit(self):
+        return torch.frombuffer(bytearray(self.out), dtype=torch.uint8) if self.out else torch.empty(0, dtype=torch.uint8)
+
+    def scatter(self, src, src_off, dst_off, dst):
+        for k in range(dst_off.numel()):
+            a, b, d = int(src_off[k]), int(src_off[k + 1]), int(dst_off[k])
+            dst[d: d + b - a] = src[a:b]
 
 
-def test_two_rank_tile_equals_single_process(tmp_path):
+def _tile_data(n=400):
     import random
 
     rng = random.Random(5)
     recs = []
-    for r in range(400):
+    for r in range(n):
         c = rng.randrange(6)
         L = rng.choice([5, 40, 300])
         qs = rng.randrange(0, 2000 - 2 * L - 10)
         tags = [f"AS:i:{rng.choice([5, 5, 80, 900])}"] + ([f"s1:i:{rng.choice([3, 3, 70])}"] if rng.random() < 0.6 else [])
         recs.append(f"c{c}\t2000\t{qs}\t{qs + 2 * L + 3}\t{rng.choice('+-')}\tt\t9000\t10\t{10 + 2 * L}\t{L}\t{L}\t60\t" +
                     "\t".join(tags) + f"\tcg:Z:{L}M3I{L}M\n")
-    data = "".join(recs).encode()
-    (tmp_path / "in.paf").write_bytes(data)
-    mp.spawn(_tile_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    want, err = O.tile(data)
+    return recs
+
+
+def _tile_worker(rank, world, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    recs = _tile_data()
+    first, n = shard.share_of_rank(rank, world, len(recs))  # this rank's contiguous share of the input, as two text batches
+    mine = [r.encode() for r in recs[first: first + n]]
+    half = len(mine) // 2
+    batches = [(torch.frombuffer(bytearray(b"".join(p)), dtype=torch.uint8), sum(len(x) for x in p)) for p in (mine[:half], mine[half:]) if p]
+    worker = OracleTileWorker()
+    res = shard.tile_sharded(worker, dist, rank, world, batches, first, "cpu")
+    out = worker.emit()
+    # every line's place is known: lines sum to the total, offsets ascend in the rank's own order
+    assert int(res["keys"][:, 3].sum()) == out.numel()
+    assert bool((res["offsets"][1:] > res["offsets"][:-1]).all()) if res["offsets"].numel() > 1 else True
+    whole = shard.gather_ordered_output(worker, dist, rank, world, out, res["keys"][:, 3].contiguous(), res["offsets"], res["total"], "cpu")
+    if rank == 0:
+        with open(os.path.join(tmpdir, "tiled.paf"), "wb") as fh:
+            fh.write(bytes(whole.numpy().tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_tile_equals_single_process(tmp_path, world):
+    """tile over ranks = partition by query contig (all-to-all of the lines), local tile, all-gather of the keys, scatter to the
+    global offsets; the exchange code is shard.tile_sharded, the one the GPU ranks run (the device work is stood in by the oracle)."""
+    mp.spawn(_tile_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want, err = O.tile("".join(_tile_data()).encode())
     assert err.code == 0
     assert (tmp_path / "tiled.paf").read_bytes() == want
+
+
+def test_sharded_tile_single_rank_and_helpers():
+    recs = [r.encode() for r in _tile_data(120)]
+    data = b"".join(recs)
+    worker = OracleTileWorker()
+    res = shard.tile_sharded(worker, None, 0, 1, [(torch.frombuffer(bytearray(data), dtype=torch.uint8), len(data))], 0, "cpu")
+    out = worker.emit()
+    whole = shard.gather_ordered_output(worker, None, 0, 1, out, res["keys"][:, 3].contiguous(), res["offsets"], res["total"], "cpu")
+    assert bytes(whole.numpy().tobytes()) == O.tile(data)[0]
+    # line_cuts: pieces end on line boundaries, cover everything, respect the size unless one line is longer
+    buf = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+    for mx in (50, 300, 5000, 10 ** 9):
+        cuts = shard.line_cuts(buf, mx)
+        assert cuts[0][0] == 0 and cuts[-1][1] == len(data) and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        assert all(data[b - 1: b] == b"\n" for _, b in cuts)
+        assert all(b - a <= mx or data[a:b].count(b"\n") == 1 for a, b in cuts)
+    assert shard.share_of_rank(0, 3, 10) == (0, 4) and shard.share_of_rank(2, 3, 10) == (7, 3)
