@@ -284,7 +284,7 @@ def bench_tile(args, wl, rank, world, dist, dev):
     in_bytes = out_bytes = rows = 0
     aligned_per_record = 0.0
     eng.profile(False)
-    elapsed, last, kernels = 0.0, None, {}
+    elapsed, last, kernels, each = 0.0, None, {}, []
     for i in range(n_steps):
         batches, first = share(i)
         if i == 0:
@@ -307,6 +307,7 @@ def bench_tile(args, wl, rank, world, dist, dev):
         dt = time.perf_counter() - t0
         if timed:
             elapsed += dt
+            each.append(round(dt * 1e3, 2))
             in_bytes += sum(n for _, n in worker.keep)
             out_bytes += int(out.numel())
             rows += int(res["keys"].shape[0])
@@ -337,6 +338,7 @@ def bench_tile(args, wl, rank, world, dist, dev):
     if rank == 0:
         records = world * args.batch * args.steps
         per_step = (in_bytes + out_bytes) / max(1, args.steps) + 4.0 * aligned_per_record * (rows / max(1, args.steps))  # this rank's share of a step
+        kernels = {k: v for k, v in kernels.items() if not k.startswith("k_synth")}  # the next step's input is generated beside the timed region
         step_ms = sum(ms for ms, _ in kernels.values()) / max(1, args.steps)
         roofline, by_kernel = None, {}
         if kernels and step_ms > 0:
@@ -362,6 +364,7 @@ def bench_tile(args, wl, rank, world, dist, dev):
                                    "then an all-gather of 32 B per record places every line in the ordered output; all inside the timed region"},
             "ordered_write": {"mode": "per-line offsets from the all-gathered keys; lines written by their owner", "total_bytes": int(last[0]["total"]),
                               "verified_against_one_process": verified},
+            "phase_ms_last_step": last[0].get("timing") or None, "ms_each_step": each,
             "roofline": roofline, "roofline_by_kernel": by_kernel, "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kernels.items()},
         }), flush=True)

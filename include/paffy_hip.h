@@ -153,7 +153,8 @@ int64_t paffy_hip_tile_keys(paffy_hip_ctx *ctx, int64_t cap_lines, void *d_keys)
  * Sharding `paffy tile` by query sequence across GPUs (what `paffy split_file -q` does with files in the reference
  * pipeline, tests/paf_pipeline_test.sh:42, impl/paf_split_file.c:142-173). Names travel as 64-bit hashes.
  *   query_names:    the distinct query names of a batch (hashes[], host) and the bytes of their lines (weights[], host): what a
- *                   partitioner balances. Returns their number (<= cap) or a negative error.
+ *                   partitioner balances. Returns their number (<= cap) or a negative error. A split_by_owner of the same batch right after
+ *                   reuses the line index built here.
  *   split_by_owner: the lines of the batch regrouped by part -- part = table_owner[i] for a query name with hash table_hash[i]
  *                   (ascending hashes; a name the table lacks goes to hash % n_parts) -- input order kept inside a part, every line
  *                   newline-terminated, into d_out (out_cap >= in_len + 1). part_bytes / part_records (host, n_parts each) say where

@@ -136,39 +136,43 @@ __global__ __launch_bounds__(PAFFY_NT) void k_line_size(const RecMeta *meta, con
     tile_state(m, level[order[k]], s);
     out_len[k] = (uint64_t)header_len(s, false) + (m.has_cg ? 6u + (uint64_t)m.cg_len : 0u) + 1u;
 }
-/* one workgroup per line: the header is built in LDS; the line leaves as 16-byte stores at 16-byte aligned output addresses, the
-   cigar read with 16-byte loads at whatever alignment it has in the input */
+/* one WAVE per line (four lines per workgroup, no barrier): the header is built in the wave's LDS; the line leaves as 16-byte stores
+   at 16-byte aligned output addresses, the cigar read with 16-byte loads at whatever alignment it has in the input */
+#define LINE_HDR_BYTES (3 * PAFFY_TMPL_MAX + 16)
 __global__ __launch_bounds__(PAFFY_NT) void k_line_emit(const uint8_t *const *batch_in, const RecMeta *meta, const uint32_t *order, const int64_t *level,
-                                                         const uint64_t *out_off, uint64_t first_line, uint64_t base_off, uint8_t *out) {
-    __shared__ uint8_t hdr[3 * PAFFY_TMPL_MAX + 16];
-    const uint64_t k = first_line + blockIdx.x;
-    const RecMeta m = meta[order[k]];
+                                                         const uint64_t *out_off, uint64_t first_line, uint64_t n_lines, uint64_t base_off, uint8_t *out) {
+    __shared__ uint8_t hdr_all[PAFFY_NWAVE][LINE_HDR_BYTES];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t li = (uint64_t)blockIdx.x * PAFFY_NWAVE + wave;
+    if (li >= n_lines) return;
+    uint8_t *hdr = hdr_all[wave];
+    const uint64_t k = first_line + li;
+    const RecMeta &m = meta[order[k]];
     const uint8_t *in = batch_in[m.pad1];
     uint8_t *o = out + (out_off[k] - base_off);
     RecState s;
     tile_state(m, level[order[k]], s);
     const uint32_t hl = header_len(s, false) + (m.has_cg ? 6u : 0u), cl = m.has_cg ? m.cg_len : 0;
     const bool direct = hl > 3 * PAFFY_TMPL_MAX; /* header longer than the LDS staging: built in place */
-    if (threadIdx.x < 64) {
+    {
         Piece w{direct ? o : hdr, 0, direct ? hl : 3 * PAFFY_TMPL_MAX, false};
         build_header(w, s, in, false);
         if (m.has_cg) w.str("\tcg:Z:", 6);
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier(); /* a wave's LDS operations execute in order */
     const uint32_t total = hl + cl + 1u;
     const uint8_t *cg = in + m.cg_off;
     const uint32_t head = (uint32_t)((16u - ((uintptr_t)o & 15u)) & 15u); /* bytes in front of the first aligned chunk */
     auto byte_at = [&](uint32_t x) -> uint8_t { return x < hl ? hdr[x] : (x < hl + cl ? cg[x - hl] : (uint8_t)'\n'); };
     const uint32_t skip = direct ? hl : 0u; /* a header built in place is not copied again */
     if (head >= total) {
-        for (uint32_t x = threadIdx.x; x < total; x += PAFFY_NT)
+        for (uint32_t x = lane; x < total; x += 64)
             if (x >= skip) o[x] = byte_at(x);
         return;
     }
-    for (uint32_t x = threadIdx.x; x < head; x += PAFFY_NT)
-        if (x >= skip) o[x] = byte_at(x);
+    if (lane < head && lane >= skip) o[lane] = byte_at(lane);
     const uint32_t n_ch = (total - head) >> 4;
-    for (uint32_t ch = threadIdx.x; ch < n_ch; ch += PAFFY_NT) {
+    for (uint32_t ch = lane; ch < n_ch; ch += 64) {
         const uint32_t x = head + 16u * ch;
         if (x >= hl && x + 16u <= hl + cl) {
             *reinterpret_cast<u32x4 *>(o + x) = *reinterpret_cast<const u32x4_unaligned *>(cg + (x - hl));
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_line_emit(const uint8_t *const *ba
             }
         }
     }
-    for (uint32_t x = head + 16u * n_ch + threadIdx.x; x < total; x += PAFFY_NT)
+    for (uint32_t x = head + 16u * n_ch + lane; x < total; x += 64)
         if (x >= skip) o[x] = byte_at(x);
 }
 
@@ -353,8 +357,8 @@ static int cov_run(paffy_hip_ctx *c, int mode, paffy_error *err) {
     if (ensure(c, S.contig_cov, sizeof(uint64_t) * ((size_t)n_contigs + 1))) return PAFFY_E_HIP;
     if (ensure(c, S.contig_slice0, sizeof(uint32_t) * ((size_t)n_contigs + 1))) return PAFFY_E_HIP;
     if (ensure(c, S.name_tab, sizeof(CovName) * (size_t)n_contigs)) return PAFFY_E_HIP;
-    HIPCHK(c, hipMemsetAsync(S.first_entry.p, 0xff, sizeof(uint32_t) * (size_t)n_contigs, c->stream));
-    LAUNCH(c, "k_cov_assign_contig", k_cov_assign_contig, dim3(g_ent), dim3(PAFFY_NT), 0, P, v32b, scan32, n_ent, static_cast<uint32_t *>(S.first_entry.p));
+    LAUNCH(c, "k_cov_assign_contig", k_cov_assign_contig, dim3(g_ent), dim3(PAFFY_NT), 0, P, v32b, static_cast<const uint32_t *>(flags), static_cast<const uint32_t *>(scan32), n_ent,
+           static_cast<uint32_t *>(S.first_entry.p));
     const uint32_t g_c = (n_contigs + PAFFY_NT - 1) / PAFFY_NT;
     LAUNCH(c, "k_cov_contig_len", k_cov_contig_len, dim3(g_c), dim3(PAFFY_NT), 0, static_cast<const uint32_t *>(S.first_entry.p),
            static_cast<const int64_t *>(S.seq_len.p), n_contigs, static_cast<int64_t *>(S.contig_len.p));

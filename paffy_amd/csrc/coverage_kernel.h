@@ -14,7 +14,7 @@
  * keeps its 64 KB of counters in LDS, and applies, in visiting order, the bitmaps of all entries that touch the slice -- a lane
  * always owns the same 32 bases of the slice, so no synchronisation is needed between entries for the counters; adding a bitmap word
  * is four packed, saturating 16-bit adds per eight bases. For `tile` the new counts feed a level histogram in LDS (indexed by
- * level mod 1024; one workgroup barrier per entry, the histogram of entry k is compacted by one wave while the others walk entry
+ * level mod 512 in four copies of packed 16-bit counters; one workgroup barrier per entry, the histogram of entry k is compacted by one wave while the others walk entry
  * k + 1), stored per (entry, slice) as a dense run of counts; k_cov_merge sums an entry's runs and takes the median level.
  * Counters live in HBM between launches (2 bytes per base, as in the reference), so any number of entries can be processed in chunks.
  */
@@ -29,7 +29,7 @@
 #define COV_WORDS (COV_SLICE / 32u)       /* bitmap words per slice */
 #define COV_NT 512                        /* threads of a slice workgroup: words tid and tid + 512 of the slice are this thread's */
 #define COV_NWAVE (COV_NT / 64)
-#define COV_HIST_W 1024u                  /* levels the LDS histogram tells apart (index = level mod 1024) */
+#define COV_HIST_W 512u                   /* levels the LDS histogram tells apart (index = level mod 512) */
 #define COV_BIAS 32769u                   /* LDS counters hold count + 32769: the clamped 16-bit add then stops at count 32766 (impl/paf.c:700) */
 
 #define COV_TEXT 4096u   /* cigar bytes per round of the bitmap kernel (256 threads x 16) */
@@ -400,19 +400,36 @@ __device__ __forceinline__ unsigned long long uniform_u64_cov(unsigned long long
 __device__ __forceinline__ uint32_t wave_min_all_u32(uint32_t v) { return wave_min_u32(v); }
 __device__ __forceinline__ uint32_t wave_max_all_u32(uint32_t v) { return ~wave_min_u32(~v); }
 
+/*
+ * Slice words and threads. Word w (bases [32 w, 32 w + 32) of the slice) belongs to wave w % 8, lane (w / 8) % 64, turn w / 512: any
+ * run of consecutive words -- what an entry touches -- spreads evenly over the eight waves, so they reach the entry's barrier
+ * together. In LDS the words of a wave are kept side by side (word w at index (w % 8) * 128 + w / 8 of the counter array): a wave's
+ * 128-bit accesses then walk consecutive 64-byte rows, which the per-lane chunk rotation of cov_word makes conflict-free.
+ */
+__device__ __forceinline__ uint32_t cov_phys_word(uint32_t w) { return (w & 7u) * (COV_WORDS / 8u) + (w >> 3); }
+
+#define COV_COPIES 4u /* level histogram copies (lane & 3): a quarter of the same-address collisions inside one ds_add */
+/* a copy: COV_HIST_W 16-bit counters, levels L and L + COV_HIST_W / 2 in one word (a count is at most 32 768) */
+
 struct CovWalkLds {
-    uint16_t cnt[COV_SLICE];           /* count + COV_BIAS */
-    uint32_t hist[2][COV_HIST_W];      /* level histograms of the entry being walked and the one before (being compacted) */
-    uint32_t mn[4], mx[4];             /* range of the new counts of entries j, j + 1, ... (index j & 3) */
+    uint16_t cnt[COV_SLICE];                    /* count + COV_BIAS, words in cov_phys_word order */
+    uint32_t hist[2][COV_COPIES][COV_HIST_W / 2]; /* level histograms of the entry being walked and the one before (being compacted) */
+    uint32_t mn[4], mx[4];                      /* range of the new counts of entries j, j + 1, ... (index j & 3) */
     unsigned long long bcast;
 };
 
-/* one bitmap word of the slice (32 bases = four 16-byte chunks of counters) for one entry */
+/* histogram slot of a (biased) count: byte offset of its word inside a copy, and the increment that adds `n` to its half */
+__device__ __forceinline__ void cov_hist_add(uint32_t *copy, uint32_t biased, uint32_t n) {
+    const uint32_t lvl = biased - COV_BIAS;
+    atomicAdd(&copy[lvl & (COV_HIST_W / 2 - 1u)], n << (((lvl / (COV_HIST_W / 2)) & 1u) * 16u));
+}
+
+/* one bitmap word of the slice (32 bases = four 16-byte chunks of counters) for one entry; `pw` = cov_phys_word of the word */
 template <bool HIST>
-__device__ __forceinline__ void cov_word(CovWalkLds &L, uint32_t word, uint32_t bits, uint32_t rot, uint32_t *hist, uint32_t &tmin, uint32_t &tmax) {
+__device__ __forceinline__ void cov_word(CovWalkLds &L, uint32_t pw, uint32_t bits, uint32_t rot, uint32_t *copy, uint32_t &tmin, uint32_t &tmax) {
     /* lane i takes its four chunks in the order (g + i / 4) mod 4: the 16-lane groups of a 128-bit LDS access then hit 16 different
        16-byte columns instead of four */
-    uint4 *base = reinterpret_cast<uint4 *>(&L.cnt[word * 32u]);
+    uint4 *base = reinterpret_cast<uint4 *>(&L.cnt[pw * 32u]);
 #pragma unroll
     for (uint32_t g = 0; g < 4; g++) {
         const uint32_t c = (g + rot) & 3u;
@@ -431,15 +448,12 @@ __device__ __forceinline__ void cov_word(CovWalkLds &L, uint32_t word, uint32_t 
                 tmax = pk_max(tmax, d[j]);
             }
             if (same == 0) {
-                /* new count of the covered bases: old + 1 (clamped) */
-                const uint32_t lvl = (pk_add_sat(o0, 0x00010001u) - COV_BIAS) & (COV_HIST_W - 1u);
-                atomicAdd(&hist[lvl], (uint32_t)__popc(b8));
+                cov_hist_add(copy, pk_add_sat(o0, 0x00010001u) & 0xffffu, (uint32_t)__popc(b8)); /* new count of the covered bases: old + 1 (clamped) */
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t l0 = ((d[j] & 0xffffu) - COV_BIAS) & (COV_HIST_W - 1u), l1 = ((d[j] >> 16) - COV_BIAS) & (COV_HIST_W - 1u);
-                    atomicAdd(&hist[l0], (b8 >> (2 * j)) & 1u);      /* an uncovered base adds 0 */
-                    atomicAdd(&hist[l1], (b8 >> (2 * j + 1)) & 1u);
+                    cov_hist_add(copy, d[j] & 0xffffu, (b8 >> (2 * j)) & 1u); /* an uncovered base adds 0 */
+                    cov_hist_add(copy, d[j] >> 16, (b8 >> (2 * j + 1)) & 1u);
                 }
             }
         } else {
@@ -453,15 +467,25 @@ __device__ __forceinline__ void cov_word(CovWalkLds &L, uint32_t word, uint32_t 
     }
 }
 
-/* histogram of entry `pair` (buffer hb), window [base, base + COV_HIST_W) only: the rare entry whose new counts spread over more
-   levels than the LDS histogram tells apart. The counters are final for this entry, so they are only read. */
-__device__ __forceinline__ void cov_rehist(CovWalkLds &L, const uint32_t *bmw, uint32_t w_lo, uint32_t w_hi, uint32_t *hist, uint32_t base) {
+/* count of level `lvl` in histogram buffer h: the sum of the copies */
+__device__ __forceinline__ uint32_t cov_hist_get(const uint32_t (*h)[COV_HIST_W / 2], uint32_t lvl) {
+    const uint32_t w = lvl & (COV_HIST_W / 2 - 1u), sh = ((lvl / (COV_HIST_W / 2)) & 1u) * 16u;
+    uint32_t c = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < COV_COPIES; k++) c += (h[k][w] >> sh) & 0xffffu;
+    return c;
+}
+
+/* histogram of one entry, window [base, base + COV_HIST_W) only, into copy 0 as plain 32-bit counters (two words per... no: one per
+   level, COV_HIST_W / 2 levels per pass): the rare entry whose new counts spread over more levels than the LDS histogram tells
+   apart. The counters are final for this entry, so they are only read. */
+__device__ __forceinline__ void cov_rehist(CovWalkLds &L, const uint32_t *bmw, uint32_t w_lo, uint32_t w_hi, uint32_t *flat, uint32_t base, uint32_t width) {
     for (uint32_t w = w_lo + threadIdx.x; w < w_hi; w += COV_NT) {
-        const uint32_t bits = bmw[w];
+        const uint32_t bits = bmw[w], pw = cov_phys_word(w);
         for (uint32_t i = 0; i < 32; i++) {
             if (!((bits >> i) & 1u)) continue;
-            const uint32_t lvl = (uint32_t)L.cnt[w * 32u + i] - COV_BIAS;
-            if (lvl >= base && lvl - base < COV_HIST_W) atomicAdd(&hist[lvl - base], 1u);
+            const uint32_t lvl = (uint32_t)L.cnt[pw * 32u + i] - COV_BIAS;
+            if (lvl >= base && lvl - base < width) atomicAdd(&flat[lvl - base], 1u);
         }
     }
 }
@@ -483,7 +507,8 @@ __global__ __launch_bounds__(COV_NT, 4) void k_cov_walk(CovParams P, uint16_t *b
     const uint32_t live = clen - s_lo >= (int64_t)COV_SLICE ? COV_SLICE : (clen > s_lo ? (uint32_t)(clen - s_lo) : 0u); /* counters that exist */
     uint16_t *cov = P.cov + P.contig_cov[contig] + (uint64_t)s_lo;
     uint16_t *bak = backup ? backup + (uint64_t)item * COV_SLICE : nullptr;
-    /* counters in: 16 bytes per lane (sequences start at multiples of 8 counters), + bias */
+    /* counters in: 16 bytes per lane (sequences start at multiples of 8 counters), + bias; base i of the slice lands in word
+       cov_phys_word(i / 32) */
     for (uint32_t i = tid * 8u; i < COV_SLICE; i += COV_NT * 8u) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (from_backup) {
@@ -499,10 +524,11 @@ __global__ __launch_bounds__(COV_NT, 4) void k_cov_walk(CovParams P, uint16_t *b
             if (bak) *reinterpret_cast<uint4 *>(bak + i) = v;
         }
         const uint32_t bias2 = COV_BIAS | (COV_BIAS << 16);
-        *reinterpret_cast<uint4 *>(&L.cnt[i]) = make_uint4(v.x + bias2, v.y + bias2, v.z + bias2, v.w + bias2); /* counts <= 32766: no carry between halves */
+        *reinterpret_cast<uint4 *>(&L.cnt[cov_phys_word(i >> 5) * 32u + (i & 31u)]) =
+            make_uint4(v.x + bias2, v.y + bias2, v.z + bias2, v.w + bias2); /* counts <= 32766: no carry between halves */
     }
     if (HIST) {
-        for (uint32_t i = tid; i < 2 * COV_HIST_W; i += COV_NT) (&L.hist[0][0])[i] = 0;
+        for (uint32_t i = tid; i < 2 * COV_COPIES * (COV_HIST_W / 2); i += COV_NT) (&L.hist[0][0][0])[i] = 0;
         if (tid < 4) {
             L.mn[tid] = 0xffffffffu;
             L.mx[tid] = 0;
@@ -510,6 +536,8 @@ __global__ __launch_bounds__(COV_NT, 4) void k_cov_walk(CovParams P, uint16_t *b
     }
     __syncthreads();
     const uint32_t rot = lane >> 2;
+    const uint32_t wa = 8u * lane + wave, wb = wa + COV_NT;          /* my two words of the slice ... */
+    const uint32_t pa = wave * (COV_WORDS / 8u) + lane, pb = pa + 64u; /* ... and where their counters are */
     for (uint32_t p = p0; p < p1; p++) {
         const uint32_t j = p - p0;
         const uint32_t e = (uint32_t)P.pairs[p];
@@ -518,15 +546,14 @@ __global__ __launch_bounds__(COV_NT, 4) void k_cov_walk(CovParams P, uint16_t *b
         const uint32_t w_lo = (uint32_t)((lo - s_lo) >> 5), w_hi = (uint32_t)((hi - 1 - s_lo) >> 5) + 1u; /* slice words the entry touches */
         /* slice word w is word (s_lo >> 5) + w - (E.lo >> 5) of the entry's bitmap */
         const uint32_t *bmw = P.bitmap + ((int64_t)(E.bm_off - P.bm_base) + ((s_lo >> 5) - (E.lo >> 5)));
-        uint32_t *hist = L.hist[j & 1u];
+        uint32_t *copy = L.hist[j & 1u][lane & (COV_COPIES - 1u)];
         uint32_t tmin = 0xffffffffu, tmax = 0;
-        const uint32_t wa = tid, wb = tid + COV_NT;
         const bool ha = wa >= w_lo && wa < w_hi, hb = wb >= w_lo && wb < w_hi;
         uint32_t ba = 0, bb = 0;
         if (ha) ba = bmw[wa]; /* words in front of the entry's bitmap are never read: wa >= w_lo */
         if (hb) bb = bmw[wb];
-        if (ha) cov_word<HIST>(L, wa, ba, rot, hist, tmin, tmax);
-        if (hb) cov_word<HIST>(L, wb, bb, rot, hist, tmin, tmax);
+        if (ha) cov_word<HIST>(L, pa, ba, rot, copy, tmin, tmax);
+        if (hb) cov_word<HIST>(L, pb, bb, rot, copy, tmin, tmax);
         if (!HIST) continue; /* to_bed: nothing is shared between entries */
         {
             uint32_t lo16 = tmin & 0xffffu, hi16 = tmin >> 16;
@@ -543,6 +570,7 @@ __global__ __launch_bounds__(COV_NT, 4) void k_cov_walk(CovParams P, uint16_t *b
         const uint32_t mn = L.mn[j & 3u], mx = L.mx[j & 3u]; /* read by every wave before anything resets them (see below) */
         const uint32_t n = mx - mn + 1u;
         CovSlot *slot = P.slots + E.pair_base + (slice - E.first_slice);
+        const uint32_t (*hbuf)[COV_HIST_W / 2] = L.hist[j & 1u];
         if (n <= COV_HIST_W) {
             if (wave == (j & (COV_NWAVE - 1u))) { /* this wave compacts entry j while the others walk entry j + 1 */
                 unsigned long long off = 0;
@@ -550,11 +578,14 @@ __global__ __launch_bounds__(COV_NT, 4) void k_cov_walk(CovParams P, uint16_t *b
                 off = uniform_u64_cov(off);
                 const bool room = off + n <= P.arena_cap;
                 for (uint32_t i = lane; i < n; i += 64) {
-                    const uint32_t idx = (mn + i) & (COV_HIST_W - 1u);
-                    const uint32_t c = hist[idx];
-                    hist[idx] = 0;
+                    const uint32_t c = cov_hist_get(hbuf, mn + i);
                     if (room) P.arena[off + i] = (uint16_t)c;
                 }
+                /* the words used (levels mn .. mx, two per word) back to zero: after every read of this wave (in order) */
+                const uint32_t nw = n < COV_HIST_W / 2 ? n : COV_HIST_W / 2;
+                for (uint32_t i = lane; i < nw; i += 64)
+#pragma unroll
+                    for (uint32_t k = 0; k < COV_COPIES; k++) L.hist[j & 1u][k][(mn + i) & (COV_HIST_W / 2 - 1u)] = 0;
                 if (lane == 0) {
                     slot->off = off;
                     slot->mn = mn;
@@ -576,17 +607,20 @@ __global__ __launch_bounds__(COV_NT, 4) void k_cov_walk(CovParams P, uint16_t *b
                 L.mx[(j + 2u) & 3u] = 0;
                 L.bcast = o;
             }
-            for (uint32_t i = tid; i < COV_HIST_W; i += COV_NT) hist[i] = 0;
+            uint32_t *flat = &L.hist[j & 1u][0][0]; /* the buffer as COV_COPIES * COV_HIST_W / 2 plain counters */
+            const uint32_t width = COV_COPIES * (COV_HIST_W / 2);
+            for (uint32_t i = tid; i < width; i += COV_NT) flat[i] = 0;
             __syncthreads();
             const unsigned long long off = L.bcast;
             const bool room = off + n <= P.arena_cap;
-            for (uint32_t base = mn; base <= mx; base += COV_HIST_W) {
-                cov_rehist(L, bmw, w_lo, w_hi, hist, base);
+            for (uint32_t base = mn; base <= mx; base += width) {
+                cov_rehist(L, bmw, w_lo, w_hi, flat, base, width);
                 __syncthreads();
-                for (uint32_t i = tid; i < COV_HIST_W && base + i <= mx; i += COV_NT) {
-                    if (room) P.arena[off + (base - mn) + i] = (uint16_t)hist[i];
-                    hist[i] = 0;
+                for (uint32_t i = tid; i < width && base + i <= mx; i += COV_NT) {
+                    if (room) P.arena[off + (base - mn) + i] = (uint16_t)flat[i];
                 }
+                __syncthreads();
+                for (uint32_t i = tid; i < width; i += COV_NT) flat[i] = 0;
                 __syncthreads();
             }
         }
@@ -595,7 +629,7 @@ __global__ __launch_bounds__(COV_NT, 4) void k_cov_walk(CovParams P, uint16_t *b
     /* counters out */
     for (uint32_t i = tid * 8u; i < COV_SLICE; i += COV_NT * 8u) {
         if (i >= live) break;
-        const uint4 v = *reinterpret_cast<const uint4 *>(&L.cnt[i]);
+        const uint4 v = *reinterpret_cast<const uint4 *>(&L.cnt[cov_phys_word(i >> 5) * 32u + (i & 31u)]);
         const uint32_t bias2 = COV_BIAS | (COV_BIAS << 16);
         const uint32_t t[4] = {v.x - bias2, v.y - bias2, v.z - bias2, v.w - bias2};
         if (i + 8u <= live) {
@@ -719,12 +753,13 @@ __global__ __launch_bounds__(PAFFY_NT) void k_cov_run_heads(const uint64_t *sort
 }
 /* after an inclusive scan of the flags: entry ids of sorted position i gets sequence id scan[i] - 1; the first entry (smallest
    index = first in visiting order) of every sequence is remembered: its length is the sequence's (impl/paf.c:680) */
-__global__ __launch_bounds__(PAFFY_NT) void k_cov_assign_contig(CovParams P, const uint32_t *sorted_entry, const uint32_t *scan, uint32_t n, uint32_t *first_entry) {
+__global__ __launch_bounds__(PAFFY_NT) void k_cov_assign_contig(CovParams P, const uint32_t *sorted_entry, const uint32_t *flag, const uint32_t *scan, uint32_t n,
+                                                                 uint32_t *first_entry) {
     const uint32_t i = blockIdx.x * PAFFY_NT + threadIdx.x;
     if (i >= n) return;
     const uint32_t c = scan[i] - 1u, e = sorted_entry[i];
     P.entries[e].contig = c;
-    atomicMin(&first_entry[c], e);
+    if (flag[i]) first_entry[c] = e; /* the sort is stable and the entries went in by ascending index: a run's head is its smallest */
 }
 __global__ __launch_bounds__(PAFFY_NT) void k_cov_contig_len(const uint32_t *first_entry, const int64_t *seq_len, uint32_t n_contigs, int64_t *contig_len) {
     const uint32_t c = blockIdx.x * PAFFY_NT + threadIdx.x;

@@ -590,6 +590,10 @@ struct paffy_hip_ctx {
     uint32_t tile_n = 0;
     const uint8_t *tile_in = nullptr;
     struct CovState *cov = nullptr; /* `paffy tile` / `paffy to_bed` over any number of batches (coverage_host.h) */
+    /* the batch paffy_hip_query_names indexed last: paffy_hip_split_by_owner on the same batch reuses the index (one use) */
+    const void *indexed_in = nullptr;
+    int64_t indexed_len = 0;
+    uint32_t indexed_n = 0;
     DevBuf one_batch;               /* table with the single text pointer of a one-batch plan (dedupe / split_file lines) */
     /* what emit writes for a line plan (tile, dedupe): record order, levels, offsets */
     const uint8_t *const *line_batches = nullptr;
@@ -743,6 +747,7 @@ static int fetch_info(paffy_hip_ctx *c) {
 /* Separator index + header parse shared by plan and tile_plan. */
 static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, uint32_t *n_lines_out, uint32_t lvl0_max = PAFFY_OPS_CAP) {
     const uint32_t n_tiles = (len + SEP_TILE - 1) / SEP_TILE;
+    c->indexed_in = nullptr; /* the index buffers are about to describe another batch */
 
     DevInfo zero;
     memset(&zero, 0, sizeof(zero));
@@ -1106,14 +1111,22 @@ __global__ __launch_bounds__(PAFFY_NT) void k_query_hash(const uint8_t *in, cons
     line_len[r] = (uint64_t)(end - start) + 1u; /* with its newline (a last line without one gets one) */
     idx[r] = r;
 }
-/* sorted by hash: weight of every run of equal hashes, at its head */
-__global__ __launch_bounds__(PAFFY_NT) void k_run_weights(const uint64_t *sorted_hash, const uint32_t *sorted_idx, const uint64_t *line_len, const uint32_t *flag,
-                                                           const uint32_t *scan, uint32_t n, uint64_t *out_hash, unsigned long long *out_weight) {
+/* sorted by hash: line bytes in sorted order (for a scan), and at the head of every run of equal hashes its hash */
+__global__ __launch_bounds__(PAFFY_NT) void k_run_lens(const uint32_t *sorted_idx, const uint64_t *line_len, uint32_t n, uint64_t *out) {
+    const uint32_t i = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (i < n) out[i] = line_len[sorted_idx[i]];
+    if (i == 0) out[n] = 0;
+}
+/* weight of run c = (bytes in front of the next run) - (bytes in front of this one): no atomics on a handful of addresses */
+__global__ __launch_bounds__(PAFFY_NT) void k_run_heads_out(const uint64_t *sorted_hash, const uint32_t *flag, const uint32_t *scan, const uint64_t *byte_off, uint32_t n,
+                                                             uint64_t *out_hash, uint64_t *out_start) {
     const uint32_t i = blockIdx.x * PAFFY_NT + threadIdx.x;
     if (i >= n) return;
-    const uint32_t c = scan[i] - 1u;
-    if (flag[i]) out_hash[c] = sorted_hash[i];
-    atomicAdd(&out_weight[c], (unsigned long long)line_len[sorted_idx[i]]);
+    if (flag[i]) {
+        out_hash[scan[i] - 1u] = sorted_hash[i];
+        out_start[scan[i] - 1u] = byte_off[i];
+    }
+    if (i == n - 1) out_start[scan[i]] = byte_off[n];
 }
 __global__ __launch_bounds__(PAFFY_NT) void k_owner_keys(const uint64_t *hash, uint32_t n, const uint64_t *tab_hash, const uint32_t *tab_owner, uint32_t n_tab, uint32_t n_parts,
                                                           uint64_t *key) {
@@ -1134,15 +1147,16 @@ __global__ __launch_bounds__(PAFFY_NT) void k_gather_len(const uint64_t *sorted_
     if (i < n) out[i] = line_len[(uint32_t)sorted_key[i]];
     if (i == 0) out[n] = 0;
 }
-__global__ __launch_bounds__(PAFFY_NT) void k_part_totals(const uint64_t *sorted_key, const uint64_t *off, uint32_t n, uint32_t n_parts, int64_t *part_bytes, int64_t *part_records,
-                                                           int64_t *rec_index) {
+/* where every part starts in the sorted order: first[p] = index of its first line, start[p] = its first byte (parts without lines keep -1) */
+__global__ __launch_bounds__(PAFFY_NT) void k_part_bounds(const uint64_t *sorted_key, const uint64_t *off, uint32_t n, int64_t *first, int64_t *start, int64_t *rec_index) {
     const uint32_t i = blockIdx.x * PAFFY_NT + threadIdx.x;
     if (i >= n) return;
     const uint32_t p = (uint32_t)(sorted_key[i] >> 32);
     rec_index[i] = (int64_t)(uint32_t)sorted_key[i];
-    atomicAdd(reinterpret_cast<unsigned long long *>(&part_records[p]), 1ull);
-    atomicAdd(reinterpret_cast<unsigned long long *>(&part_bytes[p]), (unsigned long long)(off[i + 1] - off[i]));
-    (void)n_parts;
+    if (i == 0 || (uint32_t)(sorted_key[i - 1] >> 32) != p) {
+        first[p] = i;
+        start[p] = (int64_t)off[i];
+    }
 }
 /* one workgroup per line: bytes [src_off, src_off + len) of src to dst + dst_off; a source line that ends without newline gets one */
 __device__ __forceinline__ void copy_line(const uint8_t *src, uint64_t len, uint8_t *dst, bool add_nl) {
@@ -1177,9 +1191,13 @@ int64_t paffy_hip_query_names(paffy_hip_ctx *c, const void *d_in, int64_t in_len
     CovState &S = cov_state(c);
     uint32_t n = 0;
     const uint8_t *in = static_cast<const uint8_t *>(d_in);
+    c->indexed_in = nullptr;
     int rc = index_and_parse(c, in, (uint32_t)in_len, &n);
     if (rc) return rc;
     if (n == 0) return 0;
+    c->indexed_in = d_in;
+    c->indexed_len = in_len;
+    c->indexed_n = n;
     const uint32_t g = (n + PAFFY_NT - 1) / PAFFY_NT;
     if (ensure(c, S.k64a, sizeof(uint64_t) * ((size_t)n + 1)) || ensure(c, S.k64b, sizeof(uint64_t) * ((size_t)n + 1)) || ensure(c, S.name_hash, sizeof(uint64_t) * ((size_t)n + 1)) ||
         ensure(c, S.v32a, sizeof(uint32_t) * ((size_t)n + 1)) || ensure(c, S.v32b, sizeof(uint32_t) * ((size_t)n + 1)) || ensure(c, S.flags, sizeof(uint32_t) * ((size_t)n + 1)) ||
@@ -1195,12 +1213,18 @@ int64_t paffy_hip_query_names(paffy_hip_ctx *c, const void *d_in, int64_t in_len
     uint32_t n_names = 0;
     if (cov_fetch(c, &n_names, scan + (n - 1), sizeof(uint32_t))) return PAFFY_E_HIP;
     if ((int64_t)n_names > cap) return PAFFY_E_CAPACITY;
-    if (ensure(c, S.pairs, sizeof(uint64_t) * (size_t)n_names) || ensure(c, S.pairs2, sizeof(uint64_t) * (size_t)n_names)) return PAFFY_E_HIP;
-    HIPCHK(c, hipMemsetAsync(S.pairs2.p, 0, sizeof(uint64_t) * (size_t)n_names, c->stream));
-    LAUNCH(c, "k_run_weights", k_run_weights, dim3(g), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(sorted), static_cast<const uint32_t *>(sidx), static_cast<const uint64_t *>(len),
-           static_cast<const uint32_t *>(flags), static_cast<const uint32_t *>(scan), n, static_cast<uint64_t *>(S.pairs.p), static_cast<unsigned long long *>(S.pairs2.p));
+    if (ensure(c, S.pairs, sizeof(uint64_t) * (size_t)n_names) || ensure(c, S.pairs2, sizeof(uint64_t) * ((size_t)n_names + 1)) || ensure(c, S.bm_words, sizeof(uint64_t) * ((size_t)n + 1)) ||
+        ensure(c, S.bm_off, sizeof(uint64_t) * ((size_t)n + 2)))
+        return PAFFY_E_HIP;
+    uint64_t *slen = static_cast<uint64_t *>(S.bm_words.p), *soff = static_cast<uint64_t *>(S.bm_off.p);
+    LAUNCH(c, "k_run_lens", k_run_lens, dim3(g), dim3(PAFFY_NT), 0, static_cast<const uint32_t *>(sidx), static_cast<const uint64_t *>(len), n, slen);
+    if (cov_excl_scan64(c, S, slen, soff, n)) return PAFFY_E_HIP;
+    LAUNCH(c, "k_run_heads_out", k_run_heads_out, dim3(g), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(sorted), static_cast<const uint32_t *>(flags), static_cast<const uint32_t *>(scan),
+           static_cast<const uint64_t *>(soff), n, static_cast<uint64_t *>(S.pairs.p), static_cast<uint64_t *>(S.pairs2.p));
+    std::vector<uint64_t> starts((size_t)n_names + 1);
     HIPCHK(c, hipMemcpyAsync(hashes, S.pairs.p, sizeof(uint64_t) * (size_t)n_names, hipMemcpyDeviceToHost, c->stream));
-    if (cov_fetch(c, weights, S.pairs2.p, sizeof(int64_t) * (size_t)n_names)) return PAFFY_E_HIP;
+    if (cov_fetch(c, starts.data(), S.pairs2.p, sizeof(uint64_t) * ((size_t)n_names + 1))) return PAFFY_E_HIP;
+    for (uint32_t k = 0; k < n_names; k++) weights[k] = (int64_t)(starts[k + 1] - starts[k]);
     return (int64_t)n_names;
 }
 
@@ -1215,8 +1239,13 @@ int paffy_hip_split_by_owner(paffy_hip_ctx *c, const void *d_in, int64_t in_len,
     CovState &S = cov_state(c);
     uint32_t n = 0;
     const uint8_t *in = static_cast<const uint8_t *>(d_in);
-    int rc = index_and_parse(c, in, (uint32_t)in_len, &n);
-    if (rc) return rc;
+    if (c->indexed_in == d_in && c->indexed_len == in_len) { /* indexed by paffy_hip_query_names just before */
+        n = c->indexed_n;
+    } else {
+        int rc = index_and_parse(c, in, (uint32_t)in_len, &n);
+        if (rc) return rc;
+    }
+    c->indexed_in = nullptr;
     *n_records = n;
     if (n == 0) return 0;
     if (d_rec_index && rec_index_cap < (int64_t)n) return PAFFY_E_CAPACITY;
@@ -1241,18 +1270,24 @@ int paffy_hip_split_by_owner(paffy_hip_ctx *c, const void *d_in, int64_t in_len,
     LAUNCH(c, "k_gather_len", k_gather_len, dim3(g), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(skey), static_cast<const uint64_t *>(len), n, key);
     if (cov_excl_scan64(c, S, key, off, n)) return PAFFY_E_HIP;
     int64_t *d_tot = static_cast<int64_t *>(S.pairs2.p);
-    HIPCHK(c, hipMemsetAsync(d_tot, 0, sizeof(int64_t) * 2 * (size_t)n_parts, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_tot, 0xff, sizeof(int64_t) * 2 * (size_t)n_parts, c->stream));
     if (ensure(c, S.out_len, sizeof(int64_t) * ((size_t)n + 1))) return PAFFY_E_HIP;
     int64_t *d_idx = d_rec_index ? static_cast<int64_t *>(d_rec_index) : static_cast<int64_t *>(S.out_len.p);
-    LAUNCH(c, "k_part_totals", k_part_totals, dim3(g), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(skey), static_cast<const uint64_t *>(off), n, (uint32_t)n_parts, d_tot,
-           d_tot + n_parts, d_idx);
+    LAUNCH(c, "k_part_bounds", k_part_bounds, dim3(g), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(skey), static_cast<const uint64_t *>(off), n, d_tot, d_tot + n_parts, d_idx);
     LAUNCH(c, "k_split_copy", k_split_copy, dim3(n), dim3(PAFFY_NT), 0, in, (uint32_t)in_len, static_cast<const uint32_t *>(c->sep_pos.p), static_cast<const uint32_t *>(c->nl_idx.p),
            static_cast<const uint64_t *>(skey), static_cast<const uint64_t *>(off), static_cast<uint8_t *>(d_out));
     std::vector<int64_t> tot(2 * (size_t)n_parts);
+    uint64_t all_bytes = 0;
+    HIPCHK(c, hipMemcpyAsync(&all_bytes, off + n, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     if (cov_fetch(c, tot.data(), d_tot, sizeof(int64_t) * 2 * (size_t)n_parts)) return PAFFY_E_HIP;
-    for (int32_t p = 0; p < n_parts; p++) {
-        part_bytes[p] = tot[(size_t)p];
-        part_records[p] = tot[(size_t)n_parts + p];
+    int64_t next_first = (int64_t)n, next_start = (int64_t)all_bytes; /* a part ends where the next non-empty one starts */
+    for (int32_t p = n_parts - 1; p >= 0; p--) {
+        const int64_t first = tot[(size_t)p], start = tot[(size_t)n_parts + p];
+        if (first < 0) continue;
+        part_records[p] = next_first - first;
+        part_bytes[p] = next_start - start;
+        next_first = first;
+        next_start = start;
     }
     return 0;
 }
@@ -1423,8 +1458,8 @@ int paffy_hip_emit(paffy_hip_ctx *c, void *d_out, int64_t out_cap) {
         return 0;
     }
     if (c->plan_is_tile) {
-        if (c->line_n) LAUNCH(c, "k_tile_emit", k_line_emit, dim3((unsigned)c->line_n), dim3(PAFFY_NT), 0, c->line_batches, c->line_meta, c->line_order, c->line_level,
-                              c->line_off, (uint64_t)0, (uint64_t)0, static_cast<uint8_t *>(d_out));
+        if (c->line_n) LAUNCH(c, "k_tile_emit", k_line_emit, dim3((unsigned)((c->line_n + PAFFY_NWAVE - 1) / PAFFY_NWAVE)), dim3(PAFFY_NT), 0, c->line_batches, c->line_meta,
+                              c->line_order, c->line_level, c->line_off, (uint64_t)0, c->line_n, (uint64_t)0, static_cast<uint8_t *>(d_out));
         return 0;
     }
     KParams kp = c->kp;
@@ -1456,8 +1491,8 @@ int paffy_hip_emit_lines(paffy_hip_ctx *c, int64_t first, int64_t n, void *d_out
     if ((uint64_t)(first + n) < c->line_n) HIPCHK(c, hipMemcpyAsync(&hi, c->line_off + first + n, sizeof(hi), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if ((int64_t)(hi - lo) > out_cap) return PAFFY_E_CAPACITY;
-    LAUNCH(c, "k_tile_emit", k_line_emit, dim3((unsigned)n), dim3(PAFFY_NT), 0, c->line_batches, c->line_meta, c->line_order, c->line_level, c->line_off, (uint64_t)first,
-           lo, static_cast<uint8_t *>(d_out));
+    LAUNCH(c, "k_tile_emit", k_line_emit, dim3((unsigned)((n + PAFFY_NWAVE - 1) / PAFFY_NWAVE)), dim3(PAFFY_NT), 0, c->line_batches, c->line_meta, c->line_order, c->line_level,
+           c->line_off, (uint64_t)first, (uint64_t)n, lo, static_cast<uint8_t *>(d_out));
     *bytes = (int64_t)(hi - lo);
     return 0;
 }

@@ -265,6 +265,7 @@ class GpuTileWorker:
         for buf, nbytes in batches:
             for h, w in self.eng.query_names(buf, nbytes).items():
                 out[h] = out.get(h, 0) + w
+        self._last_named = batches[-1][0].data_ptr() if batches else None
         return out
 
     def split(self, batches, owner_of, world, first_record):
@@ -317,18 +318,38 @@ def tile_sharded(worker, dist, rank, world, batches, first_record, comm_device="
     """`paffy tile` over an input spread over the ranks (this rank holds `batches`, whose first record is global record
     first_record). Returns {"offsets": byte offset of every local output line in the ordered output (int64 tensor), "total": bytes
     of the whole output, "keys": the worker's [n, 5] keys}; worker.emit() then gives the local lines."""
+    import os
+    import time
+
     import torch
+
+    timing, t0 = {}, time.perf_counter()
+    trace = bool(os.environ.get("PAFFY_SHARD_TIMING"))
+
+    def lap(name):
+        nonlocal t0
+        if trace:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            timing[name] = timing.get(name, 0.0) + (t1 - t0) * 1e3
+            t0 = t1
 
     weights = merge_name_weights(dist, worker.query_names(batches), comm_device)
     owner_of = owner_table(weights, world)
+    lap("names_ms")
     send, send_bytes, send_gidx, send_records = worker.split(batches, owner_of, world, first_record)
+    lap("split_ms")
     recv, recv_gidx, _, _ = exchange_lines(dist, send, send_bytes, send_gidx, send_records, comm_device)
+    lap("exchange_ms")
     keys = worker.tile(recv)
+    lap("tile_ms")
     gidx = recv_gidx.to(keys.device)
     k4 = torch.stack([keys[:, 0], keys[:, 1], gidx[keys[:, 2]], keys[:, 3]], dim=1) if keys.shape[0] else torch.zeros(0, 4, dtype=torch.int64, device=keys.device)
     all_keys, owner = gather_tile_keys(dist, k4, comm_device)
     offsets, total = global_line_offsets(all_keys, owner, rank)
-    return {"offsets": offsets, "total": total, "keys": keys, "owner_of": owner_of}
+    lap("keys_ms")
+    return {"offsets": offsets, "total": total, "keys": keys, "owner_of": owner_of, "timing": timing}
 
 
 def gather_ordered_output(worker, dist, rank, world, lines, line_bytes, offsets, total, comm_device="cpu", writer=0):
