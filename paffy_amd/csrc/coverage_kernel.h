@@ -90,47 +90,6 @@ __device__ __forceinline__ void cov_fail(const CovParams &P, uint32_t e, uint32_
 /* cigar text -> ops, eight bytes of digits at a time                                                                      */
 /* ---------------------------------------------------------------------------------------------------------------------- */
 
-/* bytes of w that are not ASCII digits: bit 7 of each such byte */
-__device__ __forceinline__ uint32_t nondigit4(uint32_t w) {
-    const uint32_t t = w ^ 0x30303030u;
-    return (((t & 0x7f7f7f7fu) + 0x76767676u) | t) & 0x80808080u;
-}
-/* value of four digit bytes (values 0..9, most significant in byte 0) */
-__device__ __forceinline__ uint32_t swar4(uint32_t x) {
-    const uint32_t p = (x * 10u + (x >> 8)) & 0x00ff00ffu; /* two 2-digit numbers */
-    return __umul24(p & 0xffu, 100u) + (p >> 16);
-}
-/*
- * The number that ends right before tile position q (LDS byte txt[q - 1] is its last digit): at most 8 digits are converted.
- * Returns the digit count (0..8) in *k; 8 means "eight or more": the caller takes the serial path for such a record.
- * txt must be readable from q - 8 (the halo in front of the tile) and 4-byte aligned at index 0.
- */
-__device__ __forceinline__ uint32_t number_before(const uint8_t *txt, uint32_t q, uint32_t *k) {
-    const uint32_t a = q - 8u, sh = a & 3u;
-    const uint32_t *wp = reinterpret_cast<const uint32_t *>(txt + (a - sh));
-    const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2];
-    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh); /* bytes q-8..q-5, q-4..q-1 */
-    const uint32_t nh = nondigit4(hi);
-    uint32_t kk = nh ? (uint32_t)__clz((int)nh) >> 3 : 4u; /* digits at the top of hi */
-    uint32_t v;
-    if (__all(nh != 0)) { /* the usual case, whole wave: numbers of at most three digits */
-        const uint32_t x = kk ? ((hi ^ 0x30303030u) & (0xffffffffu << (32u - 8u * kk))) : 0u; /* xor, not minus: a byte below '0' in front of the digits would borrow from them */
-        v = swar4(x);
-    } else {
-        uint32_t xl = 0;
-        if (!nh) {
-            const uint32_t nl = nondigit4(lo);
-            const uint32_t kl = nl ? (uint32_t)__clz((int)nl) >> 3 : 4u;
-            kk = 4u + kl;
-            xl = kl ? ((lo ^ 0x30303030u) & (0xffffffffu << (32u - 8u * kl))) : 0u;
-        }
-        const uint32_t xh = kk >= 4u ? hi ^ 0x30303030u : (kk ? ((hi ^ 0x30303030u) & (0xffffffffu << (32u - 8u * kk))) : 0u);
-        v = swar4(xl) * 10000u + swar4(xh);
-    }
-    *k = kk;
-    return v;
-}
-
 __device__ __forceinline__ int cov_op_code(uint32_t c) { /* impl/paf.c:96-103 */
     return c == 'M' ? OP_M : c == 'I' ? OP_I : c == 'D' ? OP_D : c == '=' ? OP_EQ : c == 'X' ? OP_X : -1;
 }

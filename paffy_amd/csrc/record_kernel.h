@@ -286,128 +286,92 @@ __device__ __forceinline__ uint32_t parse_cigar(const uint8_t *in, uint32_t cg_o
 }
 
 /*
- * cigar_parse for the usual cigar -- at most 8 KiB of text, every number at most seven digits, no op without
- * digits -- from registers: the text is cut into 8-byte words, every thread takes up to four consecutive words
- * (two loads per word position, aligned, funnelled by the cigar's byte offset) and walks its bytes once with the
- * running number in a register; the number a thread starts with is re-derived from the word before its range.
- * No text in LDS, no LDS read in the loop, one scan for the op indices. Ops go to LDS only; the HBM mirror is a
- * coalesced copy at the end. Returns 0xffffffff when the text needs the general parser (nothing it did matters then).
+ * cigar_parse for every cigar whose numbers have at most seven digits (anything else: the general parser above): the text is staged
+ * in LDS 4 KiB at a time, 16 bytes per thread at its natural alignment, and every thread converts the number in front of each op
+ * letter in its 16 bytes from the eight bytes before the letter (three aligned LDS reads, SWAR digits; device_util.h) -- one
+ * iteration per op instead of one per byte. An op without digits has length 0, as in the reference (impl/paf.c:92-95).
+ * Ops go to LDS; the HBM mirror is a coalesced copy at the end. *plain: every op is M, I or D with a length of at least 1 (what
+ * paf_shatter's asserts demand, impl/paf.c:635,649).
+ * Returns the op count, or 0xffffffff when a number has eight digits or more (nothing done here matters then).
+ * (Measured on cfg3, k_size_lds per 131 072 records: byte-serial register parser for cigars up to 8 KiB + tile parser beyond 4.68 ms;
+ * this parser 4.26 ms; the same with 32 bytes per thread staged in the top of the op store 4.39 ms -- more barriers per record.)
  */
-#define PARSE_FAST_WORDS 4
-__device__ __forceinline__ uint32_t parse_cigar_fast(const uint8_t *in, uint32_t cg_off, uint32_t cg_len, const OpsLds &ops, uint32_t cap, BlockComm &bc,
-                                                     Shared *sh, bool *fits, uint32_t *err_pos, int64_t (&sums)[4]) {
+#define PARSE_LDS_TEXT (16u * PAFFY_NT) /* bytes per round */
+__device__ __forceinline__ uint32_t parse_cigar_lds(const uint8_t *in, uint32_t cg_off, uint32_t cg_len, const OpsLds &ops, uint32_t cap, uint8_t *txt, BlockComm &bc,
+                                                    Shared *sh, bool *fits, uint32_t *err_pos, int64_t (&sums)[4], bool *plain) {
     const uint32_t tid = threadIdx.x;
     const uint32_t end = cg_off + cg_len;
-    const uint32_t n_words = (cg_len + 7u) >> 3;
-    const uint32_t nb = (n_words + PAFFY_NT - 1) / PAFFY_NT; /* words per thread */
-    if (nb > PARSE_FAST_WORDS) return 0xffffffffu;
+    const uint32_t a0 = cg_off & ~15u;
+    if (tid < PAFFY_HALO / 4) reinterpret_cast<uint32_t *>(txt)[tid] = 0; /* nothing in front of the first round */
     if (tid == 0) {
         sh->err_pos = 0xffffffffu;
         sh->flags = 0;
     }
-    const uint32_t s0 = cg_off + 8u * nb * tid; /* my first byte */
-    const uint32_t my_bytes = s0 < end ? (end - s0 < 8u * nb ? end - s0 : 8u * nb) : 0u;
-    const uint32_t shb = 8u * (cg_off & 7u); /* bit offset of my words inside the aligned ones (wave-uniform) */
-    const uint32_t a_first = (cg_off & ~7u) + 8u * nb * tid;
-    /* aligned words: one before my range (the number I may start inside), my words, one more for the funnel */
-    uint64_t a[PARSE_FAST_WORDS + 2];
+    uint32_t n = 0;
+    uint32_t sm = 0, sx = 0, sq = 0, st = 0, flags = 0; /* flags: 1 = a number of eight digits or more, 2 = not plain */
+    for (uint32_t tb = a0; tb < end; tb += PARSE_LDS_TEXT) {
+        uint4 h = make_uint4(0, 0, 0, 0);
+        if (tb != a0 && tid < 2) h = reinterpret_cast<uint4 *>(txt + PARSE_LDS_TEXT)[tid]; /* the last 32 bytes become the halo */
+        __syncthreads();
+        if (tb != a0 && tid < 2) reinterpret_cast<uint4 *>(txt)[tid] = h;
+        const uint32_t g = tb + tid * 16;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g < end) v = *reinterpret_cast<const uint4 *>(in + g);
+        reinterpret_cast<uint4 *>(txt + PAFFY_HALO)[tid] = v;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t opmask = 0;
 #pragma unroll
-    for (int k = 0; k < PARSE_FAST_WORDS + 2; k++) {
-        a[k] = 0;
-        const uint32_t at = a_first + 8u * (uint32_t)k - 8u;
-        if ((uint32_t)k <= nb + 1 && (k > 0 || tid > 0) && at < end && my_bytes > 0) a[k] = *reinterpret_cast<const uint64_t *>(in + at);
-    }
-    uint64_t w[PARSE_FAST_WORDS + 1]; /* w[0]: the 8 bytes before my range */
-#pragma unroll
-    for (int k = 0; k < PARSE_FAST_WORDS + 1; k++) w[k] = shb ? (a[k] >> shb) | (a[k + 1] << (64u - shb)) : a[k];
-    /* ops in my range: bytes that are not digits */
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int k = 1; k <= PARSE_FAST_WORDS; k++) {
-        if ((uint32_t)k > nb) break;
-        const uint32_t first = 8u * (uint32_t)(k - 1);
-        if (first >= my_bytes) break;
-        const uint64_t t = w[k] ^ 0x3030303030303030ull;
-        uint64_t nd = (((t & 0x7f7f7f7f7f7f7f7full) + 0x7676767676767676ull) | t) & 0x8080808080808080ull;
-        const uint32_t nv = my_bytes - first;
-        if (nv < 8u) nd &= (1ull << (8u * nv)) - 1ull;
-        cnt += (uint32_t)__popcll(nd);
-    }
-    uint32_t c1[1] = {cnt}, tot[1];
-    block_excl_scan_u32<1>(c1, tot, bc);
-    const uint32_t n = tot[0];
-    uint32_t idx = c1[0];
-    /* the number that runs into my range: digits at the end of the word before it */
-    uint32_t acc = 0, nd = 0;
-    if (tid > 0 && my_bytes > 0) {
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const uint32_t d = ((uint32_t)(w[0] >> (8 * b)) & 0xffu) - '0';
-            const bool dig = d < 10u;
-            acc = dig ? acc * 10u + d : 0u;
-            nd = dig ? nd + 1u : 0u;
+        for (int j = 0; j < 4; j++) {
+            uint32_t nd = nondigit4(w[j]) >> 7;
+            nd = (nd | (nd >> 7) | (nd >> 14) | (nd >> 21)) & 0xfu;
+            opmask |= nd << (4 * j);
         }
-    }
-    uint32_t sm = 0, sx = 0, sq = 0, st = 0, bad = 0;
-#pragma unroll
-    for (int k = 1; k <= PARSE_FAST_WORDS; k++) {
-        if ((uint32_t)k > nb) break;
-#pragma unroll
-        for (int pair = 0; pair < 4; pair++) {
-            uint32_t op_acc = 0, op_c = 0, op_nd = 0, had = 0;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint32_t pos = 8u * (uint32_t)(k - 1) + 2u * (uint32_t)pair + (uint32_t)h;
-                const uint32_t c = (uint32_t)(w[k] >> (8 * (2 * pair + h))) & 0xffu;
-                const uint32_t d = c - '0';
-                const bool dig = d < 10u;
-                const bool is_op = !dig && pos < my_bytes;
-                if (is_op) {
-                    op_acc = acc;
-                    op_c = c;
-                    op_nd = nd;
-                    had++;
-                }
-                acc = dig ? acc * 10u + d : 0u;
-                nd = dig ? nd + 1u : 0u;
-            }
-            if (had) { /* at most one op per byte pair in the texts this parser accepts */
-                int code = op_code_of(op_c);
-                if (code < 0) { /* the general parser reports the exact offset */
-                    code = 0;
-                    bad |= 2u;
-                }
-                if (had == 2 || op_nd > 7u || op_nd == 0u) bad |= 1u;
-                if (idx < cap) ops.p[idx] = (op_acc << 3) | (uint32_t)code;
-                idx++;
-                if (code == OP_M || code == OP_EQ) sm += op_acc;
-                else sx += op_acc;
-                if (code != OP_D) sq += op_acc;
-                if (code != OP_I) st += op_acc;
-            }
+        {
+            const uint32_t first = g < cg_off ? (cg_off - g < 16u ? cg_off - g : 16u) : 0u;
+            const uint32_t last = g + 16u > end ? (end > g ? end - g : 0u) : 16u;
+            /* a cigar that ends in digits: the reference's switch sees the NUL (impl/paf.c:96-103) */
+            if (last > first && g + last == end && !((opmask >> (last - 1)) & 1u)) atomicMin(&sh->err_pos, end);
+            opmask &= (last >= 16u ? 0xffffu : ((1u << last) - 1u)) & ~((1u << first) - 1u);
         }
+        uint32_t c1[1] = {(uint32_t)__popc(opmask)}, tot[1];
+        block_excl_scan_u32<1>(c1, tot, bc); /* its barrier also publishes the staged text */
+        uint32_t idx = n + c1[0];
+        const uint32_t q0 = PAFFY_HALO + tid * 16u;
+        while (opmask) {
+            const uint32_t j = (uint32_t)__ffs((int)opmask) - 1u;
+            opmask &= opmask - 1u;
+            const uint32_t c = (w[j >> 2] >> ((j & 3u) * 8u)) & 0xffu;
+            int code = op_code_of(c);
+            if (code < 0) {
+                atomicMin(&sh->err_pos, g + j);
+                code = 0;
+            }
+            uint32_t kk;
+            const uint32_t len = number_before(txt, q0 + j, &kk);
+            if (kk >= 8u) flags |= 1u;
+            if (len == 0u || code > OP_D) flags |= 2u;
+            if (idx < cap) ops.p[idx] = (len << 3) | (uint32_t)code;
+            idx++;
+            if (code == OP_M || code == OP_EQ) sm += len;
+            else sx += len;
+            if (code != OP_D) sq += len;
+            if (code != OP_I) st += len;
+        }
+        n += tot[0];
     }
-    /* a cigar that ends in digits: the reference's switch sees the NUL (impl/paf.c:96-103) */
-    uint32_t trailing = 0;
-    if (my_bytes > 0 && s0 + my_bytes == end) {
-        const uint32_t lw = (my_bytes - 1u) >> 3; /* selects, not an indexed array: that would live in scratch memory */
-        const uint64_t wl = lw == 0 ? w[1] : lw == 1 ? w[2] : lw == 2 ? w[3] : w[4];
-        const uint32_t last = (uint32_t)(wl >> (8u * ((my_bytes - 1u) & 7u))) & 0xffu;
-        trailing = last - '0' < 10u ? 1u : 0u;
-    }
-    /* one collective: the four sums (each below 2^44 for the block), how many threads met an odd text (bits 48..56) and
-       the trailing-digits flag (bit 60) */
-    sums[0] = (int64_t)((uint64_t)sm | ((uint64_t)(bad ? 1u : 0u) << 48) | ((uint64_t)trailing << 60));
+    /* one collective: the four sums and the flags (a thread's own sums stay below 2^32: at most eight numbers of seven digits per round) */
+    sums[0] = (int64_t)((uint64_t)sm | ((uint64_t)(flags & 1u) << 42) | ((uint64_t)((flags >> 1) & 1u) << 52));
     sums[1] = sx; sums[2] = sq; sums[3] = st;
     block_sum<4>(sums, bc);
     const uint64_t packed = (uint64_t)sums[0];
-    sums[0] = (int64_t)(packed & ((1ull << 48) - 1ull));
-    const uint32_t fl = ((packed >> 48) & 0xfffull) ? 0x200u : 0u;
-    *err_pos = (packed >> 60) ? end : 0xffffffffu;
-    if (fl & 0x200u) return 0xffffffffu;
+    sums[0] = (int64_t)(packed & ((1ull << 42) - 1ull));
+    *err_pos = sh->err_pos; /* written before the barrier of the collective */
+    if ((packed >> 42) & 0x3ffull) return 0xffffffffu;
+    *plain = ((packed >> 52) & 0x3ffull) == 0;
     *fits = n <= cap;
-    const uint32_t n_copy = n < cap ? (n < ops.g_cap ? n : ops.g_cap) : (cap < ops.g_cap ? cap : ops.g_cap);
+    const uint32_t n_live = n < cap ? n : cap, n_copy = n_live < ops.g_cap ? n_live : ops.g_cap;
     for (uint32_t i = tid; i < n_copy; i += PAFFY_NT) ops.g[i] = ops.p[i];
+    __syncthreads(); /* the text area and the error word are free again */
     return n;
 }
 
@@ -2693,12 +2657,16 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
     uint32_t n = 0;
     int64_t parse_sums[4] = {0, 0, 0, 0};
     bool have_sums = false;
+    bool parse_plain = false; /* parsed here and every op is M / I / D with a length >= 1 */
     if (s.has_cigar) {
         bool fits;
         uint32_t err_pos;
         uint32_t r;
         r = 0xffffffffu;
-        if constexpr (std::is_same<OPS, OpsLds>::value) r = parse_cigar_fast(P.in, m.cg_off, m.cg_len, ops, cap, L.bc, L.sh, &fits, &err_pos, parse_sums);
+        if constexpr (std::is_same<OPS, OpsLds>::value) {
+            r = parse_cigar_lds(P.in, m.cg_off, m.cg_len, ops, cap, L.ring, L.bc, L.sh, &fits, &err_pos, parse_sums, &parse_plain);
+            if (r == 0xffffffffu) parse_plain = false;
+        }
         if (r == 0xffffffffu) r = parse_cigar(P.in, m.cg_off, m.cg_len, ops, cap, L.ring, L.bc, L.sh, &fits, &err_pos, parse_sums);
         have_sums = true;
         if (r & 0x80000000u) {
@@ -2754,6 +2722,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
             rc = trim_fixed(s, v, 0.0f, L.bc, L.sh, true, count);
             if (!rc) rc = check_record(s, v, L.bc);
         } else if (STAGE_ON(PAFFY_REMOVE_MISMATCHES) && st.kind == PAFFY_REMOVE_MISMATCHES) {
+            parse_plain = false; /* the op array is rebuilt */
             if (s.has_cigar) {
                 bool narrow_ok = true;
                 uint32_t n2;
@@ -2777,6 +2746,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
             }
             rc = check_record(s, v, L.bc);
         } else if (STAGE_ON(PAFFY_ADD_MISMATCHES) && st.kind == PAFFY_ADD_MISMATCHES) {
+            parse_plain = false;
             if constexpr (std::is_same<OPS, OpsLds>::value) {
                 const int32_t qi = swapped ? P.rec_tseq[rec] : P.rec_qseq[rec], ti = swapped ? P.rec_qseq[rec] : P.rec_tseq[rec];
                 if (qi < 0) rc = PAFFY_ERR_MISSING_QUERY_SEQ;   /* impl/paf_add_mismatches.c:117-120 */
@@ -2897,7 +2867,31 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
         direct = !shatter_fits(k);
         rows_kernel = OPS::kNarrow && !direct && shatter_fast_ok(s, k) && k.lenA <= 48 && k.lenB <= 48 && k.lenC <= 48 &&
                       v.n <= PAFFY_ROWS_MAX_OPS; /* emitted by k_emit_rows; longer records are split over the four waves of k_emit_lds */ /* pieces too long for the LDS staging: the emit pass writes this record's rows straight to HBM */
-        int rc = shatter_size(s, v, k, bytes, rows, plan, checked, L.bc);
+        int rc = 0;
+        bool sized = false;
+        if constexpr (std::is_same<OPS, OpsLds>::value) {
+            /* plain ops, a passed paf_check, start and end coordinates of equal digit counts, the window's end ops whole, written by the
+               one-wave row kernel (which needs no per-wave starts): a row's size depends on L only and nothing can fail -- one lean sweep */
+            const uint32_t dq0 = dec_len(s.qs), dt0 = dec_len(s.ts);
+            if (parse_plain && rows_kernel && checked && (v.sub_lo | v.sub_hi) == 0 && dq0 == (uint32_t)dec_len(s.qe) && dt0 == (uint32_t)dec_len(s.te) &&
+                s.qe - s.qs < 0x7fffffffll && s.te - s.ts < 0x7fffffffll) {
+                const uint32_t fixed = k.row_const + 2 * dq0 + 2 * dt0;
+                uint32_t b, e, a[2] = {0, 0};
+                sweep_bounds(v.n, b, e);
+                for (uint32_t i = b; i < e; i++) {
+                    const uint32_t w = ops.p[v.lo + i]; /* the order of the ops does not matter here */
+                    if ((w & 7u) == (uint32_t)OP_M) {
+                        a[0] += fixed + 3u * dec_len_u32(w >> 3);
+                        a[1]++;
+                    }
+                }
+                block_sum_u32<2>(a, L.bc);
+                bytes = a[0];
+                rows = a[1];
+                sized = true;
+            }
+        }
+        if (!sized) rc = shatter_size(s, v, k, bytes, rows, plan, checked, L.bc);
         PT_MARK(4)
         if (rc) {
             report(P, rec, rc, si, 0, klass);
