@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--pipe", default=None, help="override the workload's command pipe, e.g. 'shatter' (experiments only)")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="records of the stream timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    ap.add_argument("--mean-ops", type=int, default=0, help="override the workload's mean cigar ops (experiments only)")
     ap.add_argument("--verify", action="store_true", help="cfg5: gather the ordered output of the last step on rank 0 and compare it with a one-process tile of the same records (small --batch only)")
     ap.add_argument("--rehearse", action="store_true",
                     help="plumbing rehearsal without a GPU: ranks, rendezvous, the per-step size exchange and the reductions run, the hot path does not (value is null)")
@@ -94,6 +95,8 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.pipe:
         wl["pipe"] = args.pipe
+    if args.mean_ops:
+        wl["mean_ops"] = args.mean_ops
     if wl.get("tile"):
         return bench_tile(args, wl, rank, world, dist, dev)
     eng = paffy_amd.Engine()

@@ -25,11 +25,13 @@
 
 #include "../../include/paffy_hip.h"
 #include "paf_synth_core.h"
-#include "record_kernel.h"
+#include "record_groups.h"
 #include "coverage_kernel.h"
 #include "bed_kernel.h"
 
 #define SEP_TILE 65536u /* bytes per workgroup in the separator passes */
+#define WAVE_OPS_CAP 2048u   /* op store of the one-wave sizing kernel: 8 KiB, sixteen workgroups per CU */
+#define WAVE_MAX_BYTES 6000u /* cigars up to this length go there (about 1950 ops at 3.08 bytes per op; the few denser ones are redone by the four-wave build) */
 
 /* ------------------------------------------------------------------ */
 /* separators                                                           */
@@ -836,6 +838,11 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
         return false;
     }();
     const uint32_t lvl0_max = add_not_last ? PAFFY_OPS_CAP * 5 / 8 : PAFFY_OPS_CAP;
+    /* records with at most this many cigar bytes (about WAVE_OPS_CAP ops at three bytes per op) are sized one wave per record; denser
+       cigars of that length overflow the wave's store and go to the arena class. add_mismatches rebuilds the op array: not there. */
+    static const uint32_t wave_env = getenv("PAFFY_WAVE_BYTES") ? (uint32_t)atoi(getenv("PAFFY_WAVE_BYTES")) : WAVE_MAX_BYTES;
+    static const uint32_t wave_cap_env = getenv("PAFFY_WAVE_OPS") ? (uint32_t)atoi(getenv("PAFFY_WAVE_OPS")) : WAVE_OPS_CAP;
+    const uint32_t wave_bytes = need_seqs ? 0u : wave_env;
     {
         int rc = index_and_parse(c, in, len, &n_lines, lvl0_max);
         if (rc) return rc;
@@ -927,6 +934,16 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             kp.ops_cap = PAFFY_OPS_CAP;
             kp.next_cap = 0;
             kp.level = 0;
+            kp.wave_max_bytes = wave_bytes;
+            if (wave_bytes) { /* short cigars: one wave per record, sixteen records in flight per CU */
+                KParams kw = kp;
+                kw.ops_cap = wave_cap_env;
+                const size_t wlds = (size_t)wave_cap_env * 4 + PAFFY_HALO + 64 * 16 + 64 * 8 + 64;
+                if (lean) LAUNCH(c, "k_size_wave", g64::k_size_lds<PAFFY_MASK_LEAN>, dim3(n_lines), dim3(64), wlds, kw);
+                else if (lean_add) LAUNCH(c, "k_size_wave", g64::k_size_lds<PAFFY_MASK_ADD>, dim3(n_lines), dim3(64), wlds, kw);
+                else if (plain) LAUNCH(c, "k_size_wave", g64::k_size_lds<PAFFY_MASK_PLAIN>, dim3(n_lines), dim3(64), wlds, kw);
+                else LAUNCH(c, "k_size_wave", g64::k_size_lds<PAFFY_MASK_ALL>, dim3(n_lines), dim3(64), wlds, kw);
+            }
             if (lean) LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_LEAN>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             else if (lean_add) LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_ADD>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             else if (plain) LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_PLAIN>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);

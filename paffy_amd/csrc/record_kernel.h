@@ -14,13 +14,8 @@
  * Transforms never move ops: invert / trims are edits of a View (window, direction, I<->D
  * relabel, shortened end ops) over the parsed array.
  */
-#ifndef PAFFY_RECORD_KERNEL_H_
-#define PAFFY_RECORD_KERNEL_H_
-
-#include <type_traits>
-
-#include "device_util.h"
-#include "record_types.h"
+/* Included once per workgroup size by record_groups.h (PAFFY_NT, PAFFY_NWAVE, namespace PAFFY_NS); no include guard on purpose. */
+namespace PAFFY_NS {
 
 #define INTERNAL_TMPL_TOO_LONG 1u
 #define INTERNAL_ROW_TOO_LONG 2u
@@ -148,18 +143,6 @@ struct RecState {
     bool same;
     uint8_t type;
     bool has_cigar;
-};
-
-/* What the stage list left of a record; written by the sizing pass, read by the emit pass. */
-struct RecPlan {
-    int64_t qs, qe, ts, te, sub_lo, sub_hi;
-    uint32_t lo, n;
-    uint32_t flags; /* bit0 rev, bit1 swp, bit2 query/target swapped, bit3 has_cigar, bit4 shatter, bit5 direct, bit6 k_emit_rows,
-                       bit7 dropped by a filter, bits 8-15 type, bit16 k_emit_line,
-                       bit17 the 4-byte ops live in the arena block arena_off[rec] (rebuilt by add_mismatches), not in the mirror */
-    uint32_t chunk; /* ops per lane in the sizing sweep: wave w owns view ops [64*w*chunk, 64*(w+1)*chunk) */
-    /* shatter: query / target bases consumed and output bytes produced before each wave's range */
-    int64_t wq[PAFFY_NWAVE], wt[PAFFY_NWAVE], wo[PAFFY_NWAVE];
 };
 
 struct Shared { /* small workgroup-shared words */
@@ -2928,6 +2911,10 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
                       (ops_in_arena ? 0x20000u : 0u);
         if (ops_in_arena) P.arena_off[rec] = arena_block;
         plan->chunk = ((v.n + PAFFY_NT - 1) / PAFFY_NT) | 1u; /* = sweep_bounds() */
+#if PAFFY_NWAVE == 1
+        /* sized by one wave: it owns all the ops (chunk covers them), the other three waves of a four-wave writer get empty shares */
+        for (int w = 1; w < 4; w++) plan->wq[w] = plan->wt[w] = plan->wo[w] = 0;
+#endif
     }
 #if defined(PAFFY_ABL) && PAFFY_ABL == 21
     PT_MARK(5)
@@ -3062,6 +3049,12 @@ __device__ __forceinline__ void size_lds_one(const KParams &P, uint32_t rec, uin
     uint32_t n_ops = 0, need = 0; /* need: ops of an array rebuilt by add_mismatches that did not fit this level's store */
     bool ok = size_record<OpsLds, MASK>(P, rec, ops, P.ops_cap, L, KLASS_LDS, &n_ops, &need);
     if (ok && n_ops > ((m.cg_len + 1) >> 1)) ok = false; /* digit-less ops overran the mirror: arena class */
+#if PAFFY_NWAVE == 1
+    /* the one-wave build: more ops than its store holds -> the four-wave build takes the record (it runs after this kernel) */
+    const bool to_four = !ok && need == 0 && n_ops > P.ops_cap && n_ops <= ((m.cg_len + 1) >> 1);
+    if (threadIdx.x == 0) P.n_ops[rec] = to_four ? 0xffffffffu : 0u;
+    if (to_four) return;
+#endif
     if (!ok && threadIdx.x == 0) {
         P.out_len[rec] = 0;
         P.out_rows[rec] = 0;
@@ -3087,8 +3080,13 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_SIZE_OCC) void k_size_lds(KParams P
     const uint32_t rec = P.size_order ? P.size_order[blockIdx.x] : blockIdx.x; /* long cigars first */
     /* records whose cigar text promises more ops than this store holds were queued for level 1 by k_header */
     if ((P.meta[rec].cg_len >> 1) > P.lvl0_max && P.meta[rec].err == 0) return;
+    /* short cigars belong to the one-wave build of this kernel (g64, launched first), everything else -- and what did not fit the
+       wave's op store, marked in n_ops -- to the four-wave build */
+    const bool is_short = P.meta[rec].cg_len <= P.wave_max_bytes;
+    if (PAFFY_NWAVE == 1 ? !is_short : (is_short && P.n_ops[rec] != 0xffffffffu)) return;
     size_lds_one<MASK>(P, rec, ops_lds, L);
 }
+#if PAFFY_NWAVE == 4 /* the long-record levels, every emit kernel and the arena class exist in the four-wave build only */
 template <uint32_t MASK>
 __global__ __launch_bounds__(PAFFY_NT, 2) void k_size_lds_long(KParams P) { /* two workgroups per CU at most (LDS): room for 256 registers, no spills */ /* levels 1 and 2: the queued long records */
     extern __shared__ uint4 smem4[];
@@ -3259,4 +3257,5 @@ __global__ __launch_bounds__(PAFFY_NT) void k_arena_emit(KParams P) {
     }
 }
 
-#endif
+#endif /* PAFFY_NWAVE == 4 */
+} /* namespace */

@@ -53,6 +53,19 @@ struct DevInfo {
     unsigned long long stats[6]; /* PAFFY_STATS: matches, mismatches, inserts, deletes, insert bases, delete bases */
 };
 
+/* What the stage list left of a record; written by the sizing pass, read by the emit pass. */
+struct RecPlan {
+    int64_t qs, qe, ts, te, sub_lo, sub_hi;
+    uint32_t lo, n;
+    uint32_t flags; /* bit0 rev, bit1 swp, bit2 query/target swapped, bit3 has_cigar, bit4 shatter, bit5 direct, bit6 k_emit_rows,
+                       bit7 dropped by a filter, bits 8-15 type, bit16 k_emit_line,
+                       bit17 the 4-byte ops live in the arena block arena_off[rec] (rebuilt by add_mismatches), not in the mirror */
+    uint32_t chunk; /* ops per lane in the sizing sweep: wave w owns view ops [64*w*chunk, 64*(w+1)*chunk) */
+    /* shatter: query / target bases consumed and output bytes produced before each wave's range */
+    int64_t wq[4], wt[4], wo[4]; /* four waves: the emit workgroups; a one-wave sizing workgroup fills entry 0 and zeroes the rest */
+};
+
+
 struct KParams {
     const uint8_t *in;
     uint32_t in_len;
@@ -92,6 +105,7 @@ struct KParams {
     const uint32_t *emit_order; /* records by descending output size (coarse): the one-wave-per-record writers start the long ones first */
     const uint32_t *size_order; /* records by descending cigar length (coarse), for the sizing launch */
     int64_t *rec_stats;         /* PAFFY_STATS: six sums per record (the order of paf_stats_calc's arguments), or NULL */
+    uint32_t wave_max_bytes;    /* records with at most this many cigar bytes are sized by the one-wave kernel (0: none): the four-wave kernel skips them */
 };
 
 #endif
