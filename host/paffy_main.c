@@ -5,8 +5,12 @@
  * commands (shatter, invert, trim, add_mismatches, tile) run on the GPU; the others are outside
  * this build's scope and say so with status 1.
  */
+#define _GNU_SOURCE
+#include <fcntl.h>
 #include <stdio.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "paffy_host.h"
 
@@ -38,7 +42,16 @@ static void usage(void) {
     fprintf(stderr, "\n");
 }
 
+/* `paffy a | paffy b`: a 64 KiB pipe makes writer and reader trade places every few microseconds; ask for 1 MiB on both ends */
+static void widen_pipes(void) {
+    for (int fd = 0; fd <= 1; fd++) {
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISFIFO(st.st_mode)) (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);
+    }
+}
+
 int main(int argc, char *argv[]) {
+    widen_pipes();
     if (argc < 2) {
         usage();
         return 0;

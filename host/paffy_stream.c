@@ -154,6 +154,88 @@ static int stats_chunk(paffy_hip_ctx *ctx, const paffy_stage *stages, int n_stag
     return rc;
 }
 
+/* every piece of the oldest submitted chunk to `out` */
+static int drain_chunk(paffy_hip_stream *st, FILE *out) {
+    for (;;) {
+        const char *piece = NULL;
+        int64_t len = 0;
+        if (paffy_hip_stream_read(st, &piece, &len) != 0) return 1;
+        if (len == 0) return 0;
+        if (fwrite(piece, 1, (size_t)len, out) != (size_t)len) return 1;
+    }
+}
+
+/*
+ * The stream commands (impl/paf_invert.c:84-89 and friends): chunks of whole lines go through pinned buffers; while the GPU works on
+ * chunk k + 1 (copy in, sizing, line writer) the host drains the output of chunk k piece by piece into `out`.
+ */
+static int pipelined_stream(paffy_hip_ctx *ctx, const paffy_stage *stages, int n_stages, FILE *in, FILE *out) {
+    const int64_t cap0 = (int64_t)chunk_bytes();
+    paffy_hip_stream *st = NULL;
+    if (paffy_hip_stream_open(ctx, stages, n_stages, cap0, (int64_t)64 << 20, &st) != 0) {
+        fprintf(stderr, "paffy: could not set up the streaming buffers: %s\n", paffy_hip_last_error(ctx));
+        return 1;
+    }
+    const char *carry = NULL; /* the partial last line of the chunk before, still in that chunk's buffer */
+    int64_t carry_len = 0, records_done = 0;
+    int eof = 0, rc = 0, pending = 0;
+    paffy_plan_info info;
+    memset(&info, 0, sizeof(info));
+    while (!rc && (!eof || carry_len > 0)) {
+        int64_t cap = 0;
+        char *buf = paffy_hip_stream_input(st, cap0, 0, &cap);
+        if (!buf) {
+            rc = 1;
+            break;
+        }
+        int64_t have = carry_len;
+        if (carry_len > cap) buf = paffy_hip_stream_input(st, carry_len * 2, 0, &cap);
+        if (!buf) {
+            rc = 1;
+            break;
+        }
+        if (carry_len) memcpy(buf, carry, (size_t)carry_len);
+        int64_t use = 0;
+        for (;;) {
+            if (!eof && have < cap) {
+                size_t got = fread(buf + have, 1, (size_t)(cap - have), in);
+                have += (int64_t)got;
+                if ((int64_t)got < cap - have + (int64_t)got) eof = feof(in) || ferror(in);
+            }
+            use = have;
+            if (!eof) /* keep the partial last line for the next chunk */
+                while (use > 0 && buf[use - 1] != '\n') use--;
+            if (use > 0 || eof) break;
+            buf = paffy_hip_stream_input(st, cap * 2, have, &cap); /* a single line longer than the buffer: grow */
+            if (!buf) {
+                fprintf(stderr, "paffy: a line too long for one batch (2 GiB)\n");
+                rc = 1;
+                break;
+            }
+        }
+        if (rc || use == 0) break;
+        if (paffy_hip_stream_submit(st, use, &info) != 0) {
+            fprintf(stderr, "paffy: GPU call failed: %s\n", paffy_hip_last_error(ctx));
+            rc = 1;
+            break;
+        }
+        carry = buf + use; /* stays where it is until this slot is filled again, two chunks from now */
+        carry_len = have - use;
+        if (pending && drain_chunk(st, out)) rc = 1; /* the chunk before, while the GPU works on this one */
+        pending = 1;
+        if (info.error.code) { /* everything before the failing record is written, then the process ends like the reference */
+            if (!rc) rc = drain_chunk(st, out);
+            fflush(out);
+            die_like_reference(&info.error, records_done);
+        }
+        records_done += info.n_records;
+    }
+    if (!rc && pending && drain_chunk(st, out)) rc = 1;
+    if (rc && ctx) fprintf(stderr, "paffy: streaming failed: %s\n", paffy_hip_last_error(ctx));
+    paffy_hip_stream_close(st);
+    return rc;
+}
+
 int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out) {
     paffy_hip_ctx *ctx = NULL;
     if (paffy_hip_create(&ctx, -1) != 0) {
@@ -164,6 +246,12 @@ int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out) {
     if (g_seq_n > 0 && paffy_hip_set_sequences(ctx, g_seq_n, g_seq_names, g_seq_data, g_seq_lens) != 0) {
         fprintf(stderr, "paffy: could not load the sequences onto the GPU: %s\n", paffy_hip_last_error(ctx));
         return 1;
+    }
+    if (!g_dedupe_mode && !g_stats_mode) {
+        int rc = pipelined_stream(ctx, stages, n_stages, in, out);
+        paffy_hip_destroy(ctx);
+        fflush(out);
+        return rc;
     }
     const size_t cap = chunk_bytes();
     size_t buf_cap = cap + (1 << 20), have = 0;
@@ -190,9 +278,7 @@ int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out) {
         char *h_out = NULL;
         int64_t out_len = 0;
         paffy_plan_info info;
-        int r = g_dedupe_mode ? dedupe_chunk(ctx, buf, (int64_t)use, &h_out, &out_len, &info)
-                : g_stats_mode ? stats_chunk(ctx, stages, n_stages, buf, (int64_t)use, &info)
-                               : paffy_hip_run_host(ctx, stages, n_stages, buf, (int64_t)use, &h_out, &out_len, &info);
+        int r = g_dedupe_mode ? dedupe_chunk(ctx, buf, (int64_t)use, &h_out, &out_len, &info) : stats_chunk(ctx, stages, n_stages, buf, (int64_t)use, &info);
         if (r != 0) {
             fprintf(stderr, "paffy: GPU call failed (%d): %s\n", r, paffy_hip_last_error(ctx));
             rc = 1;

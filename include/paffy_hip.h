@@ -223,6 +223,23 @@ int paffy_hip_run_host(paffy_hip_ctx *ctx, const paffy_stage *stages, int32_t n_
                        char **h_out, int64_t *out_len, paffy_plan_info *info);
 
 /*
+ * Streaming through host buffers: what the CLI drivers use (the reference's read / transform / write loop, impl/paf_invert.c:84-89,
+ * with H2D, kernels and D2H overlapped on three streams). Two slots of pinned input; the output returns in pinned pieces.
+ *   open(chunk_bytes: capacity of an input buffer, < 2 GiB - 64; piece_bytes: size of an output piece)
+ *   input(want, keep, &cap): the buffer the next chunk is written into (NULL while both slots hold unread output); with want above its
+ *                        capacity it is enlarged, the first `keep` bytes kept (a line longer than the chunk)
+ *   submit(in_len, &info): the first in_len bytes (whole lines) go through the stage list; info is complete on return
+ *   read(&piece, &len):  the next piece of the oldest submitted chunk; len = 0: that chunk is done (submit the next, or stop)
+ * Submit chunk k + 1 before reading chunk k and the GPU works on k + 1 while the host drains k.
+ */
+typedef struct paffy_hip_stream paffy_hip_stream;
+int paffy_hip_stream_open(paffy_hip_ctx *ctx, const paffy_stage *stages, int32_t n_stages, int64_t chunk_bytes, int64_t piece_bytes, paffy_hip_stream **stream);
+char *paffy_hip_stream_input(paffy_hip_stream *stream, int64_t want, int64_t keep, int64_t *cap);
+int paffy_hip_stream_submit(paffy_hip_stream *stream, int64_t in_len, paffy_plan_info *info);
+int paffy_hip_stream_read(paffy_hip_stream *stream, const char **piece, int64_t *len);
+void paffy_hip_stream_close(paffy_hip_stream *stream);
+
+/*
  * Sums of the PAFFY_STATS stages of the last plan, in the argument order of paf_stats_calc (impl/paf.c:236-260): matches (M and =
  * bases), mismatches (X bases), query inserts, query deletes, query insert bases, query delete bases -- over the whole batch;
  * meaningful when no record failed (a failing record ends the reference process before it prints anything).

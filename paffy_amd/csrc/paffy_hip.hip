@@ -1548,6 +1548,170 @@ int paffy_hip_run_host(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_st
     return rc;
 }
 
+/*
+ * Streaming through host buffers (the loop of impl/paf_invert.c:84-89 and friends with the GPU in the middle): two slots, each a
+ * pinned input buffer and device in / out buffers; the output returns through two pinned pieces. Chunk k + 1 is copied in, planned
+ * and written on the GPU while the host still drains chunk k: H2D, kernels and D2H run on three streams.
+ */
+struct StreamSlot {
+    char *h_in = nullptr;
+    size_t h_cap = 0;
+    void *d_in = nullptr;
+    size_t d_in_cap = 0;
+    void *d_out = nullptr;
+    size_t d_out_cap = 0;
+    hipEvent_t ev_in = nullptr, ev_emit = nullptr;
+    int64_t out_len = 0, read_at = 0; /* bytes of output, bytes already handed to the host */
+    bool busy = false;
+};
+struct paffy_hip_stream {
+    paffy_hip_ctx *c = nullptr;
+    paffy_stage stages[PAFFY_MAX_STAGES];
+    int32_t n_stages = 0;
+    StreamSlot slot[2];
+    int fill = 0, drain = 0; /* slot the next chunk goes to, slot being read */
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    char *piece[2] = {nullptr, nullptr};
+    size_t piece_cap = 0;
+    hipEvent_t ev_piece[2] = {nullptr, nullptr};
+    int64_t piece_len[2] = {0, 0};
+    int64_t issued_at = 0; /* bytes of the draining chunk whose copy has been issued */
+    int n_issued = 0, n_returned = 0;
+};
+
+int paffy_hip_stream_open(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages, int64_t chunk_bytes, int64_t piece_bytes, paffy_hip_stream **out) {
+    if (!c || !out || n_stages < 0 || n_stages > PAFFY_MAX_STAGES || (n_stages > 0 && !stages) || chunk_bytes < 4096 || chunk_bytes >= (1ll << 31) - 64 || piece_bytes < 4096)
+        return PAFFY_E_ARG;
+    paffy_hip_stream *s = new paffy_hip_stream();
+    s->c = c;
+    s->n_stages = n_stages;
+    for (int32_t i = 0; i < n_stages; i++) s->stages[i] = stages[i];
+    bool ok = hipStreamCreateWithFlags(&s->s_h2d, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&s->s_d2h, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 2 && ok; k++) {
+        StreamSlot &sl = s->slot[k];
+        sl.h_cap = (size_t)chunk_bytes;
+        ok = hipHostMalloc(reinterpret_cast<void **>(&sl.h_in), sl.h_cap + 64) == hipSuccess && hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&sl.ev_emit, hipEventDisableTiming) == hipSuccess &&
+             hipHostMalloc(reinterpret_cast<void **>(&s->piece[k]), (size_t)piece_bytes) == hipSuccess && hipEventCreateWithFlags(&s->ev_piece[k], hipEventDisableTiming) == hipSuccess;
+    }
+    s->piece_cap = (size_t)piece_bytes;
+    if (!ok) {
+        c->last_error = "paffy_hip_stream_open: pinned buffers / streams";
+        paffy_hip_stream_close(s);
+        return PAFFY_E_HIP;
+    }
+    *out = s;
+    return 0;
+}
+
+void paffy_hip_stream_close(paffy_hip_stream *s) {
+    if (!s) return;
+    (void)hipDeviceSynchronize();
+    for (int k = 0; k < 2; k++) {
+        StreamSlot &sl = s->slot[k];
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
+        if (sl.ev_emit) (void)hipEventDestroy(sl.ev_emit);
+        if (s->piece[k]) (void)hipHostFree(s->piece[k]);
+        if (s->ev_piece[k]) (void)hipEventDestroy(s->ev_piece[k]);
+    }
+    if (s->s_h2d) (void)hipStreamDestroy(s->s_h2d);
+    if (s->s_d2h) (void)hipStreamDestroy(s->s_d2h);
+    delete s;
+}
+
+/* the pinned buffer the next chunk is to be written into (NULL while both slots hold unread output); with want > its capacity it is
+   enlarged, keeping the first `keep` bytes (a line longer than the chunk) */
+char *paffy_hip_stream_input(paffy_hip_stream *s, int64_t want, int64_t keep, int64_t *cap) {
+    if (!s || !cap) return nullptr;
+    StreamSlot &sl = s->slot[s->fill];
+    if (sl.busy) return nullptr;
+    if (want > (int64_t)sl.h_cap) {
+        if (want >= (1ll << 31) - 64) return nullptr;
+        char *nb = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void **>(&nb), (size_t)want + 64) != hipSuccess) return nullptr;
+        if (keep > 0) memcpy(nb, sl.h_in, (size_t)keep);
+        (void)hipHostFree(sl.h_in);
+        sl.h_in = nb;
+        sl.h_cap = (size_t)want;
+    }
+    *cap = (int64_t)sl.h_cap;
+    return sl.h_in;
+}
+
+/* the first in_len bytes of the current input buffer (whole lines) go through the stage list; *info is complete on return (the
+   plan is synchronous), the output is drained with paffy_hip_stream_read */
+int paffy_hip_stream_submit(paffy_hip_stream *s, int64_t in_len, paffy_plan_info *info) {
+    if (!s || !info || in_len < 0) return PAFFY_E_ARG;
+    paffy_hip_ctx *c = s->c;
+    StreamSlot &sl = s->slot[s->fill];
+    if (sl.busy || in_len > (int64_t)sl.h_cap) return PAFFY_E_STATE;
+    if ((size_t)in_len + 64 > sl.d_in_cap) {
+        if (sl.d_in) HIPCHK(c, hipFree(sl.d_in));
+        sl.d_in = nullptr;
+        sl.d_in_cap = (size_t)in_len + (size_t)in_len / 4 + 4096;
+        HIPCHK(c, hipMalloc(&sl.d_in, sl.d_in_cap));
+    }
+    if (in_len > 0) HIPCHK(c, hipMemcpyAsync(sl.d_in, sl.h_in, (size_t)in_len, hipMemcpyHostToDevice, s->s_h2d));
+    HIPCHK(c, hipEventRecord(sl.ev_in, s->s_h2d));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, sl.ev_in, 0));
+    int rc = paffy_hip_plan(c, s->stages, s->n_stages, sl.d_in, in_len, info);
+    if (rc) return rc;
+    sl.out_len = info->out_bytes;
+    sl.read_at = 0;
+    if (sl.out_len > 0) {
+        if ((size_t)sl.out_len + 64 > sl.d_out_cap) {
+            if (sl.d_out) HIPCHK(c, hipFree(sl.d_out));
+            sl.d_out = nullptr;
+            sl.d_out_cap = (size_t)sl.out_len + (size_t)sl.out_len / 4 + 4096;
+            HIPCHK(c, hipMalloc(&sl.d_out, sl.d_out_cap));
+        }
+        rc = paffy_hip_emit(c, sl.d_out, (int64_t)sl.d_out_cap);
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipEventRecord(sl.ev_emit, c->stream));
+    sl.busy = true;
+    s->fill ^= 1;
+    return 0;
+}
+
+/* the next piece of the oldest submitted chunk's output: *len bytes at *piece, valid until the call after next; *len = 0: that chunk
+   has been read completely (or nothing was submitted) */
+int paffy_hip_stream_read(paffy_hip_stream *s, const char **piece, int64_t *len) {
+    if (!s || !piece || !len) return PAFFY_E_ARG;
+    paffy_hip_ctx *c = s->c;
+    *piece = nullptr;
+    *len = 0;
+    StreamSlot &sl = s->slot[s->drain];
+    if (!sl.busy) return 0;
+    if (s->n_issued == 0) HIPCHK(c, hipStreamWaitEvent(s->s_d2h, sl.ev_emit, 0)); /* first piece of this chunk */
+    /* keep two copies in flight: the piece handed out now and the one after it */
+    while (s->n_issued < s->n_returned + 2 && s->issued_at < sl.out_len) {
+        const int k = s->n_issued & 1;
+        const int64_t n = sl.out_len - s->issued_at < (int64_t)s->piece_cap ? sl.out_len - s->issued_at : (int64_t)s->piece_cap;
+        HIPCHK(c, hipMemcpyAsync(s->piece[k], static_cast<char *>(sl.d_out) + s->issued_at, (size_t)n, hipMemcpyDeviceToHost, s->s_d2h));
+        HIPCHK(c, hipEventRecord(s->ev_piece[k], s->s_d2h));
+        s->piece_len[k] = n;
+        s->issued_at += n;
+        s->n_issued++;
+    }
+    if (s->n_returned == s->n_issued) { /* everything of this chunk has been handed out */
+        sl.busy = false;
+        s->drain ^= 1;
+        s->issued_at = 0;
+        s->n_issued = s->n_returned = 0;
+        return 0;
+    }
+    const int k = s->n_returned & 1;
+    HIPCHK(c, hipEventSynchronize(s->ev_piece[k]));
+    *piece = s->piece[k];
+    *len = s->piece_len[k];
+    s->n_returned++;
+    return 0;
+}
+
 /* exclusive scan of n int64 values on the device (two levels); *total on the host */
 static int scan64(paffy_hip_ctx *c, const int64_t *in, uint64_t n, int64_t *out, int64_t *total) {
     const uint64_t tiles = (n + PAFFY_NT * 16 - 1) / (PAFFY_NT * 16);
