@@ -216,14 +216,14 @@ def main():
                         "step_kernels_ms": round(step_ms, 4), "dominant_kernel": dom,
                         "dominant_avg_kernel_ms": round(kernels[dom][0] / max(1, kernels[dom][1]), 4),
                         "algorithmic_bytes_per_launch": int(per_launch_bytes)}
-        cpu = None
+        cpu = cpu_all = e2e = None
         if args.cpu_sample > 0 and world == 1:  # the CPU leg runs on rank 0 of the one-GPU run only
             if wl.get("genomes"):
                 cpu = cpu_baseline_genomes(wl, stages, min(args.cpu_sample, 16384))
-            elif wl.get("tile"):
-                cpu = cpu_baseline_tile(eng, wl, min(args.cpu_sample, 8192))
             else:
                 cpu = cpu_baseline(eng, wl, stages, args.cpu_sample)
+                cpu_all = cpu_baseline_all_cores(eng, wl, stages, max(1024, args.cpu_sample // 8))
+                e2e = end_to_end(eng, stages, batches[:2], args.batch)
         line = {
             "metric": "PAF records/sec (shatter+invert+trim pipe); % HBM roofline at 1/2/4/8 GPU",
             "value": round(records / elapsed, 1),
@@ -252,6 +252,8 @@ def main():
             "roofline_by_kernel": {k: v for k, v in by_kernel.items() if kernels[k][0] >= 0.05 * max(x[0] for x in kernels.values())},
             "whole_path_frac_of_hbm_peak": round(((job_in + job_out) / world + extra_per_base * aligned_per_record * args.batch * args.steps) / elapsed / 1e9 / HBM_PEAK_GBS, 4),
             "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_all,
+            "end_to_end": e2e,
             "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kernels.items()},
         }
         print(json.dumps(line), flush=True)
@@ -554,6 +556,74 @@ def cpu_baseline(eng, wl, stages, n):
     return {"value": round(n / dt, 1), "unit": "records/s", "cores": 1, "kind": "port",
             "sample": f"first {n} records of the same stream ({len(data)} B in, {len(want)} B out), {dt:.1f} s, single thread",
             "gpu_output_matches": bool(got == want and err.code == 0)}
+
+
+def _oracle_share(job):
+    """one process of the all-cores CPU leg: the oracle over its share of the sample (module-level: it is pickled to the pool)"""
+    path, lo, hi, kinds = job
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+
+    import oracle_lib as O
+
+    with open(path, "rb") as fh:
+        fh.seek(lo)
+        data = fh.read(hi - lo)
+    L = O.lib()
+    ost = [O.stage(k, p0, p1) for k, p0, p1 in kinds]
+    arr = (O.Stage * len(ost))(*ost)
+    out, on, err = C.c_void_p(), C.c_int64(), O.Error()
+    L.po_run(arr, len(ost), data, len(data), None, 0, C.byref(out), C.byref(on), C.byref(err))
+    L.po_free(out)
+    return on.value if err.code == 0 else -1
+
+
+def cpu_baseline_all_cores(eng, wl, stages, per_core):
+    """CPU leg at N = the host cores this run may use (the reference's own parallelism is one process per split of the
+    input, tests/paf_pipeline_test.sh:42-67): N processes, each the single-threaded oracle over a contiguous share of N x per_core
+    records of the same stream, read from a RAM-backed file; wall time of the slowest."""
+    import multiprocessing as mp
+    import tempfile
+
+    cores = min(16, os.cpu_count() or 1)
+    n = cores * per_core
+    buf, nbytes = eng.synth(wl["seed"], wl["mean_ops"], 0, n)
+    data = bytes(buf[:nbytes].cpu().numpy().tobytes())
+    kinds = {1: 1, 2: 2, 4: 4}
+    st = [(kinds[s.kind], s.p0, s.p1) for s in stages]
+    cuts, at = [0], 0
+    for k in range(1, cores):  # contiguous shares cut at line ends
+        at = data.index(b"\n", max(at, len(data) * k // cores)) + 1
+        cuts.append(at)
+    cuts.append(len(data))
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.NamedTemporaryFile(dir=d, suffix=".paf", delete=False) as fh:
+        fh.write(data)
+        path = fh.name
+    try:
+        ctx = mp.get_context("spawn")  # never fork a process that has initialised the GPU
+        with ctx.Pool(cores) as pool:
+            pool.map(_oracle_share, [(path, 0, 0, st)] * cores)  # workers up, library loaded
+            t0 = time.perf_counter()
+            sizes = pool.map(_oracle_share, [(path, cuts[k], cuts[k + 1], st) for k in range(cores)])
+            dt = time.perf_counter() - t0
+    finally:
+        os.unlink(path)
+    return {"value": round(n / dt, 1), "unit": "records/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} records of the same stream in {cores} contiguous shares, one single-threaded oracle process each ({len(data)} B in, "
+                      f"{sum(sizes)} B out), {dt:.1f} s wall", "ok": bool(all(x >= 0 for x in sizes))}
+
+
+def end_to_end(eng, stages, batches, batch_records):
+    """The PCIe-inclusive rate (reported beside `value`, never as it): the same batches as host bytes through the streaming
+    runtime of the CLI (paffy_hip_stream_*: pinned staging, H2D / kernels / D2H overlapped), output pieces landing in host memory."""
+    chunks = [bytes(buf[:nbytes].cpu().numpy().tobytes()) for buf, nbytes, _ in batches]
+    eng.stream_host(stages, chunks[:1])  # buffers allocated, kernels loaded
+    t0 = time.perf_counter()
+    records, out_bytes = eng.stream_host(stages, chunks)
+    dt = time.perf_counter() - t0
+    return {"value": round(records / dt, 1), "unit": "records/s", "sample": f"{len(chunks)} batches of {batch_records} records as host bytes: "
+            f"{sum(len(c) for c in chunks)} B over PCIe in, {out_bytes} B out, {dt:.2f} s", "GBps_out": round(out_bytes / dt / 1e9, 2)}
 
 
 def cpu_baseline_tile(eng, wl, n):

@@ -12,6 +12,7 @@
  */
 #include "../include/paf.h"
 
+#include <inttypes.h>
 #include <signal.h>
 #include <stdlib.h>
 #include <string.h>
@@ -190,8 +191,14 @@ static void drop_contents(Paf *p) {
     cigar_destruct(p->cigar);
 }
 
-/* One record through a stage list, in place. */
+/*
+ * One record through a stage list, in place. The library transforms of the reference touch coordinates, names (invert) and the
+ * cigar only (impl/paf.c:463-598, 739-809, 929-953): score, type, tile level and the chain tags stay as the caller set them,
+ * whatever the line writer would show of them (it drops a score of INT_MAX and derives tp from the tile level, impl/paf.c:343-365).
+ */
 static void transform(Paf *p, const paffy_stage *st, int n, const char *qname, const char *tname) {
+    const int64_t score = p->score, tile_level = p->tile_level, chain_id = p->chain_id, chain_score = p->chain_score;
+    const char type = p->type;
     Buf b = {0};
     hand_over(&b, p, qname, tname);
     int64_t out_len = 0, n_recs = 0;
@@ -208,6 +215,11 @@ static void transform(Paf *p, const paffy_stage *st, int n, const char *qname, c
     }
     drop_contents(p);
     *p = *res[0];
+    p->score = score;
+    p->tile_level = tile_level;
+    p->chain_id = chain_id;
+    p->chain_score = chain_score;
+    p->type = type;
     free(res[0]);
     free(res);
     free(text);
@@ -302,46 +314,76 @@ void paf_write_with_buffer(Paf *paf, FILE *fh, char **paf_buffer, int64_t *paf_l
     paf_write(paf, fh);
 }
 
-void paf_check(Paf *paf) { /* impl/paf.c:427-461: both inversions run the check, the record comes back unchanged */
-    const paffy_stage st[2] = {{PAFFY_INVERT, 0.0f, 0.0f}, {PAFFY_INVERT, 0.0f, 0.0f}};
+void paf_check(Paf *paf) { /* impl/paf.c:427-461: the one call of this API that validates; the record is left as it is */
+    const paffy_stage st = {PAFFY_CHECK, 0.0f, 0.0f};
     Buf b = {0};
     hand_over(&b, paf, NULL, NULL);
     int64_t out_len = 0;
-    free(run_text(st, 2, b.p, (int64_t)b.n, &out_len));
+    free(run_text(&st, 1, b.p, (int64_t)b.n, &out_len));
     free(b.p);
 }
 
 void paf_invert(Paf *paf) { /* impl/paf.c:463-490 */
-    const paffy_stage st = {PAFFY_INVERT, 0.0f, 0.0f};
+    const paffy_stage st = {PAFFY_INVERT | PAFFY_NO_CHECK, 0.0f, 0.0f};
     transform(paf, &st, 1, NULL, NULL);
 }
 
 void paf_trim_ends(Paf *paf, int64_t end_bases_to_trim) { /* impl/paf.c:575-598 */
-    const paffy_stage st = paffy_stage_trim_ends(end_bases_to_trim);
+    paffy_stage st = paffy_stage_trim_ends(end_bases_to_trim);
+    st.kind |= PAFFY_NO_CHECK;
     transform(paf, &st, 1, NULL, NULL);
 }
 
 void paf_trim_end_fraction(Paf *paf, float percentage) { /* impl/paf.c:586-598 */
-    const paffy_stage st = {PAFFY_TRIM_FIXED, 0.0f, percentage};
+    const paffy_stage st = {PAFFY_TRIM_FIXED | PAFFY_NO_CHECK, 0.0f, percentage};
     transform(paf, &st, 1, NULL, NULL);
 }
 
 void paf_trim_unreliable_tails(Paf *paf, float score_fraction, float max_fraction_to_trim) { /* impl/paf.c:929-953 */
-    const paffy_stage st = {PAFFY_TRIM_IDENTITY, score_fraction, max_fraction_to_trim};
+    const paffy_stage st = {PAFFY_TRIM_IDENTITY | PAFFY_NO_CHECK, score_fraction, max_fraction_to_trim};
     transform(paf, &st, 1, NULL, NULL);
 }
 
 void paf_remove_mismatches(Paf *paf) { /* impl/paf.c:786-809 */
-    const paffy_stage st = {PAFFY_REMOVE_MISMATCHES, 0.0f, 0.0f};
+    const paffy_stage st = {PAFFY_REMOVE_MISMATCHES | PAFFY_NO_CHECK, 0.0f, 0.0f};
     transform(paf, &st, 1, NULL, NULL);
 }
 
-void paf_encode_mismatches(Paf *paf, char *query_seq, char *target_seq) { /* impl/paf.c:739-784 */
-    const char *names[2] = {"Q", "T"}; /* stand-in names: the two strings are the record's own sequences whatever it calls them */
+/*
+ * The pair of sequences a call works on goes to the GPU under the stand-in names "Q" and "T" (the two strings are the record's own
+ * sequences whatever it calls them). Callers walk a file of alignments over the same few sequences (impl/paf_view.c:150-172), so
+ * the last pair stays loaded: it is sent again only when a pointer, a length or the sampled bytes differ.
+ */
+static uint64_t sample_of(const char *s, int64_t len) {
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)len;
+    const int64_t step = len > 4096 ? len / 4096 : 1;
+    for (int64_t i = 0; i < len; i += step) h = (h ^ (unsigned char)s[i]) * 1099511628211ull;
+    if (len > 0) h = (h ^ (unsigned char)s[len - 1]) * 1099511628211ull;
+    return h;
+}
+static void load_pair(char *query_seq, char *target_seq) {
+    static const char *last[2];
+    static int64_t last_len[2] = {-1, -1};
+    static uint64_t last_sample[2];
+    const char *names[2] = {"Q", "T"};
     const char *seqs[2] = {query_seq, target_seq};
     const int64_t lens[2] = {(int64_t)strlen(query_seq), (int64_t)strlen(target_seq)};
+    const uint64_t smp[2] = {sample_of(query_seq, lens[0]), sample_of(target_seq, lens[1])};
+    if (last[0] == seqs[0] && last[1] == seqs[1] && last_len[0] == lens[0] && last_len[1] == lens[1] && last_sample[0] == smp[0] &&
+        last_sample[1] == smp[1])
+        return;
+    paffy_hip_keep_raw_sequences(ctx(), 1); /* paf_pretty_print shows the bases in their own case */
     if (paffy_hip_set_sequences(ctx(), 2, names, seqs, lens)) die("paffy_hip_set_sequences", paffy_hip_last_error(ctx()));
-    const paffy_stage st = {PAFFY_ADD_MISMATCHES, 0.0f, 0.0f};
+    for (int k = 0; k < 2; k++) {
+        last[k] = seqs[k];
+        last_len[k] = lens[k];
+        last_sample[k] = smp[k];
+    }
+}
+
+void paf_encode_mismatches(Paf *paf, char *query_seq, char *target_seq) { /* impl/paf.c:739-784 */
+    load_pair(query_seq, target_seq);
+    const paffy_stage st = {PAFFY_ADD_MISMATCHES | PAFFY_NO_CHECK, 0.0f, 0.0f};
     transform(paf, &st, 1, "Q", "T");
 }
 
@@ -379,6 +421,130 @@ void paf_stats_calc(Paf *paf, int64_t *matches, int64_t *mismatches, int64_t *qu
     *query_deletes += t[3];
     *query_insert_bases += t[4];
     *query_delete_bases += t[5];
+}
+
+void paf_pretty_print(Paf *paf, char *query_seq, char *target_seq, FILE *fh, bool include_alignment) { /* impl/paf.c:269-316 */
+    int64_t t[6] = {0, 0, 0, 0, 0, 0};
+    void *d_in = NULL;
+    Buf b = {0};
+    if (paf->cigar) { /* cigar_count(NULL) == 0: all sums zero, no rows */
+        if (include_alignment) load_pair(query_seq, target_seq);
+        hand_over(&b, paf, include_alignment ? "Q" : NULL, include_alignment ? "T" : NULL);
+        const paffy_stage st = {PAFFY_STATS, 0.0f, 0.0f};
+        paffy_plan_info info;
+        if (paffy_hip_malloc(&d_in, (int64_t)b.n + 64) || paffy_hip_memcpy_h2d(d_in, b.p, (int64_t)b.n) || paffy_hip_plan(ctx(), &st, 1, d_in, (int64_t)b.n, &info) ||
+            paffy_hip_plan_stats(ctx(), t))
+            die("paf_pretty_print on MI355X", paffy_hip_last_error(ctx()));
+        if (info.error.code) record_failure(&info);
+    }
+    fprintf(fh, "Query:%s\tQ-start:%" PRIi64 "\tQ-length:%" PRIi64 "\tTarget:%s\tT-start:%" PRIi64 "\tT-length:%" PRIi64
+                "\tSame-strand:%i\tScore:%" PRIi64 "\tIdentity:%f\tIdentity-with-gaps%f\tAligned-bases:%" PRIi64 "\tQuery-inserts:%" PRIi64
+                "\tQuery-deletes:%" PRIi64 "\n",
+            paf->query_name, paf->query_start, paf->query_end - paf->query_start, paf->target_name, paf->target_start,
+            paf->target_end - paf->target_start, (int)paf->same_strand, paf->score, (float)t[0] / (t[0] + t[1]),
+            (float)t[0] / (t[0] + t[1] + t[4] + t[5]), t[0] + t[1], t[2], t[3]);
+    if (include_alignment && paf->cigar) { /* the three rows per 150 columns are written by the GPU (csrc/pretty_kernel.h) */
+        int64_t off[2] = {0, 0};
+        if (paffy_hip_plan_alignment_sizes(ctx(), 0, 1, &off[1])) die("paf_pretty_print on MI355X", paffy_hip_last_error(ctx()));
+        char *rows = malloc((size_t)off[1] + 1);
+        paffy_error e;
+        if (!rows || paffy_hip_plan_alignment_rows(ctx(), 0, 1, off, rows, &e)) die("paf_pretty_print on MI355X", paffy_hip_last_error(ctx()));
+        if (e.code) {
+            paffy_plan_info bad;
+            memset(&bad, 0, sizeof(bad));
+            bad.error = e;
+            record_failure(&bad);
+        }
+        fwrite(rows, 1, (size_t)off[1], fh);
+        free(rows);
+    }
+    if (d_in) paffy_hip_free(d_in);
+    free(b.p);
+}
+
+/* ---- coverage counters per sequence: what paf_tile and paf_to_bed keep (impl/paf.c:667-712) ---- */
+
+void sequenceCountArray_destruct(SequenceCountArray *seq_count_array) { /* impl/paf.c:669-673 */
+    free(seq_count_array->name);
+    free(seq_count_array->counts);
+    free(seq_count_array);
+}
+
+SequenceCountArray *get_alignment_count_array_in(SequenceCountArray ***arrays, int64_t *n_arrays, Paf *paf) { /* impl/paf.c:675-689 over a plain array */
+    for (int64_t i = 0; i < *n_arrays; i++)
+        if (strcmp((*arrays)[i]->name, paf->query_name) == 0) {
+            if ((*arrays)[i]->length != paf->query_length) { /* the reference asserts that a name means one length */
+                fprintf(stderr, "get_alignment_count_array: sequence %s seen with two lengths\n", paf->query_name);
+                abort();
+            }
+            return (*arrays)[i];
+        }
+    SequenceCountArray *a = calloc(1, sizeof(SequenceCountArray));
+    if (!a) die("out of memory", NULL);
+    a->name = dup_slice(paf->query_name, 0, (uint32_t)strlen(paf->query_name));
+    a->length = paf->query_length;
+    a->counts = calloc(paf->query_length > 0 ? (size_t)paf->query_length : 1, sizeof(uint16_t));
+    *arrays = realloc(*arrays, sizeof(SequenceCountArray *) * (size_t)(*n_arrays + 1));
+    if (!a->counts || !*arrays) die("out of memory", NULL);
+    (*arrays)[(*n_arrays)++] = a;
+    return a;
+}
+
+/*
+ * impl/paf.c:691-712. The record goes through the coverage engine of `paffy to_bed` (csrc/coverage_kernel.h: cigar walk, one
+ * counter per query base, the same range checks) as a batch of one, and the engine's counters of [query_start, query_end) are added
+ * to the caller's on the GPU, stopping at INT16_MAX - 1 like the reference's increments.
+ */
+void increase_alignment_level_counts(SequenceCountArray *seq_count_array, Paf *paf) {
+    if (paf->query_length > seq_count_array->length) { /* assert(i + j < seq_count_array->length) */
+        fprintf(stderr, "increase_alignment_level_counts: the record's query is longer than the count array\n");
+        abort();
+    }
+    Buf b = {0};
+    hand_over(&b, paf, NULL, NULL);
+    const paffy_bed_opts opts = {0, 0, 0, 0, 1};
+    paffy_plan_info info;
+    void *d_in = NULL;
+    if (paffy_hip_malloc(&d_in, (int64_t)b.n + 64) || paffy_hip_memcpy_h2d(d_in, b.p, (int64_t)b.n) || paffy_hip_bed_plan(ctx(), d_in, (int64_t)b.n, &opts, &info))
+        die("increase_alignment_level_counts on MI355X", paffy_hip_last_error(ctx()));
+    if (info.error.code) record_failure(&info);
+    if (paf->query_end > paf->query_start &&
+        paffy_hip_bed_counts(ctx(), 0, paf->query_start, paf->query_end, seq_count_array->counts + paf->query_start, 1))
+        die("increase_alignment_level_counts on MI355X", paffy_hip_last_error(ctx()));
+    paffy_hip_free(d_in);
+    free(b.p);
+}
+
+/* ---- intervals of `paffy to_bed`-style fasta headers (impl/paf.c:714-737) ---- */
+
+void interval_destruct(Interval *interval) {
+    free(interval->name);
+    free(interval);
+}
+
+/*
+ * "name parts | length | start" -> Interval. fastaDecodeHeader / fastaEncodeHeader are sonLib's (absent here): the header is cut at
+ * every '|', the last token is the start, the one before it the length, what is left is joined with '|' again.
+ */
+Interval *decode_fasta_header(char *fasta_header) {
+    Interval *iv = calloc(1, sizeof(Interval));
+    if (!iv) die("out of memory", NULL);
+    size_t len = strlen(fasta_header);
+    const char *cut[2] = {NULL, NULL}; /* the last two '|' */
+    for (size_t i = len; i > 0 && !cut[1]; i--)
+        if (fasta_header[i - 1] == '|') cut[cut[0] ? 1 : 0] = fasta_header + i - 1;
+    if (!cut[1] || sscanf(cut[0] + 1, "%" SCNi64, &iv->start) != 1 || sscanf(cut[1] + 1, "%" SCNi64, &iv->length) != 1) {
+        fprintf(stderr, "decode_fasta_header: %s does not end in |length|start\n", fasta_header);
+        abort(); /* the reference's asserts */
+    }
+    iv->name = dup_slice(fasta_header, 0, (uint32_t)(cut[1] - fasta_header));
+    return iv;
+}
+
+int cmp_intervals(const void *i, const void *j) {
+    const Interval *x = (const Interval *)i, *y = (const Interval *)j;
+    int k = strcmp(x->name, y->name);
+    return k == 0 ? (x->start < y->start ? -1 : (x->start > y->start ? 1 : 0)) : k;
 }
 
 /* ---- whole files and lists: one batch per call ---- */

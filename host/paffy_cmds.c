@@ -387,7 +387,7 @@ int paffy_view_main(int argc, char *argv[]) {
             case 'v': min_aligned = atoi(optarg); break;
             case 'h':
             default:
-                fprintf(stderr, "paffy view [fasta_files]xN [options], MI355X build\nAlignment stats per record and overall (-s); the base-level print (-a) is not in this build\n");
+                fprintf(stderr, "paffy view [fasta_files]xN [options], MI355X build\nAlignment stats per record and overall (-s)\n-a --includeAlignment : print the base-level alignment under each stats line\n");
                 fprintf(stderr, "-i --inputFile : PAF file to read (default: stdin)\n-o --outputFile : file to write (default: stdout)\n");
                 fprintf(stderr, "-s --printAggregateStats : print overall stats at the end\n-t --noPerAlignmentStats : no stats per alignment\n");
                 fprintf(stderr, "-u --errorIfIdentityLowerThanX : assert the average identity is >= X\n-v --errorIfAlignedBasesLowerThanX : assert the aligned bases are >= X\n");
@@ -399,10 +399,6 @@ int paffy_view_main(int argc, char *argv[]) {
         fprintf(stderr, "Expected at least one sequence file\n");
         exit(1);
     }
-    if (include_alignment) {
-        fprintf(stderr, "paffy view -a (the base-level alignment print) is outside the scope of this build (hot path only)\n");
-        return 1;
-    }
     host_set_log_level(o.log_level);
     fasta_set f;
     memset(&f, 0, sizeof(f));
@@ -413,7 +409,9 @@ int paffy_view_main(int argc, char *argv[]) {
             return 1;
         }
     }
+    host_keep_raw_sequences(include_alignment); /* the rows show the bases in the case of the files */
     host_set_sequences((const char *const *)f.names, (const char *const *)f.seqs, f.lens, f.n);
+    host_set_alignment_rows(include_alignment && per_alignment); /* impl/paf_view.c:158-160: paf_pretty_print runs unless -t */
     const paffy_stage st[2] = {{PAFFY_ADD_MISMATCHES, 0.05f, 1.0f}, {PAFFY_STATS, 0.0f, 0.0f}};
     host_set_stats(1);
     FILE *in = o.in_path ? fopen(o.in_path, "r") : stdin;

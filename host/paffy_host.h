@@ -55,5 +55,8 @@ int host_split_file(FILE *in, const char *prefix, int by_query, int64_t min_leng
 
 /* Sequences handed to the context that host_stream creates (add_mismatches); pointers must stay valid. */
 void host_set_sequences(const char *const *names, const char *const *seqs, const int64_t *lens, int64_t n);
+/* paffy view -a: keep the bases as loaded beside the upper-cased store (before host_stream), and print the rows under each stats line */
+void host_keep_raw_sequences(int on);
+void host_set_alignment_rows(int on);
 
 #endif

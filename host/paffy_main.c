@@ -32,7 +32,7 @@ static const struct {
     {"trim", paffy_trim_main, "Slice off lower identity tails"},
     {"upconvert", NULL, "Convert coordinates to extracted subsequences (not in this build)"},
     {"split_file", paffy_split_file_main, "Split a PAF file per contig"},
-    {"view", paffy_view_main, "Alignment stats per record and overall (-a, the base-level print, is not in this build)"},
+    {"view", paffy_view_main, "Alignment stats per record and overall, with -a the base-level alignments"},
 };
 
 static void usage(void) {

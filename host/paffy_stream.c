@@ -24,6 +24,9 @@ void host_set_sequences(const char *const *names, const char *const *seqs, const
     g_seq_n = n;
 }
 
+static int g_keep_raw = 0;
+void host_keep_raw_sequences(int on) { g_keep_raw = on; }
+
 void host_set_log_level(const char *s) {
     g_log_level = 0;
     if (!s) return;
@@ -109,38 +112,85 @@ void host_get_stats(int64_t sums[6], int64_t *n_records) {
 static FILE *g_stats_lines = NULL; /* paffy view without -t: one paf_pretty_print stats line per record goes here */
 void host_set_stats_lines(FILE *fh) { g_stats_lines = fh; }
 
-/* the per-alignment line of paf_pretty_print (impl/paf.c:269-281): the six sums come from the GPU, the fields from the GPU's parse */
-static int stats_lines(paffy_hip_ctx *ctx, const char *buf, int64_t len, int64_t n_records) {
+static int g_alignment_rows = 0; /* paffy view -a: the base-level rows under every stats line */
+void host_set_alignment_rows(int on) { g_alignment_rows = on; }
+
+/*
+ * paf_pretty_print per record (impl/paf.c:269-315): the stats line -- the six sums come from the GPU's PAFFY_STATS stage, the
+ * fields from the GPU's parse -- and under -a the base-level rows, written by the GPU (paffy_hip_plan_alignment_rows) and fetched
+ * in pieces of at most 128 MiB.
+ */
+static int stats_lines(paffy_hip_ctx *ctx, const char *buf, const paffy_record *recs, int64_t n_records, int64_t record_base) {
     int64_t *t = (int64_t *)malloc(sizeof(int64_t) * 6 * (size_t)(n_records > 0 ? n_records : 1));
-    int64_t got = paffy_hip_plan_record_stats(ctx, n_records, t);
-    paffy_record *recs = NULL;
-    uint64_t *ops = NULL;
-    int64_t n_ops = 0;
-    paffy_plan_info pi;
-    int rc = got == n_records ? paffy_hip_parse_host(ctx, buf, len, &recs, &ops, &n_ops, &pi) : PAFFY_E_STATE;
-    if (!rc && pi.error.code == 0 && pi.n_records == n_records) {
-        for (int64_t r = 0; r < n_records; r++) {
-            const paffy_record *p = &recs[r];
-            const int64_t *s = t + 6 * r; /* matches, mismatches, inserts, deletes, insert bases, delete bases */
-            fprintf(g_stats_lines, "Query:%.*s\tQ-start:%" PRIi64 "\tQ-length:%" PRIi64 "\tTarget:%.*s\tT-start:%" PRIi64 "\tT-length:%" PRIi64
-                    "\tSame-strand:%i\tScore:%" PRIi64 "\tIdentity:%f\tIdentity-with-gaps%f\tAligned-bases:%" PRIi64 "\tQuery-inserts:%" PRIi64
-                    "\tQuery-deletes:%" PRIi64 "\n",
-                    (int)p->query_name_len, buf + p->query_name_off, p->query_start, p->query_end - p->query_start, (int)p->target_name_len,
-                    buf + p->target_name_off, p->target_start, p->target_end - p->target_start, (int)p->same_strand, p->score,
-                    (float)s[0] / (s[0] + s[1]), (float)s[0] / (s[0] + s[1] + s[4] + s[5]), s[0] + s[1], s[2], s[3]);
+    int64_t *off = NULL;
+    char *rows = NULL;
+    int64_t rows_first = 0, rows_end = 0; /* records [rows_first, rows_end) are in `rows` */
+    int rc = paffy_hip_plan_record_stats(ctx, n_records, t) == n_records ? 0 : PAFFY_E_STATE;
+    if (!rc && g_alignment_rows) {
+        off = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_records + 1));
+        rc = paffy_hip_plan_alignment_sizes(ctx, 0, n_records, off);
+        if (!rc) { /* sizes -> running sums */
+            int64_t at = 0;
+            for (int64_t r = 0; r < n_records; r++) {
+                int64_t b = off[r];
+                off[r] = at;
+                at += b;
+            }
+            off[n_records] = at;
         }
-    } else if (!rc) {
-        rc = PAFFY_E_STATE;
     }
-    free(recs);
-    free(ops);
+    for (int64_t r = 0; r < n_records && !rc; r++) {
+        const paffy_record *p = &recs[r];
+        const int64_t *s = t + 6 * r; /* matches, mismatches, inserts, deletes, insert bases, delete bases */
+        fprintf(g_stats_lines, "Query:%.*s\tQ-start:%" PRIi64 "\tQ-length:%" PRIi64 "\tTarget:%.*s\tT-start:%" PRIi64 "\tT-length:%" PRIi64
+                "\tSame-strand:%i\tScore:%" PRIi64 "\tIdentity:%f\tIdentity-with-gaps%f\tAligned-bases:%" PRIi64 "\tQuery-inserts:%" PRIi64
+                "\tQuery-deletes:%" PRIi64 "\n",
+                (int)p->query_name_len, buf + p->query_name_off, p->query_start, p->query_end - p->query_start, (int)p->target_name_len,
+                buf + p->target_name_off, p->target_start, p->target_end - p->target_start, (int)p->same_strand, p->score,
+                (float)s[0] / (s[0] + s[1]), (float)s[0] / (s[0] + s[1] + s[4] + s[5]), s[0] + s[1], s[2], s[3]);
+        if (!g_alignment_rows) continue;
+        if (r >= rows_end) { /* the next piece: as many records as fit 128 MiB (at least one) */
+            rows_first = r;
+            rows_end = r + 1;
+            while (rows_end < n_records && off[rows_end + 1] - off[rows_first] <= ((int64_t)128 << 20)) rows_end++;
+            free(rows);
+            rows = (char *)malloc((size_t)(off[rows_end] - off[rows_first]) + 1);
+            paffy_error e;
+            rc = paffy_hip_plan_alignment_rows(ctx, rows_first, rows_end - rows_first, off + rows_first, rows, &e);
+            if (!rc && e.code) {
+                fflush(g_stats_lines);
+                e.record += rows_first;
+                die_like_reference(&e, record_base);
+            }
+            if (rc) break;
+        }
+        fwrite(rows + (off[r] - off[rows_first]), 1, (size_t)(off[r + 1] - off[r]), g_stats_lines);
+    }
+    free(rows);
+    free(off);
     free(t);
     return rc;
 }
 
-static int stats_chunk(paffy_hip_ctx *ctx, const paffy_stage *stages, int n_stages, const char *buf, int64_t len, paffy_plan_info *info) {
+static int stats_chunk(paffy_hip_ctx *ctx, const paffy_stage *stages, int n_stages, const char *buf, int64_t len, int64_t record_base,
+                       paffy_plan_info *info) {
+    /* the fields of the stats lines first: parsing is a plan of its own and the stage plan must be the current one afterwards */
+    paffy_record *recs = NULL;
+    uint64_t *ops = NULL;
+    int64_t n_ops = 0;
+    if (g_stats_lines) {
+        int rc0 = paffy_hip_parse_host(ctx, buf, len, &recs, &ops, &n_ops, info);
+        free(ops);
+        if (rc0 || info->error.code) {
+            free(recs);
+            return rc0;
+        }
+    }
     void *d_in = NULL;
-    if (paffy_hip_malloc(&d_in, len + 64) != 0) return PAFFY_E_HIP;
+    if (paffy_hip_malloc(&d_in, len + 64) != 0) {
+        free(recs);
+        return PAFFY_E_HIP;
+    }
     int rc = paffy_hip_memcpy_h2d(d_in, buf, len);
     if (!rc) rc = paffy_hip_plan(ctx, stages, n_stages, d_in, len, info);
     int64_t sums[6];
@@ -148,9 +198,10 @@ static int stats_chunk(paffy_hip_ctx *ctx, const paffy_stage *stages, int n_stag
     if (!rc && info->error.code == 0) {
         for (int k = 0; k < 6; k++) g_stats[k] += sums[k];
         g_stats_records += info->n_records;
-        if (g_stats_lines) rc = stats_lines(ctx, buf, len, info->n_records);
+        if (g_stats_lines) rc = stats_lines(ctx, buf, recs, info->n_records, record_base);
     }
     paffy_hip_free(d_in);
+    free(recs);
     return rc;
 }
 
@@ -243,6 +294,7 @@ int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out) {
         return 1;
     }
     paffy_hip_set_filter(ctx, &g_filter);
+    if (g_keep_raw) paffy_hip_keep_raw_sequences(ctx, 1);
     if (g_seq_n > 0 && paffy_hip_set_sequences(ctx, g_seq_n, g_seq_names, g_seq_data, g_seq_lens) != 0) {
         fprintf(stderr, "paffy: could not load the sequences onto the GPU: %s\n", paffy_hip_last_error(ctx));
         return 1;
@@ -278,7 +330,7 @@ int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out) {
         char *h_out = NULL;
         int64_t out_len = 0;
         paffy_plan_info info;
-        int r = g_dedupe_mode ? dedupe_chunk(ctx, buf, (int64_t)use, &h_out, &out_len, &info) : stats_chunk(ctx, stages, n_stages, buf, (int64_t)use, &info);
+        int r = g_dedupe_mode ? dedupe_chunk(ctx, buf, (int64_t)use, &h_out, &out_len, &info) : stats_chunk(ctx, stages, n_stages, buf, (int64_t)use, records_done, &info);
         if (r != 0) {
             fprintf(stderr, "paffy: GPU call failed (%d): %s\n", r, paffy_hip_last_error(ctx));
             rc = 1;

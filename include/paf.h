@@ -13,11 +13,9 @@
  *    that expose sonLib containers (read_pafs, write_pafs, paf_chain, paf_shatter, get_alignment_count_array) are declared
  *    only when PAFFY_WITH_SONLIB is defined before including this file; sonLib-free equivalents over plain arrays are
  *    always available (read_pafs_array, write_pafs_array, paf_shatter_array).
- *  - the transforms validate the record like the command loops do (paf_check after the transform,
- *    impl/paf_invert.c:84-89): a record the reference would reject at its next paf_check is rejected here at once.
+ *    (get_alignment_count_array_in keeps the count arrays in a plain array instead of a stHash.)
  *  - errors end the process the way st_errAbort / assert do in the reference (message on stderr, exit 1 or abort()).
- *  - outside the hot path and not provided: paf_pretty_print, paf_chain, the SequenceCountArray helpers (`paffy tile` runs
- *    as one batch call, paffy_hip_tile_plan), decode_fasta_header / cmp_intervals / interval_destruct.
+ *  - like the reference's, the transforms validate nothing: paf_check is the call that does (impl/paf.c:427-461).
  */
 #ifndef ST_PAF_H_
 #define ST_PAF_H_
@@ -87,6 +85,7 @@ Paf *paf_read_with_buffer(FILE *fh, bool parse_cigar_string, char **paf_buffer, 
 char *paf_print(Paf *paf);                                           /* inc/paf.h:140 */
 void paf_stats_calc(Paf *paf, int64_t *matches, int64_t *mismatches, int64_t *query_inserts, int64_t *query_deletes,
                     int64_t *query_insert_bases, int64_t *query_delete_bases, bool zero_counts); /* inc/paf.h:145 */
+void paf_pretty_print(Paf *paf, char *query_seq, char *target_seq, FILE *fh, bool include_alignment); /* inc/paf.h:151 */
 void paf_write(Paf *paf, FILE *fh);                                  /* inc/paf.h:156 */
 void paf_write_with_buffer(Paf *paf, FILE *fh, char **paf_buffer, int64_t *paf_length_buffer); /* inc/paf.h:161 */
 void paf_check(Paf *paf);                                            /* inc/paf.h:167 */
@@ -103,6 +102,24 @@ void paf_trim_unreliable_tails(Paf *paf, float score_fraction, float max_fractio
 Paf **read_pafs_array(FILE *paf_file, bool parse_cigar_string, int64_t *n_pafs);
 void write_pafs_array(FILE *paf_file, Paf **pafs, int64_t n_pafs);
 Paf **paf_shatter_array(Paf *paf, int64_t *n_pafs);
+
+typedef struct _sequenceCountArray { /* inc/paf.h:214-218: alignment coverage along a sequence */
+    char *name;
+    int64_t length;
+    uint16_t *counts; /* one per base */
+} SequenceCountArray;
+void sequenceCountArray_destruct(SequenceCountArray *seq_count_array);                    /* inc/paf.h:223 */
+void increase_alignment_level_counts(SequenceCountArray *seq_count_array, Paf *paf);      /* inc/paf.h:233 */
+/* get_alignment_count_array (inc/paf.h:228) over a plain array of count arrays (*arrays grows by realloc) instead of a stHash */
+SequenceCountArray *get_alignment_count_array_in(SequenceCountArray ***arrays, int64_t *n_arrays, Paf *paf);
+
+typedef struct _interval { /* inc/paf.h:235-238 */
+    char *name;
+    int64_t start, end, length;
+} Interval;
+void interval_destruct(Interval *interval);       /* inc/paf.h:243 */
+Interval *decode_fasta_header(char *fasta_header); /* inc/paf.h:248 */
+int cmp_intervals(const void *i, const void *j);  /* inc/paf.h:253 */
 
 #ifdef PAFFY_WITH_SONLIB /* needs sonLib's stList at compile and link time */
 stList *read_pafs(FILE *paf_file, bool parse_cigar_string);

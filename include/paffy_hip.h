@@ -39,9 +39,13 @@ enum {
     PAFFY_FILTER = 8,            /* impl/paf_filter.c:120-156: records failing the thresholds of paffy_hip_set_filter vanish */
     PAFFY_STATS = 10,            /* paf_stats_calc(.., zero_counts = 0) of every record into the plan's running sums (the aggregate of
                                     `paffy view -s`, impl/paf_view.c:163-168); the record passes on unchanged. See paffy_hip_plan_stats() */
-    PAFFY_TRIM_ENDS = 9          /* paf_trim_ends(paf, n), impl/paf.c:575-598: n aligned bases off each end; n = the 64 bits of (p0, p1),
+    PAFFY_TRIM_ENDS = 9,         /* paf_trim_ends(paf, n), impl/paf.c:575-598: n aligned bases off each end; n = the 64 bits of (p0, p1),
                                     see paffy_stage_trim_ends(); then paf_check like the other trims */
+    PAFFY_CHECK = 11             /* paf_check alone (impl/paf.c:427-461): the record passes on unchanged or fails */
 };
+/* OR-ed into a transform's kind: without the paf_check that the command loops run after it (impl/paf_invert.c:84-89) -- what the
+ * library functions of inc/paf.h do (paf_invert, paf_trim_ends ... check nothing, impl/paf.c:463-598) */
+#define PAFFY_NO_CHECK 0x100
 #define PAFFY_MAX_STAGES 8
 
 typedef struct {
@@ -203,6 +207,14 @@ int paffy_hip_bed_plan(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len, con
 int paffy_hip_bed_begin(paffy_hip_ctx *ctx, const paffy_bed_opts *opts);
 int paffy_hip_bed_add(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len);
 int paffy_hip_bed_run(paffy_hip_ctx *ctx, const paffy_bed_opts *opts, paffy_plan_info *info);
+/*
+ * After a bed run: the per-base counters themselves (what get_alignment_count_array / increase_alignment_level_counts keep per
+ * sequence, impl/paf.c:667-712). _sequences = how many sequences the run saw; they are numbered in order of first appearance.
+ * _counts copies counters [start, end) of one of them to h_counts; with accumulate != 0 it adds them to the values already in
+ * h_counts instead, on the GPU, stopping at INT16_MAX - 1 as the reference's increments do (impl/paf.c:701).
+ */
+int64_t paffy_hip_bed_sequences(paffy_hip_ctx *ctx);
+int paffy_hip_bed_counts(paffy_hip_ctx *ctx, int64_t sequence, int64_t start, int64_t end, uint16_t *h_counts, int accumulate);
 
 /*
  * After a tile or dedupe plan: the lines emit will write, in output order -- record[k] = zero-based input record of line k,
@@ -248,6 +260,20 @@ int paffy_hip_plan_stats(paffy_hip_ctx *ctx, int64_t sums[6]);
 /* The same six sums for every record of the batch (6 * n_records values, record by record): the numbers of the per-alignment line of
  * `paffy view` (paf_pretty_print, impl/paf.c:269-281). Returns n_records or a negative error. */
 int64_t paffy_hip_plan_record_stats(paffy_hip_ctx *ctx, int64_t cap_records, int64_t *sums);
+
+/*
+ * The base-level rows of paf_pretty_print(..., include_alignment = true) (impl/paf.c:283-315; `paffy view -a`, impl/paf_view.c:158-160)
+ * for records [first, first + count) of the planned batch, as the plan's stages left them: per window of 150 columns the target
+ * row, the query row ('-' strand: read backwards and complemented) and the row of '*' under agreeing columns. The bases are shown
+ * in the case they were loaded in, so the sequences must have been set after paffy_hip_keep_raw_sequences(ctx, 1).
+ * _sizes gives the bytes of each record's block (0: no cigar); _rows writes the blocks to h_out at h_off[i] - h_off[0] (h_off:
+ * count + 1 running sums of the sizes, so that a batch can be fetched in pieces). A record whose sequences are missing or shorter
+ * than its coordinates (the reference reads outside the strings) is reported in *err (stage -1) and h_out is then not complete.
+ * The batch text must still be in place (names are looked up in it when the plan had no PAFFY_ADD_MISMATCHES stage).
+ */
+int paffy_hip_keep_raw_sequences(paffy_hip_ctx *ctx, int on);
+int paffy_hip_plan_alignment_sizes(paffy_hip_ctx *ctx, int64_t first, int64_t count, int64_t *h_bytes);
+int paffy_hip_plan_alignment_rows(paffy_hip_ctx *ctx, int64_t first, int64_t count, const int64_t *h_off, char *h_out, paffy_error *err);
 
 /*
  * Records as structs, for hosts that hold `Paf` objects (the per-record API of inc/paf.h:75-269, host/paf_api.c): the text is

@@ -11,6 +11,7 @@
  */
 #include "paf_oracle.h"
 
+#include <inttypes.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1213,6 +1214,73 @@ int po_trim_ends_line(const char *line, int64_t line_len, int64_t end_bases, cha
     obuf b = {0, 0, 0};
     if (!rc) rc = trim_ends(&r, end_bases);
     if (!rc) write_rec(&r, &b);
+    rec_free(&r);
+    *out = b.p;
+    *out_len = b.n;
+    return rc;
+}
+
+/*
+ * paf_pretty_print, impl/paf.c:262-316, of one PAF line (already carrying the cigar to show: `paffy view` encodes the mismatches
+ * first, impl/paf_view.c:167). The stats line is formatted with the reference's own float expression; with include_alignment the
+ * three rows per 150 columns follow. Sequences are NUL-terminated strings as the reference holds them.
+ */
+int po_pretty_print(const char *line, int64_t line_len, const char *query_seq, const char *target_seq, int include_alignment, char **out,
+                    int64_t *out_len) {
+    rec r; int64_t aux = 0;
+    const char *e = line + line_len;
+    if (line_len && e[-1] == '\n') e--;
+    int rc = parse_line(line, e, 1, &r, &aux);
+    obuf b = {0, 0, 0};
+    if (!rc) {
+        int64_t s[6] = {0, 0, 0, 0, 0, 0};
+        for (int64_t i = 0; r.has_cigar && i < r.n; i++) { /* paf_stats_calc, impl/paf.c:236-260 */
+            const oop *o = &r.ops[r.lo + i];
+            if (o->op == OP_EQ || o->op == OP_M) s[0] += o->len;
+            else if (o->op == OP_X) s[1] += o->len;
+            else if (o->op == OP_I) { s[2]++; s[4] += o->len; }
+            else { s[3]++; s[5] += o->len; }
+        }
+        int need = snprintf(NULL, 0, "Query:%.*s\tQ-start:%" PRIi64 "\tQ-length:%" PRIi64 "\tTarget:%.*s\tT-start:%" PRIi64 "\tT-length:%" PRIi64
+                            "\tSame-strand:%i\tScore:%" PRIi64 "\tIdentity:%f\tIdentity-with-gaps%f\tAligned-bases:%" PRIi64 "\tQuery-inserts:%" PRIi64
+                            "\tQuery-deletes:%" PRIi64 "\n",
+                            (int)r.qname_len, r.qname, r.qs, r.qe - r.qs, (int)r.tname_len, r.tname, r.ts, r.te - r.ts, r.same_strand, r.score,
+                            (float)s[0] / (s[0] + s[1]), (float)s[0] / (s[0] + s[1] + s[4] + s[5]), s[0] + s[1], s[2], s[3]);
+        ob_need(&b, need + 1);
+        snprintf(b.p + b.n, (size_t)need + 1, "Query:%.*s\tQ-start:%" PRIi64 "\tQ-length:%" PRIi64 "\tTarget:%.*s\tT-start:%" PRIi64 "\tT-length:%" PRIi64
+                 "\tSame-strand:%i\tScore:%" PRIi64 "\tIdentity:%f\tIdentity-with-gaps%f\tAligned-bases:%" PRIi64 "\tQuery-inserts:%" PRIi64
+                 "\tQuery-deletes:%" PRIi64 "\n",
+                 (int)r.qname_len, r.qname, r.qs, r.qe - r.qs, (int)r.tname_len, r.tname, r.ts, r.te - r.ts, r.same_strand, r.score,
+                 (float)s[0] / (s[0] + s[1]), (float)s[0] / (s[0] + s[1] + s[4] + s[5]), s[0] + s[1], s[2], s[3]);
+        b.n += need;
+        if (include_alignment) { /* impl/paf.c:283-315 */
+            int64_t max_len = r.qe - r.qs + r.te - r.ts;
+            char *qa = (char *)malloc((size_t)max_len + 1), *ta = (char *)malloc((size_t)max_len + 1), *sa = (char *)malloc((size_t)max_len + 1);
+            int64_t i = 0, j = r.ts, k = 0;
+            for (int64_t ci = 0; r.has_cigar && ci < r.n; ci++) {
+                const oop *o = &r.ops[r.lo + ci];
+                for (int64_t l = 0; l < o->len; l++) {
+                    char m = '-', n = '-';
+                    if (o->op != OP_I) m = target_seq[j++];
+                    if (o->op != OP_D) {
+                        if (r.same_strand) n = query_seq[r.qs + i++];
+                        else n = rc_char(query_seq[r.qe - (++i)]);
+                    }
+                    ta[k] = m;
+                    qa[k] = n;
+                    sa[k++] = up(m) == up(n) ? '*' : ' ';
+                }
+            }
+            const int64_t window = 150;
+            for (int64_t l = 0; l < k; l += window) {
+                int64_t hi = l + window < k ? l + window : k;
+                ob_bytes(&b, ta + l, hi - l); ob_char(&b, '\n');
+                ob_bytes(&b, qa + l, hi - l); ob_char(&b, '\n');
+                ob_bytes(&b, sa + l, hi - l); ob_char(&b, '\n');
+            }
+            free(qa); free(ta); free(sa);
+        }
+    }
     rec_free(&r);
     *out = b.p;
     *out_len = b.n;

@@ -146,6 +146,10 @@ int64_t po_cigar_aligned_bases(const char *cigar);
 /* paf_trim_ends (impl/paf.c:578-587) on one PAF line with an explicit base count. */
 int po_trim_ends_line(const char *line, int64_t line_len, int64_t end_bases, char **out, int64_t *out_len);
 
+/* paf_pretty_print (impl/paf.c:262-316) of one line: the stats line and, with include_alignment, the base-level rows */
+int po_pretty_print(const char *line, int64_t line_len, const char *query_seq, const char *target_seq, int include_alignment, char **out,
+                    int64_t *out_len);
+
 /* Coverage counters (impl/paf.c:675-709): apply the records of a buffer in input order to
  * the counter array of query `name` (length `len`, caller zeroed); returns records applied. */
 int64_t po_coverage_counts(const char *in, int64_t in_len, const char *name, uint16_t *counts, int64_t len);

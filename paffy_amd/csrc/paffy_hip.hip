@@ -585,6 +585,9 @@ struct paffy_hip_ctx {
     DevBuf scan_part, emit_order, order_cnt, tile_keys, tile_order, tile_rank, tile_coff, tile_cbase, tile_cov, tile_level, tile_len, tile_items, tile_slots, tile_parts;
     bool plan_is_tile = false;
     bool plan_is_bed = false; /* paffy to_bed: emit writes the run lines */
+    bool keep_raw = false;    /* paffy_hip_keep_raw_sequences: seq_raw holds the bases as loaded (paf_pretty_print shows their case) */
+    bool plan_seq_lookup = false; /* rec_qseq / rec_tseq belong to the current plan */
+    DevBuf seq_raw, pretty_off, pretty_out, pretty_err;
     DevBuf rec_stats; /* six sums per record of the PAFFY_STATS stage */
     DevBuf bed_keys, bed_tab, bed_starts, bed_len, bed_off, bed_tiles;
     struct BedParams *bed_params = nullptr; /* host copy */
@@ -719,7 +722,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     cov_free(c);
     if (c->one_batch.p) (void)hipFree(c->one_batch.p);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
-                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->rec_stats, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
+                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->seq_raw, &c->pretty_off, &c->pretty_out, &c->pretty_err, &c->rec_stats, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
                       &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts, &c->scan_part, &c->dedupe_keys, &c->emit_order, &c->order_cnt};
     for (DevBuf *b : bufs)
@@ -796,9 +799,17 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     if (!c || !info || (n_stages > 0 && !stages) || n_stages < 0 || n_stages > PAFFY_MAX_STAGES) return PAFFY_E_ARG;
     if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
     bool need_seqs = false;
+    paffy_stage norm[PAFFY_MAX_STAGES]; /* kinds without the PAFFY_NO_CHECK flag */
+    uint32_t nocheck_mask = 0;
+    for (int32_t i = 0; i < n_stages; i++) {
+        norm[i] = stages[i];
+        if (stages[i].kind & PAFFY_NO_CHECK) nocheck_mask |= 1u << i;
+        norm[i].kind = stages[i].kind & ~PAFFY_NO_CHECK;
+    }
+    stages = norm;
     for (int32_t i = 0; i < n_stages; i++) {
         int k = stages[i].kind;
-        bool ok = k == PAFFY_INVERT || k == PAFFY_TRIM_IDENTITY || k == PAFFY_TRIM_FIXED || k == PAFFY_TRIM_ENDS || k == PAFFY_PASS || k == PAFFY_FILTER || k == PAFFY_STATS ||
+        bool ok = k == PAFFY_CHECK || k == PAFFY_INVERT || k == PAFFY_TRIM_IDENTITY || k == PAFFY_TRIM_FIXED || k == PAFFY_TRIM_ENDS || k == PAFFY_PASS || k == PAFFY_FILTER || k == PAFFY_STATS ||
                   k == PAFFY_REMOVE_MISMATCHES || (k == PAFFY_ADD_MISMATCHES && c->n_seqs > 0) ||
                   (k == PAFFY_SHATTER && i == n_stages - 1);
         if (k == PAFFY_ADD_MISMATCHES) need_seqs = true;
@@ -855,6 +866,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     kp.meta = static_cast<const RecMeta *>(c->meta.p);
     for (int32_t i = 0; i < n_stages; i++) kp.stages[i] = stages[i];
     kp.n_stages = n_stages;
+    kp.nocheck_mask = nocheck_mask;
     kp.out_len = static_cast<int64_t *>(c->out_len.p);
     kp.out_rows = static_cast<int64_t *>(c->out_rows.p);
     kp.status = static_cast<uint32_t *>(c->status.p);
@@ -863,6 +875,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     kp.arena_off = static_cast<uint64_t *>(c->arena_off.p);
     kp.rec_plan = c->rec_plan.p;
     kp.ops_mirror = static_cast<uint32_t *>(c->ops_mirror.p);
+    c->plan_seq_lookup = need_seqs && n_lines > 0;
     if (need_seqs && n_lines > 0) {
         if (ensure(c, c->rec_qseq, sizeof(int32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
         if (ensure(c, c->rec_tseq, sizeof(int32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
@@ -1024,6 +1037,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
 } /* extern "C" */
 
 #include "coverage_host.h"
+#include "pretty_kernel.h"
 
 static CovState &cov_state(paffy_hip_ctx *c) {
     if (!c->cov) c->cov = new CovState();
@@ -1870,6 +1884,123 @@ int64_t paffy_hip_plan_record_stats(paffy_hip_ctx *c, int64_t cap_records, int64
     return n;
 }
 
+/* ---- the counters of a to_bed run, for hosts that keep SequenceCountArray objects (inc/paf.h:214-233) ---- */
+__global__ __launch_bounds__(PAFFY_NT) void k_counts_add_sat(uint16_t *acc, const uint16_t *add, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = (uint32_t)acc[i] + add[i]; /* one record at a time stops at INT16_MAX - 1 (impl/paf.c:701); so does the sum */
+    acc[i] = acc[i] >= 32766 ? acc[i] : (uint16_t)(s < 32766u ? s : 32766u);
+}
+int64_t paffy_hip_bed_sequences(paffy_hip_ctx *c) {
+    if (!c) return PAFFY_E_ARG;
+    if (!c->planned || !c->plan_is_bed || !c->cov) return PAFFY_E_STATE;
+    return (int64_t)c->cov->appearance.size();
+}
+int paffy_hip_bed_counts(paffy_hip_ctx *c, int64_t sequence, int64_t start, int64_t end, uint16_t *h_counts, int accumulate) {
+    if (!c || !h_counts || sequence < 0 || start < 0 || end < start) return PAFFY_E_ARG;
+    if (!c->planned || !c->plan_is_bed || !c->cov) return PAFFY_E_STATE;
+    CovState &S = *c->cov;
+    if ((size_t)sequence >= S.appearance.size()) return PAFFY_E_ARG;
+    const uint32_t ci = S.appearance[(size_t)sequence];
+    if (end > S.h_contig_len[ci]) return PAFFY_E_ARG;
+    const uint64_t n = (uint64_t)(end - start);
+    if (n == 0) return 0;
+    const uint16_t *src = static_cast<const uint16_t *>(S.cov.p) + S.h_contig_cov[ci] + start;
+    if (!accumulate) {
+        HIPCHK(c, hipMemcpyAsync(h_counts, src, sizeof(uint16_t) * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    if (ensure(c, c->pretty_out, sizeof(uint16_t) * n + 64)) return PAFFY_E_HIP;
+    uint16_t *acc = static_cast<uint16_t *>(c->pretty_out.p);
+    HIPCHK(c, hipMemcpyAsync(acc, h_counts, sizeof(uint16_t) * n, hipMemcpyHostToDevice, c->stream));
+    LAUNCH(c, "k_counts_add_sat", k_counts_add_sat, dim3((unsigned)((n + PAFFY_NT - 1) / PAFFY_NT)), dim3(PAFFY_NT), 0, acc, src, n);
+    HIPCHK(c, hipMemcpyAsync(h_counts, acc, sizeof(uint16_t) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+/* ---- paf_pretty_print's base-level rows (pretty_kernel.h) ---- */
+int paffy_hip_keep_raw_sequences(paffy_hip_ctx *c, int on) {
+    if (!c) return PAFFY_E_ARG;
+    c->keep_raw = on != 0;
+    return 0;
+}
+
+static int pretty_params(paffy_hip_ctx *c, int64_t first, int64_t count, PrettyParams *pp) {
+    if (!c->planned || c->plan_is_tile || c->plan_is_bed) return PAFFY_E_STATE;
+    if (first < 0 || count < 0 || first + count > c->plan.n_records) return PAFFY_E_ARG;
+    if (c->n_seqs <= 0 || !c->seq_raw.p) {
+        c->last_error = "alignment rows: no sequences loaded with paffy_hip_keep_raw_sequences on";
+        return PAFFY_E_STATE;
+    }
+    const uint32_t n = c->kp.n_rec;
+    if (!c->plan_seq_lookup && n > 0) { /* a plan without the mismatch encoder did not look the names up */
+        if (ensure(c, c->rec_qseq, sizeof(int32_t) * (size_t)(n + 1))) return PAFFY_E_HIP;
+        if (ensure(c, c->rec_tseq, sizeof(int32_t) * (size_t)(n + 1))) return PAFFY_E_HIP;
+        LAUNCH(c, "k_seq_lookup", k_seq_lookup, dim3((n + PAFFY_NT - 1) / PAFFY_NT), dim3(PAFFY_NT), 0, c->kp.in, c->kp.meta, n,
+               static_cast<const uint8_t *>(c->seq_names.p), static_cast<const uint32_t *>(c->seq_name_off.p), c->n_seqs,
+               static_cast<int32_t *>(c->rec_qseq.p), static_cast<int32_t *>(c->rec_tseq.p));
+        c->plan_seq_lookup = true;
+    }
+    memset(pp, 0, sizeof(*pp));
+    pp->meta = c->kp.meta;
+    pp->plan = static_cast<const RecPlan *>(c->rec_plan.p);
+    pp->status = c->kp.status;
+    pp->arena = c->kp.arena;
+    pp->arena_off = c->kp.arena_off;
+    pp->ops_mirror = c->kp.ops_mirror;
+    pp->seq_raw = static_cast<const uint8_t *>(c->seq_raw.p);
+    pp->seqs = static_cast<const SeqEntry *>(c->seq_table.p);
+    pp->rec_qseq = static_cast<const int32_t *>(c->rec_qseq.p);
+    pp->rec_tseq = static_cast<const int32_t *>(c->rec_tseq.p);
+    pp->first = (uint32_t)first;
+    return 0;
+}
+
+int paffy_hip_plan_alignment_sizes(paffy_hip_ctx *c, int64_t first, int64_t count, int64_t *h_bytes) {
+    if (!c || (count > 0 && !h_bytes)) return PAFFY_E_ARG;
+    PrettyParams pp;
+    int rc = pretty_params(c, first, count, &pp);
+    if (rc || count == 0) return rc;
+    if (ensure(c, c->pretty_off, sizeof(int64_t) * (size_t)(count + 1))) return PAFFY_E_HIP;
+    LAUNCH(c, "k_pretty_size", k_pretty_size, dim3((unsigned)count), dim3(PRETTY_NT), 0, pp, static_cast<int64_t *>(c->pretty_off.p));
+    HIPCHK(c, hipMemcpyAsync(h_bytes, c->pretty_off.p, sizeof(int64_t) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int paffy_hip_plan_alignment_rows(paffy_hip_ctx *c, int64_t first, int64_t count, const int64_t *h_off, char *h_out, paffy_error *err) {
+    if (!c || !err || (count > 0 && (!h_off || !h_out))) return PAFFY_E_ARG;
+    memset(err, 0, sizeof(*err));
+    PrettyParams pp;
+    int rc = pretty_params(c, first, count, &pp);
+    if (rc || count == 0) return rc;
+    const int64_t total = h_off[count] - h_off[0];
+    if (total < 0) return PAFFY_E_ARG;
+    if (ensure(c, c->pretty_off, sizeof(int64_t) * (size_t)(count + 1))) return PAFFY_E_HIP;
+    if (ensure(c, c->pretty_out, (size_t)total + 64)) return PAFFY_E_HIP;
+    if (ensure(c, c->pretty_err, sizeof(unsigned long long))) return PAFFY_E_HIP;
+    std::vector<int64_t> off((size_t)count + 1);
+    for (int64_t i = 0; i <= count; i++) off[(size_t)i] = h_off[i] - h_off[0];
+    HIPCHK(c, hipMemcpyAsync(c->pretty_off.p, off.data(), sizeof(int64_t) * (size_t)(count + 1), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pretty_err.p, 0xff, sizeof(unsigned long long), c->stream));
+    pp.row_off = static_cast<const int64_t *>(c->pretty_off.p);
+    pp.out = static_cast<uint8_t *>(c->pretty_out.p);
+    pp.err = static_cast<unsigned long long *>(c->pretty_err.p);
+    LAUNCH(c, "k_pretty_rows", k_pretty_rows, dim3((unsigned)count), dim3(PRETTY_NT), 0, pp);
+    unsigned long long e = 0;
+    HIPCHK(c, hipMemcpyAsync(&e, c->pretty_err.p, sizeof(e), hipMemcpyDeviceToHost, c->stream));
+    if (total > 0) HIPCHK(c, hipMemcpyAsync(h_out, c->pretty_out.p, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (e != ~0ull) {
+        err->code = (int32_t)(e & 0xff);
+        err->record = (int64_t)(e >> 8);
+        err->stage = -1;
+    }
+    return 0;
+}
+
 int paffy_hip_parse_host(paffy_hip_ctx *c, const char *h_in, int64_t in_len, paffy_record **recs, uint64_t **ops, int64_t *n_ops_total,
                          paffy_plan_info *info) {
     if (!c || !recs || !ops || !n_ops_total || !info || in_len < 0 || (in_len > 0 && !h_in)) return PAFFY_E_ARG;
@@ -1980,6 +2111,10 @@ static int seq_store_layout(paffy_hip_ctx *c, int64_t n, const char *const *name
 /* After the bases are in seq_blob: upper-case them and build the complemented copy. */
 static int seq_store_canon(paffy_hip_ctx *c) {
     const size_t bytes = c->seq_blob.cap & ~(size_t)15; /* the whole allocation, whole 16-byte words */
+    if (c->keep_raw) {
+        if (ensure(c, c->seq_raw, c->seq_blob.cap)) return PAFFY_E_HIP;
+        HIPCHK(c, hipMemcpyAsync(c->seq_raw.p, c->seq_blob.p, c->seq_blob.cap, hipMemcpyDeviceToDevice, c->stream));
+    }
     if (ensure(c, c->seq_comp, c->seq_blob.cap)) return PAFFY_E_HIP;
     const uint64_t n16 = bytes / 16;
     if (n16) {

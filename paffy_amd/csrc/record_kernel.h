@@ -2686,24 +2686,27 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
             if (s.type == 0 && s.tile_level != -1) s.type = s.tile_level > 1 ? 'S' : 'P';
         }
         int rc = 0;
+        const bool do_check = !((P.nocheck_mask >> si) & 1u); /* the command loops check after every transform; the library calls of inc/paf.h do not */
         if (STAGE_ON(PAFFY_INVERT) && st.kind == PAFFY_INVERT) {
             invert_state(s);
             invert_view(s, v);
             swapped = !swapped;
-            rc = check_record(s, v, L.bc);
+            if (do_check) rc = check_record(s, v, L.bc);
             PT_MARK(1)
         } else if (STAGE_ON(PAFFY_TRIM_IDENTITY) && st.kind == PAFFY_TRIM_IDENTITY) {
             rc = trim_identity(s, v, st.p0, st.p1, L.bc, L.sh);
             PT_MARK(2)
-            if (!rc) rc = check_record(s, v, L.bc);
+            if (!rc && do_check) rc = check_record(s, v, L.bc);
             PT_MARK(3)
         } else if (STAGE_ON(PAFFY_TRIM_FIXED) && st.kind == PAFFY_TRIM_FIXED) {
             rc = trim_fixed(s, v, st.p1, L.bc, L.sh);
-            if (!rc) rc = check_record(s, v, L.bc);
+            if (!rc && do_check) rc = check_record(s, v, L.bc);
         } else if (STAGE_ON(PAFFY_TRIM_ENDS) && st.kind == PAFFY_TRIM_ENDS) {
             const int64_t count = (int64_t)(((uint64_t)__float_as_uint(st.p1) << 32) | (uint64_t)__float_as_uint(st.p0));
             rc = trim_fixed(s, v, 0.0f, L.bc, L.sh, true, count);
-            if (!rc) rc = check_record(s, v, L.bc);
+            if (!rc && do_check) rc = check_record(s, v, L.bc);
+        } else if (STAGE_ON(PAFFY_CHECK) && st.kind == PAFFY_CHECK) {
+            rc = check_record(s, v, L.bc); /* paf_check alone, impl/paf.c:427-461 */
         } else if (STAGE_ON(PAFFY_REMOVE_MISMATCHES) && st.kind == PAFFY_REMOVE_MISMATCHES) {
             parse_plain = false; /* the op array is rebuilt */
             if (s.has_cigar) {
@@ -2727,7 +2730,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
                 }
                 v.reset(ops, n2);
             }
-            rc = check_record(s, v, L.bc);
+            if (do_check) rc = check_record(s, v, L.bc);
         } else if (STAGE_ON(PAFFY_ADD_MISMATCHES) && st.kind == PAFFY_ADD_MISMATCHES) {
             parse_plain = false;
             if constexpr (std::is_same<OPS, OpsLds>::value) {
@@ -2839,7 +2842,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
             report(P, rec, rc, si, 0, klass);
             return true;
         }
-        if (st.kind != PAFFY_STATS) checked = st.kind != PAFFY_PASS && st.kind != PAFFY_FILTER; /* every other stage ends with a passed paf_check */
+        if (st.kind != PAFFY_STATS) checked = st.kind != PAFFY_PASS && st.kind != PAFFY_FILTER && (do_check || st.kind == PAFFY_CHECK); /* a passed paf_check ends the stage */
     }
     RecPlan *plan = static_cast<RecPlan *>(P.rec_plan) + rec;
     int64_t bytes, rows;

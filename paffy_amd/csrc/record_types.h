@@ -105,6 +105,7 @@ struct KParams {
     const uint32_t *emit_order; /* records by descending output size (coarse): the one-wave-per-record writers start the long ones first */
     const uint32_t *size_order; /* records by descending cigar length (coarse), for the sizing launch */
     int64_t *rec_stats;         /* PAFFY_STATS: six sums per record (the order of paf_stats_calc's arguments), or NULL */
+    uint32_t nocheck_mask;      /* bit i: stage i runs without the paf_check the command loops append (PAFFY_NO_CHECK) */
     uint32_t wave_max_bytes;    /* records with at most this many cigar bytes are sized by the one-wave kernel (0: none): the four-wave kernel skips them */
 };
 

@@ -107,6 +107,12 @@ def lib():
         L.paffy_hip_split_by_owner.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), i64, vp, i64, C.POINTER(i64), C.POINTER(i64), vp, i64,
                                                C.POINTER(i64)]
         L.paffy_hip_scatter_lines.argtypes = [vp, vp, vp, vp, i64, vp]
+        L.paffy_hip_stream_open.argtypes = [vp, C.POINTER(Stage), i32, i64, i64, C.POINTER(vp)]
+        L.paffy_hip_stream_input.restype = vp
+        L.paffy_hip_stream_input.argtypes = [vp, i64, i64, C.POINTER(i64)]
+        L.paffy_hip_stream_submit.argtypes = [vp, i64, C.POINTER(PlanInfo)]
+        L.paffy_hip_stream_read.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+        L.paffy_hip_stream_close.argtypes = [vp]
         L.paffy_hip_sync.argtypes = [vp]
         L.paffy_hip_dedupe_plan.argtypes = [vp, vp, i64, C.c_int, C.POINTER(PlanInfo)]
         L.paffy_hip_dedupe_reset.argtypes = [vp]
@@ -407,6 +413,50 @@ class Engine:
         buf = self.torch.zeros(_pad16(nbytes.value), dtype=self.torch.uint8, device=self.device)
         self._check(lib().paffy_hip_synth4(self._ctx, r0, n, C.c_void_p(buf.data_ptr()), buf.numel(), C.byref(nbytes)), "paffy_hip_synth4(fill)")
         return buf, nbytes.value
+
+    # ---- host buffers in, host buffers out: the streaming runtime of the CLI ----
+    def stream_host(self, stages, chunks, sink=None):
+        """Push host chunks (bytes objects of whole lines) through paffy_hip_stream_*: pinned staging, H2D / kernels / D2H
+        overlapped. sink(piece_bytes) gets the output pieces in order (default: they are only counted). Returns (records, output bytes)."""
+        L = lib()
+        arr = (Stage * max(1, len(stages)))(*stages)
+        st = C.c_void_p()
+        cap0 = max(4096, max((len(c) for c in chunks), default=4096))
+        self._check(L.paffy_hip_stream_open(self._ctx, arr, len(stages), cap0, 64 << 20, C.byref(st)), "paffy_hip_stream_open")
+        records = out_bytes = 0
+
+        def drain():
+            nonlocal out_bytes
+            while True:
+                piece, n = C.c_void_p(), C.c_int64()
+                self._check(L.paffy_hip_stream_read(st, C.byref(piece), C.byref(n)), "paffy_hip_stream_read")
+                if n.value == 0:
+                    return
+                out_bytes += n.value
+                if sink:
+                    sink(C.string_at(piece.value, n.value))
+
+        try:
+            pending = False
+            for chunk in chunks:
+                cap = C.c_int64()
+                buf = L.paffy_hip_stream_input(st, len(chunk), 0, C.byref(cap))
+                if not buf:
+                    raise RuntimeError("paffy_hip_stream_input: no free slot")
+                C.memmove(buf, chunk, len(chunk))
+                info = PlanInfo()
+                self._check(L.paffy_hip_stream_submit(st, len(chunk), C.byref(info)), "paffy_hip_stream_submit")
+                if info.error.code:
+                    raise PafError(f"record {info.error.record}: {L.paffy_hip_error_string(info.error.code).decode()}", info, L.paffy_hip_error_exit_status(info.error.code))
+                records += info.n_records
+                if pending:
+                    drain()  # the chunk before, while the GPU works on this one
+                pending = True
+            if pending:
+                drain()
+        finally:
+            L.paffy_hip_stream_close(st)
+        return records, out_bytes
 
     # ---- per-kernel HIP-event timing ----
     def profile(self, on=True):

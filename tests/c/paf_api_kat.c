@@ -4,6 +4,7 @@
  * invert :334-399, aligned bases :403-409, trimming :413-467, shatter :471-560, mismatches :565-700), rebuilt here against
  * this repo's header. Usage: paf_api_kat [fixture.paf out.paf]  -- exit status 0 = all checks passed.
  */
+#define _GNU_SOURCE
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -217,6 +218,114 @@ static void mismatches(void) {
     paf_destruct(p);
 }
 
+/* paf_pretty_print (impl/paf.c:262-316): the answers are the columns derived by hand in tests/test_oracle_kat.py */
+static void pretty(void) {
+    char q[] = "ACGTTGGACA", t[] = "NACGTAACTAGG";
+    Paf *p = make_paf("q", 10, 0, 10, true, "t", 12, 1, 10, 8, 10, 60, "4=1X2I2=1D1=");
+    p->score = 7;
+    char *text = NULL;
+    size_t len = 0;
+    FILE *fh = open_memstream(&text, &len);
+    paf_pretty_print(p, q, t, fh, true);
+    fclose(fh);
+    CHECK(strcmp(text, "Query:q\tQ-start:0\tQ-length:10\tTarget:t\tT-start:1\tT-length:9\tSame-strand:1\tScore:7\tIdentity:0.875000"
+                       "\tIdentity-with-gaps0.636364\tAligned-bases:8\tQuery-inserts:1\tQuery-deletes:1\n"
+                       "ACGTA--ACTA\nACGTTGGAC-A\n****   ** *\n") == 0);
+    free(text);
+    fh = open_memstream(&text, &len);
+    paf_pretty_print(p, q, t, fh, false);
+    fclose(fh);
+    CHECK(strchr(text, '\n') == text + len - 1 && strncmp(text, "Query:q\tQ-start:0", 17) == 0);
+    free(text);
+    paf_destruct(p);
+    /* - strand, mixed case, and a second pair of sequences right after the first (the loaded pair must be replaced) */
+    char q2[] = "GTaCGn", t2[] = "NCGTAC";
+    p = make_paf("q", 6, 0, 6, false, "t", 6, 0, 6, 6, 6, 60, "6M");
+    fh = open_memstream(&text, &len);
+    paf_pretty_print(p, q2, t2, fh, true);
+    fclose(fh);
+    const char *rows = strchr(text, '\n');
+    CHECK(rows && strcmp(rows + 1, "NCGTAC\nnCGtAC\n******\n") == 0);
+    free(text);
+    paf_destruct(p);
+    /* three windows: 150 + 150 + 10 columns */
+    char *qa = malloc(311), *ta = malloc(311);
+    memset(qa, 'A', 310);
+    memset(ta, 'A', 310);
+    qa[310] = ta[310] = '\0';
+    ta[200] = 'c';
+    p = make_paf("q", 310, 0, 310, true, "t", 310, 0, 310, 310, 310, 60, "310M");
+    fh = open_memstream(&text, &len);
+    paf_pretty_print(p, qa, ta, fh, true);
+    fclose(fh);
+    rows = strchr(text, '\n') + 1;
+    CHECK(strlen(rows) == 3 * 310 + 9);
+    CHECK(rows[150] == '\n' && rows[3 * 151 + 50] == 'c' && rows[3 * 151 + 2 * 151 + 50] == ' ' && rows[3 * 151 + 2 * 151 + 49] == '*');
+    CHECK(rows[6 * 151 + 10] == '\n' && rows[6 * 151 + 32] == '\n');
+    free(text);
+    free(qa);
+    free(ta);
+    paf_destruct(p);
+}
+
+/* the library transforms check nothing and keep the tags they do not compute (impl/paf.c:463-490) */
+static void unchecked_and_preserved(void) {
+    Paf *p = make_paf("q", 100, 0, 9, true, "t", 100, 0, 10, 10, 10, 60, "10M"); /* cigar and query coordinates disagree */
+    p->score = 2147483647; /* INT_MAX: the writer leaves the tag out; the struct must keep the value */
+    p->tile_level = 3;
+    p->type = '\0';
+    p->chain_id = 5;
+    p->chain_score = 77;
+    paf_invert(p);
+    CHECK(strcmp(p->query_name, "t") == 0 && p->query_end == 10 && p->target_end == 9);
+    CHECK(p->score == 2147483647 && p->tile_level == 3 && p->type == '\0' && p->chain_id == 5 && p->chain_score == 77);
+    paf_invert(p);
+    CHECK(strcmp(p->query_name, "q") == 0 && p->query_end == 9 && p->target_end == 10);
+    paf_destruct(p);
+    p = make_paf("q", 100, 10, 20, true, "t", 100, 30, 40, 10, 10, 60, "10M");
+    paf_check(p); /* a sound record passes and is left alone */
+    CHECK(p->query_start == 10 && cigar_count(p->cigar) == 1);
+    paf_destruct(p);
+}
+
+/* coverage counters and fasta-header intervals (impl/paf.c:667-737) */
+static void counts_and_intervals(void) {
+    SequenceCountArray **arrays = NULL;
+    int64_t n = 0;
+    Paf *a = make_paf("q", 30, 2, 12, true, "t", 100, 0, 9, 10, 10, 60, "4M1D2M2I2=");  /* query bases 2-5, 6-7, 10-11 */
+    Paf *b = make_paf("q", 30, 4, 8, false, "u", 100, 50, 54, 4, 4, 60, "4M");
+    Paf *c = make_paf("r", 8, 0, 8, true, "t", 100, 0, 8, 8, 8, 60, "8M");
+    SequenceCountArray *ca = get_alignment_count_array_in(&arrays, &n, a);
+    CHECK(n == 1 && ca->length == 30 && strcmp(ca->name, "q") == 0 && ca->counts[0] == 0);
+    increase_alignment_level_counts(ca, a);
+    CHECK(get_alignment_count_array_in(&arrays, &n, b) == ca && n == 1);
+    increase_alignment_level_counts(ca, b);
+    SequenceCountArray *cr = get_alignment_count_array_in(&arrays, &n, c);
+    CHECK(n == 2 && cr != ca && cr->length == 8);
+    increase_alignment_level_counts(cr, c);
+    const uint16_t want[14] = {0, 0, 1, 1, 2, 2, 2, 2, 0, 0, 1, 1, 0, 0};
+    for (int i = 0; i < 14; i++) CHECK(ca->counts[i] == want[i]);
+    for (int i = 0; i < 8; i++) CHECK(cr->counts[i] == 1);
+    ca->counts[4] = 32766; /* INT16_MAX - 1 stays (impl/paf.c:701) */
+    ca->counts[5] = 32765;
+    increase_alignment_level_counts(ca, b);
+    CHECK(ca->counts[4] == 32766 && ca->counts[5] == 32766 && ca->counts[6] == 3 && ca->counts[8] == 0);
+    sequenceCountArray_destruct(ca);
+    sequenceCountArray_destruct(cr);
+    free(arrays);
+    paf_destruct(a);
+    paf_destruct(b);
+    paf_destruct(c);
+    char h1[] = "chr1|1000|50", h2[] = "id=3|chr1|1000|7", h3[] = "chr1|1000|7";
+    Interval *i1 = decode_fasta_header(h1), *i2 = decode_fasta_header(h2), *i3 = decode_fasta_header(h3);
+    CHECK(strcmp(i1->name, "chr1") == 0 && i1->length == 1000 && i1->start == 50);
+    CHECK(strcmp(i2->name, "id=3|chr1") == 0 && i2->length == 1000 && i2->start == 7);
+    CHECK(cmp_intervals(i3, i1) < 0 && cmp_intervals(i1, i3) > 0 && cmp_intervals(i1, i1) == 0 && cmp_intervals(i1, i2) < 0);
+    interval_destruct(i1);
+    interval_destruct(i2);
+    interval_destruct(i3);
+}
+
 static void files(const char *in_path, const char *out_path) {
     FILE *in = fopen(in_path, "r");
     if (!in) {
@@ -262,7 +371,8 @@ static void must_fail(int which) {
         parse_str("q\t100\t0\t50\t*\tt\t200\t10\t60\t50\t50\t255", true);
     } else if (which == 4) { /* impl/paf.c:452: cigar and coordinates disagree */
         Paf *p = make_paf("q", 100, 0, 9, true, "t", 100, 0, 10, 10, 10, 60, "10M");
-        paf_invert(p);
+        paf_invert(p); /* no check here (impl/paf.c:463-490) ... */
+        paf_check(p);  /* ... this is the call that ends the process */
     }
 }
 
@@ -277,6 +387,9 @@ int main(int argc, char **argv) {
     trimming();
     shattering();
     mismatches();
+    pretty();
+    unchecked_and_preserved();
+    counts_and_intervals();
     if (argc >= 3) files(argv[1], argv[2]);
     fprintf(stderr, "%d checks, %d failures\n", checks, failures);
     return failures ? 1 : 0;

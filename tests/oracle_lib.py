@@ -66,6 +66,7 @@ def lib():
         L.po_cigar_aligned_bases.restype = C.c_int64
         L.po_cigar_aligned_bases.argtypes = [C.c_char_p]
         L.po_trim_ends_line.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.po_pretty_print.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.po_coverage_counts.restype = C.c_int64
         L.po_coverage_counts.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.POINTER(C.c_uint16), C.c_int64]
         _lib = L
@@ -176,3 +177,10 @@ def coverage_counts(data, name, length):
     counts = (C.c_uint16 * length)()
     applied = lib().po_coverage_counts(data, len(data), name.encode(), counts, length)
     return applied, list(counts)
+
+
+def pretty_print(line, query_seq, target_seq, include_alignment=True):
+    """paf_pretty_print (impl/paf.c:262-316) of one PAF line."""
+    out, n = C.c_void_p(), C.c_int64()
+    rc = lib().po_pretty_print(line, len(line), query_seq, target_seq, 1 if include_alignment else 0, C.byref(out), C.byref(n))
+    return rc, _take(out, n)

@@ -246,3 +246,23 @@ def test_writer_quirks():
     # negative and duplicate tags: last cg wins (A-7)
     src = line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, None, "AS:i:-12\tcg:Z:9M\tcg:Z:5M")
     assert run1([S(O.PASS)], src) == out_line("q", 100, 0, 5, "+", "t", 100, 0, 5, 5, 5, 60, "5M", "AS:i:-12")
+
+
+def test_pretty_print_known_answer():
+    """paf_pretty_print (impl/paf.c:262-316), columns derived by hand: 4= 1X 2I 2= 1D 1= of q[0:10) on t[1:10)."""
+    line = b"q\t10\t0\t10\t+\tt\t12\t1\t10\t8\t10\t60\tAS:i:7\tcg:Z:4=1X2I2=1D1="
+    rc, out = O.pretty_print(line, b"ACGTTGGACA", b"NACGTAACTAGG")
+    assert rc == 0
+    assert out == (b"Query:q\tQ-start:0\tQ-length:10\tTarget:t\tT-start:1\tT-length:9\tSame-strand:1\tScore:7\tIdentity:0.875000"
+                   b"\tIdentity-with-gaps0.636364\tAligned-bases:8\tQuery-inserts:1\tQuery-deletes:1\n"
+                   b"ACGTA--ACTA\nACGTTGGAC-A\n****   ** *\n")
+    # - strand: column i pairs t[i] with the complement of q[qe - 1 - i]; the case of the bases is kept, the stars ignore it
+    rc, out = O.pretty_print(b"q\t6\t0\t6\t-\tt\t6\t0\t6\t6\t6\t60\tcg:Z:6M", b"GTaCGn", b"NCGTAC")
+    assert rc == 0 and out.split(b"\n")[1:4] == [b"NCGTAC", b"nCGtAC", b"******"]
+    # windows of 150 columns: 310 columns -> 150, 150, 10
+    rc, out = O.pretty_print(b"q\t310\t0\t310\t+\tt\t310\t0\t310\t310\t310\t60\tcg:Z:310M", b"A" * 310, b"A" * 310)
+    rows = out.split(b"\n")[1:-1]
+    assert [len(x) for x in rows] == [150] * 6 + [10] * 3
+    # without the alignment: the stats line alone
+    rc, out2 = O.pretty_print(b"q\t310\t0\t310\t+\tt\t310\t0\t310\t310\t310\t60\tcg:Z:310M", b"A" * 310, b"A" * 310, include_alignment=False)
+    assert out2 == out.split(b"\n")[0] + b"\n"

@@ -1,4 +1,4 @@
-"""`paffy view -s -t` (impl/paf_view.c:42-213, aggregate line only): PAFFY_STATS sums on the GPU against the oracle's
+"""`paffy view` (impl/paf_view.c:42-213; aggregate line, per-record lines, -a rows): PAFFY_STATS sums on the GPU against the oracle's
 paf_stats_calc over the same records, and the CLI line with the reference's float arithmetic and format."""
 import os
 import struct
@@ -76,4 +76,27 @@ def test_stats_stage_and_cli(tmp_path, human_chimp):
                      % (f[0].decode(), int(f[2]), int(f[3]) - int(f[2]), f[5].decode(), int(f[7]), int(f[8]) - int(f[7]), 1 if f[4] == b"+" else 0,
                         int([t for t in f if t.startswith(b"AS:i:")][0][5:]), f32(f32(m1) / f32(m1 + x1)), f32(f32(m1) / f32(m1 + x1 + ib1 + db1)), m1 + x1, i1, d1))
         assert got[k] == want_line, k
-    assert subprocess.run([PAFFY, "view", "-a", "-i", str(paf), str(fa)], capture_output=True).returncode == 1  # base-level print: not in this build
+    # -a: the base-level rows under every stats line (impl/paf.c:283-315), written by the GPU; whole output against the oracle's
+    # paf_pretty_print of the encoded records, in one batch and in many
+    by_name = {k: v for k, v in seqs.items()}
+    want_all = b"".join(O.pretty_print(ln, by_name[ln.split(b"\t")[0].decode()], by_name[ln.split(b"\t")[5].decode()])[1] for ln in enc)
+    for env in ({}, {"PAFFY_CHUNK_MB": "1"}):
+        r = subprocess.run([PAFFY, "view", "-a", "-s", "-i", str(paf), str(fa)], capture_output=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-500:]
+        assert r.stdout == want_all + line.encode()
+    # without -s the totals stay zero and the reference's closing assert (NaN >= 0) ends it with SIGABRT after everything is printed
+    r = subprocess.run([PAFFY, "view", "-a", "-i", str(paf), str(fa)], capture_output=True)
+    assert r.returncode == -6 and r.stdout == want_all
+    # lower-case bases are shown as they are in the file and still compare equal
+    low = {k: (v.lower() if i % 2 else v) for i, (k, v) in enumerate(seqs.items())}
+    with open(fa, "wb") as fh:
+        for name, s in low.items():
+            fh.write(b">" + name.encode() + b"\n" + s + b"\n")
+    want_low = b"".join(O.pretty_print(ln, low[ln.split(b"\t")[0].decode()], low[ln.split(b"\t")[5].decode()])[1] for ln in enc[:200])
+    small = tmp_path / "small.paf"
+    small.write_bytes(b"".join(data.splitlines(keepends=True)[:200]))
+    r = subprocess.run([PAFFY, "view", "-a", "-s", "-i", str(small), str(fa)], capture_output=True)
+    assert r.returncode == 0 and r.stdout.startswith(want_low) and r.stdout[len(want_low):].startswith(b"Total-alignments:200\t")
+    # -a -t prints nothing per record (paf_pretty_print is not called, impl/paf_view.c:170-172)
+    r = subprocess.run([PAFFY, "view", "-a", "-t", "-s", "-i", str(small), str(fa)], capture_output=True)
+    assert r.returncode == 0 and r.stdout.startswith(b"Total-alignments:200\t") and r.stdout.count(b"\n") == 1
