@@ -583,7 +583,60 @@ Paf **paf_shatter_array(Paf *paf, int64_t *n_pafs) { /* impl/paf.c:629-663 */
     return res;
 }
 
+/*
+ * paf_chain (impl/chaining.c:266-343) over a plain array and with the gap cost of its one caller spelled out (impl/paf_chain.c:36-45:
+ * no gap costs nothing, otherwise gap_open + gap_extend * (query gap + target gap)) -- a cost function cannot be handed to the GPU
+ * as a C callback. The records go to the GPU as one batch; like the reference the same Paf objects come back, in a new array
+ * ordered by descending score, with chain_id and chain_score set.
+ */
+Paf **paf_chain_array(Paf **pafs, int64_t n_pafs, int64_t gap_open, int64_t gap_extend, int64_t max_gap_length, float percentage_to_trim, int64_t *n_out) {
+    *n_out = 0;
+    Paf **out = malloc(sizeof(Paf *) * (size_t)(n_pafs > 0 ? n_pafs : 1));
+    if (!out) die("out of memory", NULL);
+    if (n_pafs <= 0) return out;
+    Buf b = {0};
+    for (int64_t i = 0; i < n_pafs; i++) hand_over(&b, pafs[i], NULL, NULL);
+    const paffy_chain_opts opts = {gap_open, gap_extend, max_gap_length, percentage_to_trim};
+    paffy_plan_info info;
+    void *d_in = NULL;
+    if (paffy_hip_malloc(&d_in, (int64_t)b.n + 64) || paffy_hip_memcpy_h2d(d_in, b.p, (int64_t)b.n) || paffy_hip_chain_begin(ctx()) ||
+        paffy_hip_chain_add(ctx(), d_in, (int64_t)b.n) || paffy_hip_chain_run(ctx(), &opts, &info))
+        die("paf_chain on MI355X", paffy_hip_last_error(ctx()));
+    if (info.error.code) record_failure(&info);
+    uint32_t *rows = malloc(sizeof(uint32_t) * (size_t)(n_pafs + 1));
+    int64_t *offs = malloc(sizeof(int64_t) * (size_t)(n_pafs + 1)), *ids = malloc(sizeof(int64_t) * (size_t)n_pafs), *scores = malloc(sizeof(int64_t) * (size_t)n_pafs);
+    if (!rows || !offs || !ids || !scores) die("out of memory", NULL);
+    if (info.n_records != n_pafs || paffy_hip_plan_rows(ctx(), n_pafs + 1, rows, offs) != n_pafs || paffy_hip_chain_tags(ctx(), n_pafs, ids, scores) != n_pafs)
+        die("paf_chain on MI355X", paffy_hip_last_error(ctx()));
+    for (int64_t k = 0; k < n_pafs; k++) {
+        out[k] = pafs[rows[k]];
+        out[k]->chain_id = ids[k];
+        out[k]->chain_score = scores[k];
+    }
+    *n_out = n_pafs;
+    free(rows); free(offs); free(ids); free(scores);
+    paffy_hip_free(d_in);
+    free(b.p);
+    return out;
+}
+
 #ifdef PAFFY_WITH_SONLIB
+/* the stList form: the callback is probed and must be the affine cost above (it is, for the reference's only caller) */
+stList *paf_chain(stList *pafs, int64_t (*gap_cost)(int64_t, int64_t, void *), void *gap_cost_params, int64_t max_gap_length, float percentage_to_trim) {
+    const int64_t zero = gap_cost(0, 0, gap_cost_params), c1 = gap_cost(1, 0, gap_cost_params), c2 = gap_cost(2, 0, gap_cost_params);
+    const int64_t extend = c2 - c1, open = c1 - extend;
+    if (zero != 0 || gap_cost(0, 1, gap_cost_params) != c1 || gap_cost(1000, 234, gap_cost_params) != open + extend * 1234)
+        die("paf_chain on MI355X", "the gap cost must be 0 for no gap and open + extend * (query gap + target gap) otherwise");
+    int64_t n = stList_length(pafs), n_out = 0;
+    Paf **a = malloc(sizeof(Paf *) * (size_t)(n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; i++) a[i] = stList_get(pafs, i);
+    Paf **res = paf_chain_array(a, n, open, extend, max_gap_length, percentage_to_trim, &n_out);
+    stList *l = stList_construct3(0, (void (*)(void *))paf_destruct);
+    for (int64_t i = 0; i < n_out; i++) stList_append(l, res[i]);
+    free(a);
+    free(res);
+    return l;
+}
 stList *read_pafs(FILE *paf_file, bool parse_cigar_string) {
     int64_t n = 0;
     Paf **a = read_pafs_array(paf_file, parse_cigar_string, &n);

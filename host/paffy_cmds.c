@@ -357,8 +357,58 @@ int paffy_tile_main(int argc, char *argv[]) {
 }
 
 /*
- * impl/paf_view.c:42-213 restricted to the aggregate line (`-s -t`): every record is encoded against the sequences
- * (paf_encode_mismatches) and its paf_stats_calc sums are added up; the per-alignment pretty print is outside this build.
+ * impl/paf_chain.c:47-153: the records are chained per (query, target, strand) with the affine gap cost of :36-45; every record
+ * gets the id (cn) and the score (s1) of its chain and the output is ordered by descending alignment score.
+ */
+int paffy_chain_main(int argc, char *argv[]) {
+    static struct option opts[] = {{"logLevel", required_argument, 0, 'l'}, {"inputFile", required_argument, 0, 'i'}, {"outputFile", required_argument, 0, 'o'},
+                                   {"maxGapLength", required_argument, 0, 'g'}, {"trimFraction", required_argument, 0, 't'}, {"chainGapOpen", required_argument, 0, 'd'},
+                                   {"chainGapExtend", required_argument, 0, 'e'}, {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+    cmd_opts o;
+    memset(&o, 0, sizeof(o));
+    paffy_chain_opts c = {5000, 1, 1000000, 1.0f}; /* impl/paf_chain.c:18-21 */
+    optind = 1;
+    for (;;) {
+        int idx = 0;
+        int key = getopt_long(argc, argv, "l:i:o:hg:t:d:e:", opts, &idx);
+        if (key == -1) break;
+        switch (key) {
+            case 'l': o.log_level = optarg; break;
+            case 'i': o.in_path = optarg; break;
+            case 'o': o.out_path = optarg; break;
+            case 'g': c.max_gap_length = atoi(optarg); break;
+            case 't': c.trim_fraction = (float)atof(optarg); break;
+            case 'd': c.gap_open = atoi(optarg); break;
+            case 'e': c.gap_extend = atoi(optarg); break;
+            case 'h':
+            default:
+                fprintf(stderr, "paffy chain [options], MI355X build\nChains the records in the PAF file into chains, rescoring them as chains.\nChains are indicated with the cn tag.\n");
+                fprintf(stderr, "-i --inputFile : Input paf file. If not specified reads from stdin\n-o --outputFile : Output paf file. If not specified outputs to stdout\n");
+                fprintf(stderr, "-g --maxGapLength [INT] : The maximum allowable length of a gap in either sequence to chain (default:1000000bp)\n");
+                fprintf(stderr, "-d --chainGapOpen [INT] : The cost of opening a chain gap (default:5000)\n-e --chainGapExtend [INT] : The cost of extending a chain gap (default:1)\n");
+                fprintf(stderr, "-t --trimFraction : Fraction (from 0 to 1) of aligned bases to discount from the ends of the alignments when chaining (default:1.0)\n");
+                usage_tail();
+                return key == 'h' ? 0 : 1;
+        }
+    }
+    host_set_log_level(o.log_level);
+    host_log_info("Input file string : %s\nOutput file string : %s\nMaximum gap length : %lld\nChain gap open : %lld\nChain gap extend : %lld\n", o.in_path, o.out_path,
+                  (long long)c.max_gap_length, (long long)c.gap_open, (long long)c.gap_extend);
+    FILE *in = o.in_path ? fopen(o.in_path, "r") : stdin;
+    FILE *out = o.out_path ? fopen(o.out_path, "w") : stdout;
+    if (!in || !out) {
+        fprintf(stderr, "paffy chain: cannot open %s\n", !in ? o.in_path : o.out_path);
+        return 1;
+    }
+    int rc = host_chain(in, out, &c);
+    if (o.in_path) fclose(in);
+    if (o.out_path) fclose(out);
+    return rc;
+}
+
+/*
+ * impl/paf_view.c:42-213: every record is encoded against the sequences (paf_encode_mismatches); its stats line and, with -a, its
+ * base-level rows are printed (paf_pretty_print) and its paf_stats_calc sums are added up for the aggregate line (-s).
  */
 int paffy_view_main(int argc, char *argv[]) {
     static struct option opts[] = {{"logLevel", required_argument, 0, 'l'}, {"inputFile", required_argument, 0, 'i'},

@@ -21,6 +21,7 @@ int paffy_split_file_main(int argc, char *argv[]);
 int paffy_trim_main(int argc, char *argv[]);
 int paffy_add_mismatches_main(int argc, char *argv[]);
 int paffy_tile_main(int argc, char *argv[]);
+int paffy_chain_main(int argc, char *argv[]);
 int paffy_view_main(int argc, char *argv[]);
 int paffy_to_bed_main(int argc, char *argv[]);
 
@@ -50,6 +51,8 @@ void host_set_stats_lines(FILE *fh);
 int host_tile(FILE *in, FILE *out);
 /* `paffy to_bed`: reads all of `in`, one bed_plan + emit, writes `out` */
 int host_to_bed(FILE *in, FILE *out, const paffy_bed_opts *opts);
+/* `paffy chain`: reads all of `in`, chains on the GPU, writes the records with their cn / s1 tags by descending score */
+int host_chain(FILE *in, FILE *out, const paffy_chain_opts *opts);
 /* paffy split_file: normalised lines (cigar text verbatim) routed to "<prefix><contig>.paf" / "<prefix>small_<k>.paf" */
 int host_split_file(FILE *in, const char *prefix, int by_query, int64_t min_length);
 

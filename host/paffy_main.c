@@ -21,7 +21,7 @@ static const struct {
     const char *help;
 } COMMANDS[] = {
     {"add_mismatches", paffy_add_mismatches_main, "Replace Ms with =/Xs in the cigar (or -a: the reverse)"},
-    {"chain", NULL, "Chain alignments (not in this build)"},
+    {"chain", paffy_chain_main, "Chain alignments: every record gets the id and score of its chain"},
     {"dechunk", NULL, "Map chunk coordinates back (not in this build)"},
     {"dedupe", paffy_dedupe_main, "Drop duplicate alignments"},
     {"filter", paffy_filter_main, "Filter alignments on their stats"},

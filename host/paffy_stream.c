@@ -528,23 +528,25 @@ int host_split_file(FILE *in, const char *prefix, int by_query, int64_t min_leng
     return rc;
 }
 
-static int whole_file(FILE *in, FILE *out, const paffy_bed_opts *bed);
-int host_tile(FILE *in, FILE *out) { return whole_file(in, out, NULL); }
+static int whole_file(FILE *in, FILE *out, const paffy_bed_opts *bed, const paffy_chain_opts *chain);
+int host_tile(FILE *in, FILE *out) { return whole_file(in, out, NULL, NULL); }
 /* paffy to_bed: every record counts before anything is written, like tile */
-int host_to_bed(FILE *in, FILE *out, const paffy_bed_opts *opts) { return whole_file(in, out, opts); }
+int host_to_bed(FILE *in, FILE *out, const paffy_bed_opts *opts) { return whole_file(in, out, opts, NULL); }
+/* paffy chain: read_pafs, paf_chain, write_pafs (impl/paf_chain.c:123-127) */
+int host_chain(FILE *in, FILE *out, const paffy_chain_opts *opts) { return whole_file(in, out, NULL, opts); }
 
 /*
- * tile / to_bed read the whole input before they write (read_pafs, impl/paf.c:492-499; the loop of impl/paf_to_bed.c:166-190).
+ * tile / to_bed / chain read the whole input before they write (read_pafs, impl/paf.c:492-499; the loop of impl/paf_to_bed.c:166-190).
  * The text goes to the GPU in batches of whole lines (at most PAFFY_CHUNK_MB each, below the 2 GiB a batch may hold) and stays
  * there; the output comes back through a bounded staging buffer. Inputs are limited by the GPU's memory, not by a batch.
  */
-static int whole_file(FILE *in, FILE *out, const paffy_bed_opts *bed) {
+static int whole_file(FILE *in, FILE *out, const paffy_bed_opts *bed, const paffy_chain_opts *chain) {
     paffy_hip_ctx *ctx = NULL;
     if (paffy_hip_create(&ctx, -1) != 0) {
         fprintf(stderr, "paffy: no usable GPU (this build has no CPU path)\n");
         return 1;
     }
-    const char *what = bed ? "to_bed" : "tile";
+    const char *what = bed ? "to_bed" : (chain ? "chain" : "tile");
     const size_t cap = chunk_bytes();
     size_t buf_cap = cap + (1 << 20), have = 0;
     char *buf = (char *)malloc(buf_cap);
@@ -555,7 +557,7 @@ static int whole_file(FILE *in, FILE *out, const paffy_bed_opts *bed) {
         fprintf(stderr, "paffy %s: out of memory\n", what);
         return 1;
     }
-    if ((bed ? paffy_hip_bed_begin(ctx, bed) : paffy_hip_tile_begin(ctx)) != 0) rc = 1;
+    if ((bed ? paffy_hip_bed_begin(ctx, bed) : (chain ? paffy_hip_chain_begin(ctx) : paffy_hip_tile_begin(ctx))) != 0) rc = 1;
     while (!rc && (!eof || have > 0)) {
         if (!eof) {
             if (have == buf_cap) { /* a single line longer than the chunk: grow */
@@ -586,7 +588,7 @@ static int whole_file(FILE *in, FILE *out, const paffy_bed_opts *bed) {
         }
         void *d = NULL;
         if (paffy_hip_malloc(&d, (int64_t)use + 64) != 0 || paffy_hip_memcpy_h2d(d, buf, (int64_t)use) != 0 ||
-            (bed ? paffy_hip_bed_add(ctx, d, (int64_t)use) : paffy_hip_tile_add(ctx, d, (int64_t)use)) != 0) {
+            (bed ? paffy_hip_bed_add(ctx, d, (int64_t)use) : (chain ? paffy_hip_chain_add(ctx, d, (int64_t)use) : paffy_hip_tile_add(ctx, d, (int64_t)use))) != 0) {
             fprintf(stderr, "paffy %s: GPU call failed: %s (the input must fit the GPU's memory)\n", what, paffy_hip_last_error(ctx));
             if (d) paffy_hip_free(d);
             rc = 1;
@@ -600,7 +602,7 @@ static int whole_file(FILE *in, FILE *out, const paffy_bed_opts *bed) {
     free(buf);
     paffy_plan_info info;
     memset(&info, 0, sizeof(info));
-    if (!rc && (bed ? paffy_hip_bed_run(ctx, bed, &info) : paffy_hip_tile_run(ctx, &info)) != 0) {
+    if (!rc && (bed ? paffy_hip_bed_run(ctx, bed, &info) : (chain ? paffy_hip_chain_run(ctx, chain, &info) : paffy_hip_tile_run(ctx, &info))) != 0) {
         fprintf(stderr, "paffy %s: GPU call failed: %s\n", what, paffy_hip_last_error(ctx));
         rc = 1;
     }

@@ -12,7 +12,7 @@
  *  - no `#include "sonLib.h"` (inc/paf.h:10; sonLib is an external library this build does not carry). The five prototypes
  *    that expose sonLib containers (read_pafs, write_pafs, paf_chain, paf_shatter, get_alignment_count_array) are declared
  *    only when PAFFY_WITH_SONLIB is defined before including this file; sonLib-free equivalents over plain arrays are
- *    always available (read_pafs_array, write_pafs_array, paf_shatter_array).
+ *    always available (read_pafs_array, write_pafs_array, paf_shatter_array, paf_chain_array).
  *    (get_alignment_count_array_in keeps the count arrays in a plain array instead of a stHash.)
  *  - errors end the process the way st_errAbort / assert do in the reference (message on stderr, exit 1 or abort()).
  *  - like the reference's, the transforms validate nothing: paf_check is the call that does (impl/paf.c:427-461).
@@ -102,6 +102,9 @@ void paf_trim_unreliable_tails(Paf *paf, float score_fraction, float max_fractio
 Paf **read_pafs_array(FILE *paf_file, bool parse_cigar_string, int64_t *n_pafs);
 void write_pafs_array(FILE *paf_file, Paf **pafs, int64_t n_pafs);
 Paf **paf_shatter_array(Paf *paf, int64_t *n_pafs);
+/* paf_chain (inc/paf.h:187) over a plain array, with the affine gap cost of its caller (impl/paf_chain.c:36-45) as two numbers: the
+ * same Paf objects in a new malloc'ed array, by descending score, chain_id and chain_score set */
+Paf **paf_chain_array(Paf **pafs, int64_t n_pafs, int64_t gap_open, int64_t gap_extend, int64_t max_gap_length, float percentage_to_trim, int64_t *n_out);
 
 typedef struct _sequenceCountArray { /* inc/paf.h:214-218: alignment coverage along a sequence */
     char *name;
@@ -125,6 +128,7 @@ int cmp_intervals(const void *i, const void *j);  /* inc/paf.h:253 */
 stList *read_pafs(FILE *paf_file, bool parse_cigar_string);
 void write_pafs(FILE *paf_file, stList *pafs);
 stList *paf_shatter(Paf *paf);
+stList *paf_chain(stList *pafs, int64_t (*gap_cost)(int64_t, int64_t, void *), void *gap_cost_params, int64_t max_gap_length, float percentage_to_trim);
 #endif
 
 #ifdef __cplusplus

@@ -87,7 +87,8 @@ enum {
     PAFFY_ERR_MISSING_QUERY_SEQ = 17,  /* impl/paf_add_mismatches.c:117-120 exit(1)     */
     PAFFY_ERR_MISSING_TARGET_SEQ = 18, /* impl/paf_add_mismatches.c:123-127 exit(1)     */
     PAFFY_ERR_TILE_ASSERT = 19,        /* impl/paf.c:685,698,708; impl/paf_tile.c:57,86,171 */
-    PAFFY_ERR_SEQ_RANGE = 21           /* paf_encode_mismatches would read outside a sequence */
+    PAFFY_ERR_SEQ_RANGE = 21,          /* paf_encode_mismatches would read outside a sequence */
+    PAFFY_ERR_CHAIN_ASSERT = 22        /* impl/chaining.c:275,278-281 asserts              */
 };
 
 /* Call-level failures (negative return values). */
@@ -215,6 +216,24 @@ int paffy_hip_bed_run(paffy_hip_ctx *ctx, const paffy_bed_opts *opts, paffy_plan
  */
 int64_t paffy_hip_bed_sequences(paffy_hip_ctx *ctx);
 int paffy_hip_bed_counts(paffy_hip_ctx *ctx, int64_t sequence, int64_t start, int64_t end, uint16_t *h_counts, int accumulate);
+
+/*
+ * `paffy chain` (impl/paf_chain.c:123-127, paf_chain impl/chaining.c:266-343): the records of all batches are chained per (query,
+ * target, strand) with the affine gap cost of impl/paf_chain.c:36-45 (no gap: 0, else gap_open + gap_extend * (query gap + target
+ * gap)); every record gets its chain's id (cn) and score (s1) and the lines come out by descending own score. begin / add / run
+ * as for tile; the text stays where it is until the output has been emitted (paffy_hip_emit, paffy_hip_emit_lines).
+ * paffy_hip_plan_rows gives the input record of every output line, paffy_hip_chain_tags its two tags.
+ * Where the reference's comparators fall back on object addresses (impl/chaining.c:18,47,62) creation order is used.
+ */
+typedef struct {
+    int64_t gap_open, gap_extend; /* defaults of the command: 5000, 1 */
+    int64_t max_gap_length;       /* 1000000 */
+    float trim_fraction;          /* 1.0: alignments are shortened to their centre while chaining */
+} paffy_chain_opts;
+int paffy_hip_chain_begin(paffy_hip_ctx *ctx);
+int paffy_hip_chain_add(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len);
+int paffy_hip_chain_run(paffy_hip_ctx *ctx, const paffy_chain_opts *opts, paffy_plan_info *info);
+int64_t paffy_hip_chain_tags(paffy_hip_ctx *ctx, int64_t cap, int64_t *chain_id, int64_t *chain_score);
 
 /*
  * After a tile or dedupe plan: the lines emit will write, in output order -- record[k] = zero-based input record of line k,

@@ -887,6 +887,244 @@ static void split_add(split_slot **v, int64_t *n, int64_t *cap, const char *name
     (*v)[*n].fh = fh;
     (*n)++;
 }
+/* ---- paffy chain: impl/chaining.c:1-343, impl/paf_chain.c:36-45,123-130 ---- */
+
+/*
+ * The reference keeps the chains it can still extend in a sonLib stSortedSet (libavl underneath; sonLib is an un-vendored
+ * submodule, absent here) ordered by chain_cmp_by_location, and every comparator ends in a comparison of object addresses
+ * (impl/chaining.c:18,47,62). Restated with a sorted array and, for the addresses, the order the objects were made in: Paf objects
+ * in input order (read_pafs), Chain objects in processing order. Parity on exact ties is therefore unpinned (heap layout).
+ * When no active chain sorts <= the search key the reference takes a fresh iterator and calls stSortedSet_getPrevious
+ * (impl/chaining.c:74-76): with libavl's avl_t_prev that starts at the largest element of the set; restated so, and every
+ * candidate evaluated from such a start is counted in *fresh_hits (it can only be an exactly abutting alignment whose address
+ * is higher -- the same unpinned tie).
+ */
+typedef struct {
+    int64_t rec;   /* index into recs (input order = address order) */
+    int64_t score; /* best chain score ending here */
+    int64_t prev;  /* chain index or -1 */
+} ochain;
+
+static int name_cmp(const char *a, int64_t al, const char *b, int64_t bl) { /* strcmp of the NUL-terminated names */
+    int64_t m = al < bl ? al : bl;
+    int d = memcmp(a, b, (size_t)m);
+    if (d) return d < 0 ? -1 : 1;
+    return al < bl ? -1 : (al > bl ? 1 : 0);
+}
+static int icmp(int64_t i, int64_t j) { return i > j ? 1 : (i < j ? -1 : 0); }
+
+/* chain_cmp_by_location, impl/chaining.c:37-54, with explicit end coordinates for the searched key */
+static int loc_cmp(const rec *a, int64_t a_te, int64_t a_qe, int64_t a_ptr, const rec *b, int64_t b_ptr) {
+    int i = name_cmp(a->qname, a->qname_len, b->qname, b->qname_len);
+    if (i == 0) i = name_cmp(a->tname, a->tname_len, b->tname, b->tname_len);
+    if (i == 0) i = icmp(a_te, b->te);
+    if (i == 0) i = icmp(a_qe, b->qe);
+    if (i == 0) i = icmp(a_ptr, b_ptr);
+    return i;
+}
+
+static int64_t chain_gap_cost(int64_t dq, int64_t dt, int64_t gap_open, int64_t gap_extend) { /* impl/paf_chain.c:36-45 */
+    return dq + dt == 0 ? 0 : gap_open + gap_extend * (dq + dt);
+}
+
+static const rec *g_chain_recs;
+static int cmp_query_location(const void *a, const void *b) { /* paf_cmp_by_query_location, impl/chaining.c:14-21 */
+    int64_t i = *(const int64_t *)a, j = *(const int64_t *)b;
+    int c = icmp(g_chain_recs[i].qs, g_chain_recs[j].qs);
+    return c ? c : icmp(i, j);
+}
+static const ochain *g_chain_set;
+static int cmp_chain_score(const void *a, const void *b) { /* chain_cmp_by_score, impl/chaining.c:59-66 */
+    int64_t i = *(const int64_t *)a, j = *(const int64_t *)b;
+    int c = icmp(g_chain_set[i].score, g_chain_set[j].score);
+    return c ? c : icmp(i, j);
+}
+static int cmp_paf_score(const void *a, const void *b) { /* paf_cmp_by_score, impl/chaining.c:261-264; ties: the stable merge sort of glibc */
+    int64_t i = ((const int64_t *)a)[0], j = ((const int64_t *)b)[0];
+    int c = icmp(g_chain_recs[j].score, g_chain_recs[i].score);
+    return c ? c : icmp(((const int64_t *)a)[1], ((const int64_t *)b)[1]);
+}
+
+/* paf_chain_ignore_strand, impl/chaining.c:136-250: `list` (n records of one strand) -> appended to out_order; sets chain_id / chain_score */
+static void chain_one_strand(rec *recs, int64_t *list, int64_t n, int64_t gap_open, int64_t gap_extend, int64_t max_gap, int64_t *chain_id,
+                             int64_t *out_order, int64_t *n_out, int64_t *fresh_hits) {
+    if (n == 0) return;
+    g_chain_recs = recs;
+    qsort(list, (size_t)n, sizeof(int64_t), cmp_query_location);
+    ochain *ch = (ochain *)malloc(sizeof(ochain) * (size_t)n);
+    int64_t *act = (int64_t *)malloc(sizeof(int64_t) * (size_t)n), n_act = 0; /* chain indices sorted by location */
+    int64_t *to_remove = (int64_t *)malloc(sizeof(int64_t) * (size_t)n), n_rm = 0;
+    for (int64_t k = 0; k < n; k++) {
+        const rec *paf = &recs[list[k]];
+        ch[k].rec = list[k];
+        ch[k].score = paf->score;
+        ch[k].prev = -1;
+        /* get_predecessor_chains: the largest active chain <= (names, target_start, query_start, this paf's address) */
+        int64_t lo = 0, hi = n_act; /* first position whose element is > key */
+        while (lo < hi) {
+            int64_t mid = (lo + hi) / 2;
+            const ochain *e = &ch[act[mid]];
+            /* cmp(key, e) >= 0  <=>  e <= key */
+            if (loc_cmp(paf, paf->ts, paf->qs, list[k], &recs[e->rec], e->rec) >= 0) lo = mid + 1;
+            else hi = mid;
+        }
+        int fresh = lo == 0;
+        int64_t it = fresh ? n_act - 1 : lo - 1; /* fresh iterator: getPrevious gives the last element (libavl avl_t_prev) */
+        for (; it >= 0; it--) {
+            ochain *pc = &ch[act[it]];
+            const rec *pp = &recs[pc->rec];
+            if (name_cmp(paf->qname, paf->qname_len, pp->qname, pp->qname_len) != 0 || name_cmp(paf->tname, paf->tname_len, pp->tname, pp->tname_len) != 0 ||
+                paf->same_strand != pp->same_strand)
+                break;
+            if (paf->qs < pp->qe) continue;
+            if (paf->qs - pp->qe > max_gap) {
+                to_remove[n_rm++] = act[it];
+                continue;
+            }
+            if (paf->ts < pp->te) continue;
+            if (paf->ts - pp->te > max_gap) break;
+            if (fresh) (*fresh_hits)++;
+            int64_t g = chain_gap_cost(paf->qs - pp->qe, paf->ts - pp->te, gap_open, gap_extend);
+            int64_t cs = paf->score + pc->score - g;
+            if (g < paf->score && cs > ch[k].score) {
+                ch[k].score = cs;
+                ch[k].prev = act[it];
+            }
+        }
+        /* insert into the active set */
+        lo = 0; hi = n_act;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) / 2;
+            const ochain *e = &ch[act[mid]];
+            if (loc_cmp(paf, paf->te, paf->qe, list[k], &recs[e->rec], e->rec) > 0) lo = mid + 1;
+            else hi = mid;
+        }
+        memmove(act + lo + 1, act + lo, sizeof(int64_t) * (size_t)(n_act - lo));
+        act[lo] = k;
+        n_act++;
+        while (n_rm > 0) {
+            int64_t victim = to_remove[--n_rm];
+            for (int64_t a = 0; a < n_act; a++)
+                if (act[a] == victim) {
+                    memmove(act + a, act + a + 1, sizeof(int64_t) * (size_t)(n_act - a - 1));
+                    n_act--;
+                    break;
+                }
+        }
+    }
+    /* chains from the highest score down, impl/chaining.c:213-230 */
+    int64_t *by_score = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+    char *in_set = (char *)malloc((size_t)n);
+    for (int64_t k = 0; k < n; k++) { by_score[k] = k; in_set[k] = 1; }
+    g_chain_set = ch;
+    qsort(by_score, (size_t)n, sizeof(int64_t), cmp_chain_score);
+    for (int64_t top = n - 1; top >= 0; top--) {
+        int64_t k = by_score[top];
+        if (!in_set[k]) continue;
+        in_set[k] = 0;
+        int64_t tail = k;
+        while (ch[k].prev != -1) {
+            if (!in_set[ch[k].prev]) { ch[k].prev = -1; break; }
+            k = ch[k].prev;
+            in_set[k] = 0;
+        }
+        /* chain_to_pafs, impl/chaining.c:118-135 + get_chain_score :93-116 */
+        int64_t total = recs[ch[tail].rec].score;
+        for (int64_t c = tail; ch[c].prev != -1; c = ch[c].prev) {
+            const rec *q = &recs[ch[c].rec], *p = &recs[ch[ch[c].prev].rec];
+            total += p->score - chain_gap_cost(q->qs - p->qe, q->ts - p->te, gap_open, gap_extend);
+        }
+        for (int64_t c = tail; c != -1; c = ch[c].prev) {
+            recs[ch[c].rec].chain_id = *chain_id;
+            recs[ch[c].rec].chain_score = total;
+            out_order[(*n_out)++] = ch[c].rec;
+        }
+        (*chain_id)++;
+    }
+    free(by_score); free(in_set); free(to_remove); free(act); free(ch);
+}
+
+int po_chain(const char *in, int64_t in_len, int64_t gap_open, int64_t gap_extend, int64_t max_gap, float pct, char **out, int64_t *out_len,
+             int64_t *fresh_hits, po_error *err) {
+    run_ctx c;
+    memset(&c, 0, sizeof(c));
+    c.err = err;
+    if (err) memset(err, 0, sizeof(*err));
+    int rc = PO_OK;
+    int64_t nrec = 0, rcap = 1024, fresh = 0;
+    rec *recs = (rec *)malloc(sizeof(rec) * (size_t)rcap);
+    const char *p = in, *end = in + in_len;
+    while (p < end) { /* read_pafs(input, 0), impl/paf_chain.c:123 */
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        if (nrec == rcap) {
+            rcap *= 2;
+            recs = (rec *)realloc(recs, sizeof(rec) * (size_t)rcap);
+        }
+        int64_t aux = 0;
+        c.record = nrec;
+        rc = parse_line(p, le, 0, &recs[nrec], &aux);
+        if (rc) {
+            fail(&c, rc, -1, aux);
+            break;
+        }
+        nrec++;
+        p = nl ? nl + 1 : end;
+    }
+    int64_t *trim = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nrec + 1));
+    int64_t *pos = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nrec + 1)), *neg = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nrec + 1));
+    int64_t *order = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)(nrec + 1));
+    int64_t npos = 0, nneg = 0, n_out = 0;
+    for (int64_t i = 0; i < nrec && !rc; i++) { /* paf_chain, impl/chaining.c:266-300 */
+        rec *r = &recs[i];
+        c.record = i;
+        if (!(pct >= 0 && pct <= 1.0)) { rc = fail(&c, PO_ERR_CHAIN_ASSERT, 0, 0); break; }
+        volatile float fq = (float)(r->qe - r->qs) * pct, ft = (float)(r->te - r->ts) * pct; /* int64 * float -> float */
+        int64_t mq = (int64_t)fq, mt = (int64_t)ft;
+        if (mq < 0 || mt < 0) { rc = fail(&c, PO_ERR_CHAIN_ASSERT, 0, 1); break; }
+        int64_t t = (mq < mt ? mq : mt) / 2;
+        trim[i] = t;
+        r->qs += t; r->qe -= t; r->ts += t; r->te -= t;
+        if (r->same_strand) pos[npos++] = i;
+        else { /* invert_query_strand, impl/chaining.c:255-259 */
+            int64_t k = r->qs; r->qs = -r->qe; r->qe = -k;
+            neg[nneg++] = i;
+        }
+    }
+    if (!rc) {
+        int64_t chain_id = 0;
+        chain_one_strand(recs, pos, npos, gap_open, gap_extend, max_gap, &chain_id, order, &n_out, &fresh);
+        int64_t first_neg = n_out;
+        chain_one_strand(recs, neg, nneg, gap_open, gap_extend, max_gap, &chain_id, order, &n_out, &fresh);
+        for (int64_t k = first_neg; k < n_out; k++) {
+            rec *r = &recs[order[k]];
+            int64_t q = r->qs; r->qs = -r->qe; r->qe = -q;
+        }
+        for (int64_t k = 0; k < n_out && !rc; k++) { /* remove the trim, paf_check, impl/chaining.c:323-335 */
+            rec *r = &recs[order[k]];
+            int64_t t = trim[order[k]];
+            r->qs -= t; r->qe += t; r->ts -= t; r->te += t;
+            int chk = check_rec(r);
+            if (chk) { c.record = order[k]; rc = fail(&c, chk, 0, 0); }
+        }
+        if (!rc) {
+            int64_t *keyed = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)(n_out + 1));
+            for (int64_t k = 0; k < n_out; k++) { keyed[2 * k] = order[k]; keyed[2 * k + 1] = k; }
+            g_chain_recs = recs;
+            qsort(keyed, (size_t)n_out, 2 * sizeof(int64_t), cmp_paf_score);
+            for (int64_t k = 0; k < n_out; k++) write_rec(&recs[keyed[2 * k]], &c.out); /* write_pafs, impl/paf_chain.c:127 */
+            free(keyed);
+        }
+    }
+    for (int64_t i = 0; i < nrec; i++) rec_free(&recs[i]);
+    free(recs); free(trim); free(pos); free(neg); free(order);
+    if (fresh_hits) *fresh_hits = fresh;
+    if (rc) { free(c.out.p); c.out.p = NULL; c.out.n = 0; }
+    *out = c.out.p;
+    *out_len = c.out.n;
+    return rc;
+}
+
 int po_split_file(const char *in, int64_t in_len, const char *prefix, int by_query, int64_t min_length, po_error *err) {
     run_ctx c;
     memset(&c, 0, sizeof(c));

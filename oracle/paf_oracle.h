@@ -61,7 +61,8 @@ enum {
     PO_ERR_MISSING_TARGET_SEQ = 18, /* exit(1) impl/paf_add_mismatches.c:123-127 */
     PO_ERR_TILE_ASSERT = 19,   /* asserts impl/paf.c:685,698,708, impl/paf_tile.c:57,86,171 */
     PO_ERR_STATS_BAD_OP = 20,  /* assert impl/paf.c:255 */
-    PO_ERR_SEQ_RANGE = 21      /* encode_mismatches would read outside a sequence (undefined in the reference) */
+    PO_ERR_SEQ_RANGE = 21,     /* encode_mismatches would read outside a sequence (undefined in the reference) */
+    PO_ERR_CHAIN_ASSERT = 22   /* asserts impl/chaining.c:275,278-281 */
 };
 
 typedef struct {
@@ -117,6 +118,15 @@ int po_to_bed(const char *in, int64_t in_len, int binary, int exclude_unaligned,
  * case paf_check runs on the record (impl/paf_dedupe.c:122-127: only then).
  */
 int po_dedupe(const char *in, int64_t in_len, int check_inverse, char **out, int64_t *out_len, po_error *err);
+
+/*
+ * `paffy chain` over a whole buffer (impl/paf_chain.c:123-127, impl/chaining.c:136-343) with the affine gap cost of
+ * impl/paf_chain.c:36-45 (0 for no gap, else gap_open + gap_extend * (query gap + target gap)). Address comparisons are restated
+ * as creation order (see the .c file): parity on exact ties is unpinned. *fresh_hits counts the candidates that were only seen
+ * because a search found no active chain <= the key (libavl's avl_t_prev from a fresh traverser starts at the largest element).
+ */
+int po_chain(const char *in, int64_t in_len, int64_t gap_open, int64_t gap_extend, int64_t max_gap, float pct, char **out, int64_t *out_len,
+             int64_t *fresh_hits, po_error *err);
 
 /*
  * `paffy split_file` (impl/paf_split_file.c:131-173): every record (cigar text verbatim) goes to "<prefix><contig>.paf"

@@ -594,6 +594,7 @@ struct paffy_hip_ctx {
     uint64_t bed_runs = 0;
     uint32_t tile_n = 0;
     const uint8_t *tile_in = nullptr;
+    struct ChainState *chain = nullptr; /* `paffy chain` (chain_host.h) */
     struct CovState *cov = nullptr; /* `paffy tile` / `paffy to_bed` over any number of batches (coverage_host.h) */
     /* the batch paffy_hip_query_names indexed last: paffy_hip_split_by_owner on the same batch reuses the index (one use) */
     const void *indexed_in = nullptr;
@@ -715,11 +716,13 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
 }
 
 static void cov_free(paffy_hip_ctx *c); /* coverage_host.h state */
+static void chain_free(paffy_hip_ctx *c);
 
 void paffy_hip_destroy(paffy_hip_ctx *c) {
     if (!c) return;
     prof_collect(c);
     cov_free(c);
+    chain_free(c);
     if (c->one_batch.p) (void)hipFree(c->one_batch.p);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
                       &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->seq_raw, &c->pretty_off, &c->pretty_out, &c->pretty_err, &c->rec_stats, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
@@ -1037,11 +1040,28 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
 } /* extern "C" */
 
 #include "coverage_host.h"
+#include "chain_host.h"
 #include "pretty_kernel.h"
 
 static CovState &cov_state(paffy_hip_ctx *c) {
     if (!c->cov) c->cov = new CovState();
     return *c->cov;
+}
+static ChainState &chain_state(paffy_hip_ctx *c) {
+    if (!c->chain) c->chain = new ChainState();
+    return *c->chain;
+}
+static void chain_free(paffy_hip_ctx *c) {
+    if (!c->chain) return;
+    ChainState &H = *c->chain;
+    DevBuf *bufs[] = {&H.qkey, &H.ghash, &H.ord1, &H.ord2, &H.rank, &H.start, &H.gid, &H.idx, &H.prank, &H.pred, &H.neg, &H.taken, &H.is_tail, &H.tail_of, &H.link, &H.total,
+                      &H.chain_of_tail, &H.chain_id, &H.score_key, &H.o1, &H.o2, &H.o3, &H.cls, &H.tag_chain, &H.tag_score, &H.check_key, &H.iota};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (DevBuf &b : H.i64)
+        if (b.p) (void)hipFree(b.p);
+    delete c->chain;
+    c->chain = nullptr;
 }
 static void cov_free(paffy_hip_ctx *c) {
     if (!c->cov) return;
@@ -1057,6 +1077,26 @@ static void cov_free(paffy_hip_ctx *c) {
 }
 
 extern "C" {
+
+/* the lines of S.order (records) with the levels of S.level: sizes, offsets, and the line table emit reads */
+static int lines_plan(paffy_hip_ctx *c, CovState &S, uint64_t n) {
+    if (ensure(c, S.out_len, sizeof(uint64_t) * (size_t)(n + 1))) return PAFFY_E_HIP;
+    if (ensure(c, S.out_off, sizeof(uint64_t) * (size_t)(n + 1))) return PAFFY_E_HIP;
+    LAUNCH(c, "k_line_size", k_line_size, dim3((unsigned)((n + 1 + PAFFY_NT - 1) / PAFFY_NT)), dim3(PAFFY_NT), 0, static_cast<const RecMeta *>(S.meta.p),
+           static_cast<const uint32_t *>(S.order.p), static_cast<const int64_t *>(S.level.p), n, static_cast<uint64_t *>(S.out_len.p));
+    if (cov_excl_scan64(c, S, static_cast<uint64_t *>(S.out_len.p), static_cast<uint64_t *>(S.out_off.p), (size_t)n)) return PAFFY_E_HIP;
+    uint64_t total = 0;
+    if (cov_fetch(c, &total, static_cast<uint64_t *>(S.out_off.p) + n, sizeof(total))) return PAFFY_E_HIP;
+    c->plan.out_bytes = (int64_t)total;
+    c->plan.n_rows = (int64_t)n;
+    c->line_batches = static_cast<const uint8_t *const *>(S.batch_ptrs.p);
+    c->line_meta = static_cast<const RecMeta *>(S.meta.p);
+    c->line_order = static_cast<const uint32_t *>(S.order.p);
+    c->line_level = static_cast<const int64_t *>(S.level.p);
+    c->line_off = static_cast<const uint64_t *>(S.out_off.p);
+    c->line_n = n;
+    return 0;
+}
 
 /*
  * `paffy tile` (impl/paf_tile.c:156-178) over any number of text batches: begin, add every batch (the text stays where it is until
@@ -1090,22 +1130,8 @@ int paffy_hip_tile_run(paffy_hip_ctx *c, paffy_plan_info *info) {
         int rc = cov_run(c, 0, &c->plan.error);
         if (rc) return rc;
         if (c->plan.error.code == 0) {
-            /* sizes and offsets in visiting order */
-            if (ensure(c, S.out_len, sizeof(uint64_t) * (size_t)(n + 1))) return PAFFY_E_HIP;
-            if (ensure(c, S.out_off, sizeof(uint64_t) * (size_t)(n + 1))) return PAFFY_E_HIP;
-            LAUNCH(c, "k_line_size", k_line_size, dim3((unsigned)((n + 1 + PAFFY_NT - 1) / PAFFY_NT)), dim3(PAFFY_NT), 0, static_cast<const RecMeta *>(S.meta.p),
-                   static_cast<const uint32_t *>(S.order.p), static_cast<const int64_t *>(S.level.p), n, static_cast<uint64_t *>(S.out_len.p));
-            if (cov_excl_scan64(c, S, static_cast<uint64_t *>(S.out_len.p), static_cast<uint64_t *>(S.out_off.p), (size_t)n)) return PAFFY_E_HIP;
-            uint64_t total = 0;
-            if (cov_fetch(c, &total, static_cast<uint64_t *>(S.out_off.p) + n, sizeof(total))) return PAFFY_E_HIP;
-            c->plan.out_bytes = (int64_t)total;
-            c->plan.n_rows = (int64_t)n;
-            c->line_batches = static_cast<const uint8_t *const *>(S.batch_ptrs.p);
-            c->line_meta = static_cast<const RecMeta *>(S.meta.p);
-            c->line_order = static_cast<const uint32_t *>(S.order.p);
-            c->line_level = static_cast<const int64_t *>(S.level.p);
-            c->line_off = static_cast<const uint64_t *>(S.out_off.p);
-            c->line_n = n;
+            int rl = lines_plan(c, S, n);
+            if (rl) return rl;
         }
         if (c->profile) prof_collect(c);
     }
@@ -1121,6 +1147,58 @@ int paffy_hip_tile_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, paff
     if (!rc) rc = paffy_hip_tile_add(c, d_in, in_len);
     if (!rc) rc = paffy_hip_tile_run(c, info);
     return rc;
+}
+
+/*
+ * `paffy chain` (impl/paf_chain.c:123-127, impl/chaining.c:266-343) over any number of text batches, like tile: begin, add, run;
+ * the output lines (cn / s1 tags set, cigar text verbatim) are written by paffy_hip_emit or paffy_hip_emit_lines.
+ */
+int paffy_hip_chain_begin(paffy_hip_ctx *c) {
+    if (!c) return PAFFY_E_ARG;
+    c->planned = false;
+    return cov_begin(c, 1);
+}
+int paffy_hip_chain_add(paffy_hip_ctx *c, const void *d_in, int64_t in_len) {
+    if (!c) return PAFFY_E_ARG;
+    return cov_add(c, d_in, in_len, false);
+}
+int paffy_hip_chain_run(paffy_hip_ctx *c, const paffy_chain_opts *opts, paffy_plan_info *info) {
+    if (!c || !info || !opts) return PAFFY_E_ARG;
+    CovState &S = cov_state(c);
+    c->planned = false;
+    c->plan_is_tile = true; /* the output is a line table, as for tile */
+    c->plan_is_bed = false;
+    memset(info, 0, sizeof(*info));
+    memset(&c->plan, 0, sizeof(c->plan));
+    memset(&c->kp, 0, sizeof(c->kp));
+    c->line_n = 0;
+    for (const CovBatch &b : S.batches) c->plan.in_bytes += b.len;
+    c->plan.n_records = (int64_t)S.n_rec;
+    const uint64_t n = S.n_rec;
+    if (n > 0) {
+        const ChainOpts o{opts->gap_open, opts->gap_extend, opts->max_gap_length, opts->trim_fraction};
+        int rc = chain_run(c, o, &c->plan.error);
+        if (rc) return rc;
+        if (c->plan.error.code == 0) {
+            int rl = lines_plan(c, S, n);
+            if (rl) return rl;
+        }
+        if (c->profile) prof_collect(c);
+    }
+    *info = c->plan;
+    c->planned = true;
+    return 0;
+}
+int64_t paffy_hip_chain_tags(paffy_hip_ctx *c, int64_t cap, int64_t *chain_id, int64_t *chain_score) {
+    if (!c || cap < 0 || !chain_id || !chain_score) return PAFFY_E_ARG;
+    if (!c->planned || !c->chain || c->plan.error.code) return PAFFY_E_STATE;
+    const int64_t n = (int64_t)c->chain->n_out;
+    if (cap < n) return PAFFY_E_CAPACITY;
+    if (n > 0) {
+        HIPCHK(c, hipMemcpy(chain_id, c->chain->tag_chain.p, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(chain_score, c->chain->tag_score.p, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost));
+    }
+    return n;
 }
 
 /*
@@ -2185,6 +2263,7 @@ const char *paffy_hip_error_string(int32_t code) {
         case PAFFY_ERR_MISSING_TARGET_SEQ: return "No target sequence found";
         case PAFFY_ERR_TILE_ASSERT: return "tile: coverage assertion failed";
         case PAFFY_ERR_SEQ_RANGE: return "alignment reaches outside a sequence";
+        case PAFFY_ERR_CHAIN_ASSERT: return "chain: trim fraction outside [0, 1] or a negative alignment length";
         default: return "unknown error";
     }
 }

@@ -39,6 +39,10 @@ class PlanInfo(C.Structure):
                 ("error", _Error)]
 
 
+class ChainOpts(C.Structure):
+    _fields_ = [("gap_open", C.c_int64), ("gap_extend", C.c_int64), ("max_gap_length", C.c_int64), ("trim_fraction", C.c_float)]
+
+
 class PafError(RuntimeError):
     """A record the reference would abort on; .info holds the plan (records before it are emitted)."""
 
@@ -96,6 +100,11 @@ def lib():
         L.paffy_hip_tile_begin.argtypes = [vp]
         L.paffy_hip_tile_add.argtypes = [vp, vp, i64]
         L.paffy_hip_tile_run.argtypes = [vp, C.POINTER(PlanInfo)]
+        L.paffy_hip_chain_begin.argtypes = [vp]
+        L.paffy_hip_chain_add.argtypes = [vp, vp, i64]
+        L.paffy_hip_chain_run.argtypes = [vp, C.POINTER(ChainOpts), C.POINTER(PlanInfo)]
+        L.paffy_hip_chain_tags.restype = i64
+        L.paffy_hip_chain_tags.argtypes = [vp, i64, C.POINTER(i64), C.POINTER(i64)]
         L.paffy_hip_tile_keys.restype = i64
         L.paffy_hip_tile_keys.argtypes = [vp, i64, vp]
         L.paffy_hip_emit_lines.argtypes = [vp, i64, i64, vp, i64, C.POINTER(i64)]
@@ -290,6 +299,37 @@ class Engine:
             raise PafError(f"record {info.error.record}: {L.paffy_hip_error_string(info.error.code).decode()}", info,
                            L.paffy_hip_error_exit_status(info.error.code))
         return out, info
+
+    def chain(self, data, gap_open=5000, gap_extend=1, max_gap=1000000, trim=1.0, raise_on_error=True, batch_bytes=None):
+        """paffy chain (impl/paf_chain.c, impl/chaining.c) over PAF text; returns (output bytes, PlanInfo). The keyword defaults are
+        the command's (-d, -e, -g, -t)."""
+        pieces = self.split_lines(data, batch_bytes) if batch_bytes else [data]
+        bufs = [(self.to_device(p), len(p)) for p in pieces if len(p)]
+        self._check(lib().paffy_hip_chain_begin(self._ctx), "paffy_hip_chain_begin")
+        for buf, nbytes in bufs:
+            self._check(lib().paffy_hip_chain_add(self._ctx, C.c_void_p(buf.data_ptr()), nbytes), "paffy_hip_chain_add")
+        info, opts = PlanInfo(), ChainOpts(gap_open, gap_extend, max_gap, trim)
+        self._check(lib().paffy_hip_chain_run(self._ctx, C.byref(opts), C.byref(info)), "paffy_hip_chain_run")
+        out = b""
+        if info.out_bytes and not info.error.code:
+            d_out = self.alloc_out(info.out_bytes)
+            self.emit(d_out)
+            self.sync()
+            out = bytes(d_out[: info.out_bytes].cpu().numpy().tobytes())
+        del bufs  # the batches had to stay in place until the lines were written
+        if info.error.code and raise_on_error:
+            L = lib()
+            raise PafError(f"record {info.error.record}: {L.paffy_hip_error_string(info.error.code).decode()}", info,
+                           L.paffy_hip_error_exit_status(info.error.code))
+        return out, info
+
+    def chain_tags(self, n):
+        """(chain ids, chain scores) of the n output lines of the last chain run."""
+        ids, scores = (C.c_int64 * max(n, 1))(), (C.c_int64 * max(n, 1))()
+        got = lib().paffy_hip_chain_tags(self._ctx, n, ids, scores)
+        if got < 0:
+            self._check(int(got), "paffy_hip_chain_tags")
+        return list(ids[:got]), list(scores[:got])
 
     def dedupe_plan(self, d_in, in_len, check_inverse=False):
         info = PlanInfo()
@@ -507,6 +547,11 @@ def add_mismatches(data, seqs=None, remove=False):
 def tile(data):
     """paffy tile (impl/paf_tile.c)."""
     return _engine().tile(data)[0]
+
+
+def chain(data, gap_open=5000, gap_extend=1, max_gap=1000000, trim=1.0):
+    """paffy chain [-d gap_open] [-e gap_extend] [-g max_gap] [-t trim] (impl/paf_chain.c)."""
+    return _engine().chain(data, gap_open, gap_extend, max_gap, trim)[0]
 
 
 def trim(data, trim_identity=0.05, trim_fraction=1.0, fixed_trim=False):

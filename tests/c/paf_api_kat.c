@@ -326,6 +326,22 @@ static void counts_and_intervals(void) {
     interval_destruct(i3);
 }
 
+/* paf_chain (impl/chaining.c:266-343): the example worked by hand in tests/test_oracle_kat.py */
+static void chaining(void) {
+    Paf *in[4] = {make_paf("q", 1000, 0, 100, true, "t", 1000, 0, 100, 10, 20, 60, "5M"), make_paf("q", 1000, 110, 200, true, "t", 1000, 120, 200, 10, 20, 60, "5M"),
+                  make_paf("q", 1000, 105, 150, true, "t", 1000, 300, 350, 10, 20, 60, "5M"), make_paf("q", 1000, 210, 300, true, "t", 1000, 210, 300, 10, 20, 60, "5M")};
+    const int64_t score[4] = {100, 80, 50, 90};
+    for (int i = 0; i < 4; i++) in[i]->score = score[i];
+    int64_t n = 0;
+    Paf **out = paf_chain_array(in, 4, 10, 1, 1000, 0.0f, &n);
+    CHECK(n == 4 && out[0] == in[0] && out[1] == in[3] && out[2] == in[1] && out[3] == in[2]); /* by descending score: the same objects */
+    CHECK(in[0]->chain_id == 0 && in[1]->chain_id == 0 && in[3]->chain_id == 0 && in[2]->chain_id == 1);
+    CHECK(in[0]->chain_score == 200 && in[3]->chain_score == 200 && in[2]->chain_score == 50);
+    CHECK(in[1]->query_start == 110 && in[1]->target_end == 200); /* coordinates untouched */
+    for (int i = 0; i < 4; i++) paf_destruct(in[i]);
+    free(out);
+}
+
 static void files(const char *in_path, const char *out_path) {
     FILE *in = fopen(in_path, "r");
     if (!in) {
@@ -390,6 +406,7 @@ int main(int argc, char **argv) {
     pretty();
     unchecked_and_preserved();
     counts_and_intervals();
+    chaining();
     if (argc >= 3) files(argv[1], argv[2]);
     fprintf(stderr, "%d checks, %d failures\n", checks, failures);
     return failures ? 1 : 0;

@@ -11,6 +11,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "libpaf_oracle.so")
 
 INVERT, TRIM_IDENTITY, TRIM_FIXED, SHATTER, ADD_MISMATCHES, REMOVE_MISMATCHES, PASS, FILTER = 1, 2, 3, 4, 5, 6, 7, 8
+ERR_STRAND, ERR_CHECK_QSTART, ERR_CHECK_QEND, ERR_CHAIN_ASSERT = 2, 5, 6, 22  # PO_ERR_* of oracle/paf_oracle.h
 
 
 class Stage(C.Structure):
@@ -67,6 +68,7 @@ def lib():
         L.po_cigar_aligned_bases.argtypes = [C.c_char_p]
         L.po_trim_ends_line.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.po_pretty_print.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.po_chain.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(Error)]
         L.po_coverage_counts.restype = C.c_int64
         L.po_coverage_counts.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.POINTER(C.c_uint16), C.c_int64]
         _lib = L
@@ -184,3 +186,10 @@ def pretty_print(line, query_seq, target_seq, include_alignment=True):
     out, n = C.c_void_p(), C.c_int64()
     rc = lib().po_pretty_print(line, len(line), query_seq, target_seq, 1 if include_alignment else 0, C.byref(out), C.byref(n))
     return rc, _take(out, n)
+
+
+def chain(data, gap_open=5000, gap_extend=1, max_gap=1000000, trim=1.0):
+    """`paffy chain` (impl/paf_chain.c defaults). Returns (output, error, fresh_hits)."""
+    out, n, fresh, err = C.c_void_p(), C.c_int64(), C.c_int64(), Error()
+    lib().po_chain(data, len(data), gap_open, gap_extend, max_gap, trim, C.byref(out), C.byref(n), C.byref(fresh), C.byref(err))
+    return _take(out, n), err, fresh.value

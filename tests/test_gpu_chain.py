@@ -1,0 +1,130 @@
+"""`paffy chain` (impl/paf_chain.c, impl/chaining.c) on the GPU against the oracle's literal restatement (sorted set, removal list,
+chains pulled out by score). Exact ties that the reference settles by object addresses are settled by creation order on both
+sides; the oracle counts the candidates it only saw through a fresh iterator (fresh_hits) and those cases are not compared."""
+import os
+import random
+import subprocess
+
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PAFFY = os.path.join(ROOT, "bin", "paffy")
+
+
+def line(q, qs, qe, t, ts, te, score, strand="+", ql=10_000_000, tl=10_000_000, extra=b""):
+    f = [q, str(ql), str(qs), str(qe), strand, t, str(tl), str(ts), str(te), "10", "20", "60", "AS:i:%d" % score]
+    return "\t".join(f).encode() + extra + b"\tcg:Z:%dM\n" % max(1, qe - qs)
+
+
+def collinear_set(rng, n, n_q=3, n_t=3, span=2_000_000, exact=0.2, score_hi=20000):
+    """Runs of roughly collinear alignments on a few (query, target) pairs and both strands, shuffled; a share of them abut exactly."""
+    out = []
+    while len(out) < n:
+        q, t = "q%d" % rng.randrange(n_q), "t%d" % rng.randrange(n_t)
+        strand = rng.choice("+-")
+        qs, ts = rng.randrange(span), rng.randrange(span)
+        for _ in range(rng.randrange(1, 12)):
+            ln = rng.randrange(50, 5000)
+            tln = ln + rng.randrange(-20, 21)
+            if strand == "+":
+                out.append(line(q, qs, qs + ln, t, ts, ts + max(1, tln), rng.randrange(1, score_hi), "+"))
+                gap = 0 if rng.random() < exact else rng.randrange(0, 30000)
+                qs += ln + gap
+            else:
+                out.append(line(q, max(0, qs - ln), max(1, qs), t, ts, ts + max(1, tln), rng.randrange(1, score_hi), "-"))
+                gap = 0 if rng.random() < exact else rng.randrange(0, 30000)
+                qs = max(ln + 1, qs - ln - gap)
+            ts += max(1, tln) + (0 if gap == 0 else rng.randrange(0, 30000))
+    rng.shuffle(out)
+    return b"".join(out[:n])
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import paffy_amd
+
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    e = paffy_amd.Engine()
+    yield e
+    e.close()
+
+
+def test_hand_example_and_tags(eng):
+    data = (line("q", 0, 100, "t", 0, 100, 100) + line("q", 110, 200, "t", 120, 200, 80) + line("q", 105, 150, "t", 300, 350, 50) +
+            line("q", 210, 300, "t", 210, 300, 90))
+    want, err, fresh = O.chain(data, 10, 1, 1000, 0.0)
+    assert err.code == 0 and fresh == 0
+    got, info = eng.chain(data, 10, 1, 1000, 0.0)
+    assert got == want and info.n_rows == 4
+    assert eng.chain_tags(4) == ([0, 0, 0, 1], [200, 200, 200, 50])  # output order: scores 100, 90, 80, 50
+    assert eng.chain(b"")[0] == b""
+
+
+@pytest.mark.parametrize("seed,kw", [(1, {}), (2, dict(gap_open=100, gap_extend=3)), (3, dict(max_gap=20000)), (4, dict(trim=0.0)), (5, dict(trim=0.3, gap_open=0)),
+                                     (6, dict(gap_open=50, max_gap=5000, trim=0.0))])
+def test_random_sets_match_the_oracle(eng, seed, kw):
+    rng = random.Random(seed)
+    compared = 0
+    for n in (1, 2, 7, 60, 400, 3000):
+        data = collinear_set(rng, n, exact=0.0 if seed % 2 else 0.3, score_hi=50 if seed == 6 else 20000)
+        want, err, fresh = O.chain(data, **kw)
+        assert err.code == 0
+        if fresh:
+            continue  # the reference's fresh-iterator walk saw a candidate: an address tie, not restated on the GPU
+        got, info = eng.chain(data, **kw)
+        assert got == want, (seed, n)
+        compared += 1
+    assert compared >= 3
+
+
+def test_batches_cli_and_errors(eng, tmp_path):
+    rng = random.Random(77)
+    data = collinear_set(rng, 5000, n_q=5, n_t=4)
+    want, err, fresh = O.chain(data)
+    assert err.code == 0 and fresh == 0
+    assert eng.chain(data, batch_bytes=40_000)[0] == want  # 20-odd batches
+    p = tmp_path / "in.paf"
+    p.write_bytes(data)
+    for env in ({}, {"PAFFY_CHUNK_MB": "1"}):
+        r = subprocess.run([PAFFY, "chain", "-i", str(p)], capture_output=True, env=dict(os.environ, **env))
+        assert r.returncode == 0 and r.stdout == want, r.stderr[-400:]
+    want2 = O.chain(data, 200, 2, 50000, 0.5)[0]
+    r = subprocess.run([PAFFY, "chain", "-d", "200", "-e", "2", "-g", "50000", "-t", "0.5"], input=data, capture_output=True)
+    assert r.returncode == 0 and r.stdout == want2
+    # a line that does not parse: the first one in input order, before anything is chained
+    bad = data[:2000].rsplit(b"\n", 1)[0] + b"\nq\t10\t0\t5\t*\tt\t10\t0\t5\t5\t5\t60\n" + data[2000:].split(b"\n", 1)[1]
+    _, e1, _ = O.chain(bad)
+    out, info = eng.chain(bad, raise_on_error=False)
+    assert e1.code == O.ERR_STRAND == info.error.code and info.error.record == e1.record and out == b""
+    # paf_check after the chains are written out (impl/chaining.c:333): a record outside its sequence
+    broken = line("q", 0, 100, "t", 0, 100, 100) + line("q", 110, 200, "t", 120, 200, 80, ql=150) + line("q", 300, 400, "t", 300, 400, 70)
+    _, e2, _ = O.chain(broken)
+    out, info = eng.chain(broken, raise_on_error=False)
+    assert e2.code == info.error.code == O.ERR_CHECK_QEND and info.error.record == e2.record == 1
+    r = subprocess.run([PAFFY, "chain"], input=broken, capture_output=True)
+    assert r.returncode == 1 and r.stdout == b""
+    # trim fraction outside [0, 1]: assert
+    _, e3, _ = O.chain(data[:1000].rsplit(b"\n", 1)[0] + b"\n", trim=1.5)
+    out, info = eng.chain(data[:1000].rsplit(b"\n", 1)[0] + b"\n", trim=1.5, raise_on_error=False)
+    assert e3.code == O.ERR_CHAIN_ASSERT == info.error.code
+
+
+def test_one_large_group(eng):
+    """Everything on one (query, target, strand): the recurrence and the pulling-out of chains run inside one group."""
+    rng = random.Random(5)
+    rows, qs, ts = [], 0, 0
+    for _ in range(20000):
+        ln = rng.randrange(100, 3000)
+        rows.append(line("chrA", qs, qs + ln, "chrB", ts, ts + ln, rng.randrange(500, 30000), ql=10**9, tl=10**9))
+        if rng.random() < 0.1:  # an off-diagonal piece
+            rows.append(line("chrA", qs + 5, qs + ln // 2, "chrB", rng.randrange(10**8), rng.randrange(10**8, 2 * 10**8), rng.randrange(500, 30000), ql=10**9, tl=10**9))
+        qs += ln + rng.randrange(0, 4000)
+        ts += ln + rng.randrange(0, 4000)
+    rng.shuffle(rows)
+    data = b"".join(rows)
+    want, err, fresh = O.chain(data)
+    assert err.code == 0 and fresh == 0
+    assert eng.chain(data)[0] == want

@@ -266,3 +266,34 @@ def test_pretty_print_known_answer():
     # without the alignment: the stats line alone
     rc, out2 = O.pretty_print(b"q\t310\t0\t310\t+\tt\t310\t0\t310\t310\t310\t60\tcg:Z:310M", b"A" * 310, b"A" * 310, include_alignment=False)
     assert out2 == out.split(b"\n")[0] + b"\n"
+
+
+def _chain_line(q, qs, qe, t, ts, te, score, strand=b"+"):
+    return b"\t".join([q, b"1000", b"%d" % qs, b"%d" % qe, strand, t, b"1000", b"%d" % ts, b"%d" % te, b"10", b"20", b"60", b"AS:i:%d" % score, b"cg:Z:5M"]) + b"\n"
+
+
+def test_chain_known_answer():
+    """paf_chain (impl/chaining.c:136-343) worked by hand, gap cost 10 + 1 per base, max gap 1000, no trim:
+    A q[0,100) t[0,100) 100; B q[110,200) t[120,200) 80: gap (10, 20) costs 40 < 80, chain score 80 + 100 - 40 = 140;
+    C q[105,150) t[300,350) 50: gap (5, 200) from A costs 215 >= 50, stays alone; D q[210,300) t[210,300) 90: from B the gap
+    (10, 10) costs 30, 90 + 140 - 30 = 200 (from A 230 >= 90). Chains: D-B-A = 90 + (80 - 30) + (100 - 40) = 200 (id 0), C = 50 (id 1);
+    printed by descending alignment score."""
+    data = (_chain_line(b"q", 0, 100, b"t", 0, 100, 100) + _chain_line(b"q", 110, 200, b"t", 120, 200, 80) + _chain_line(b"q", 105, 150, b"t", 300, 350, 50) +
+            _chain_line(b"q", 210, 300, b"t", 210, 300, 90))
+    out, err, fresh = O.chain(data, 10, 1, 1000, 0.0)
+    assert err.code == 0 and fresh == 0
+    tags = [(ln.split(b"\t")[12], ln.split(b"\t")[13], ln.split(b"\t")[14]) for ln in out.splitlines()]
+    assert tags == [(b"AS:i:100", b"cn:i:0", b"s1:i:200"), (b"AS:i:90", b"cn:i:0", b"s1:i:200"), (b"AS:i:80", b"cn:i:0", b"s1:i:200"), (b"AS:i:50", b"cn:i:1", b"s1:i:50")]
+    # the same four on the - strand, query mirrored (q' = 1000 - q): the + chains are numbered first
+    neg = (_chain_line(b"q", 900, 1000, b"t", 0, 100, 100, b"-") + _chain_line(b"q", 800, 890, b"t", 120, 200, 80, b"-") +
+           _chain_line(b"q", 700, 790, b"t", 210, 300, 90, b"-"))
+    out2, err, fresh = O.chain(neg + data, 10, 1, 1000, 0.0)
+    by_strand = {(ln.split(b"\t")[4], ln.split(b"\t")[12]): ln.split(b"\t")[13:15] for ln in out2.splitlines()}
+    assert by_strand[(b"-", b"AS:i:90")] == [b"cn:i:2", b"s1:i:200"] and by_strand[(b"+", b"AS:i:90")] == [b"cn:i:0", b"s1:i:200"]
+    # the default trim of 1.0 shrinks every alignment to its centre: B overlaps A by 10 on the query and still chains
+    over = _chain_line(b"q", 0, 100, b"t", 0, 100, 9000) + _chain_line(b"q", 90, 200, b"t", 95, 200, 8000)
+    out3, err, fresh = O.chain(over)
+    assert [ln.split(b"\t")[13] for ln in out3.splitlines()] == [b"cn:i:0", b"cn:i:0"]
+    assert O.chain(over, trim=0.0)[0].count(b"cn:i:1") == 1  # untrimmed they overlap: two chains
+    # coordinates come back untrimmed
+    assert out3.splitlines()[0].split(b"\t")[2:4] == [b"0", b"100"]
