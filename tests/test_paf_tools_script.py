@@ -1,6 +1,6 @@
 """The command lines of the reference's tests/paf_tools_test.sh, run as real shell pipes of `bin/paffy` processes on a synthetic
 alignment set (records on homologous bases of two generated genomes stand in for the wget + lastz steps, which need the network;
-`paffy chain` is not in this build). Exit statuses as the script expects them; the aggregate lines against the oracle."""
+the pipeline script too). Exit statuses as the script expects them; the aggregate lines against the oracle."""
 import os
 import re
 import subprocess
@@ -64,3 +64,49 @@ def test_paf_tools_script(tmp_path):
     sh("paffy invert -i output.paf > output_inv.paf", d)
     out = sh(f"cat output.paf output_inv.paf | paffy dedupe -a | {view}", d)
     assert out.split("\t")[0] == "Total-alignments:1200" and aligned(out) == total
+
+
+def test_paf_pipeline_script(tmp_path):
+    """The reference's tests/paf_pipeline_test.sh:32-94 (the Cactus-style pipeline) as real shell pipes, on the synthetic set instead of
+    the wget + lastz steps: invert, cat, split_file -q, per contig add_mismatches | chain | tile | trim, cat, filter -w 1, chain,
+    filter -s, view. Every intermediate file against the oracle run through the same steps."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s"])
+    host = synth_lib.Synth4(0x5EED0004, 512, n_contigs=4, tlen_min=400_000, tlen_span=300_000)
+    data, seqs = host.records(0, 1500), host.genomes()
+    (tmp_path / "lastz.paf").write_bytes(data)
+    for name, s in seqs.items():
+        (tmp_path / (name + ".fa")).write_bytes(b">" + name.encode() + b"\n" + s + b"\n")
+    d = str(tmp_path)
+    sh("paffy invert -i lastz.paf > inverted.paf && cat lastz.paf inverted.paf > combined.paf && mkdir -p split && paffy split_file -q -i combined.paf -p split/", d)
+    sh("for f in split/*.paf; do b=$(basename $f .paf); mkdir -p parallel_$b; "
+       "paffy add_mismatches -i $f *.fa | paffy chain | paffy tile | paffy trim > parallel_$b/trimmed.paf || exit 1; done; cat parallel_*/trimmed.paf > trimmed.paf", d)
+    sh("paffy view -i trimmed.paf *.fa -s -t && paffy filter -i trimmed.paf -w 1 > primary.paf && paffy chain -i primary.paf > primary_chained.paf && "
+       "paffy filter -i primary_chained.paf -s 20000 > primary_final.paf", d)
+    # the same steps on the oracle
+    inv = O.run([O.stage(O.INVERT)], data)[0]
+    combined = data + inv
+    assert (tmp_path / "combined.paf").read_bytes() == combined
+    by_query = {}
+    for ln in combined.splitlines(keepends=True):
+        by_query.setdefault(ln.split(b"\t")[0], []).append(ln)
+    names = sorted(p.name for p in (tmp_path / "split").iterdir())
+    assert names == sorted(q.decode() + ".paf" for q in by_query)
+    trimmed = b""
+    for nm in sorted("parallel_" + n[:-4] for n in names):  # the order `cat parallel_*/trimmed.paf` expands to
+        part = b"".join(by_query[nm[len("parallel_"):].encode()])
+        enc = O.run([O.stage(O.ADD_MISMATCHES)], part, seqs)[0]
+        chained, err, _ = O.chain(enc)
+        assert err.code == 0
+        tiled = O.tile(chained)[0]
+        want = O.run([O.stage(O.TRIM_IDENTITY, 0.05, 1.0)], tiled)[0]
+        assert (tmp_path / nm / "trimmed.paf").read_bytes() == want, nm
+        trimmed += want
+    assert (tmp_path / "trimmed.paf").read_bytes() == trimmed
+    primary = O.filter(trimmed, max_tile_level=1)[0]
+    assert (tmp_path / "primary.paf").read_bytes() == primary and 0 < primary.count(b"\n") < trimmed.count(b"\n")
+    rechained, err, _ = O.chain(primary)
+    assert err.code == 0 and (tmp_path / "primary_chained.paf").read_bytes() == rechained
+    final = O.filter(rechained, min_chain_score=20000)[0]
+    assert (tmp_path / "primary_final.paf").read_bytes() == final and final.count(b"\n") > 0
+    out = sh("paffy view -i primary_final.paf *.fa -s -t -u 0.74 -v 1000", d)
+    assert out.startswith("Total-alignments:%d\t" % final.count(b"\n"))
