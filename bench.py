@@ -197,8 +197,16 @@ def main():
         readers = ("k_size_lds", "k_tile_walk", "k_tile_slices", "k_bed_cover")
         writers = ("k_emit_rows", "k_emit_lds", "k_emit_lds<line>", "k_emit_line", "k_tile_emit", "k_arena_emit", "k_arena_emit<line>")
         by_kernel = {}
+        if "k_size_wave" in kernels and "k_size_lds" in kernels:
+            # the sizing pass is two launches of one kernel: short cigars one wave per record, the rest four waves per record;
+            # together they read the batch's text once
+            ms = kernels["k_size_wave"][0] / max(1, kernels["k_size_wave"][1]) + kernels["k_size_lds"][0] / max(1, kernels["k_size_lds"][1])
+            own = per_step_in + per_step_extra
+            tr = [measured_traffic(args, k) for k in ("k_size_wave", "k_size_lds")]
+            by_kernel["k_size_wave+k_size_lds"] = {"avg_kernel_ms": round(ms, 4), "own_algorithmic_bytes": int(own), "achieved": round(own / (ms * 1e-3) / 1e9, 1),
+                                                   "frac": round(own / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": int(sum(tr)) if all(tr) else None}
         for name, (ms, launches) in kernels.items():
-            if launches <= 0 or ms <= 0 or name not in readers + writers:
+            if launches <= 0 or ms <= 0 or name not in readers + writers or (name == "k_size_lds" and "k_size_wave" in kernels):
                 continue
             own = per_step_in + per_step_extra if name in readers else per_step_out
             ach = own / (ms / launches * 1e-3) / 1e9

@@ -42,7 +42,11 @@ def main():
                         continue
                     name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()
                     name = {"k_emit_lds<true>": "k_emit_lds", "k_emit_lds<false>": "k_emit_lds<line>"}.get(name, name)
+                    name = re.sub(r"^g256::", "", name)  # the four-wave build of the record kernels
+                    if name.startswith("g64::k_size_lds"):
+                        name = "k_size_wave"  # the one-wave build, launched under this name (bench.py's kernel_ms key)
                     name = re.sub(r"^(k_size_lds(?:_long)?)<.*>$", r"\1", name)
+                    name = re.sub(r"^(k_cov_walk)<.*>$", r"\1", name)
                     sums.setdefault(name, {}).setdefault(counter, 0.0)
                     sums[name][counter] += float(row["Counter_Value"])
                     launches.setdefault(name, {}).setdefault(counter, 0)
@@ -59,7 +63,7 @@ def main():
                    "per-launch averages; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); KB counters * 1024" % args.steps}
     with open(args.out, "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
-    for k in ("k_size_lds", "k_emit_rows", "k_emit_lds"):
+    for k in ("k_size_wave", "k_size_lds", "k_emit_rows", "k_emit_lds", "k_cov_bitmap", "k_cov_walk"):
         if k in kernels:
             print(k, kernels[k])
 
