@@ -257,7 +257,7 @@ def main():
                               "rank0_first_offsets": [int(x) for x in my_offsets[:4].tolist()]},
             "whole_path_GBps_per_gpu": round(((job_in + job_out) / world + extra_per_base * aligned_per_record * args.batch * args.steps) / elapsed / 1e9, 1),
             "roofline": roofline,
-            "roofline_by_kernel": {k: v for k, v in by_kernel.items() if kernels[k][0] >= 0.05 * max(x[0] for x in kernels.values())},
+            "roofline_by_kernel": {k: v for k, v in by_kernel.items() if "+" in k or kernels[k][0] >= 0.05 * max(x[0] for x in kernels.values())},
             "whole_path_frac_of_hbm_peak": round(((job_in + job_out) / world + extra_per_base * aligned_per_record * args.batch * args.steps) / elapsed / 1e9 / HBM_PEAK_GBS, 4),
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
