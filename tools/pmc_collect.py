@@ -9,6 +9,7 @@ import csv
 import glob
 import json
 import os
+import shutil
 import subprocess
 import sys
 
@@ -27,6 +28,7 @@ def main():
     res = {}
     for gi, grp in enumerate(GROUPS):
         d = os.path.join(root, "gpurun_out", f"pmc_pass{gi}")
+        shutil.rmtree(d, ignore_errors=True)  # an earlier run's files would be summed in
         cmd = ["rocprofv3", "--pmc", *grp, "-d", d, "--output-format", "csv", "--", sys.executable, os.path.join(root, "bench.py"), *bench_args]
         print(f"pass {gi}: {' '.join(grp)}", flush=True)
         r = subprocess.run(cmd, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)

@@ -12,6 +12,7 @@ import glob
 import json
 import os
 import re
+import shutil
 import subprocess
 import sys
 
@@ -28,6 +29,7 @@ def main():
     sums, launches = {}, {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = os.path.join(root, "gpurun_out", f"traffic_{counter.lower()}")
+        shutil.rmtree(d, ignore_errors=True)  # an earlier run's files would be summed in
         cmd = ["rocprofv3", "--pmc", counter, "-d", d, "--output-format", "csv", "--", sys.executable, os.path.join(root, "bench.py"), "--steps", str(args.steps),
                "--warmup", "2", "--cpu-sample", "0", "--no-kernel-events", "--workload", args.workload, "--batch", str(args.batch)]
         print("pass", counter, flush=True)
