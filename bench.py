@@ -527,16 +527,18 @@ def rehearse(args):
 
 
 def measured_traffic(args, kernel):
-    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (rocprofv3 cannot run
-    inside this process); only reported when they were taken on this workload and batch size."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        with open(path) as fh:
-            t = json.load(fh)
-        if t.get("workload") == args.workload and t.get("batch") == args.batch and not args.pipe:
-            return t["kernels"][kernel]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process;
+    tools/traffic_collect.py writes the files): the newest profiles/*traffic*.json taken on this workload and batch size."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                t = json.load(fh)
+            if t.get("workload") == args.workload and t.get("batch") == args.batch and not args.pipe:
+                return t["kernels"][kernel]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
     return None
 
 

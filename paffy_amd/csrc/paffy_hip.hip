@@ -853,10 +853,11 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     }();
     const uint32_t lvl0_max = add_not_last ? PAFFY_OPS_CAP * 5 / 8 : PAFFY_OPS_CAP;
     /* records with at most this many cigar bytes (about WAVE_OPS_CAP ops at three bytes per op) are sized one wave per record; denser
-       cigars of that length overflow the wave's store and go to the arena class. add_mismatches rebuilds the op array: not there. */
+       cigars of that length overflow the wave's store and are redone by the four-wave build. add_mismatches rebuilds the op array: when
+       a stage follows it the new array must fit the store, so only pipes that end with it take the one-wave build. */
     static const uint32_t wave_env = getenv("PAFFY_WAVE_BYTES") ? (uint32_t)atoi(getenv("PAFFY_WAVE_BYTES")) : WAVE_MAX_BYTES;
     static const uint32_t wave_cap_env = getenv("PAFFY_WAVE_OPS") ? (uint32_t)atoi(getenv("PAFFY_WAVE_OPS")) : WAVE_OPS_CAP;
-    const uint32_t wave_bytes = need_seqs ? 0u : wave_env;
+    const uint32_t wave_bytes = (need_seqs && add_not_last) ? 0u : wave_env;
     {
         int rc = index_and_parse(c, in, len, &n_lines, lvl0_max);
         if (rc) return rc;

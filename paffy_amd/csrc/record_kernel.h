@@ -22,6 +22,12 @@ namespace PAFFY_NS {
 #define INTERNAL_DIGIT_RUN 4u
 
 __device__ __forceinline__ uint32_t dec_len_u32(uint32_t x);
+/* the same for values that are almost always below 10^5 (run lengths): four compares, the other five only when some lane needs them */
+__device__ __forceinline__ uint32_t dec_len_short(uint32_t x) {
+    uint32_t n = 1u + (x >= 10u) + (x >= 100u) + (x >= 1000u) + (x >= 10000u);
+    if (__any(x >= 100000u)) n += (x >= 100000u) + (x >= 1000000u) + (x >= 10000000u) + (x >= 100000000u) + (x >= 1000000000u);
+    return n;
+}
 
 /* ---------------- op stores ---------------- */
 
@@ -996,8 +1002,8 @@ __device__ __forceinline__ uint32_t comp4(uint32_t x) { /* complement of four up
     return x ^ (a | (a << 2) | (a << 4)) ^ (cg >> 5);
 }
 __device__ __forceinline__ uint32_t equal4(uint32_t a, uint32_t b) { /* bit j = byte j equal */
-    const uint32_t r = (~nonzero4(a ^ b) & 0x80808080u) >> 7;
-    return (r | (r >> 7) | (r >> 14) | (r >> 21)) & 0xfu;
+    const uint32_t r = (~nonzero4(a ^ b) & 0x80808080u) >> 7; /* bits 0, 8, 16, 24 */
+    return (r * 0x01020408u) >> 24 & 0xfu;                       /* bit 8 k -> bit 24 + k; the other partial products stay below bit 24 or leave the word */
 }
 /* bit j = T[j] == query base of column j, j < 16, on the canonical copies of the sequences (upper case; for the - strand the
  * complemented copy): q points at column 0 (+ strand: columns go up; - strand: column j is q[-j]). `lowest`: first byte of the
@@ -1053,10 +1059,12 @@ __device__ __forceinline__ int32_t wave_incl_max_i32(int32_t v) {
 template <class OPS>
 __device__ __forceinline__ uint32_t mismatch_count_wave(const KParams &P, const RecState &s, const View<OPS> &v, const uint8_t *Q, int64_t qseq_len,
                                                         const uint8_t *T, int64_t tseq_len, uint32_t wb, uint32_t we, int64_t q0, int64_t t0,
-                                                        uint32_t *items, uint32_t *n_items_out, int64_t *bad) {
+                                                        uint32_t *items, uint32_t *nm_list, uint32_t *n_items_out, uint32_t *n_nm_out, int64_t *bad) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t qpos = (uint32_t)q0, tpos = (uint32_t)t0; /* wave-uniform */
     uint32_t lane_cnt = 0, written = 0;
+    uint32_t nm_written = 0; /* ops other than M seen so far: they are kept as they are, in nm_list */
+    uint32_t nm_run = 0;     /* how many of them since the last M op (wave-uniform) */
     int64_t first_bad = INT64_MAX;
     for (uint32_t base = wb; base < we; base += 64) {
         const uint32_t i = base + lane;
@@ -1079,11 +1087,34 @@ __device__ __forceinline__ uint32_t mismatch_count_wave(const KParams &P, const 
         }
         qpos += wave_last_u32(qinc);
         tpos += wave_last_u32(tinc);
-        /* items of this op: chunks of an M op; one for any other op; none for an M op of length 0 (impl/paf.c:747-779 writes nothing) */
-        const uint32_t nch = is_m ? (uint32_t)((len + 15) >> 4) : ((i < we && op != OP_M) ? 1u : 0u);
+        /* items of this op: the chunks of an M op; none for an M op of length 0 (impl/paf.c:747-779 writes nothing). Any other op
+           passes through: its word goes to nm_list, and the first chunk of the next M op says how many such ops stand in front of it */
+        const bool is_nm = i < we && op != OP_M;
+        const uint32_t nch = is_m ? (uint32_t)((len + 15) >> 4) : 0u;
         const uint32_t iinc = wave_incl_scan_u32(nch);
         const uint32_t ioff = iinc - nch, n_items = wave_last_u32(iinc);
         const uint32_t opw = ((uint32_t)len << 3) | (uint32_t)op;
+        const uint32_t nminc = wave_incl_scan_u32(is_nm ? 1u : 0u), nm_here = wave_last_u32(nminc);
+        const uint32_t nmex = nminc - (is_nm ? 1u : 0u);
+        if (is_nm) {
+            nm_list[nm_written + nmex] = opw;
+            lane_cnt++;
+        }
+        /* ops other than M between the M op before (the nearest lane before with items, or the windows before) and this one */
+        const int32_t m_incl = wave_incl_max_i32(nch ? (int32_t)lane : -1);
+        int32_t m_src = __shfl_up(m_incl, 1);
+        if (lane == 0) m_src = -1;
+        const uint32_t nm_at_src = __shfl(nmex, m_src < 0 ? 0 : m_src);
+        uint32_t gap = m_src < 0 ? nm_run + nmex : nmex - nm_at_src;
+        if (nch && gap > 62u) { /* does not fit the item word: the general encoder takes the record */
+            gap = 62u;
+            first_bad = -1;
+        }
+        {
+            const int32_t last_m = __builtin_amdgcn_readlane(m_incl, 63);
+            nm_run = last_m < 0 ? nm_run + nm_here : nm_here - (uint32_t)__builtin_amdgcn_readlane((int)nmex, last_m);
+        }
+        nm_written += nm_here;
         const uint8_t *Tw = T + tj0, *Qw = (s.same ? Q : P.seq_comp + (Q - P.seq_base)) + qoff0; /* - strand: the complemented copy */
         uint32_t carry_m = 0; /* mask of the last item of the iteration before */
         for (uint32_t c0 = 0; c0 < n_items; c0 += 64) {
@@ -1099,25 +1130,20 @@ __device__ __forceinline__ uint32_t mismatch_count_wave(const KParams &P, const 
             const uint32_t ow = __shfl(opw, (int)ol);
             const uint32_t o_first = __shfl(ioff, (int)ol);
             const uint32_t oq = __shfl(qrel, (int)ol), ot = __shfl(trel, (int)ol); /* by every lane: the source lanes must be live */
+            const uint32_t og = __shfl(gap, (int)ol);
             const uint32_t olen = ow >> 3;
-            const bool item_m = act && (ow & 7u) == (uint32_t)OP_M;
             const uint32_t k = (c - o_first) << 4;
-            uint32_t m = 0, word = ow;
-            if (item_m) {
+            uint32_t m = 0;
+            if (act) { /* every item is a chunk of an M op */
                 const uint32_t nb = olen - k < 16u ? olen - k : 16u;
                 m = match_mask16(P.seq_comp, s.same ? Qw + (oq + k) : Qw - (oq + k), Tw + (ot + k), s.same) & ((1u << nb) - 1u);
-                word = (uint32_t)OP_M | (nb << 3) | (m << 8) | (k == 0 ? 1u << 24 : 0u) | (k + 16u >= olen ? 1u << 25 : 0u);
-            }
-            if (act) items[written + c] = word;
-            uint32_t pm = __shfl_up(m, 1);
-            if (lane == 0) pm = carry_m;
-            if (item_m) { /* a column starts a run when its match bit differs from the column before; the chunk before is full */
-                uint32_t starts = m ^ ((m << 1) | ((pm >> 15) & 1u));
-                starts &= (1u << ((word >> 3) & 31u)) - 1u;
+                items[written + c] = (uint32_t)OP_M | (nb << 3) | (m << 8) | (k == 0 ? (1u << 24) | (og << 26) : 0u) | (k + 16u >= olen ? 1u << 25 : 0u);
+                uint32_t pm = __shfl_up(m, 1); /* only the bit of a chunk of the same op is used: k != 0 */
+                if (lane == 0) pm = carry_m;
+                /* a column starts a run when its match bit differs from the column before; the chunk before is full */
+                uint32_t starts = (m ^ ((m << 1) | ((pm >> 15) & 1u))) & ((1u << nb) - 1u);
                 if (k == 0) starts |= 1u;
                 lane_cnt += (uint32_t)__popc(starts);
-            } else if (act) {
-                lane_cnt++;
             }
             carry_m = __builtin_amdgcn_readlane((int)m, 63);
         }
@@ -1125,43 +1151,56 @@ __device__ __forceinline__ uint32_t mismatch_count_wave(const KParams &P, const 
     }
     *bad = first_bad;
     *n_items_out = written;
+    *n_nm_out = nm_written;
     return wave_last_u32(wave_incl_scan_u32(lane_cnt));
 }
 
-/* Walk 2: the wave's item words, 64 at a time, become the ops blk[out_base ..): no op is looked at again. */
-__device__ __forceinline__ uint32_t mismatch_fill_wave(const uint32_t *items, uint32_t n_items, uint32_t out_base, uint32_t *blk) {
+/*
+ * Walk 2: the wave's item words, 64 at a time, become the ops blk[out_base ..): no op is looked at again. The ops other than M
+ * are copied from nm_list: the first chunk of an M op carries the number of them that stand right in front of it, the rest follow
+ * the last M op.
+ */
+__device__ __forceinline__ uint32_t mismatch_fill_wave(const uint32_t *items, uint32_t n_items, const uint32_t *nm_list, uint32_t n_nm, uint32_t out_base, uint32_t *blk) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t text = 0; /* bytes of cigar text of the ops this lane wrote (digits + letter) */
-    uint32_t done = out_base; /* ops written so far; wave-uniform */
+    uint32_t done = out_base; /* ops written so far, the passed-through ones included; wave-uniform */
+    uint32_t nm_done = 0;     /* ops of nm_list placed so far; wave-uniform */
     uint32_t carry_m = 0;     /* mask of the last item of the iteration before */
     int32_t carry_start = 0;  /* column (16 * item + bit) of the last run start seen */
     for (uint32_t c0 = 0; c0 < n_items; c0 += 64) {
         const uint32_t c = c0 + lane;
         const bool act = c < n_items;
         /* past the L1: a line may predate the stores of walk 1 */
-        const uint32_t w = act ? __hip_atomic_load(items + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
-        const bool item_m = (w & 7u) == (uint32_t)OP_M;
-        const uint32_t m = item_m ? (w >> 8) & 0xffffu : 0u, nb = (w >> 3) & 31u;
+        const uint32_t w = act ? __hip_atomic_load(items + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t m = (w >> 8) & 0xffffu, nb = (w >> 3) & 31u;
+        const bool first = (w >> 24) & 1u;
+        const uint32_t gap = first ? w >> 26 : 0u;
         uint32_t pm = __shfl_up(m, 1);
         if (lane == 0) pm = carry_m;
         const uint32_t prevbit = (pm >> 15) & 1u;
         uint32_t starts = 0;
-        if (item_m) starts = ((m ^ ((m << 1) | prevbit)) & ((1u << nb) - 1u)) | ((w >> 24) & 1u);
-        const uint32_t cnt = item_m ? (uint32_t)__popc(starts) : (act ? 1u : 0u);
+        if (act) starts = ((m ^ ((m << 1) | prevbit)) & ((1u << nb) - 1u)) | (first ? 1u : 0u);
+        const uint32_t cnt = (uint32_t)__popc(starts) + gap;
         const uint32_t cinc = wave_incl_scan_u32(cnt);
-        uint32_t idx = done + cinc - cnt; /* ops in front of this item's first start */
+        uint32_t idx = done + cinc - cnt + gap; /* ops in front of this item's first start */
         done += wave_last_u32(cinc);
+        const uint32_t ginc = wave_incl_scan_u32(gap);
+        for (uint32_t t = 0; t < gap; t++) { /* the ops that stand between the M op before and this one */
+            const uint32_t ow = __hip_atomic_load(nm_list + nm_done + ginc - gap + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            blk[idx - gap + t] = ow;
+            text += dec_len_short(ow >> 3) + 1u;
+        }
+        nm_done += wave_last_u32(ginc);
         /* column of the previous start: the nearest lane before with a start (always one of the same op), or the carry */
         const int32_t col0 = (int32_t)(c << 4);
         const int32_t my_last = starts ? col0 + 31 - __clz((int)starts) : 0;
         const int32_t src_incl = wave_incl_max_i32(starts ? (int32_t)lane : -1);
         int32_t src = __shfl_up(src_incl, 1);
         if (lane == 0) src = -1;
-        const int32_t from = __shfl(my_last, src < 0 ? 0 : src);
-        int32_t prev = src < 0 ? carry_start : from;
-        if (item_m) {
+        const int32_t from_col = __shfl(my_last, src < 0 ? 0 : src);
+        int32_t prev = src < 0 ? carry_start : from_col;
+        if (act) {
             uint32_t st = starts;
-            const bool first = (w >> 24) & 1u;
             while (st) {
                 const uint32_t j = (uint32_t)__ffs((int)st) - 1u;
                 st &= st - 1u;
@@ -1169,7 +1208,7 @@ __device__ __forceinline__ uint32_t mismatch_fill_wave(const uint32_t *items, ui
                 if (!(first && j == 0)) { /* the run in front of this start ends here */
                     const uint32_t before = j ? (m >> (j - 1u)) & 1u : prevbit;
                     blk[idx - 1u] = ((uint32_t)(pos - prev) << 3) | (before ? (uint32_t)OP_EQ : (uint32_t)OP_X);
-                    text += dec_len_u32((uint32_t)(pos - prev)) + 1u;
+                    text += dec_len_short((uint32_t)(pos - prev)) + 1u;
                 }
                 prev = pos;
                 idx++;
@@ -1177,15 +1216,18 @@ __device__ __forceinline__ uint32_t mismatch_fill_wave(const uint32_t *items, ui
             if ((w >> 25) & 1u) {
                 const uint32_t rl = (uint32_t)(col0 + (int32_t)nb - prev);
                 blk[idx - 1u] = (rl << 3) | (((m >> (nb - 1u)) & 1u) ? (uint32_t)OP_EQ : (uint32_t)OP_X);
-                text += dec_len_u32(rl) + 1u;
+                text += dec_len_short(rl) + 1u;
             }
-        } else if (act) {
-            blk[idx] = w;
-            text += dec_len_u32(w >> 3) + 1u;
         }
         const int32_t top = __builtin_amdgcn_readlane(src_incl, 63);
         if (top >= 0) carry_start = __shfl(my_last, top);
         carry_m = __builtin_amdgcn_readlane((int)m, 63);
+    }
+    /* what follows the last M op */
+    for (uint32_t t = nm_done + lane; t < n_nm; t += 64) {
+        const uint32_t ow = __hip_atomic_load(nm_list + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        blk[done + (t - nm_done)] = ow;
+        text += dec_len_short(ow >> 3) + 1u;
     }
     return wave_last_u32(wave_incl_scan_u32(text));
 }
@@ -1205,20 +1247,21 @@ __device__ __forceinline__ int encode_mismatch_runs_lds(const KParams &P, const 
     ABL23_DECL
     /* an even split of the ops over the threads, so that the four waves get a quarter each whatever the record's size */
     const uint32_t b = (uint32_t)((uint64_t)v.n * threadIdx.x / PAFFY_NT), e = (uint32_t)((uint64_t)v.n * (threadIdx.x + 1) / PAFFY_NT);
-    int64_t c[3] = {0, 0, 0}, tot[3]; /* query bases, target bases, items (16-column chunks of M ops + the other ops) */
+    int64_t c[4] = {0, 0, 0, 0}, tot[4]; /* query bases, target bases, items (16-column chunks of M ops), the other ops */
     for (uint32_t i = b; i < e; i++) {
         int64_t len;
         int op;
         v.get(i, len, op);
         if (op != OP_D) c[0] += len;
         if (op != OP_I) c[1] += len;
-        c[2] += op == OP_M ? (len + 15) >> 4 : 1;
+        if (op == OP_M) c[2] += (len + 15) >> 4;
+        else c[3]++;
     }
-    block_excl_scan<3>(c, tot, bc);
+    block_excl_scan<4>(c, tot, bc);
     ABL23_MARK(0)
     if (tot[0] >= (1ll << 30) || tot[1] >= (1ll << 30)) return -1; /* 32-bit columns and op counts below */
-    /* scratch for the item words: 4 bytes per item, in the arena */
-    const uint64_t mslots = ((uint64_t)tot[2] + 1) >> 1;
+    /* scratch for the item words and the words of the ops that pass through: 4 bytes each, in the arena */
+    const uint64_t mslots = ((uint64_t)tot[2] + (uint64_t)tot[3] + 1) >> 1;
     if (threadIdx.x == 0) sh->bcast[3] = (int64_t)atomicAdd(&P.info->arena_used, (unsigned long long)mslots);
     __syncthreads();
     const uint64_t moff = (uint64_t)sh->bcast[3];
@@ -1228,11 +1271,13 @@ __device__ __forceinline__ int encode_mismatch_runs_lds(const KParams &P, const 
     const uint32_t wb = (uint32_t)((uint64_t)v.n * (64u * wave) / PAFFY_NT), we = (uint32_t)((uint64_t)v.n * (64u * wave + 64u) / PAFFY_NT);
     const int64_t q0 = wave_first_i64(c[0]), t0 = wave_first_i64(c[1]);
     uint32_t *items = reinterpret_cast<uint32_t *>(P.arena + moff) + wave_first_i64(c[2]);
+    uint32_t *nm_list = reinterpret_cast<uint32_t *>(P.arena + moff) + tot[2] + wave_first_i64(c[3]);
     int64_t bad = INT64_MAX;
-    uint32_t n_items = 0;
-    const uint32_t wcnt = mismatch_count_wave(P, s, v, Q, qseq_len, T, tseq_len, wb, we, q0, t0, items, &n_items, &bad);
+    uint32_t n_items = 0, n_nm = 0;
+    const uint32_t wcnt = mismatch_count_wave(P, s, v, Q, qseq_len, T, tseq_len, wb, we, q0, t0, items, nm_list, &n_items, &n_nm, &bad);
     ABL23_MARK(1)
     bad = block_min_i64(wave_min(bad), bc);
+    if (bad == -1) return -1; /* a run of more than 62 ops other than M: the general encoder (arena class) */
     uint32_t cw[1] = {lane == 0 ? wcnt : 0u}, ctot[1];
     block_excl_scan_u32<1>(cw, ctot, bc);
     const uint32_t out_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[0]);
@@ -1247,7 +1292,7 @@ __device__ __forceinline__ int encode_mismatch_runs_lds(const KParams &P, const 
     if (off + slots > P.arena_cap) return -2;
     uint32_t *blk = reinterpret_cast<uint32_t *>(P.arena + off);
     ABL23_MARK(2)
-    const uint32_t wtext = mismatch_fill_wave(items, n_items, out_base, blk);
+    const uint32_t wtext = mismatch_fill_wave(items, n_items, nm_list, n_nm, out_base, blk);
     ABL23_MARK(3)
     __syncthreads(); /* every op of the old array has been read, every op of the new one written */
     *blk_off = off;
