@@ -1156,72 +1156,157 @@ __device__ __forceinline__ uint32_t mismatch_count_wave(const KParams &P, const 
 }
 
 /*
- * Walk 2: the wave's item words, 64 at a time, become the ops blk[out_base ..): no op is looked at again. The ops other than M
- * are copied from nm_list: the first chunk of an M op carries the number of them that stand right in front of it, the rest follow
- * the last M op.
+ * Loads that are waited for by hand. One counter (vmcnt) tracks a wave's loads and stores in issue order, so the compiler's wait
+ * for a load is a wait for every store issued before it -- microseconds when the write queues are full. A word needed in the next
+ * iteration is therefore requested before this iteration's stores and waited for with s_waitcnt vmcnt(N), N = a lower bound of
+ * the store instructions issued since: everything older than the newest N operations, the load included, is complete.
+ * sc1: past the L1 (the words were written by this wave's other walk; a line may predate those stores).
  */
-__device__ __forceinline__ uint32_t mismatch_fill_wave(const uint32_t *items, uint32_t n_items, const uint32_t *nm_list, uint32_t n_nm, uint32_t out_base, uint32_t *blk) {
+#define PAFFY_LOAD32_AHEAD(dst, ptr) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory")
+/* the wait and the first read of the two loaded registers in one statement: nothing can slip a copy of them in front of the wait */
+#define PAFFY_WAIT_TAKE2(N, out0, out1, in0, in1) \
+    asm volatile("s_waitcnt vmcnt(" #N ")\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(out0), "=&v"(out1) : "v"(in0), "v"(in1) : "memory")
+__device__ __forceinline__ void wait_all_but_newest(uint32_t n, uint32_t a, uint32_t b, uint32_t &out_a, uint32_t &out_b) { /* a, b: the registers the loads fill */
+    if (n >= 32) PAFFY_WAIT_TAKE2(32, out_a, out_b, a, b);
+    else if (n >= 16) PAFFY_WAIT_TAKE2(16, out_a, out_b, a, b);
+    else if (n >= 8) PAFFY_WAIT_TAKE2(8, out_a, out_b, a, b);
+    else if (n >= 4) PAFFY_WAIT_TAKE2(4, out_a, out_b, a, b);
+    else if (n >= 2) PAFFY_WAIT_TAKE2(2, out_a, out_b, a, b);
+    else if (n >= 1) PAFFY_WAIT_TAKE2(1, out_a, out_b, a, b);
+    else PAFFY_WAIT_TAKE2(0, out_a, out_b, a, b);
+}
+
+/*
+ * Walk 2: the wave's item words, 64 at a time, become the ops blk[out_base ..): no op is looked at again.
+ *
+ * A run of equal match bits starts at a column whose bit differs from the one before, and at an op's first column. The lanes hold
+ * one item (16 columns) each and know its run starts as a bit mask; what an op needs is one lane per RUN. So the starts of the
+ * 64 items are first spread out: every lane walks its own mask (the walk does nothing but write a 4-byte word per start to the
+ * wave's LDS window, slot = runs before it), then lane v takes start v - 1 and its successor from LDS: the run is as long as the
+ * distance to the next start (less the unused columns of an op's last chunk when that start opens an op), its letter is the match
+ * bit at its own first column, its place in blk[] the number of runs and passed-through ops before it. The last start of a batch
+ * waits for the first of the next (`pend`).
+ * The ops other than M are copied from nm_list: the first chunk of an M op carries the number of them that stand right in front
+ * of it, the rest follow the last M op. The item words and the next 64 words of nm_list are requested one iteration ahead.
+ *   start word: bits 0-9 column in the batch (16 * lane + bit), 10 match bit, 11-15 unused columns in front (op's first start only),
+ *               16-31 passed-through ops in front of the run, counted from the batch's first
+ */
+#define PAFFY_FILL_SLOTS 256u /* starts per pass: 1 KiB of the wave's text staging area */
+__device__ __forceinline__ uint32_t mismatch_fill_wave(const uint32_t *items, uint32_t n_items, const uint32_t *nm_list, uint32_t n_nm, uint32_t out_base, uint32_t *blk,
+                                                        uint32_t *slots) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t text = 0; /* bytes of cigar text of the ops this lane wrote (digits + letter) */
-    uint32_t done = out_base; /* ops written so far, the passed-through ones included; wave-uniform */
+    uint32_t done = out_base; /* ops placed so far (the pending run included), the passed-through ones too; wave-uniform */
     uint32_t nm_done = 0;     /* ops of nm_list placed so far; wave-uniform */
-    uint32_t carry_m = 0;     /* mask of the last item of the iteration before */
-    int32_t carry_start = 0;  /* column (16 * item + bit) of the last run start seen */
+    uint32_t carry_w = 0;     /* word of the last item of the iteration before */
+    bool pend = false;        /* a run whose end is not known yet: first column (16 * item + bit), match bit, place */
+    uint32_t pend_col = 0, pend_bit = 0, pend_out = 0;
+    uint32_t w_next = 0, nm_next = 0; /* item word c0 + lane and nm_list[nm_done + lane] of the coming iteration */
+    uint32_t since = 0;               /* store instructions issued after those two loads (a lower bound) */
+    if (n_items) {
+        if (lane < n_items) PAFFY_LOAD32_AHEAD(w_next, items + lane);
+        if (lane < n_nm) PAFFY_LOAD32_AHEAD(nm_next, nm_list + lane);
+    }
     for (uint32_t c0 = 0; c0 < n_items; c0 += 64) {
         const uint32_t c = c0 + lane;
         const bool act = c < n_items;
-        /* past the L1: a line may predate the stores of walk 1 */
-        const uint32_t w = act ? __hip_atomic_load(items + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        uint32_t w_got, nmw;
+        wait_all_but_newest(since, w_next, nm_next, w_got, nmw);
+        const uint32_t w = act ? w_got : 0u;
         const uint32_t m = (w >> 8) & 0xffffu, nb = (w >> 3) & 31u;
         const bool first = (w >> 24) & 1u;
         const uint32_t gap = first ? w >> 26 : 0u;
-        uint32_t pm = __shfl_up(m, 1);
-        if (lane == 0) pm = carry_m;
-        const uint32_t prevbit = (pm >> 15) & 1u;
+        const uint32_t ginc = wave_incl_scan_u32(gap), gtot = wave_last_u32(ginc);
+        /* the words of the iteration after this one, before any store of this one */
+        since = 0;
+        w_next = 0;
+        nm_next = 0;
+        if (c0 + 64 < n_items) {
+            if (c + 64 < n_items) PAFFY_LOAD32_AHEAD(w_next, items + c + 64);
+            if (nm_done + gtot + lane < n_nm) PAFFY_LOAD32_AHEAD(nm_next, nm_list + nm_done + gtot + lane);
+        }
+        uint32_t pw = __shfl_up(w, 1); /* the item before: its last match bit, and how many of its 16 columns it used */
+        if (lane == 0) pw = carry_w;
+        const uint32_t prevbit = (pw >> 23) & 1u;
         uint32_t starts = 0;
         if (act) starts = ((m ^ ((m << 1) | prevbit)) & ((1u << nb) - 1u)) | (first ? 1u : 0u);
-        const uint32_t cnt = (uint32_t)__popc(starts) + gap;
-        const uint32_t cinc = wave_incl_scan_u32(cnt);
-        uint32_t idx = done + cinc - cnt + gap; /* ops in front of this item's first start */
-        done += wave_last_u32(cinc);
-        const uint32_t ginc = wave_incl_scan_u32(gap);
-        for (uint32_t t = 0; t < gap; t++) { /* the ops that stand between the M op before and this one */
-            const uint32_t ow = __hip_atomic_load(nm_list + nm_done + ginc - gap + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            blk[idx - gap + t] = ow;
-            text += dec_len_short(ow >> 3) + 1u;
-        }
-        nm_done += wave_last_u32(ginc);
-        /* column of the previous start: the nearest lane before with a start (always one of the same op), or the carry */
-        const int32_t col0 = (int32_t)(c << 4);
-        const int32_t my_last = starts ? col0 + 31 - __clz((int)starts) : 0;
-        const int32_t src_incl = wave_incl_max_i32(starts ? (int32_t)lane : -1);
-        int32_t src = __shfl_up(src_incl, 1);
-        if (lane == 0) src = -1;
-        const int32_t from_col = __shfl(my_last, src < 0 ? 0 : src);
-        int32_t prev = src < 0 ? carry_start : from_col;
-        if (act) {
-            uint32_t st = starts;
-            while (st) {
-                const uint32_t j = (uint32_t)__ffs((int)st) - 1u;
-                st &= st - 1u;
-                const int32_t pos = col0 + (int32_t)j;
-                if (!(first && j == 0)) { /* the run in front of this start ends here */
-                    const uint32_t before = j ? (m >> (j - 1u)) & 1u : prevbit;
-                    blk[idx - 1u] = ((uint32_t)(pos - prev) << 3) | (before ? (uint32_t)OP_EQ : (uint32_t)OP_X);
-                    text += dec_len_short((uint32_t)(pos - prev)) + 1u;
+        const uint32_t cnt = (uint32_t)__popc(starts);
+        const uint32_t rinc = wave_incl_scan_u32(cnt), rtot = wave_last_u32(rinc);
+        const uint32_t rex = rinc - cnt; /* starts of the batch in front of this item's */
+        /* the ops that stand between the M op before and this one: word ginc - gap + t of the 64 held by the lanes; they go right
+           in front of the item's first run */
+        const uint32_t gmax = (uint32_t)__builtin_amdgcn_readlane(wave_incl_max_i32((int32_t)gap), 63);
+        if (gtot <= 64u) {
+            for (uint32_t t = 0; t < gmax; t++) {
+                const uint32_t ow = __shfl(nmw, (int)((ginc - gap + t) & 63u)); /* by every lane: the source lanes must be live */
+                if (t < gap) {
+                    blk[done + rex + ginc - gap + t] = ow;
+                    text += dec_len_short(ow >> 3) + 1u;
                 }
-                prev = pos;
-                idx++;
+                since++;
             }
-            if ((w >> 25) & 1u) {
-                const uint32_t rl = (uint32_t)(col0 + (int32_t)nb - prev);
-                blk[idx - 1u] = (rl << 3) | (((m >> (nb - 1u)) & 1u) ? (uint32_t)OP_EQ : (uint32_t)OP_X);
-                text += dec_len_short(rl) + 1u;
+        } else { /* more of them than the lanes hold (hundreds of ops other than M in a row of short M ops) */
+            for (uint32_t t = 0; t < gap; t++) {
+                const uint32_t ow = __hip_atomic_load(nm_list + nm_done + ginc - gap + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                blk[done + rex + ginc - gap + t] = ow;
+                text += dec_len_short(ow >> 3) + 1u;
             }
         }
-        const int32_t top = __builtin_amdgcn_readlane(src_incl, 63);
-        if (top >= 0) carry_start = __shfl(my_last, top);
-        carry_m = __builtin_amdgcn_readlane((int)m, 63);
+        nm_done += gtot;
+        const uint32_t pad = first ? 16u - ((pw >> 3) & 31u) : 0u; /* columns the op before left unused in its last chunk */
+        for (uint32_t s0 = 0; s0 < rtot; s0 += PAFFY_FILL_SLOTS) { /* one pass unless the batch has more than 256 starts */
+            __builtin_amdgcn_wave_barrier();
+            {
+                uint32_t st = starts, k = rex;
+                while (st) {
+                    const uint32_t j = (uint32_t)__ffs((int)st) - 1u;
+                    st &= st - 1u;
+                    if (k - s0 < PAFFY_FILL_SLOTS) slots[k - s0] = (16u * lane + j) | (((m >> j) & 1u) << 10) | ((k == rex ? pad : 0u) << 11) | (ginc << 16);
+                    k++;
+                }
+            }
+            __builtin_amdgcn_wave_barrier(); /* a wave's LDS operations execute in order */
+            const uint32_t here = rtot - s0 < PAFFY_FILL_SLOTS ? rtot - s0 : PAFFY_FILL_SLOTS;
+            /* virtual run v of the pass: the run that ends at start s0 + v; v = 0 is the pending one */
+            for (uint32_t v0 = 0; v0 < here; v0 += 64) {
+                const uint32_t v = v0 + lane;
+                if (v < here) {
+                    const uint32_t nxt = slots[v];
+                    const uint32_t end = 16u * c0 + (nxt & 1023u) - ((nxt >> 11) & 31u);
+                    uint32_t col, bit, out;
+                    bool have = true;
+                    if (v == 0) {
+                        col = pend_col; bit = pend_bit; out = pend_out;
+                        have = pend;
+                    } else {
+                        const uint32_t cur = slots[v - 1u];
+                        col = 16u * c0 + (cur & 1023u);
+                        bit = (cur >> 10) & 1u;
+                        out = done + (s0 + v - 1u) + (cur >> 16);
+                    }
+                    if (have) {
+                        const uint32_t rl = end - col;
+                        blk[out] = (rl << 3) | (bit ? (uint32_t)OP_EQ : (uint32_t)OP_X);
+                        text += dec_len_short(rl) + 1u;
+                    }
+                }
+                since += (v0 > 0 || here > 1u || pend) ? 1u : 0u; /* a round of one start with nothing pending stores nothing */
+            }
+            { /* the pass's last start waits for its successor */
+                const uint32_t last = slots[here - 1u]; /* every lane reads the same word */
+                pend = true;
+                pend_col = 16u * c0 + (last & 1023u);
+                pend_bit = (last >> 10) & 1u;
+                pend_out = done + (s0 + here - 1u) + (last >> 16);
+            }
+        }
+        done += rtot + gtot;
+        carry_w = (uint32_t)__builtin_amdgcn_readlane((int)w, (int)(n_items - c0 > 64u ? 63u : n_items - c0 - 1u)); /* the last item so far */
+    }
+    if (pend && lane == 0) { /* the last run ends with its op: the used columns of the wave's last item */
+        const uint32_t rl = 16u * (n_items - 1u) + ((carry_w >> 3) & 31u) - pend_col;
+        blk[pend_out] = (rl << 3) | (pend_bit ? (uint32_t)OP_EQ : (uint32_t)OP_X);
+        text += dec_len_short(rl) + 1u;
     }
     /* what follows the last M op */
     for (uint32_t t = nm_done + lane; t < n_nm; t += 64) {
@@ -1242,8 +1327,8 @@ __device__ __forceinline__ uint32_t mismatch_fill_wave(const uint32_t *items, ui
 #define ABL23_PRINT
 #endif
 __device__ __forceinline__ int encode_mismatch_runs_lds(const KParams &P, const RecState &s, View<OpsLds> &v, OpsLds &ops, uint32_t cap, const uint8_t *Q,
-                                                        int64_t qseq_len, const uint8_t *T, int64_t tseq_len, BlockComm &bc, Shared *sh, uint32_t *n_out,
-                                                        uint64_t *blk_off, bool keep_lds, int64_t *text_out) {
+                                                        int64_t qseq_len, const uint8_t *T, int64_t tseq_len, BlockComm &bc, Shared *sh, uint8_t *stage,
+                                                        uint32_t *n_out, uint64_t *blk_off, bool keep_lds, int64_t *text_out) {
     ABL23_DECL
     /* an even split of the ops over the threads, so that the four waves get a quarter each whatever the record's size */
     const uint32_t b = (uint32_t)((uint64_t)v.n * threadIdx.x / PAFFY_NT), e = (uint32_t)((uint64_t)v.n * (threadIdx.x + 1) / PAFFY_NT);
@@ -1292,7 +1377,8 @@ __device__ __forceinline__ int encode_mismatch_runs_lds(const KParams &P, const 
     if (off + slots > P.arena_cap) return -2;
     uint32_t *blk = reinterpret_cast<uint32_t *>(P.arena + off);
     ABL23_MARK(2)
-    const uint32_t wtext = mismatch_fill_wave(items, n_items, nm_list, n_nm, out_base, blk);
+    /* every wave has 1 KiB of the text staging area (free since the cigar was parsed) for the starts of a batch */
+    const uint32_t wtext = mismatch_fill_wave(items, n_items, nm_list, n_nm, out_base, blk, reinterpret_cast<uint32_t *>(stage) + wave * PAFFY_FILL_SLOTS);
     ABL23_MARK(3)
     __syncthreads(); /* every op of the old array has been read, every op of the new one written */
     *blk_off = off;
@@ -2786,7 +2872,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
                     uint32_t n2 = 0;
                     const bool last = si == P.n_stages - 1; /* nothing reads the new ops but the line writer: they need not fit LDS */
                     const int r = encode_mismatch_runs_lds(P, s, v, ops, cap, P.seq_base + P.seqs[qi].off, P.seqs[qi].len, P.seq_base + P.seqs[ti].off,
-                                                           P.seqs[ti].len, L.bc, L.sh, &n2, &arena_block, !last, &block_text);
+                                                           P.seqs[ti].len, L.bc, L.sh, L.ring, &n2, &arena_block, !last, &block_text);
                     if (r == -1) return false; /* wider than the narrow path: arena class */
                     if (r == -2) return true;  /* arena full: repeated by the host */
                     if (r == -3) {             /* more ops than this store holds */
