@@ -1117,7 +1117,11 @@ __device__ __forceinline__ uint32_t mismatch_count_wave(const KParams &P, const 
         nm_written += nm_here;
         const uint8_t *Tw = T + tj0, *Qw = (s.same ? Q : P.seq_comp + (Q - P.seq_base)) + qoff0; /* - strand: the complemented copy */
         uint32_t carry_m = 0; /* mask of the last item of the iteration before */
+#if defined(PAFFY_ABL) && (PAFFY_ABL == 32 || PAFFY_ABL == 33) /* timing only: no item loop in the count walk */
+        for (uint32_t c0 = 0; c0 < (n_items & 0u); c0 += 64) {
+#else
         for (uint32_t c0 = 0; c0 < n_items; c0 += 64) {
+#endif
             const uint32_t c = c0 + lane;
             const bool act = c < n_items;
             uint32_t ol = 0; /* the op of item c: the last lane whose first item is <= c */
@@ -1169,10 +1173,15 @@ __device__ __forceinline__ uint32_t mismatch_count_wave(const KParams &P, const 
 __device__ __forceinline__ void wait_all_but_newest(uint32_t n, uint32_t a, uint32_t b, uint32_t &out_a, uint32_t &out_b) { /* a, b: the registers the loads fill */
     if (n >= 32) PAFFY_WAIT_TAKE2(32, out_a, out_b, a, b);
     else if (n >= 16) PAFFY_WAIT_TAKE2(16, out_a, out_b, a, b);
+    else if (n >= 12) PAFFY_WAIT_TAKE2(12, out_a, out_b, a, b);
     else if (n >= 8) PAFFY_WAIT_TAKE2(8, out_a, out_b, a, b);
-    else if (n >= 4) PAFFY_WAIT_TAKE2(4, out_a, out_b, a, b);
-    else if (n >= 2) PAFFY_WAIT_TAKE2(2, out_a, out_b, a, b);
-    else if (n >= 1) PAFFY_WAIT_TAKE2(1, out_a, out_b, a, b);
+    else if (n == 7) PAFFY_WAIT_TAKE2(7, out_a, out_b, a, b);
+    else if (n == 6) PAFFY_WAIT_TAKE2(6, out_a, out_b, a, b);
+    else if (n == 5) PAFFY_WAIT_TAKE2(5, out_a, out_b, a, b);
+    else if (n == 4) PAFFY_WAIT_TAKE2(4, out_a, out_b, a, b);
+    else if (n == 3) PAFFY_WAIT_TAKE2(3, out_a, out_b, a, b);
+    else if (n == 2) PAFFY_WAIT_TAKE2(2, out_a, out_b, a, b);
+    else if (n == 1) PAFFY_WAIT_TAKE2(1, out_a, out_b, a, b);
     else PAFFY_WAIT_TAKE2(0, out_a, out_b, a, b);
 }
 
@@ -1203,6 +1212,9 @@ __device__ __forceinline__ uint32_t mismatch_fill_wave(const uint32_t *items, ui
     uint32_t pend_col = 0, pend_bit = 0, pend_out = 0;
     uint32_t w_next = 0, nm_next = 0; /* item word c0 + lane and nm_list[nm_done + lane] of the coming iteration */
     uint32_t since = 0;               /* store instructions issued after those two loads (a lower bound) */
+#if defined(PAFFY_ABL) && (PAFFY_ABL == 31 || PAFFY_ABL == 33) /* timing only: no fill walk */
+    n_items = 0;
+#endif
     if (n_items) {
         if (lane < n_items) PAFFY_LOAD32_AHEAD(w_next, items + lane);
         if (lane < n_nm) PAFFY_LOAD32_AHEAD(nm_next, nm_list + lane);

@@ -25,7 +25,10 @@ def main():
     if a.cmd == "add":
         # cfg4: 24 + 24 contigs of 50-250 Mb generated on the device, records on homologous bases (2 % substitutions)
         t0 = time.perf_counter()
-        eng.synth4_setup(0x5EED0004, a.mean_ops)
+        if os.environ.get("PAFFY_X_SMALL_GENOME"):  # experiment: genomes small enough to stay in the caches
+            eng.synth4_setup(0x5EED0004, a.mean_ops, n_contigs=4, tlen_min=2_000_000, tlen_span=1_000_000)
+        else:
+            eng.synth4_setup(0x5EED0004, a.mean_ops)
         print(f"cfg4 genomes resident in HBM ({time.perf_counter() - t0:.1f} s to generate)", file=sys.stderr)
         buf, nbytes = eng.synth4(0, a.records)
     else:
