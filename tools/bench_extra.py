@@ -15,7 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--records", type=int, default=200000)
     ap.add_argument("--mean-ops", type=int, default=2048)
-    ap.add_argument("--cmd", default="tile", choices=["tile", "invert", "trim", "shatter", "remove", "filter", "add", "dedupe", "bed", "stats"])
+    ap.add_argument("--cmd", default="tile", choices=["tile", "invert", "trim", "shatter", "remove", "filter", "add", "dedupe", "bed", "stats", "chain"])
     a = ap.parse_args()
     import torch
 
@@ -47,6 +47,12 @@ def main():
             info = paffy_amd.engine.PlanInfo()
             rc = paffy_amd.engine.lib().paffy_hip_bed_plan(eng._ctx, buf.data_ptr(), nbytes, opts, info)
             assert rc == 0, rc
+        elif a.cmd == "chain":
+            L = paffy_amd.engine.lib()
+            assert L.paffy_hip_chain_begin(eng._ctx) == 0 and L.paffy_hip_chain_add(eng._ctx, buf.data_ptr(), nbytes) == 0
+            info = paffy_amd.engine.PlanInfo()
+            opts = paffy_amd.engine.ChainOpts(5000, 1, 1000000, 1.0)
+            assert L.paffy_hip_chain_run(eng._ctx, opts, info) == 0
         elif a.cmd == "dedupe":
             paffy_amd.engine.lib().paffy_hip_dedupe_reset(eng._ctx)
             info = eng.dedupe_plan(buf, nbytes, True)
