@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak test (GPU box): random records through random pipes, HIP path vs the CPU oracle, for a time budget.
-usage: python tools/fuzz_gpu.py [seconds] [seed] [pipe|tile|mism|bed]   -- prints the first mismatch (and saves it under gpurun_out/) or a summary."""
+usage: python tools/fuzz_gpu.py [seconds] [seed] [pipe|tile|mism|bed|chain]   -- prints the first mismatch (and saves it under gpurun_out/) or a summary."""
 import hashlib
 import os
 import random
@@ -58,10 +58,16 @@ def rand_record(rng):
             + "".join("\t" + x for x in tags) + "\n")
 
 
-def consistent_record(rng, qn, qlen, tn, tlen, n_ops, lens, alphabet="MID", strand=None):
+def consistent_record(rng, qn, qlen, tn, tlen, n_ops, lens, alphabet="MID", strand=None, gap_runs=0):
     ops, q, t = [], 0, 0
+    burst = 0  # ops other than M still to come in a row (gap_runs: bursts of up to that many)
     for k in range(n_ops):
-        op = "M" if k % 2 == 0 else rng.choice(alphabet)
+        if burst:
+            op, burst = rng.choice("ID"), burst - 1
+        else:
+            op = "M" if k % 2 == 0 else rng.choice(alphabet)
+            if gap_runs and rng.random() < 0.05:
+                burst = rng.randrange(1, gap_runs + 1)
         L = rng.choice(lens)
         if (op != "D" and q + L >= qlen - 2) or (op != "I" and t + L >= tlen - 2):
             break
@@ -140,7 +146,8 @@ def fuzz_mismatches(eng, rng, budget):
         for _ in range(rng.choice([1, 20, 120])):
             i = rng.randrange(len(seqs) // 2)
             L = len(seqs[f"t{i}"])
-            recs.append(consistent_record(rng, f"q{i}", L, f"t{i}", L, rng.choice([1, 9, 200, 200, 3000, 9000, 20000]), rng.choice([[1, 2], [7, 30], [100, 900], [1, 17, 40]])))
+            recs.append(consistent_record(rng, f"q{i}", L, f"t{i}", L, rng.choice([1, 9, 200, 200, 3000, 9000, 20000]), rng.choice([[1, 2], [7, 30], [100, 900], [1, 17, 40]]),
+                                          alphabet=rng.choice(["MID", "ID", "MMMID"]), gap_runs=rng.choice([0, 0, 3, 70, 200])))
         data = "".join(recs).encode()
         want, werr = O.run([O.stage(O.ADD_MISMATCHES)], data, seqs)
         eng.set_sequences(seqs)
@@ -166,6 +173,31 @@ def fuzz_mismatches(eng, rng, budget):
     print(f"add_mismatches fuzz ok: {rounds} rounds")
 
 
+def fuzz_chain(eng, rng, budget):
+    """paffy chain on collinear runs over a few (query, target, strand) groups, random options; inputs where the reference's fresh
+    iterator admits a candidate (an address tie, see oracle/paf_oracle.c) are counted, not compared."""
+    from test_gpu_chain import collinear_set
+
+    t0, rounds, skipped = time.time(), 0, 0
+    while time.time() - t0 < budget:
+        n = rng.choice([1, 3, 30, 300, 2500, 12000])
+        data = collinear_set(rng, n, n_q=rng.choice([1, 2, 6]), n_t=rng.choice([1, 3]), span=rng.choice([50_000, 2_000_000]), exact=rng.choice([0.0, 0.0, 0.3]),
+                             score_hi=rng.choice([30, 20000]))
+        kw = dict(gap_open=rng.choice([0, 50, 5000]), gap_extend=rng.choice([0, 1, 3]), max_gap=rng.choice([500, 20000, 1000000]), trim=rng.choice([0.0, 0.3, 1.0]))
+        want, werr, fresh = O.chain(data, **kw)
+        if fresh:
+            skipped += 1
+            continue
+        got, info = eng.chain(data, raise_on_error=False, batch_bytes=rng.choice([None, 50_000]), **kw)
+        if got != want or info.error.code != werr.code:
+            with open(os.path.join(ROOT, "gpurun_out", "fuzz_chain_fail.paf"), "wb") as fh:
+                fh.write(data)
+            print("CHAIN MISMATCH", kw, info.error.code, werr.code, len(got), len(want))
+            sys.exit(1)
+        rounds += 1
+    print(f"chain fuzz ok: {rounds} rounds ({skipped} inputs with an address tie skipped)")
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -179,6 +211,8 @@ def main():
         return fuzz_bed(eng, rng, budget)
     if mode == "mism":
         return fuzz_mismatches(eng, rng, budget)
+    if mode == "chain":
+        return fuzz_chain(eng, rng, budget)
     kinds = [O.INVERT, O.TRIM_IDENTITY, O.TRIM_FIXED, O.REMOVE_MISMATCHES, O.PASS, O.FILTER]
     t0, rounds, nbytes = time.time(), 0, 0
     while time.time() - t0 < budget:
