@@ -9,7 +9,7 @@
 
 struct ChainState {
     DevBuf i64[12]; /* per record: qs qe ts te sc (5), level (kept in CovState), per position: qs qe ts te sc mq best (7) */
-    DevBuf qkey, ghash, ord1, ord2, rank, start, gid, idx, prank, pred, neg, taken, is_tail, tail_of, link, total, chain_of_tail, chain_id, score_key, o1, o2, o3, cls,
+    DevBuf qkey, ghash, ord1, ord2, rank, start, gid, idx, prank, pred, neg, taken, is_tail, tail_of, link, total, chain_of_tail, chain_id, score_key, o1, o2, o3, cls, big_list, n_big, rank_of, claim,
         tag_chain, tag_score, check_key, iota;
     uint64_t n_out = 0;
 };
@@ -50,7 +50,7 @@ static int chain_run(paffy_hip_ctx *c, const ChainOpts &o, paffy_error *err) {
     DevBuf *u64s[] = {&H.qkey, &H.ghash, &H.score_key, &S.k64a, &S.k64b};
     for (DevBuf *b : u64s)
         if (ensure(c, *b, sizeof(uint64_t) * n1)) return PAFFY_E_HIP;
-    DevBuf *u32s[] = {&H.ord1, &H.ord2, &H.rank, &H.start, &H.gid, &H.idx, &H.prank, &H.pred, &H.tail_of, &H.link, &H.chain_of_tail, &H.chain_id, &H.o1, &H.o2, &H.o3, &H.cls,
+    DevBuf *u32s[] = {&H.ord1, &H.ord2, &H.rank, &H.start, &H.gid, &H.idx, &H.prank, &H.pred, &H.tail_of, &H.link, &H.chain_of_tail, &H.chain_id, &H.o1, &H.o2, &H.o3, &H.cls, &H.big_list, &H.rank_of, &H.claim,
                       &H.iota, &S.flags, &S.scan32, &S.v32a, &S.v32b, &S.order};
     for (DevBuf *b : u32s)
         if (ensure(c, *b, sizeof(uint32_t) * (n1 + 1))) return PAFFY_E_HIP;
@@ -58,7 +58,7 @@ static int chain_run(paffy_hip_ctx *c, const ChainOpts &o, paffy_error *err) {
     for (DevBuf *b : u8s)
         if (ensure(c, *b, n1)) return PAFFY_E_HIP;
     if (ensure(c, H.total, sizeof(int64_t) * n1) || ensure(c, H.tag_chain, sizeof(int64_t) * n1) || ensure(c, H.tag_score, sizeof(int64_t) * n1) ||
-        ensure(c, S.level, sizeof(int64_t) * n1) || ensure(c, H.check_key, sizeof(unsigned long long)))
+        ensure(c, S.level, sizeof(int64_t) * n1) || ensure(c, H.check_key, sizeof(unsigned long long)) || ensure(c, H.n_big, sizeof(uint32_t)))
         return PAFFY_E_HIP;
     auto I64 = [&](int k) { return static_cast<int64_t *>(H.i64[k].p); };
     auto U32 = [&](DevBuf &b) { return static_cast<uint32_t *>(b.p); };
@@ -89,18 +89,25 @@ static int chain_run(paffy_hip_ctx *c, const ChainOpts &o, paffy_error *err) {
            static_cast<const uint32_t *>(U32(H.rank)), n, Q);
     const uint32_t wgrid = (n_groups + PAFFY_NWAVE - 1) / PAFFY_NWAVE;
     LAUNCH(c, "k_chain_prefix_max", k_chain_prefix_max, dim3(wgrid), dim3(PAFFY_NT), 0, static_cast<const uint32_t *>(U32(H.start)), n_groups, Q);
+    HIPCHK(c, hipMemsetAsync(H.n_big.p, 0, sizeof(uint32_t), c->stream));
+    LAUNCH(c, "k_chain_big_list", k_chain_big_list, dim3((n_groups + PAFFY_NT - 1) / PAFFY_NT), dim3(PAFFY_NT), 0, static_cast<const uint32_t *>(U32(H.start)), n_groups,
+           U32(H.big_list), U32(H.n_big));
     LAUNCH(c, "k_chain_dp", k_chain_dp, dim3(wgrid), dim3(PAFFY_NT), 0, static_cast<const uint32_t *>(U32(H.start)), n_groups, o, Q);
+    LAUNCH(c, "k_chain_dp_big", k_chain_dp_big, dim3(256), dim3(CHAIN_BIG_NT), 0, static_cast<const uint32_t *>(U32(H.start)), static_cast<const uint32_t *>(U32(H.big_list)),
+           static_cast<const uint32_t *>(U32(H.n_big)), o, Q);
     /* (chain score desc, processing index desc): least significant key first, stable sorts */
     LAUNCH(c, "k_chain_not", k_chain_not, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const uint32_t *>(U32(H.prank)), n, U32(S.v32a));
     if (cov_sort_pairs32(c, S, U32(S.v32a), U32(S.v32b), U32(H.iota), U32(H.o1), n)) return PAFFY_E_HIP;
     LAUNCH(c, "k_chain_desc_keys", k_chain_desc_keys, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const int64_t *>(I64(11)), static_cast<const uint32_t *>(U32(H.o1)), n, U64(S.k64b));
     if (cov_sort_pairs(c, S, U64(S.k64b), U64(S.k64a), U32(H.o1), U32(H.o2), n)) return PAFFY_E_HIP; /* o2: all positions by (score desc, index desc) */
-    LAUNCH(c, "k_gather_u32", k_gather_u32, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const uint32_t *>(U32(H.gid)), static_cast<const uint32_t *>(U32(H.o2)), n, U32(S.v32a));
-    if (cov_sort_pairs32(c, S, U32(S.v32a), U32(S.v32b), U32(H.o2), U32(H.o3), n)) return PAFFY_E_HIP; /* o3: the same inside every group */
-    HIPCHK(c, hipMemsetAsync(H.taken.p, 0, n1, c->stream));
-    HIPCHK(c, hipMemsetAsync(H.is_tail.p, 0, n1, c->stream));
-    LAUNCH(c, "k_chain_extract", k_chain_extract, dim3((n_groups + PAFFY_NT - 1) / PAFFY_NT), dim3(PAFFY_NT), 0, static_cast<const uint32_t *>(U32(H.start)), n_groups,
-           static_cast<const uint32_t *>(U32(H.o3)), o, Q, U8(H.taken), U32(H.tail_of), U32(H.link), static_cast<int64_t *>(H.total.p), U8(H.is_tail));
+    /* every chain end walks its chain (o2 gives the ranks) */
+    HIPCHK(c, hipMemsetAsync(H.taken.p, 0, n1, c->stream));          /* has_child */
+    HIPCHK(c, hipMemsetAsync(H.claim.p, 0xff, sizeof(uint32_t) * n1, c->stream));
+    LAUNCH(c, "k_chain_rank_and_children", k_chain_rank_and_children, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const uint32_t *>(U32(H.o2)), Q, n, U32(H.rank_of), U8(H.taken));
+    LAUNCH(c, "k_chain_claim", k_chain_claim, dim3(grid), dim3(PAFFY_NT), 0, Q, static_cast<const uint32_t *>(U32(H.rank_of)), static_cast<const uint8_t *>(U8(H.taken)), n,
+           U32(H.claim));
+    LAUNCH(c, "k_chain_own", k_chain_own, dim3(grid), dim3(PAFFY_NT), 0, o, Q, static_cast<const uint32_t *>(U32(H.rank_of)), static_cast<const uint8_t *>(U8(H.taken)),
+           static_cast<const uint32_t *>(U32(H.claim)), n, U32(H.tail_of), U32(H.link), static_cast<int64_t *>(H.total.p), U8(H.is_tail));
     /* chain ids: the tails by (strand, score desc, index desc) */
     LAUNCH(c, "k_chain_class", k_chain_class, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const uint32_t *>(U32(H.o2)), static_cast<const uint8_t *>(U8(H.is_tail)),
            static_cast<const uint8_t *>(U8(H.neg)), n, U32(H.cls));

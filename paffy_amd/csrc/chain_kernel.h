@@ -12,14 +12,17 @@
  * target_end(p) <= target_start(i), query_end(p) <= query_start(i), both gaps <= max_gap; the set's descending scan takes the
  * first best one, i.e. the largest (target_end, query_end, address) among equal scores. Dropping chains from the set
  * (impl/chaining.c:176-179) changes nothing: what is dropped can never pass the query-gap test again, the query starts only grow.
- * Groups are independent: one wave per group for the recurrence (the 64 lanes share the candidates of a record), one lane per
- * group for pulling out its chains; sorting, grouping and numbering are device radix sorts (chain_host.h).
+ * Groups are independent: one wave per group for the recurrence (the 64 lanes share the candidates of a record; a workgroup of 1024
+ * for groups of more than 4096 records), every chain end walks its own chain; sorting, grouping and numbering are device radix sorts
+ * (chain_host.h).
  * Addresses (the last key of every comparator of the reference) are restated as creation order: the input index for records, the
  * processing index for chains (parity on exact ties is unpinned).
  */
 #pragma once
 
 #define CHAIN_NONE 0xffffffffu
+#define CHAIN_BIG_GROUP 4096u /* groups above this size run their recurrence on a whole workgroup */
+#define CHAIN_BIG_NT 1024
 
 struct ChainOpts {
     int64_t gap_open, gap_extend, max_gap;
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_chain_dp(const uint32_t *start, ui
     const uint32_t g = blockIdx.x * PAFFY_NWAVE + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (g >= n_groups) return;
     const uint32_t g0 = start[g], g1 = start[g + 1];
+    if (g1 - g0 > CHAIN_BIG_GROUP) return; /* k_chain_dp_big has it */
     uint32_t lo = g0; /* everything before lo ends more than max_gap before the current query start */
     for (uint32_t i = g0; i < g1; i++) {
         const int64_t qs_i = Q.qs[i], ts_i = Q.ts[i], sc_i = Q.sc[i];
@@ -196,39 +200,141 @@ __global__ __launch_bounds__(PAFFY_NT) void k_chain_dp(const uint32_t *start, ui
     }
 }
 
-/*
- * Chains from the highest score down, impl/chaining.c:213-230 + chain_to_pafs :118-135: one lane per group walks its positions in
- * (score desc, processing index desc) order. tail_of / link: the chain a position ends up in and its distance from that chain's
- * tail; total[tail] = get_chain_score of the chain as cut (:93-116).
- */
-__global__ __launch_bounds__(PAFFY_NT) void k_chain_extract(const uint32_t *start, uint32_t n_groups, const uint32_t *by_score, ChainOpts o, ChainPos Q, uint8_t *taken,
-                                                             uint32_t *tail_of, uint32_t *link, int64_t *total, uint8_t *is_tail) {
+/* the groups the one-wave kernel leaves alone */
+__global__ __launch_bounds__(PAFFY_NT) void k_chain_big_list(const uint32_t *start, uint32_t n_groups, uint32_t *big_list, uint32_t *n_big) {
     const uint32_t g = blockIdx.x * PAFFY_NT + threadIdx.x;
-    if (g >= n_groups) return;
-    const uint32_t g0 = start[g], g1 = start[g + 1];
-    for (uint32_t k = g0; k < g1; k++) {
-        const uint32_t tail = by_score[k];
-        if (taken[tail]) continue;
-        taken[tail] = 1;
-        is_tail[tail] = 1;
-        tail_of[tail] = tail;
-        link[tail] = 0;
-        int64_t sum = Q.sc[tail];
-        uint32_t cur = tail, depth = 0;
-        while (Q.pred[cur] != CHAIN_NONE) {
-            const uint32_t p = Q.pred[cur];
-            if (taken[p]) { /* the next link already belongs to a better chain: this one ends here */
-                Q.pred[cur] = CHAIN_NONE;
-                break;
+    if (g < n_groups && start[g + 1] - start[g] > CHAIN_BIG_GROUP) big_list[atomicAdd(n_big, 1u)] = g;
+}
+/*
+ * The same recurrence for a large group on a 1024-thread workgroup: a record's candidates (thousands when the alignments are dense:
+ * everything that ends within max_gap in front of it) are spread over all threads, the best one is reduced per wave with shuffles and
+ * across the sixteen waves through LDS. The records still go one after the other -- each needs the chain scores of those before it.
+ */
+__global__ __launch_bounds__(CHAIN_BIG_NT) void k_chain_dp_big(const uint32_t *start, const uint32_t *big_list, const uint32_t *n_big, ChainOpts o, ChainPos Q) {
+    __shared__ int64_t r_cs[CHAIN_BIG_NT / 64], r_te[CHAIN_BIG_NT / 64], r_qe[CHAIN_BIG_NT / 64];
+    __shared__ uint32_t r_idx[CHAIN_BIG_NT / 64], r_p[CHAIN_BIG_NT / 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t count = *n_big;
+    for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
+        const uint32_t g = big_list[k], g0 = start[g], g1 = start[g + 1];
+        uint32_t lo = g0;
+        for (uint32_t i = g0; i < g1; i++) {
+            const int64_t qs_i = Q.qs[i], ts_i = Q.ts[i], sc_i = Q.sc[i];
+            const uint32_t idx_i = Q.idx[i];
+            while (lo < i && Q.mq[lo] < qs_i - o.max_gap) lo++;
+            int64_t b_cs = INT64_MIN, b_te = 0, b_qe = 0;
+            uint32_t b_idx = 0, b_p = CHAIN_NONE;
+            for (uint32_t base = lo + threadIdx.x; base < i; base += 4 * CHAIN_BIG_NT) { /* four candidates' loads in flight per thread */
+                int64_t qe4[4], te4[4], best4[4];
+                uint32_t idx4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t p = base + u * CHAIN_BIG_NT;
+                    const bool in = p < i;
+                    qe4[u] = in ? Q.qe[p] : INT64_MAX; /* fails the first test */
+                    te4[u] = in ? Q.te[p] : 0;
+                    idx4[u] = in ? Q.idx[p] : 0u;
+                    best4[u] = in ? Q.best[p] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t p = base + u * CHAIN_BIG_NT;
+                    const int64_t qe_p = qe4[u], te_p = te4[u];
+                    if (qs_i < qe_p || qs_i - qe_p > o.max_gap) continue;
+                    if (ts_i < te_p || ts_i - te_p > o.max_gap) continue;
+                    const uint32_t idx_p = idx4[u];
+                    if (te_p == ts_i && qe_p == qs_i && idx_p > idx_i) continue;
+                    const int64_t gc = chain_gap_cost(o, qs_i - qe_p, ts_i - te_p);
+                    if (!(gc < sc_i)) continue;
+                    const int64_t cs = sc_i + best4[u] - gc;
+                    const bool better = cs > b_cs || (cs == b_cs && (te_p > b_te || (te_p == b_te && (qe_p > b_qe || (qe_p == b_qe && idx_p > b_idx)))));
+                    if (better) {
+                        b_cs = cs; b_te = te_p; b_qe = qe_p; b_idx = idx_p; b_p = p;
+                    }
+                }
             }
-            sum += Q.sc[p] - chain_gap_cost(o, Q.qs[cur] - Q.qe[p], Q.ts[cur] - Q.te[p]);
-            taken[p] = 1;
-            tail_of[p] = tail;
-            link[p] = ++depth;
-            cur = p;
+            for (int stage = 0; stage < 2; stage++) { /* inside every wave, then wave 0 over the sixteen results */
+                for (int msk = 32; msk >= 1; msk >>= 1) {
+                    const int64_t o_cs = wave_shfl_xor64(b_cs, msk), o_te = wave_shfl_xor64(b_te, msk), o_qe = wave_shfl_xor64(b_qe, msk);
+                    const uint32_t o_idx = (uint32_t)__shfl_xor((int)b_idx, msk), o_p = (uint32_t)__shfl_xor((int)b_p, msk);
+                    const bool better = o_p != CHAIN_NONE && (b_p == CHAIN_NONE || o_cs > b_cs ||
+                                                              (o_cs == b_cs && (o_te > b_te || (o_te == b_te && (o_qe > b_qe || (o_qe == b_qe && o_idx > b_idx))))));
+                    if (better) {
+                        b_cs = o_cs; b_te = o_te; b_qe = o_qe; b_idx = o_idx; b_p = o_p;
+                    }
+                }
+                if (stage == 0) {
+                    if (lane == 0) {
+                        r_cs[wave] = b_cs; r_te[wave] = b_te; r_qe[wave] = b_qe; r_idx[wave] = b_idx; r_p[wave] = b_p;
+                    }
+                    __syncthreads();
+                    b_p = CHAIN_NONE;
+                    if (lane < CHAIN_BIG_NT / 64) {
+                        b_cs = r_cs[lane]; b_te = r_te[lane]; b_qe = r_qe[lane]; b_idx = r_idx[lane]; b_p = r_p[lane];
+                    }
+                }
+            }
+            if (threadIdx.x == 0) {
+                const bool take = b_p != CHAIN_NONE && b_cs > sc_i;
+                Q.best[i] = take ? b_cs : sc_i;
+                Q.pred[i] = take ? b_p : CHAIN_NONE;
+                __threadfence_block();
+            }
+            __syncthreads(); /* the score is there for the records that follow; the LDS slots are free again */
         }
-        total[tail] = sum;
     }
+}
+
+/*
+ * Chains from the highest score down, impl/chaining.c:213-230 + chain_to_pafs :118-135. The reference takes the best remaining chain
+ * end, follows its links and cuts where a link already belongs to a better chain. A link always leads to a lower chain score (a record
+ * is only chained when the gap costs less than it scores), so every record that something links to has been taken by the time its own
+ * turn would come: the chain ends are exactly the records nothing links to, and a record goes to the best-ranked end that reaches it.
+ * All ends walk at once: an end claims the records on its way with an atomic minimum of its rank (position in the order by score desc,
+ * processing index desc) and stops where a better rank has been; a second walk over what it kept gives tail_of / link (distance from the
+ * end) and total[end] = get_chain_score of the chain as cut (:93-116).
+ */
+__global__ __launch_bounds__(PAFFY_NT) void k_chain_rank_and_children(const uint32_t *by_score, ChainPos Q, uint32_t n, uint32_t *rank_of, uint8_t *has_child) {
+    const uint32_t k = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (k >= n) return;
+    rank_of[by_score[k]] = k;
+    const uint32_t p = Q.pred[k];
+    if (p != CHAIN_NONE) has_child[p] = 1;
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_chain_claim(ChainPos Q, const uint32_t *rank_of, const uint8_t *has_child, uint32_t n, uint32_t *claim) {
+    const uint32_t e = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (e >= n || has_child[e]) return;
+    const uint32_t r = rank_of[e];
+    uint32_t cur = e;
+    for (;;) {
+        if (atomicMin(&claim[cur], r) < r) break; /* a better end has been here: the rest of the way is its */
+        cur = Q.pred[cur];
+        if (cur == CHAIN_NONE) break;
+    }
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_chain_own(ChainOpts o, ChainPos Q, const uint32_t *rank_of, const uint8_t *has_child, const uint32_t *claim, uint32_t n,
+                                                         uint32_t *tail_of, uint32_t *link, int64_t *total, uint8_t *is_tail) {
+    const uint32_t e = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (e >= n) return;
+    is_tail[e] = has_child[e] ? 0 : 1;
+    if (has_child[e]) return;
+    const uint32_t r = rank_of[e];
+    tail_of[e] = e;
+    link[e] = 0;
+    int64_t sum = Q.sc[e];
+    uint32_t cur = e, depth = 0;
+    while (Q.pred[cur] != CHAIN_NONE) {
+        const uint32_t p = Q.pred[cur];
+        if (claim[p] != r) { /* the next link belongs to a better chain: this one ends here */
+            Q.pred[cur] = CHAIN_NONE;
+            break;
+        }
+        sum += Q.sc[p] - chain_gap_cost(o, Q.qs[cur] - Q.qe[p], Q.ts[cur] - Q.te[p]);
+        tail_of[p] = e;
+        link[p] = ++depth;
+        cur = p;
+    }
+    total[e] = sum;
 }
 
 /* numbering: + strand chains first, each strand from the highest chain score down (the order they were pulled out in) */

@@ -1056,7 +1056,7 @@ static void chain_free(paffy_hip_ctx *c) {
     if (!c->chain) return;
     ChainState &H = *c->chain;
     DevBuf *bufs[] = {&H.qkey, &H.ghash, &H.ord1, &H.ord2, &H.rank, &H.start, &H.gid, &H.idx, &H.prank, &H.pred, &H.neg, &H.taken, &H.is_tail, &H.tail_of, &H.link, &H.total,
-                      &H.chain_of_tail, &H.chain_id, &H.score_key, &H.o1, &H.o2, &H.o3, &H.cls, &H.tag_chain, &H.tag_score, &H.check_key, &H.iota};
+                      &H.chain_of_tail, &H.chain_id, &H.score_key, &H.o1, &H.o2, &H.o3, &H.cls, &H.tag_chain, &H.tag_score, &H.check_key, &H.iota, &H.big_list, &H.n_big, &H.rank_of, &H.claim};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (DevBuf &b : H.i64)

@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--records", type=int, default=200000)
     ap.add_argument("--mean-ops", type=int, default=2048)
+    ap.add_argument("--contigs", type=int, default=24, help="contigs of the synthetic stream (chain: fewer contigs = larger groups)")
     ap.add_argument("--cmd", default="tile", choices=["tile", "invert", "trim", "shatter", "remove", "filter", "add", "dedupe", "bed", "stats", "chain"])
     a = ap.parse_args()
     import torch
@@ -32,7 +33,7 @@ def main():
         print(f"cfg4 genomes resident in HBM ({time.perf_counter() - t0:.1f} s to generate)", file=sys.stderr)
         buf, nbytes = eng.synth4(0, a.records)
     else:
-        buf, nbytes = eng.synth(0x5EED0005, a.mean_ops, 0, a.records)
+        buf, nbytes = eng.synth(0x5EED0005, a.mean_ops, 0, a.records, n_contigs=a.contigs)
     torch.cuda.synchronize()
     kinds = {"invert": paffy_amd.INVERT, "trim": paffy_amd.TRIM_IDENTITY, "shatter": paffy_amd.SHATTER, "remove": paffy_amd.REMOVE_MISMATCHES, "filter": paffy_amd.FILTER}
     eng.set_filter(min_identity=0.9)
