@@ -44,15 +44,15 @@ __device__ __forceinline__ void sep_masks(const uint8_t *in, uint32_t in_len, ui
     uint4 v = *reinterpret_cast<const uint4 *>(in + g);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        uint32_t c = (w[j >> 2] >> ((j & 3) * 8)) & 0xffu;
-        bool valid = g + j < in_len;
-        if (valid && c == '\n') {
-            nl |= 1u << j;
-            tabs_nl |= 1u << j;
-        } else if (valid && c == '\t') {
-            tabs_nl |= 1u << j;
-        }
+    for (int k = 0; k < 4; k++) { /* four bytes at a time: a byte equals the pattern where the xor has a zero byte */
+        const uint32_t t = equal4(w[k], 0x09090909u), n = equal4(w[k], 0x0a0a0a0au);
+        tabs_nl |= (t | n) << (4 * k);
+        nl |= n << (4 * k);
+    }
+    if (in_len - g < 16u) { /* the text ends inside these 16 bytes */
+        const uint32_t keep = (1u << (in_len - g)) - 1u;
+        tabs_nl &= keep;
+        nl &= keep;
     }
 }
 
