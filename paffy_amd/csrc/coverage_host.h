@@ -162,32 +162,29 @@ __global__ __launch_bounds__(PAFFY_NT) void k_line_emit(const uint8_t *const *ba
     __builtin_amdgcn_wave_barrier(); /* a wave's LDS operations execute in order */
     const uint32_t total = hl + cl + 1u;
     const uint8_t *cg = in + m.cg_off;
-    const uint32_t head = (uint32_t)((16u - ((uintptr_t)o & 15u)) & 15u); /* bytes in front of the first aligned chunk */
     auto byte_at = [&](uint32_t x) -> uint8_t { return x < hl ? hdr[x] : (x < hl + cl ? cg[x - hl] : (uint8_t)'\n'); };
     const uint32_t skip = direct ? hl : 0u; /* a header built in place is not copied again */
-    if (head >= total) {
-        for (uint32_t x = lane; x < total; x += 64)
-            if (x >= skip) o[x] = byte_at(x);
-        return;
+    /* three stretches: the header and the cigar's first bytes up to a 16-byte boundary of the output (byte by byte, the lanes side by
+       side), whole 16-byte chunks of cigar text (aligned stores, loads at whatever alignment the input has, four in flight per lane),
+       the last bytes and the newline (byte by byte) */
+    const uint32_t head = (uint32_t)((16u - (((uintptr_t)o + hl) & 15u)) & 15u); /* cigar bytes in front of the first aligned chunk */
+    const uint32_t x0 = hl + head < total ? hl + head : total;
+    const uint32_t n_ch = x0 + 16u <= hl + cl ? (hl + cl - x0) >> 4 : 0u;
+    const uint32_t x1 = x0 + 16u * n_ch;
+    for (uint32_t x = skip + lane; x < x0; x += 64) o[x] = byte_at(x);
+    const uint8_t *src = cg + (x0 - hl);
+    uint8_t *dst = o + x0;
+    uint32_t ch = lane;
+    for (; ch + 192u < n_ch; ch += 256u) {
+        const u32x4 v0 = *reinterpret_cast<const u32x4_unaligned *>(src + 16u * ch), v1 = *reinterpret_cast<const u32x4_unaligned *>(src + 16u * (ch + 64u));
+        const u32x4 v2 = *reinterpret_cast<const u32x4_unaligned *>(src + 16u * (ch + 128u)), v3 = *reinterpret_cast<const u32x4_unaligned *>(src + 16u * (ch + 192u));
+        *reinterpret_cast<u32x4 *>(dst + 16u * ch) = v0;
+        *reinterpret_cast<u32x4 *>(dst + 16u * (ch + 64u)) = v1;
+        *reinterpret_cast<u32x4 *>(dst + 16u * (ch + 128u)) = v2;
+        *reinterpret_cast<u32x4 *>(dst + 16u * (ch + 192u)) = v3;
     }
-    if (lane < head && lane >= skip) o[lane] = byte_at(lane);
-    const uint32_t n_ch = (total - head) >> 4;
-    for (uint32_t ch = lane; ch < n_ch; ch += 64) {
-        const uint32_t x = head + 16u * ch;
-        if (x >= hl && x + 16u <= hl + cl) {
-            *reinterpret_cast<u32x4 *>(o + x) = *reinterpret_cast<const u32x4_unaligned *>(cg + (x - hl));
-        } else if (x + 16u > skip) {
-            if (x >= skip) {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (uint32_t b = 0; b < 16; b++) w[b >> 2] |= (uint32_t)byte_at(x + b) << (8u * (b & 3u));
-                *reinterpret_cast<uint4 *>(o + x) = make_uint4(w[0], w[1], w[2], w[3]);
-            } else {
-                for (uint32_t b = 0; b < 16; b++)
-                    if (x + b >= skip) o[x + b] = byte_at(x + b);
-            }
-        }
-    }
-    for (uint32_t x = head + 16u * n_ch + lane; x < total; x += 64)
+    for (; ch < n_ch; ch += 64u) *reinterpret_cast<u32x4 *>(dst + 16u * ch) = *reinterpret_cast<const u32x4_unaligned *>(src + 16u * ch);
+    for (uint32_t x = x1 + lane; x < total; x += 64)
         if (x >= skip) o[x] = byte_at(x);
 }
 
