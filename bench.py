@@ -51,9 +51,9 @@ def stages_for(pipe, mod):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=75, help="timed batches per GPU (75 x 131072 = the 10M-record stream of cfg3)")
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=131072, help="records per step per GPU")
+    ap.add_argument("--steps", type=int, default=None, help="timed batches per GPU (default 75: 75 x 131072 = the 10M-record stream of cfg3; cfg5: 4)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 2 (cfg5: 1)")
+    ap.add_argument("--batch", type=int, default=None, help="records per step per GPU (default 131072; cfg5: 2000000, a fifth of a GPU's share of the 80M records)")
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a one-GPU rehearsal)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -65,6 +65,13 @@ def main():
     ap.add_argument("--rehearse", action="store_true",
                     help="plumbing rehearsal without a GPU: ranks, rendezvous, the per-step size exchange and the reductions run, the hot path does not (value is null)")
     args = ap.parse_args()
+    tile_wl = bool(WORKLOADS[args.workload].get("tile"))
+    if args.steps is None:
+        args.steps = 4 if tile_wl else 75
+    if args.warmup is None:
+        args.warmup = 1 if tile_wl else 2
+    if args.batch is None:
+        args.batch = 2_000_000 if tile_wl else 131072
 
     # `python bench.py --gpus N` outside a launcher: start the N ranks here, before anything touches the GPU
     if args.gpus > 1 and "RANK" not in os.environ:
