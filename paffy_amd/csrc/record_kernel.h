@@ -2653,13 +2653,30 @@ __device__ __forceinline__ void write_emit_range(const View<OPS> &v, uint32_t wb
             if (b + jj < e) raw[jj] = v.ops.raw(v.raw_index(b + jj));
         }
         int64_t nb[1] = {0}, nbt[1];
+        /* the usual window: every length has at most four digits -- 24-bit multiplies instead of the 64-bit digit text */
+        bool short_lens = true;
 #pragma unroll
         for (int jj = 0; jj < WRITE_PER; jj++) {
             if (b + jj < e) {
                 int64_t len;
                 int op;
                 v.decode(raw[jj], v.raw_index(b + jj), len, op);
-                nb[0] += dec_len(len) + 1;
+                short_lens = short_lens && len >= 0 && len < 10000;
+            }
+        }
+        short_lens = __all(short_lens) != 0;
+#pragma unroll
+        for (int jj = 0; jj < WRITE_PER; jj++) {
+            if (b + jj < e) {
+                int64_t len;
+                int op;
+                v.decode(raw[jj], v.raw_index(b + jj), len, op);
+                if (short_lens) {
+                    const uint32_t x = (uint32_t)len;
+                    nb[0] += 2 + (x >= 10u) + (x >= 100u) + (x >= 1000u);
+                } else {
+                    nb[0] += dec_len(len) + 1;
+                }
             }
         }
         if (last && e == v.n && b < e) nb[0] += 1; /* '\n' goes with the last op */
@@ -2676,6 +2693,13 @@ __device__ __forceinline__ void write_emit_range(const View<OPS> &v, uint32_t wb
                 int64_t len;
                 int op;
                 v.decode(raw[jj], v.raw_index(b + jj), len, op);
+                if (short_lens) {
+                    const uint32_t x = (uint32_t)len;
+                    const uint32_t nd = 1u + (x >= 10u) + (x >= 100u) + (x >= 1000u);
+                    const uint32_t digits = (bcd4(x) + 0x30303030u) >> (8u * (4u - nd)); /* most significant digit in byte 0 */
+                    rw.put((uint64_t)digits | ((uint64_t)op_char_of(op) << (8u * nd)), nd + 1u);
+                    continue;
+                }
                 DecText d;
                 dec_text(len, d);
                 if (d.groups == 0 && !d.neg_separate && d.ntop <= 7) { /* digits + op letter in one word */
