@@ -2596,7 +2596,8 @@ __device__ __forceinline__ int64_t cigar_text_len(const View<OPS> &v, RecPlan *p
         int64_t len;
         int op;
         v.get(i, len, op);
-        a[0] += dec_len(len) + 1;
+        if constexpr (OPS::kNarrow) a[0] += dec_len_short((uint32_t)len) + 1; /* 4-byte ops: 0 <= length < 2^29 */
+        else a[0] += dec_len(len) + 1;
     }
     block_excl_scan<1>(a, at, bc);
     if ((threadIdx.x & 63) == 0) plan_out->wo[threadIdx.x >> 6] = a[0];
