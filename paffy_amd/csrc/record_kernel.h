@@ -329,14 +329,13 @@ __device__ __forceinline__ uint32_t parse_cigar_lds(const uint8_t *in, uint32_t 
         while (opmask) {
             const uint32_t j = (uint32_t)__ffs((int)opmask) - 1u;
             opmask &= opmask - 1u;
-            const uint32_t c = (w[j >> 2] >> ((j & 3u) * 8u)) & 0xffu;
+            uint32_t kk, c; /* the letter comes with the words the number is read from: no indexing into w[] by a variable */
+            const uint32_t len = number_before(txt, q0 + j, &kk, &c);
             int code = op_code_of(c);
             if (code < 0) {
                 atomicMin(&sh->err_pos, g + j);
                 code = 0;
             }
-            uint32_t kk;
-            const uint32_t len = number_before(txt, q0 + j, &kk);
             if (kk >= 8u) flags |= 1u;
             if (len == 0u || code > OP_D) flags |= 2u;
             if (idx < cap) ops.p[idx] = (len << 3) | (uint32_t)code;
