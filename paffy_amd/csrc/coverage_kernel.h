@@ -368,11 +368,12 @@ __device__ __forceinline__ uint32_t wave_max_all_u32(uint32_t v) { return ~wave_
 __device__ __forceinline__ uint32_t cov_phys_word(uint32_t w) { return (w & 7u) * (COV_WORDS / 8u) + (w >> 3); }
 
 #define COV_COPIES 4u /* level histogram copies (lane & 3): a quarter of the same-address collisions inside one ds_add */
+#define COV_HIST_ROW (COV_HIST_W / 2 + 8u) /* words per copy: eight spare, so that one level lies on four different banks in the four copies */
 /* a copy: COV_HIST_W 16-bit counters, levels L and L + COV_HIST_W / 2 in one word (a count is at most 32 768) */
 
 struct CovWalkLds {
     uint16_t cnt[COV_SLICE];                    /* count + COV_BIAS, words in cov_phys_word order */
-    uint32_t hist[2][COV_COPIES][COV_HIST_W / 2]; /* level histograms of the entry being walked and the one before (being compacted) */
+    uint32_t hist[2][COV_COPIES][COV_HIST_ROW]; /* level histograms of the entry being walked and the one before (being compacted) */
     uint32_t mn[4], mx[4];                      /* range of the new counts of entries j, j + 1, ... (index j & 3) */
     unsigned long long bcast;
 };
@@ -386,8 +387,8 @@ __device__ __forceinline__ void cov_hist_add(uint32_t *copy, uint32_t biased, ui
 /* one bitmap word of the slice (32 bases = four 16-byte chunks of counters) for one entry; `pw` = cov_phys_word of the word */
 template <bool HIST>
 __device__ __forceinline__ void cov_word(CovWalkLds &L, uint32_t pw, uint32_t bits, uint32_t rot, uint32_t *copy, uint32_t &tmin, uint32_t &tmax) {
-    /* lane i takes its four chunks in the order (g + i / 4) mod 4: the 16-lane groups of a 128-bit LDS access then hit 16 different
-       16-byte columns instead of four */
+    /* lane i takes its four chunks in the order (g + rot) mod 4, rot chosen by the caller so that neither the lane groups of the
+       128-bit reads nor those of the 128-bit writes meet on a bank */
     uint4 *base = reinterpret_cast<uint4 *>(&L.cnt[pw * 32u]);
 #pragma unroll
     for (uint32_t g = 0; g < 4; g++) {
@@ -427,7 +428,7 @@ __device__ __forceinline__ void cov_word(CovWalkLds &L, uint32_t pw, uint32_t bi
 }
 
 /* count of level `lvl` in histogram buffer h: the sum of the copies */
-__device__ __forceinline__ uint32_t cov_hist_get(const uint32_t (*h)[COV_HIST_W / 2], uint32_t lvl) {
+__device__ __forceinline__ uint32_t cov_hist_get(const uint32_t (*h)[COV_HIST_ROW], uint32_t lvl) {
     const uint32_t w = lvl & (COV_HIST_W / 2 - 1u), sh = ((lvl / (COV_HIST_W / 2)) & 1u) * 16u;
     uint32_t c = 0;
 #pragma unroll
@@ -487,14 +488,17 @@ __global__ __launch_bounds__(COV_NT, 4) void k_cov_walk(CovParams P, uint16_t *b
             make_uint4(v.x + bias2, v.y + bias2, v.z + bias2, v.w + bias2); /* counts <= 32766: no carry between halves */
     }
     if (HIST) {
-        for (uint32_t i = tid; i < 2 * COV_COPIES * (COV_HIST_W / 2); i += COV_NT) (&L.hist[0][0][0])[i] = 0;
+        for (uint32_t i = tid; i < 2 * COV_COPIES * COV_HIST_ROW; i += COV_NT) (&L.hist[0][0][0])[i] = 0;
         if (tid < 4) {
             L.mn[tid] = 0xffffffffu;
             L.mx[tid] = 0;
         }
     }
     __syncthreads();
-    const uint32_t rot = lane >> 2;
+    /* chunk rotation of a lane (cov_word): the four 16-lane groups of ds_read_b128 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32;
+       banks from the address mod 256) and the eight 8-lane groups of ds_write_b128 (contiguous lanes; banks from the address mod 128)
+       must both see every 16-byte column once: lanes 64 bytes apart, bits b1 b2 b3 of the lane -> 2 (b2 ^ b3) + (b1 ^ b3) */
+    const uint32_t rot = ((((lane >> 2) ^ (lane >> 3)) & 1u) << 1) | (((lane >> 1) ^ (lane >> 3)) & 1u);
     const uint32_t wa = 8u * lane + wave, wb = wa + COV_NT;          /* my two words of the slice ... */
     const uint32_t pa = wave * (COV_WORDS / 8u) + lane, pb = pa + 64u; /* ... and where their counters are */
     for (uint32_t p = p0; p < p1; p++) {
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(COV_NT, 4) void k_cov_walk(CovParams P, uint16_t *b
         const uint32_t mn = L.mn[j & 3u], mx = L.mx[j & 3u]; /* read by every wave before anything resets them (see below) */
         const uint32_t n = mx - mn + 1u;
         CovSlot *slot = P.slots + E.pair_base + (slice - E.first_slice);
-        const uint32_t (*hbuf)[COV_HIST_W / 2] = L.hist[j & 1u];
+        const uint32_t (*hbuf)[COV_HIST_ROW] = L.hist[j & 1u];
         if (n <= COV_HIST_W) {
             if (wave == (j & (COV_NWAVE - 1u))) { /* this wave compacts entry j while the others walk entry j + 1 */
                 unsigned long long off = 0;
