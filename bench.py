@@ -52,7 +52,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed batches per GPU (default 75: 75 x 131072 = the 10M-record stream of cfg3; cfg5: 4)")
-    ap.add_argument("--warmup", type=int, default=None, help="default 2 (cfg5: 1)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 2")
     ap.add_argument("--batch", type=int, default=None, help="records per step per GPU (default 131072; cfg5: 2000000, a fifth of a GPU's share of the 80M records)")
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a one-GPU rehearsal)")
@@ -69,7 +69,7 @@ def main():
     if args.steps is None:
         args.steps = 4 if tile_wl else 75
     if args.warmup is None:
-        args.warmup = 1 if tile_wl else 2
+        args.warmup = 2
     if args.batch is None:
         args.batch = 2_000_000 if tile_wl else 131072
 

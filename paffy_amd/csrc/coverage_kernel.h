@@ -29,7 +29,7 @@
 #define COV_WORDS (COV_SLICE / 32u)       /* bitmap words per slice */
 #define COV_NT 512                        /* threads of a slice workgroup: words tid and tid + 512 of the slice are this thread's */
 #define COV_NWAVE (COV_NT / 64)
-#define COV_HIST_W 512u                   /* levels the LDS histogram tells apart (index = level mod 512) */
+#define COV_HIST_W 256u                   /* levels the LDS histogram tells apart (index = level mod 256) */
 #define COV_BIAS 32769u                   /* LDS counters hold count + 32769: the clamped 16-bit add then stops at count 32766 (impl/paf.c:700) */
 
 #define COV_TEXT 4096u   /* cigar bytes per round of the bitmap kernel (256 threads x 16) */
@@ -367,8 +367,8 @@ __device__ __forceinline__ uint32_t wave_max_all_u32(uint32_t v) { return ~wave_
  */
 __device__ __forceinline__ uint32_t cov_phys_word(uint32_t w) { return (w & 7u) * (COV_WORDS / 8u) + (w >> 3); }
 
-#define COV_COPIES 4u /* level histogram copies (lane & 3): a quarter of the same-address collisions inside one ds_add */
-#define COV_HIST_ROW (COV_HIST_W / 2 + 8u) /* words per copy: eight spare, so that one level lies on four different banks in the four copies */
+#define COV_COPIES 8u /* level histogram copies (lane & 7): an eighth of the same-address collisions inside one ds_add */
+#define COV_HIST_ROW (COV_HIST_W / 2 + 32u / COV_COPIES) /* words per copy: the spare ones put one level on a different bank in every copy */
 /* a copy: COV_HIST_W 16-bit counters, levels L and L + COV_HIST_W / 2 in one word (a count is at most 32 768) */
 
 struct CovWalkLds {
