@@ -634,7 +634,7 @@ static int ensure(paffy_hip_ctx *c, DevBuf &b, size_t bytes) {
     if (b.p) HIPCHK(c, hipFree(b.p));
     b.p = nullptr;
     b.cap = 0;
-    size_t want = bytes + bytes / 4 + 256;
+    size_t want = bytes + bytes / 2 + 256; /* room to grow: a batch a little larger than the last must not cost a free and an allocation */
     HIPCHK(c, hipMalloc(&b.p, want));
     b.cap = want;
     return 0;
