@@ -600,6 +600,15 @@ struct paffy_hip_ctx {
     const void *indexed_in = nullptr;
     int64_t indexed_len = 0;
     uint32_t indexed_n = 0;
+    /* the index of batches whose names were asked for (paffy_hip_query_names), kept until the batch is split: a sharded tile asks
+       for the names of all its batches before it splits the first one */
+    struct KeptIndex {
+        const void *in;
+        int64_t len;
+        uint32_t n, n_seps;
+        DevBuf meta, sep_pos, nl_idx;
+    };
+    std::vector<KeptIndex> kept_index;
     DevBuf one_batch;               /* table with the single text pointer of a one-batch plan (dedupe / split_file lines) */
     /* what emit writes for a line plan (tile, dedupe): record order, levels, offsets */
     const uint8_t *const *line_batches = nullptr;
@@ -716,6 +725,7 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
 }
 
 static void cov_free(paffy_hip_ctx *c); /* coverage_host.h state */
+static void index_drop(paffy_hip_ctx *c, const void *d_in);
 static void chain_free(paffy_hip_ctx *c);
 
 void paffy_hip_destroy(paffy_hip_ctx *c) {
@@ -723,6 +733,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     prof_collect(c);
     cov_free(c);
     chain_free(c);
+    while (!c->kept_index.empty()) index_drop(c, c->kept_index.back().in);
     if (c->one_batch.p) (void)hipFree(c->one_batch.p);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
                       &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->seq_raw, &c->pretty_off, &c->pretty_out, &c->pretty_err, &c->rec_stats, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
@@ -753,7 +764,9 @@ static int fetch_info(paffy_hip_ctx *c) {
 }
 
 /* Separator index + header parse shared by plan and tile_plan. */
+static void index_drop(paffy_hip_ctx *c, const void *d_in);
 static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, uint32_t *n_lines_out, uint32_t lvl0_max = PAFFY_OPS_CAP) {
+    index_drop(c, in); /* a kept index of this buffer describes what it held before */
     const uint32_t n_tiles = (len + SEP_TILE - 1) / SEP_TILE;
     c->indexed_in = nullptr; /* the index buffers are about to describe another batch */
 
@@ -1294,6 +1307,53 @@ __global__ __launch_bounds__(PAFFY_NT) void k_scatter_lines(const uint8_t *src, 
     copy_line(src + src_off[k], (uint64_t)(src_off[k + 1] - src_off[k]), dst + dst_off[k], false);
 }
 
+/* the kept indexes (see paffy_hip_ctx::kept_index): copy out after query_names, copy back for split_by_owner */
+static void index_drop(paffy_hip_ctx *c, const void *d_in) {
+    for (size_t i = 0; i < c->kept_index.size(); i++)
+        if (c->kept_index[i].in == d_in) {
+            paffy_hip_ctx::KeptIndex &k = c->kept_index[i];
+            if (k.meta.p) (void)hipFree(k.meta.p);
+            if (k.sep_pos.p) (void)hipFree(k.sep_pos.p);
+            if (k.nl_idx.p) (void)hipFree(k.nl_idx.p);
+            c->kept_index.erase(c->kept_index.begin() + (long)i);
+            return;
+        }
+}
+static int index_keep(paffy_hip_ctx *c, const void *d_in, int64_t in_len, uint32_t n) {
+    index_drop(c, d_in);
+    if (c->kept_index.size() >= 64) return 0; /* a caller that never splits: stop keeping */
+    paffy_hip_ctx::KeptIndex k;
+    k.in = d_in;
+    k.len = in_len;
+    k.n = n;
+    k.n_seps = c->h_info->n_seps;
+    const size_t mb = sizeof(RecMeta) * (size_t)n, sb = sizeof(uint32_t) * ((size_t)k.n_seps + 1), nb = sizeof(uint32_t) * ((size_t)n + 1);
+    if (ensure(c, k.meta, mb) || ensure(c, k.sep_pos, sb) || ensure(c, k.nl_idx, nb)) return PAFFY_E_HIP;
+    HIPCHK(c, hipMemcpyAsync(k.meta.p, c->meta.p, mb, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(k.sep_pos.p, c->sep_pos.p, sb, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(k.nl_idx.p, c->nl_idx.p, nb, hipMemcpyDeviceToDevice, c->stream));
+    c->kept_index.push_back(k);
+    return 0;
+}
+/* 0: the index buffers describe d_in again; 1: nothing kept for it */
+static int index_restore(paffy_hip_ctx *c, const void *d_in, int64_t in_len, uint32_t *n) {
+    for (size_t i = 0; i < c->kept_index.size(); i++) {
+        paffy_hip_ctx::KeptIndex &k = c->kept_index[i];
+        if (k.in != d_in || k.len != in_len) continue;
+        const size_t mb = sizeof(RecMeta) * (size_t)k.n, sb = sizeof(uint32_t) * ((size_t)k.n_seps + 1), nb = sizeof(uint32_t) * ((size_t)k.n + 1);
+        if (ensure(c, c->meta, mb) || ensure(c, c->sep_pos, sb) || ensure(c, c->nl_idx, nb)) return 1;
+        if (hipMemcpyAsync(c->meta.p, k.meta.p, mb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(c->sep_pos.p, k.sep_pos.p, sb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(c->nl_idx.p, k.nl_idx.p, nb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) /* the kept copy is freed below */
+            return 1;
+        *n = k.n;
+        index_drop(c, d_in);
+        return 0;
+    }
+    return 1;
+}
+
 int64_t paffy_hip_query_names(paffy_hip_ctx *c, const void *d_in, int64_t in_len, int64_t cap, uint64_t *hashes, int64_t *weights) {
     if (!c || !hashes || !weights || cap < 0) return PAFFY_E_ARG;
     if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
@@ -1308,6 +1368,7 @@ int64_t paffy_hip_query_names(paffy_hip_ctx *c, const void *d_in, int64_t in_len
     c->indexed_in = d_in;
     c->indexed_len = in_len;
     c->indexed_n = n;
+    if (index_keep(c, d_in, in_len, n)) return PAFFY_E_HIP;
     const uint32_t g = (n + PAFFY_NT - 1) / PAFFY_NT;
     if (ensure(c, S.k64a, sizeof(uint64_t) * ((size_t)n + 1)) || ensure(c, S.k64b, sizeof(uint64_t) * ((size_t)n + 1)) || ensure(c, S.name_hash, sizeof(uint64_t) * ((size_t)n + 1)) ||
         ensure(c, S.v32a, sizeof(uint32_t) * ((size_t)n + 1)) || ensure(c, S.v32b, sizeof(uint32_t) * ((size_t)n + 1)) || ensure(c, S.flags, sizeof(uint32_t) * ((size_t)n + 1)) ||
@@ -1351,7 +1412,8 @@ int paffy_hip_split_by_owner(paffy_hip_ctx *c, const void *d_in, int64_t in_len,
     const uint8_t *in = static_cast<const uint8_t *>(d_in);
     if (c->indexed_in == d_in && c->indexed_len == in_len) { /* indexed by paffy_hip_query_names just before */
         n = c->indexed_n;
-    } else {
+        index_drop(c, d_in);
+    } else if (index_restore(c, d_in, in_len, &n) != 0) { /* ... or some batches ago: its index comes back from the kept copy */
         int rc = index_and_parse(c, in, (uint32_t)in_len, &n);
         if (rc) return rc;
     }
