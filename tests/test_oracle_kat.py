@@ -297,3 +297,49 @@ def test_chain_known_answer():
     assert O.chain(over, trim=0.0)[0].count(b"cn:i:1") == 1  # untrimmed they overlap: two chains
     # coordinates come back untrimmed
     assert out3.splitlines()[0].split(b"\t")[2:4] == [b"0", b"100"]
+
+
+def _cov_line(q, ql, qs, qe, score, cg, extra=b""):
+    return b"\t".join([q, b"%d" % ql, b"%d" % qs, b"%d" % qe, b"+", b"t", b"100", b"0", b"%d" % (qe - qs), b"5", b"5", b"60", b"AS:i:%d" % score]) + extra + b"\tcg:Z:" + cg + b"\n"
+
+
+def test_tile_and_to_bed_known_answer():
+    """paffy tile (impl/paf_tile.c:28-93,156-178) and to_bed (impl/paf_to_bed.c:33-55) worked by hand on three records of one query of
+    20 bases: by descending score R1 q[0,10) 100, R2 q[5,15) 90, R3 q[8,12) 80. Counters after R1: 1 on [0,10) -> its ten bases all at
+    level 1; after R2: [5,10) = 2, [10,15) = 1 -> five bases at 1, five at 2, half of ten is reached at level 1; after R3: [8,10) = 3,
+    [10,12) = 2 -> two at 2, two at 3, half of four is reached at level 2. tp is P for level 1, S above (impl/paf.c:343-348)."""
+    data = _cov_line(b"q", 20, 8, 12, 80, b"4M") + _cov_line(b"q", 20, 0, 10, 100, b"10M") + _cov_line(b"q", 20, 5, 15, 90, b"10M")
+    out, err = O.tile(data)
+    assert err.code == 0
+    assert out == (b"q\t20\t0\t10\t+\tt\t100\t0\t10\t5\t5\t60\ttp:A:P\tAS:i:100\ttl:i:1\tcg:Z:10M\n"
+                   b"q\t20\t5\t15\t+\tt\t100\t0\t10\t5\t5\t60\ttp:A:P\tAS:i:90\ttl:i:1\tcg:Z:10M\n"
+                   b"q\t20\t8\t12\t+\tt\t100\t0\t4\t5\t5\t60\ttp:A:S\tAS:i:80\ttl:i:2\tcg:Z:4M\n")
+    # a chain score outranks the alignment score (paf_cmp_by_descending_score): R3 first -> it sees an empty query: level 1
+    data2 = _cov_line(b"q", 20, 8, 12, 80, b"4M", b"\ts1:i:7") + _cov_line(b"q", 20, 0, 10, 100, b"10M")
+    out2, _ = O.tile(data2)
+    assert [ln.split(b"\t")[14] for ln in out2.splitlines()] == [b"tl:i:1", b"tl:i:1"] and out2.startswith(b"q\t20\t8\t12")
+    # insertions count, deletions do not (impl/paf.c:691-712): 2M1D2M1I1M covers q[0,6) at 0,1,2,3 and 5
+    bed, err = O.to_bed(_cov_line(b"q", 8, 0, 6, 1, b"2M1D2M1I1M"))
+    assert err.code == 0 and bed == b"q 0 4 1\nq 4 5 0\nq 5 6 1\nq 6 8 0\n"
+    bed, _ = O.to_bed(data)
+    assert bed == b"q 0 5 1\nq 5 8 2\nq 8 10 3\nq 10 12 2\nq 12 15 1\nq 15 20 0\n"
+    assert O.to_bed(data, binary=True)[0] == b"q 0 15 1\nq 15 20 0\n"
+    assert O.to_bed(data, exclude_unaligned=True, min_size=3)[0] == b"q 0 5 1\nq 5 8 2\nq 12 15 1\n"
+
+
+def test_dedupe_known_answer():
+    """paffy dedupe (impl/paf_dedupe.c:27-46,117-143): a record is dropped when an earlier written one has the same names, strand and
+    four coordinates; with -a also when an earlier one equals it with query and target swapped."""
+    a = b"q\t100\t0\t10\t+\tt\t200\t5\t15\t10\t10\t60\tcg:Z:10M\n"
+    a_again = b"q\t100\t0\t10\t+\tt\t200\t5\t15\t9\t10\t7\tAS:i:5\tcg:Z:4M2I4M2D\n"  # same key, everything else differs
+    a_minus = a.replace(b"\t+\t", b"\t-\t")
+    a_inv = b"t\t200\t5\t15\t+\tq\t100\t0\t10\t10\t10\t60\tcg:Z:10M\n"
+    data = a + a_again + a_minus + a_inv
+
+    def written(x):  # the writer prints AS for every record, 0 when the line had none (score is calloc'ed, impl/paf.c:349)
+        return x.rstrip(b"\n").replace(b"\tcg:Z:", b"\tAS:i:0\tcg:Z:")
+
+    out, err = O.dedupe(data)
+    assert err.code == 0 and out.splitlines() == [written(x) for x in (a, a_minus, a_inv)]
+    out, err = O.dedupe(data, check_inverse=True)
+    assert err.code == 0 and out.splitlines() == [written(x) for x in (a, a_minus)]
