@@ -587,7 +587,7 @@ struct paffy_hip_ctx {
     bool plan_is_bed = false; /* paffy to_bed: emit writes the run lines */
     bool keep_raw = false;    /* paffy_hip_keep_raw_sequences: seq_raw holds the bases as loaded (paf_pretty_print shows their case) */
     bool plan_seq_lookup = false; /* rec_qseq / rec_tseq belong to the current plan */
-    DevBuf seq_raw, pretty_off, pretty_out, pretty_err;
+    DevBuf seq_raw, pretty_off, pretty_out, pretty_err, host_in, host_out;
     DevBuf rec_stats; /* six sums per record of the PAFFY_STATS stage */
     DevBuf bed_keys, bed_tab, bed_starts, bed_len, bed_off, bed_tiles;
     struct BedParams *bed_params = nullptr; /* host copy */
@@ -736,7 +736,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     while (!c->kept_index.empty()) index_drop(c, c->kept_index.back().in);
     if (c->one_batch.p) (void)hipFree(c->one_batch.p);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
-                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->seq_raw, &c->pretty_off, &c->pretty_out, &c->pretty_err, &c->rec_stats, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
+                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->seq_raw, &c->pretty_off, &c->pretty_out, &c->pretty_err, &c->host_in, &c->host_out, &c->rec_stats, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
                       &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts, &c->scan_part, &c->dedupe_keys, &c->emit_order, &c->order_cnt};
     for (DevBuf *b : bufs)
@@ -1681,25 +1681,27 @@ int paffy_hip_run_host(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_st
     if (!c || !h_out || !out_len || !info) return PAFFY_E_ARG;
     *h_out = nullptr;
     *out_len = 0;
+    /* the device buffers stay with the context: the record API (host/paf_api.c) makes one such call per record */
     void *d_in = nullptr, *d_out = nullptr;
     int rc = 0;
     if (in_len > 0) {
-        HIPCHK(c, hipMalloc(&d_in, (size_t)in_len + 64));
-        if (hipMemcpy(d_in, h_in, (size_t)in_len, hipMemcpyHostToDevice) != hipSuccess) rc = PAFFY_E_HIP;
+        if (ensure(c, c->host_in, (size_t)in_len + 64)) return PAFFY_E_HIP;
+        d_in = c->host_in.p;
+        if (hipMemcpyAsync(d_in, h_in, (size_t)in_len, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = PAFFY_E_HIP;
     }
     if (!rc) rc = paffy_hip_plan(c, stages, n_stages, d_in, in_len, info);
     if (!rc && info->out_bytes > 0) {
-        if (hipMalloc(&d_out, (size_t)info->out_bytes + 64) != hipSuccess) rc = PAFFY_E_HIP;
-        if (!rc) rc = paffy_hip_emit(c, d_out, info->out_bytes + 64);
-        if (!rc) rc = paffy_hip_sync(c);
+        if (ensure(c, c->host_out, (size_t)info->out_bytes + 64)) return PAFFY_E_HIP;
+        d_out = c->host_out.p;
+        rc = paffy_hip_emit(c, d_out, info->out_bytes + 64);
         if (!rc) {
             *h_out = static_cast<char *>(malloc((size_t)info->out_bytes));
-            if (hipMemcpy(*h_out, d_out, (size_t)info->out_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = PAFFY_E_HIP;
+            if (!*h_out || hipMemcpyAsync(*h_out, d_out, (size_t)info->out_bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = PAFFY_E_HIP;
             *out_len = info->out_bytes;
         }
+        if (!rc) rc = paffy_hip_sync(c);
     }
-    if (d_in) (void)hipFree(d_in);
-    if (d_out) (void)hipFree(d_out);
+    c->planned = false; /* the input buffer will be overwritten by the next call */
     return rc;
 }
 
@@ -2150,8 +2152,9 @@ int paffy_hip_parse_host(paffy_hip_ctx *c, const char *h_in, int64_t in_len, paf
     *n_ops_total = 0;
     void *d_in = nullptr;
     int rc = 0;
-    if (in_len > 0) {
-        HIPCHK(c, hipMalloc(&d_in, (size_t)in_len + 64));
+    if (in_len > 0) { /* the context's own input buffer, like paffy_hip_run_host */
+        if (ensure(c, c->host_in, (size_t)in_len + 64)) return PAFFY_E_HIP;
+        d_in = c->host_in.p;
         if (hipMemcpy(d_in, h_in, (size_t)in_len, hipMemcpyHostToDevice) != hipSuccess) rc = PAFFY_E_HIP;
     }
     const paffy_stage pass = {PAFFY_PASS, 0.0f, 0.0f};
@@ -2205,8 +2208,7 @@ int paffy_hip_parse_host(paffy_hip_ctx *c, const char *h_in, int64_t in_len, paf
             *n_ops_total = at;
         }
     }
-    c->planned = false; /* the input buffer goes away */
-    if (d_in) (void)hipFree(d_in);
+    c->planned = false; /* the input buffer will be overwritten by the next call */
     return rc;
 }
 
