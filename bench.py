@@ -57,10 +57,15 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a one-GPU rehearsal)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even with one rank, so that the collectives of the N-rank path (RCCL with the nccl backend) run at world size 1")
     ap.add_argument("--pipe", default=None, help="override the workload's command pipe, e.g. 'shatter' (experiments only)")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="records of the stream timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--mean-ops", type=int, default=0, help="override the workload's mean cigar ops (experiments only)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="stream workloads: contexts that take the batches in turn, each on its own HIP stream, so that the sizing pass of batch k + 1 runs beside "
+                         "the writers of batch k (1 = one context, batches strictly one after the other)")
     ap.add_argument("--verify", action="store_true", help="cfg5: gather the ordered output of the last step on rank 0 and compare it with a one-process tile of the same records (small --batch only)")
     ap.add_argument("--rehearse", action="store_true",
                     help="plumbing rehearsal without a GPU: ranks, rendezvous, the per-step size exchange and the reductions run, the hot path does not (value is null)")
@@ -87,9 +92,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(_free_port())
         torch.cuda.set_device(0 if args.one_device else local_rank)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
@@ -107,6 +117,12 @@ def main():
     if wl.get("tile"):
         return bench_tile(args, wl, rank, world, dist, dev)
     eng = paffy_amd.Engine()
+    # --pipeline P: P contexts (workspace + stream each) take the batches in turn; the host plans batch k + 1 on one stream while the
+    # GPU still writes batch k on another. Every batch is still one whole pass of the hot path (plan + emit).
+    engs = [eng] + [paffy_amd.Engine() for _ in range(max(1, args.pipeline) - 1)]
+    if len(engs) > 1:
+        for e in engs:
+            e.use_stream(torch.cuda.Stream(device=dev))
     stages = [] if wl.get("tile") else stages_for(wl["pipe"], paffy_amd)
     n_batches = args.warmup + args.steps
 
@@ -116,6 +132,8 @@ def main():
     batches = []
     mine = shard.batches_of_rank(rank, world, n_batches * world * args.batch, args.batch)  # rank r: batches r, r+N, ...
     if wl.get("genomes"):
+        if len(engs) > 1:
+            raise SystemExit("--pipeline > 1 is for the stream workloads without genomes (every context would hold its own copy)")
         eng.synth4_setup(wl["seed"], wl["mean_ops"])  # both genomes replicated on every GPU
     for _, first, n in mine:
         r0 = first % max(1, wl["total"] - args.batch + 1)  # weak scaling: past the end the stream repeats
@@ -132,28 +150,34 @@ def main():
     def plan(buf, nbytes):
         return eng.tile_plan(buf, nbytes) if wl.get("tile") else eng.plan(stages, buf, nbytes)
 
-    # one untimed plan to size the output slab (reused by every step)
+    # one untimed plan to size the output slabs (one per context, reused by every step)
+    eng.sync()
+    torch.cuda.synchronize()
     info0 = plan(batches[0][0], batches[0][1])
-    out_cap = int(info0.out_bytes * 1.25) + (1 << 20)
-    d_out = eng.alloc_out(out_cap)
+    out_cap = [int(info0.out_bytes * 1.25) + (1 << 20)] * len(engs)
+    d_out = [e.alloc_out(out_cap[0]) for e in engs]
 
     def step(i):
-        nonlocal d_out, out_cap
+        k = i % len(engs)
+        e = engs[k]
         buf, nbytes, _ = batches[i]
-        info = plan(buf, nbytes)
+        info = e.tile_plan(buf, nbytes) if wl.get("tile") else e.plan(stages, buf, nbytes)
         if info.error.code:
             raise RuntimeError(f"synthetic record failed: code {info.error.code} record {info.error.record}")
-        if info.out_bytes > out_cap:
-            out_cap = int(info.out_bytes * 1.25)
-            d_out = eng.alloc_out(out_cap)
-        eng.emit(d_out)
+        if info.out_bytes > out_cap[k]:
+            e.sync()
+            out_cap[k] = int(info.out_bytes * 1.25)
+            d_out[k] = e.alloc_out(out_cap[k])
+        e.emit(d_out[k])
         return info
 
-    for i in range(args.warmup):
-        step(i)
-    eng.sync()
+    for i in range(max(args.warmup, len(engs) if args.warmup else 0)):
+        step(i % n_batches)
+    for e in engs:
+        e.sync()
 
-    eng.profile(not args.no_kernel_events)
+    for e in engs:
+        e.profile(not args.no_kernel_events)
     # the ordered write across ranks: every step's output sizes are exchanged (RCCL all-gather) inside the timed region, and each
     # rank's bytes stay in its own HBM at a known offset of the ordered output (per-rank ranges, no gather of the bytes)
     exch = SizeExchange(dist, world, args.steps, dev if (dist is None or args.dist_backend == "nccl") else "cpu")
@@ -165,14 +189,19 @@ def main():
     for i in range(args.steps):
         infos.append(step(args.warmup + i))
         exch.post(i, infos[-1].out_bytes)
-    eng.sync()
+    for e in engs:
+        e.sync()
     my_offsets, ordered_total = exch.finish(rank)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kernels = eng.profile_read()
-    eng.profile(False)
+    kernels = {}
+    for e in engs:
+        for name, (ms, cnt) in e.profile_read().items():
+            have = kernels.get(name, (0.0, 0))
+            kernels[name] = (have[0] + ms, have[1] + cnt)
+        e.profile(False)
 
     if dist:
         red_dev = dev if args.dist_backend == "nccl" else "cpu"
@@ -223,12 +252,17 @@ def main():
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k][0])
             step_ms = sum(ms for ms, _ in kernels.values()) / args.steps  # all kernels of one step, HIP events on the launch stream
+            kernel_sum_ms = step_ms
+            if len(engs) > 1:
+                # pipelined contexts: kernels of neighbouring batches run beside each other, so their event times add up to more than
+                # the time a step takes; the pass is priced with the wall time of a step instead (barrier to barrier / steps)
+                step_ms = elapsed / args.steps * 1e3
             achieved = per_launch_bytes / (step_ms * 1e-3) / 1e9
             traffic = [measured_traffic(args, k) for k in kernels]
             roofline = {"bound": "hbm", "kernel": f"all kernels of one step (dominant: {dom})", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": int(sum(t for t in traffic if t)) if any(traffic) else None,
-                        "step_kernels_ms": round(step_ms, 4), "dominant_kernel": dom,
+                        "step_kernels_ms": round(step_ms, 4), "kernel_event_sum_ms": round(kernel_sum_ms, 4), "pipeline_contexts": len(engs), "dominant_kernel": dom,
                         "dominant_avg_kernel_ms": round(kernels[dom][0] / max(1, kernels[dom][1]), 4),
                         "algorithmic_bytes_per_launch": int(per_launch_bytes)}
         cpu = cpu_all = e2e = None
@@ -252,7 +286,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/int64 (float32 identity predicate)",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {wl['desc']}", "pipe": wl["pipe"], "records_per_step_per_gpu": args.batch,
+            "config": {"workload": f"{args.workload}: {wl['desc']}", "pipe": wl["pipe"], "records_per_step_per_gpu": args.batch, "pipeline_contexts": len(engs),
                        "records_timed": records, "stream_records": wl["total"], "mean_cigar_ops": wl["mean_ops"],
                        "input_bytes_per_record": round(in_bytes / (args.batch * args.steps), 1),
                        "output_bytes_per_record": round(out_bytes / (args.batch * args.steps), 1),
@@ -306,6 +340,7 @@ def bench_tile(args, wl, rank, world, dist, dev):
     eng.profile(False)
     elapsed, last, kernels, each = 0.0, None, {}, []
     for i in range(n_steps):
+        last = None  # the step before: its output and keys are let go before this step's input is generated
         batches, first = share(i)
         if i == 0:
             head = bytes(batches[0][0][: min(batches[0][1], 4 << 20)].cpu().numpy().tobytes())
@@ -318,7 +353,7 @@ def bench_tile(args, wl, rank, world, dist, dev):
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res = shard.tile_sharded(worker, dist, rank, world, batches, first, comm)
+        res = shard.tile_sharded(worker, dist, rank, world, batches, first, comm, consume=True)  # the batches are handed over: freed as they are split
         out = worker.emit()
         eng.sync()
         torch.cuda.synchronize()
@@ -331,7 +366,9 @@ def bench_tile(args, wl, rank, world, dist, dev):
             in_bytes += sum(n for _, n in worker.keep)
             out_bytes += int(out.numel())
             rows += int(res["keys"].shape[0])
-        last = (res, out, batches, first)
+        last = (res, out, None, first)
+        free_b, total_b = torch.cuda.mem_get_info()
+        hbm_used_after_step = total_b - free_b
     kernels = eng.profile_read()
     eng.profile(False)
     red = dev if (dist is not None and args.dist_backend == "nccl") else "cpu"
@@ -374,7 +411,8 @@ def bench_tile(args, wl, rank, world, dist, dev):
                     by_kernel[name] = {"avg_kernel_ms": round(ms / launches, 4), "launches_per_step": round(launches / max(1, args.steps), 2)}
         cpu = cpu_baseline_tile(eng, wl, min(args.cpu_sample, 8192)) if (args.cpu_sample > 0 and world == 1) else None
         print(json.dumps({
-            "metric": "PAF records/sec (shatter+invert+trim pipe); % HBM roofline at 1/2/4/8 GPU", "value": round(records / elapsed, 1), "unit": "records/s",
+            "metric": "PAF records/sec (tile, records partitioned by query contig + ordered write; BASELINE cfg5); % HBM roofline at 1/2/4/8 GPU",
+            "value": round(records / elapsed, 1), "unit": "records/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u16 counters / int64 keys", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "pipe": "tile", "records_per_step_per_gpu": args.batch, "records_timed": records,
@@ -385,6 +423,11 @@ def bench_tile(args, wl, rank, world, dist, dev):
             "ordered_write": {"mode": "per-line offsets from the all-gathered keys; lines written by their owner", "total_bytes": int(last[0]["total"]),
                               "verified_against_one_process": verified},
             "phase_ms_last_step": last[0].get("timing") or None, "ms_each_step": each,
+            "hbm": {"in_use_after_last_step_GB": round(hbm_used_after_step / 1e9, 2), "peak_in_use_GB": (round(last[0]["hbm_peak"] / 1e9, 2) if last[0].get("hbm_peak") else None),
+                    "peak_live_GB": (round(last[0]["hbm_live_peak"] / 1e9, 2) if last[0].get("hbm_live_peak") else None),
+                    "share_text_GB": round(in_bytes / max(1, args.steps) / 1e9, 2),
+                    "note": "device memory in use by this process (hipMemGetInfo: torch's cache and the library's buffers alike); the peaks are sampled at the phase "
+                            "boundaries of the sharded tile with PAFFY_SHARD_TIMING=1; live = in use minus the blocks torch's caching allocator holds empty"},
             "roofline": roofline, "roofline_by_kernel": by_kernel, "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kernels.items()},
         }), flush=True)
@@ -403,18 +446,44 @@ def _free_port():
     return port
 
 
+def visible_gpus():
+    """GPUs this process could use, counted WITHOUT a HIP / torch.cuda call (torch.cuda.device_count() ends in hipGetDeviceCount when
+    amdsmi discovery fails, and the launcher must not have initialised the GPU when it starts its ranks): the KFD topology nodes that
+    have SIMDs (CPUs are nodes too, with simd_count 0), cut down by a HIP_/ROCR_/CUDA_VISIBLE_DEVICES list. None when there is a
+    /dev/kfd whose topology cannot be read (the ranks then find out themselves); 0 without a KFD device."""
+    import glob
+
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None if os.path.exists("/dev/kfd") else 0
+    have = 0
+    for path in nodes:
+        try:
+            with open(path) as fh:
+                for ln in fh:
+                    f = ln.split()
+                    if len(f) == 2 and f[0] == "simd_count" and int(f[1]) > 0:
+                        have += 1
+        except (OSError, ValueError):
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            have = min(have, len([x for x in v.split(",") if x.strip() != ""]))
+    return have
+
+
 def launch_ranks(args):
     """Start one process per GPU (rank r -> cuda:r, or cuda:0 with --one-device) with the torch.distributed environment set, as
-    `python -m torch.distributed.run --nproc-per-node N` would; rank 0 prints the JSON line. Nothing in this process has touched
-    the GPU (no exec of a GPU-initialised process). Returns the exit status: non-zero when any rank failed."""
+    `python -m torch.distributed.run --nproc-per-node N` would; rank 0 prints the JSON line. Nothing in this process touches
+    the GPU, torch is not even imported (no fork / exec from a GPU-initialised process). Returns the exit status: non-zero when
+    any rank failed."""
     import subprocess
 
     n = args.gpus
     if not args.rehearse and not args.one_device:
-        import torch
-
-        have = torch.cuda.device_count()  # counting devices does not initialise the GPU
-        if have < n:
+        have = visible_gpus()  # from sysfs: no HIP call (and no torch) in the process that starts the ranks
+        if have is not None and have < n:
             print(f"bench.py: --gpus {n} but {have} device(s) visible (use --one-device for a one-GPU rehearsal)", file=sys.stderr)
             return 2
     env0 = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -352,14 +352,21 @@ void paf_remove_mismatches(Paf *paf) { /* impl/paf.c:786-809 */
 /*
  * The pair of sequences a call works on goes to the GPU under the stand-in names "Q" and "T" (the two strings are the record's own
  * sequences whatever it calls them). Callers walk a file of alignments over the same few sequences (impl/paf_view.c:150-172), so
- * the last pair stays loaded: it is sent again only when a pointer, a length or the sampled bytes differ.
+ * the last pair stays loaded: it is sent again only when a pointer, a length or a hash over EVERY byte differs (the reference reads the
+ * caller's strings on every call, impl/paf.c:752-757: a base edited in place between two calls must be seen; hashing costs about
+ * as much as the strlen beside it and far less than the copy to the GPU it saves).
  */
-static uint64_t sample_of(const char *s, int64_t len) {
+static uint64_t hash_of(const char *s, int64_t len) {
     uint64_t h = 1469598103934665603ull ^ (uint64_t)len;
-    const int64_t step = len > 4096 ? len / 4096 : 1;
-    for (int64_t i = 0; i < len; i += step) h = (h ^ (unsigned char)s[i]) * 1099511628211ull;
-    if (len > 0) h = (h ^ (unsigned char)s[len - 1]) * 1099511628211ull;
-    return h;
+    int64_t i = 0;
+    for (; i + 8 <= len; i += 8) { /* eight bytes per step: multiply, fold the high half back in */
+        uint64_t w;
+        memcpy(&w, s + i, 8);
+        h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+    }
+    for (; i < len; i++) h = (h ^ (unsigned char)s[i]) * 1099511628211ull;
+    return h ^ (h >> 32);
 }
 static void load_pair(char *query_seq, char *target_seq) {
     static const char *last[2];
@@ -368,7 +375,7 @@ static void load_pair(char *query_seq, char *target_seq) {
     const char *names[2] = {"Q", "T"};
     const char *seqs[2] = {query_seq, target_seq};
     const int64_t lens[2] = {(int64_t)strlen(query_seq), (int64_t)strlen(target_seq)};
-    const uint64_t smp[2] = {sample_of(query_seq, lens[0]), sample_of(target_seq, lens[1])};
+    const uint64_t smp[2] = {hash_of(query_seq, lens[0]), hash_of(target_seq, lens[1])};
     if (last[0] == seqs[0] && last[1] == seqs[1] && last_len[0] == lens[0] && last_len[1] == lens[1] && last_sample[0] == smp[0] &&
         last_sample[1] == smp[1])
         return;

@@ -158,20 +158,36 @@ int64_t paffy_hip_tile_keys(paffy_hip_ctx *ctx, int64_t cap_lines, void *d_keys)
  * Sharding `paffy tile` by query sequence across GPUs (what `paffy split_file -q` does with files in the reference
  * pipeline, tests/paf_pipeline_test.sh:42, impl/paf_split_file.c:142-173). Names travel as 64-bit hashes.
  *   query_names:    the distinct query names of a batch (hashes[], host) and the bytes of their lines (weights[], host): what a
- *                   partitioner balances. Returns their number (<= cap) or a negative error. A split_by_owner of the same batch right after
- *                   reuses the line index built here.
+ *                   partitioner balances. Returns their number (<= cap) or a negative error. The line index built here is KEPT for
+ *                   the batch (keyed by d_in and in_len, up to 64 batches) and consumed by the split of the same batch. Contract:
+ *                   the bytes of the batch must not change between its query_names and its split -- the kept index is not
+ *                   re-validated against the text. A batch that will not be split after all: paffy_hip_drop_index(ctx, d_in)
+ *                   (d_in NULL: every kept index). Kept indexes are also dropped by any query_names / split call that fails and
+ *                   by paffy_hip_tile_begin / _bed_begin / _chain_begin; paffy_hip_plan and the other index-building calls on the
+ *                   same d_in drop that batch's entry.
  *   split_by_owner: the lines of the batch regrouped by part -- part = table_owner[i] for a query name with hash table_hash[i]
  *                   (ascending hashes; a name the table lacks goes to hash % n_parts) -- input order kept inside a part, every line
  *                   newline-terminated, into d_out (out_cap >= in_len + 1). part_bytes / part_records (host, n_parts each) say where
  *                   the parts end; d_rec_index (device, rec_index_cap int64, may be NULL) gets the batch index of every output line.
  *                   This is the send buffer of the all-to-all that gives every rank the records of its sequences.
+ *   split_to:       the same, straight into a send buffer that gathers the parts of several batches per destination: part p's lines
+ *                   go to d_out + part_dst[p], its record indices (+ rec_base: the batch's first global record) to
+ *                   d_rec_index + rec_dst[p] (host arrays of n_parts byte / entry offsets; checked against out_cap / rec_index_cap
+ *                   before anything is written: PAFFY_E_CAPACITY). No second copy of the text is needed to build the send buffer.
  *   scatter_lines:  line k = d_src[src_off[k], src_off[k + 1]) goes to d_dst + dst_off[k] (int64 offsets in device memory; n_lines + 1
  *                   source offsets): the ordered write once every line's place in the global output is known.
  */
 int64_t paffy_hip_query_names(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len, int64_t cap, uint64_t *hashes, int64_t *weights);
+/* the same, with the number of lines of every name (records[], host): with bytes AND records per name a caller can lay out the send
+   buffer of the partition before it splits the first batch (paffy_hip_split_to) */
+int64_t paffy_hip_query_names_counts(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len, int64_t cap, uint64_t *hashes, int64_t *weights, int64_t *records);
 int paffy_hip_split_by_owner(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len, int32_t n_parts, const uint64_t *table_hash, const uint32_t *table_owner,
                              int64_t n_table, void *d_out, int64_t out_cap, int64_t *part_bytes, int64_t *part_records, void *d_rec_index, int64_t rec_index_cap,
                              int64_t *n_records);
+int paffy_hip_split_to(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len, int32_t n_parts, const uint64_t *table_hash, const uint32_t *table_owner,
+                       int64_t n_table, void *d_out, int64_t out_cap, const int64_t *part_dst, const int64_t *rec_dst, int64_t rec_base, int64_t *part_bytes,
+                       int64_t *part_records, void *d_rec_index, int64_t rec_index_cap, int64_t *n_records);
+int paffy_hip_drop_index(paffy_hip_ctx *ctx, const void *d_in);
 int paffy_hip_scatter_lines(paffy_hip_ctx *ctx, const void *d_src, const void *d_src_off, const void *d_dst_off, int64_t n_lines, void *d_dst);
 /*
  * Lines [first, first + n) of a tile / dedupe plan into d_out, the first of them at d_out[0] (16-byte aligned): for hosts that
@@ -260,7 +276,8 @@ int paffy_hip_run_host(paffy_hip_ctx *ctx, const paffy_stage *stages, int32_t n_
  *   input(want, keep, &cap): the buffer the next chunk is written into (NULL while both slots hold unread output); with want above its
  *                        capacity it is enlarged, the first `keep` bytes kept (a line longer than the chunk)
  *   submit(in_len, &info): the first in_len bytes (whole lines) go through the stage list; info is complete on return
- *   read(&piece, &len):  the next piece of the oldest submitted chunk; len = 0: that chunk is done (submit the next, or stop)
+ *   read(&piece, &len):  the next piece of the oldest submitted chunk; len = 0: that chunk is done (submit the next, or stop).
+ *                        A piece stays valid until the call after next (three pinned pieces rotate) or close.
  * Submit chunk k + 1 before reading chunk k and the GPU works on k + 1 while the host drains k.
  */
 typedef struct paffy_hip_stream paffy_hip_stream;

@@ -12,6 +12,7 @@ struct ChainState {
     DevBuf qkey, ghash, ord1, ord2, rank, start, gid, idx, prank, pred, neg, taken, is_tail, tail_of, link, total, chain_of_tail, chain_id, score_key, o1, o2, o3, cls, big_list, n_big, rank_of, claim,
         tag_chain, tag_score, check_key, iota;
     uint64_t n_out = 0;
+    uint32_t group_salt = 0; /* salt the last run's grouping passed its name check with (0 unless group keys collided) */
 };
 static ChainState &chain_state(paffy_hip_ctx *c);
 
@@ -67,23 +68,37 @@ static int chain_run(paffy_hip_ctx *c, const ChainOpts &o, paffy_error *err) {
     const uint32_t grid = (n + PAFFY_NT - 1) / PAFFY_NT;
     RecMeta *meta = static_cast<RecMeta *>(S.meta.p);
     ChainRecs R{I64(0), I64(1), I64(2), I64(3), I64(4), U64(H.qkey), U64(H.ghash), static_cast<int64_t *>(S.level.p)};
-    LAUNCH(c, "k_chain_keys", k_chain_keys, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const uint8_t *const *>(S.batch_ptrs.p), static_cast<const RecMeta *>(meta), n, o, R,
-           static_cast<DevInfo *>(S.info.p));
-    if (cov_fetch(c, &hinfo, S.info.p, sizeof(hinfo))) return PAFFY_E_HIP;
-    if (hinfo.first_err_key != ~0ull) return report(hinfo.first_err_key);
-    /* processing order: query start, then input order (impl/chaining.c:14-21, 139) */
-    LAUNCH(c, "k_iota32", k_iota32, dim3(grid), dim3(PAFFY_NT), 0, U32(H.iota), n);
-    if (cov_sort_pairs(c, S, U64(H.qkey), U64(S.k64a), U32(H.iota), U32(H.ord1), n)) return PAFFY_E_HIP;
-    LAUNCH(c, "k_chain_rank", k_chain_rank, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const uint32_t *>(U32(H.ord1)), n, U32(H.rank));
-    /* groups: (query name, target name, strand), members in processing order */
-    LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(U64(H.ghash)), static_cast<const uint32_t *>(U32(H.ord1)), n, U64(S.k64b));
-    if (cov_sort_pairs(c, S, U64(S.k64b), U64(S.k64a), U32(H.ord1), U32(H.ord2), n)) return PAFFY_E_HIP;
-    LAUNCH(c, "k_cov_run_heads", k_cov_run_heads, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(U64(S.k64a)), n, U32(S.flags));
-    if (cov_incl_scan32(c, S, U32(S.flags), U32(S.scan32), n)) return PAFFY_E_HIP;
     uint32_t n_groups = 0;
-    if (cov_fetch(c, &n_groups, U32(S.scan32) + (n - 1), sizeof(uint32_t))) return PAFFY_E_HIP;
-    LAUNCH(c, "k_chain_group_starts", k_chain_group_starts, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const uint32_t *>(U32(S.flags)), static_cast<const uint32_t *>(U32(S.scan32)),
-           n, U32(H.start), U32(H.gid));
+    for (uint32_t salt = 0;; salt++) {
+        LAUNCH(c, "k_chain_keys", k_chain_keys, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const uint8_t *const *>(S.batch_ptrs.p), static_cast<const RecMeta *>(meta), n, o, R,
+               static_cast<DevInfo *>(S.info.p), salt);
+        if (cov_fetch(c, &hinfo, S.info.p, sizeof(hinfo))) return PAFFY_E_HIP;
+        if (hinfo.first_err_key != ~0ull) return report(hinfo.first_err_key);
+        /* processing order: query start, then input order (impl/chaining.c:14-21, 139) */
+        LAUNCH(c, "k_iota32", k_iota32, dim3(grid), dim3(PAFFY_NT), 0, U32(H.iota), n);
+        if (cov_sort_pairs(c, S, U64(H.qkey), U64(S.k64a), U32(H.iota), U32(H.ord1), n)) return PAFFY_E_HIP;
+        LAUNCH(c, "k_chain_rank", k_chain_rank, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const uint32_t *>(U32(H.ord1)), n, U32(H.rank));
+        /* groups: (query name, target name, strand), members in processing order */
+        LAUNCH(c, "k_gather_u64", k_gather_u64, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(U64(H.ghash)), static_cast<const uint32_t *>(U32(H.ord1)), n, U64(S.k64b));
+        if (cov_sort_pairs(c, S, U64(S.k64b), U64(S.k64a), U32(H.ord1), U32(H.ord2), n)) return PAFFY_E_HIP;
+        LAUNCH(c, "k_cov_run_heads", k_cov_run_heads, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(U64(S.k64a)), n, U32(S.flags));
+        if (cov_incl_scan32(c, S, U32(S.flags), U32(S.scan32), n)) return PAFFY_E_HIP;
+        if (cov_fetch(c, &n_groups, U32(S.scan32) + (n - 1), sizeof(uint32_t))) return PAFFY_E_HIP;
+        LAUNCH(c, "k_chain_group_starts", k_chain_group_starts, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const uint32_t *>(U32(S.flags)), static_cast<const uint32_t *>(U32(S.scan32)),
+               n, U32(H.start), U32(H.gid));
+        /* the names behind the hashes (impl/chaining.c:37-54 compares strings): a group holding two different keys is regrouped under the next salt */
+        uint32_t *collide = U32(H.n_big), hit = 0;
+        HIPCHK(c, hipMemsetAsync(collide, 0, sizeof(uint32_t), c->stream));
+        LAUNCH(c, "k_chain_verify_groups", k_chain_verify_groups, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const uint8_t *const *>(S.batch_ptrs.p), static_cast<const RecMeta *>(meta),
+               static_cast<const uint32_t *>(U32(H.ord2)), static_cast<const uint32_t *>(U32(H.start)), static_cast<const uint32_t *>(U32(H.gid)), n, collide);
+        if (cov_fetch(c, &hit, collide, sizeof(uint32_t))) return PAFFY_E_HIP;
+        H.group_salt = salt;
+        if (!hit) break;
+        if (salt == 7) {
+            c->last_error = "chain groups keep colliding under eight differently salted 64-bit hashes";
+            return PAFFY_E_UNSUPPORTED;
+        }
+    }
     ChainPos Q{I64(5), I64(6), I64(7), I64(8), I64(9), I64(10), U32(H.idx), U32(H.prank), I64(11), U32(H.pred), U8(H.neg)};
     LAUNCH(c, "k_chain_gather", k_chain_gather, dim3(grid), dim3(PAFFY_NT), 0, static_cast<const RecMeta *>(meta), R, static_cast<const uint32_t *>(U32(H.ord2)),
            static_cast<const uint32_t *>(U32(H.rank)), n, Q);

@@ -41,7 +41,7 @@ struct ChainRecs {
     int64_t *level;
 };
 
-__global__ __launch_bounds__(PAFFY_NT) void k_chain_keys(const uint8_t *const *batch_in, const RecMeta *meta, uint32_t n, ChainOpts o, ChainRecs R, DevInfo *info) {
+__global__ __launch_bounds__(PAFFY_NT) void k_chain_keys(const uint8_t *const *batch_in, const RecMeta *meta, uint32_t n, ChainOpts o, ChainRecs R, DevInfo *info, uint32_t salt) {
     const uint32_t r = blockIdx.x * PAFFY_NT + threadIdx.x;
     if (r >= n) return;
     const RecMeta m = meta[r];
@@ -70,13 +70,29 @@ __global__ __launch_bounds__(PAFFY_NT) void k_chain_keys(const uint8_t *const *b
     R.sc[r] = m.score;
     R.qkey[r] = (uint64_t)qs ^ 0x8000000000000000ull;
     const uint8_t *in = batch_in[m.pad1];
-    uint64_t h = 1469598103934665603ull;
+    /* the group of a record: a 64-bit hash first, the names behind it checked against the group's first record afterwards
+       (k_chain_verify_groups; the reference compares the strings, impl/chaining.c:37-54); a collision regroups with the next salt */
+    uint64_t h = 1469598103934665603ull ^ ((uint64_t)salt * 0x9E3779B97F4A7C15ull);
     for (uint32_t i = 0; i < m.qname_len; i++) h = (h ^ in[m.qname_off + i]) * 1099511628211ull;
     h = (h ^ 0xffu) * 1099511628211ull;
     for (uint32_t i = 0; i < m.tname_len; i++) h = (h ^ in[m.tname_off + i]) * 1099511628211ull;
     h = (h ^ (m.same_strand ? 0x2bu : 0x2du)) * 1099511628211ull;
     h ^= (uint64_t)m.qname_len << 32 | m.tname_len; /* names of different lengths never share a hash by accident of their bytes alone */
     R.ghash[r] = h ^ (h >> 31);
+}
+
+/* position j of the grouped order against the first position of its group: query name, target name and strand, byte for byte */
+__global__ __launch_bounds__(PAFFY_NT) void k_chain_verify_groups(const uint8_t *const *batch_in, const RecMeta *meta, const uint32_t *ord, const uint32_t *start, const uint32_t *gid,
+                                                                   uint32_t n, uint32_t *collide) {
+    const uint32_t j = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t h = start[gid[j]];
+    if (h == j) return;
+    const RecMeta &a = meta[ord[j]], &b = meta[ord[h]];
+    const uint8_t *ia = batch_in[a.pad1], *ib = batch_in[b.pad1];
+    if ((a.same_strand != 0) != (b.same_strand != 0) || !cov_same_bytes(ia + a.qname_off, a.qname_len, ib + b.qname_off, b.qname_len) ||
+        !cov_same_bytes(ia + a.tname_off, a.tname_len, ib + b.tname_off, b.tname_len))
+        atomicOr(collide, 1u);
 }
 
 __global__ __launch_bounds__(PAFFY_NT) void k_chain_rank(const uint32_t *ord, uint32_t n, uint32_t *rank) {

@@ -31,13 +31,19 @@ struct CovState {
     std::vector<uint64_t> h_contig_cov;
     uint64_t n_out = 0; /* lines emit writes */
     uint32_t sides = 1; /* entries per record: 2 for to_bed -n */
+    uint32_t name_salt = 0; /* salt of the name hash the last run's grouping passed its byte check with (0 unless names collided) */
 };
 
 static int ensure_keep(paffy_hip_ctx *c, DevBuf &b, size_t bytes, size_t used) {
     if (bytes <= b.cap) return 0;
     void *p = nullptr;
-    const size_t want = bytes + bytes / 2 + 4096;
-    HIPCHK(c, hipMalloc(&p, want));
+    size_t want = bytes + bytes / 2 + 4096;
+    if (hipMalloc(&p, want) != hipSuccess) { /* no room for the slack: the exact size must still work */
+        (void)hipGetLastError();
+        p = nullptr;
+        want = bytes;
+        HIPCHK(c, hipMalloc(&p, want));
+    }
     if (b.p && used) HIPCHK(c, hipMemcpyAsync(p, b.p, used, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (b.p) HIPCHK(c, hipFree(b.p));
@@ -337,25 +343,38 @@ static int cov_run(paffy_hip_ctx *c, int mode, paffy_error *err) {
     P.level = static_cast<int64_t *>(S.level.p);
     P.info = static_cast<DevInfo *>(S.info.p);
     P.err_aux = static_cast<int32_t *>(S.err_aux.p);
-    LAUNCH(c, "k_cov_entry_init", k_cov_entry_init, dim3(g_ent), dim3(PAFFY_NT), 0, P, mode == 0 ? order : nullptr, sides, static_cast<uint64_t *>(S.name_hash.p),
-           static_cast<int64_t *>(S.seq_len.p));
-    /* sequences: entries grouped by name hash */
-    LAUNCH(c, "k_iota32", k_iota32, dim3(g_ent), dim3(PAFFY_NT), 0, v32a, n_ent);
-    if (cov_sort_pairs(c, S, static_cast<const uint64_t *>(S.name_hash.p), k64a, v32a, v32b, n_ent)) return PAFFY_E_HIP;
-    if (ensure(c, S.flags, sizeof(uint32_t) * ((size_t)n_ent + 1))) return PAFFY_E_HIP;
+    if (ensure(c, S.flags, sizeof(uint32_t) * ((size_t)n_ent + 2))) return PAFFY_E_HIP;
     if (ensure(c, S.scan32, sizeof(uint32_t) * ((size_t)n_ent + 1))) return PAFFY_E_HIP;
     uint32_t *flags = static_cast<uint32_t *>(S.flags.p), *scan32 = static_cast<uint32_t *>(S.scan32.p);
-    LAUNCH(c, "k_cov_run_heads", k_cov_run_heads, dim3(g_ent), dim3(PAFFY_NT), 0, k64a, n_ent, flags);
-    if (cov_incl_scan32(c, S, flags, scan32, n_ent)) return PAFFY_E_HIP;
     uint32_t n_contigs = 0;
-    if (cov_fetch(c, &n_contigs, scan32 + (n_ent - 1), sizeof(uint32_t))) return PAFFY_E_HIP;
-    if (ensure(c, S.first_entry, sizeof(uint32_t) * (size_t)n_contigs)) return PAFFY_E_HIP;
+    /* sequences: entries grouped by name hash, the names then checked against their group's first (impl/paf.c:675-688 looks the name up
+       by string equality): two names under one hash -> the grouping again with the next salt */
+    for (uint32_t salt = 0;; salt++) {
+        LAUNCH(c, "k_cov_entry_init", k_cov_entry_init, dim3(g_ent), dim3(PAFFY_NT), 0, P, mode == 0 ? order : nullptr, sides, static_cast<uint64_t *>(S.name_hash.p),
+               static_cast<int64_t *>(S.seq_len.p), salt);
+        LAUNCH(c, "k_iota32", k_iota32, dim3(g_ent), dim3(PAFFY_NT), 0, v32a, n_ent);
+        if (cov_sort_pairs(c, S, static_cast<const uint64_t *>(S.name_hash.p), k64a, v32a, v32b, n_ent)) return PAFFY_E_HIP;
+        LAUNCH(c, "k_cov_run_heads", k_cov_run_heads, dim3(g_ent), dim3(PAFFY_NT), 0, k64a, n_ent, flags);
+        if (cov_incl_scan32(c, S, flags, scan32, n_ent)) return PAFFY_E_HIP;
+        if (cov_fetch(c, &n_contigs, scan32 + (n_ent - 1), sizeof(uint32_t))) return PAFFY_E_HIP;
+        if (ensure(c, S.first_entry, sizeof(uint32_t) * (size_t)n_contigs)) return PAFFY_E_HIP;
+        LAUNCH(c, "k_cov_assign_contig", k_cov_assign_contig, dim3(g_ent), dim3(PAFFY_NT), 0, P, v32b, static_cast<const uint32_t *>(flags), static_cast<const uint32_t *>(scan32), n_ent,
+               static_cast<uint32_t *>(S.first_entry.p));
+        uint32_t *collide = flags + n_ent + 1, hit = 0;
+        HIPCHK(c, hipMemsetAsync(collide, 0, sizeof(uint32_t), c->stream));
+        LAUNCH(c, "k_cov_verify_names", k_cov_verify_names, dim3(g_ent), dim3(PAFFY_NT), 0, P, static_cast<const uint32_t *>(S.first_entry.p), collide);
+        if (cov_fetch(c, &hit, collide, sizeof(uint32_t))) return PAFFY_E_HIP;
+        S.name_salt = salt;
+        if (!hit) break;
+        if (salt == 7) {
+            c->last_error = "sequence names keep colliding under eight differently salted 64-bit hashes";
+            return PAFFY_E_UNSUPPORTED;
+        }
+    }
     if (ensure(c, S.contig_len, sizeof(int64_t) * (size_t)n_contigs)) return PAFFY_E_HIP;
     if (ensure(c, S.contig_cov, sizeof(uint64_t) * ((size_t)n_contigs + 1))) return PAFFY_E_HIP;
     if (ensure(c, S.contig_slice0, sizeof(uint32_t) * ((size_t)n_contigs + 1))) return PAFFY_E_HIP;
     if (ensure(c, S.name_tab, sizeof(CovName) * (size_t)n_contigs)) return PAFFY_E_HIP;
-    LAUNCH(c, "k_cov_assign_contig", k_cov_assign_contig, dim3(g_ent), dim3(PAFFY_NT), 0, P, v32b, static_cast<const uint32_t *>(flags), static_cast<const uint32_t *>(scan32), n_ent,
-           static_cast<uint32_t *>(S.first_entry.p));
     const uint32_t g_c = (n_contigs + PAFFY_NT - 1) / PAFFY_NT;
     LAUNCH(c, "k_cov_contig_len", k_cov_contig_len, dim3(g_c), dim3(PAFFY_NT), 0, static_cast<const uint32_t *>(S.first_entry.p),
            static_cast<const int64_t *>(S.seq_len.p), n_contigs, static_cast<int64_t *>(S.contig_len.p));

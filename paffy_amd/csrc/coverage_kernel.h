@@ -650,8 +650,11 @@ __global__ __launch_bounds__(PAFFY_NT) void k_cov_merge(CovParams P) {
 /* small kernels around the walk                                                                                           */
 /* ---------------------------------------------------------------------------------------------------------------------- */
 
-__device__ __forceinline__ uint64_t cov_name_hash(const uint8_t *in, uint32_t off, uint32_t len) {
-    uint64_t h = 0xcbf29ce484222325ull; /* FNV-1a over the name, then its length */
+/* Names are grouped by a 64-bit hash and then CHECKED byte for byte against the head of their group (k_cov_verify_names; the reference
+   keys its tables by string equality, impl/paf_tile.c:160-161 stHash_stringEqualKey, impl/paf.c:675-688): when two different names
+   share a hash the grouping is redone with the next salt. Salt 0 is the hash that travels between ranks (shard.name_hash). */
+__device__ __forceinline__ uint64_t cov_name_hash(const uint8_t *in, uint32_t off, uint32_t len, uint32_t salt = 0) {
+    uint64_t h = 0xcbf29ce484222325ull ^ ((uint64_t)salt * 0x9E3779B97F4A7C15ull); /* FNV-1a over the name, then its length */
     for (uint32_t i = 0; i < len; i++) h = (h ^ in[off + i]) * 0x100000001b3ull;
     h = (h ^ (0x100u + len)) * 0x100000001b3ull;
     return h ^ (h >> 29);
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_gather_u64(const uint64_t *src, co
 }
 
 /* entry e (visiting order) -> record, side, clamped range, sequence name hash, sequence length */
-__global__ __launch_bounds__(PAFFY_NT) void k_cov_entry_init(CovParams P, const uint32_t *order, uint32_t sides, uint64_t *name_hash, int64_t *seq_len) {
+__global__ __launch_bounds__(PAFFY_NT) void k_cov_entry_init(CovParams P, const uint32_t *order, uint32_t sides, uint64_t *name_hash, int64_t *seq_len, uint32_t salt) {
     const uint32_t e = blockIdx.x * PAFFY_NT + threadIdx.x;
     if (e >= P.n_entries) return;
     const uint32_t rec = order ? order[e / sides] : e / sides;
@@ -706,8 +709,26 @@ __global__ __launch_bounds__(PAFFY_NT) void k_cov_entry_init(CovParams P, const 
     E.n_slices = hi > lo ? (uint32_t)(((hi - 1) >> COV_SLICE_SHIFT) - (lo >> COV_SLICE_SHIFT)) + 1u : 0u;
     P.entries[e] = E;
     const uint8_t *in = P.batch_in[m.pad1];
-    name_hash[e] = side ? cov_name_hash(in, m.tname_off, m.tname_len) : cov_name_hash(in, m.qname_off, m.qname_len);
+    name_hash[e] = side ? cov_name_hash(in, m.tname_off, m.tname_len, salt) : cov_name_hash(in, m.qname_off, m.qname_len, salt);
     seq_len[e] = S.len;
+}
+/* the name behind a hash: every entry against the first entry of its sequence, byte for byte; *collide != 0: two names share a hash */
+__device__ __forceinline__ bool cov_same_bytes(const uint8_t *a, uint32_t la, const uint8_t *b, uint32_t lb) {
+    if (la != lb) return false;
+    for (uint32_t i = 0; i < la; i++)
+        if (a[i] != b[i]) return false;
+    return true;
+}
+__global__ __launch_bounds__(PAFFY_NT) void k_cov_verify_names(CovParams P, const uint32_t *first_entry, uint32_t *collide) {
+    const uint32_t e = blockIdx.x * PAFFY_NT + threadIdx.x;
+    if (e >= P.n_entries) return;
+    const CovEntry &E = P.entries[e];
+    const uint32_t h = first_entry[E.contig];
+    if (h == e) return;
+    const CovEntry &H = P.entries[h];
+    const RecMeta &m = P.meta[E.rec], &mh = P.meta[H.rec];
+    const uint8_t *a = P.batch_in[m.pad1] + (E.side ? m.tname_off : m.qname_off), *b = P.batch_in[mh.pad1] + (H.side ? mh.tname_off : mh.qname_off);
+    if (!cov_same_bytes(a, E.side ? m.tname_len : m.qname_len, b, H.side ? mh.tname_len : mh.qname_len)) atomicOr(collide, 1u);
 }
 /* sorted name hashes -> sequence ids: flag[i] = first of its run */
 __global__ __launch_bounds__(PAFFY_NT) void k_cov_run_heads(const uint64_t *sorted, uint32_t n, uint32_t *flag) {

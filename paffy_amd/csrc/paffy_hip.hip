@@ -644,7 +644,12 @@ static int ensure(paffy_hip_ctx *c, DevBuf &b, size_t bytes) {
     b.p = nullptr;
     b.cap = 0;
     size_t want = bytes + bytes / 2 + 256; /* room to grow: a batch a little larger than the last must not cost a free and an allocation */
-    HIPCHK(c, hipMalloc(&b.p, want));
+    if (hipMalloc(&b.p, want) != hipSuccess) { /* no room for the slack: an input that fits HBM at its exact size must not fail here */
+        (void)hipGetLastError();
+        b.p = nullptr;
+        want = bytes;
+        HIPCHK(c, hipMalloc(&b.p, want));
+    }
     b.cap = want;
     return 0;
 }
@@ -726,6 +731,7 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
 
 static void cov_free(paffy_hip_ctx *c); /* coverage_host.h state */
 static void index_drop(paffy_hip_ctx *c, const void *d_in);
+static void index_drop_all(paffy_hip_ctx *c);
 static void chain_free(paffy_hip_ctx *c);
 
 void paffy_hip_destroy(paffy_hip_ctx *c) {
@@ -1121,6 +1127,7 @@ static int lines_plan(paffy_hip_ctx *c, CovState &S, uint64_t n) {
 int paffy_hip_tile_begin(paffy_hip_ctx *c) {
     if (!c) return PAFFY_E_ARG;
     c->planned = false;
+    index_drop_all(c); /* indexes kept by paffy_hip_query_names for batches that were never split */
     return cov_begin(c, 1);
 }
 int paffy_hip_tile_add(paffy_hip_ctx *c, const void *d_in, int64_t in_len) {
@@ -1170,6 +1177,7 @@ int paffy_hip_tile_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, paff
 int paffy_hip_chain_begin(paffy_hip_ctx *c) {
     if (!c) return PAFFY_E_ARG;
     c->planned = false;
+    index_drop_all(c); /* indexes kept by paffy_hip_query_names for batches that were never split */
     return cov_begin(c, 1);
 }
 int paffy_hip_chain_add(paffy_hip_ctx *c, const void *d_in, int64_t in_len) {
@@ -1242,14 +1250,18 @@ __global__ __launch_bounds__(PAFFY_NT) void k_run_lens(const uint32_t *sorted_id
 }
 /* weight of run c = (bytes in front of the next run) - (bytes in front of this one): no atomics on a handful of addresses */
 __global__ __launch_bounds__(PAFFY_NT) void k_run_heads_out(const uint64_t *sorted_hash, const uint32_t *flag, const uint32_t *scan, const uint64_t *byte_off, uint32_t n,
-                                                             uint64_t *out_hash, uint64_t *out_start) {
+                                                             uint64_t *out_hash, uint64_t *out_start, uint64_t *out_first) {
     const uint32_t i = blockIdx.x * PAFFY_NT + threadIdx.x;
     if (i >= n) return;
     if (flag[i]) {
         out_hash[scan[i] - 1u] = sorted_hash[i];
         out_start[scan[i] - 1u] = byte_off[i];
+        out_first[scan[i] - 1u] = i; /* lines in front of the run: run lengths are differences */
     }
-    if (i == n - 1) out_start[scan[i]] = byte_off[n];
+    if (i == n - 1) {
+        out_start[scan[i]] = byte_off[n];
+        out_first[scan[i]] = n;
+    }
 }
 __global__ __launch_bounds__(PAFFY_NT) void k_owner_keys(const uint64_t *hash, uint32_t n, const uint64_t *tab_hash, const uint32_t *tab_owner, uint32_t n_tab, uint32_t n_parts,
                                                           uint64_t *key) {
@@ -1271,11 +1283,10 @@ __global__ __launch_bounds__(PAFFY_NT) void k_gather_len(const uint64_t *sorted_
     if (i == 0) out[n] = 0;
 }
 /* where every part starts in the sorted order: first[p] = index of its first line, start[p] = its first byte (parts without lines keep -1) */
-__global__ __launch_bounds__(PAFFY_NT) void k_part_bounds(const uint64_t *sorted_key, const uint64_t *off, uint32_t n, int64_t *first, int64_t *start, int64_t *rec_index) {
+__global__ __launch_bounds__(PAFFY_NT) void k_part_bounds(const uint64_t *sorted_key, const uint64_t *off, uint32_t n, int64_t *first, int64_t *start) {
     const uint32_t i = blockIdx.x * PAFFY_NT + threadIdx.x;
     if (i >= n) return;
     const uint32_t p = (uint32_t)(sorted_key[i] >> 32);
-    rec_index[i] = (int64_t)(uint32_t)sorted_key[i];
     if (i == 0 || (uint32_t)(sorted_key[i - 1] >> 32) != p) {
         first[p] = i;
         start[p] = (int64_t)off[i];
@@ -1296,11 +1307,23 @@ __device__ __forceinline__ void copy_line(const uint8_t *src, uint64_t len, uint
     }
     if (add_nl && threadIdx.x == 0) dst[body] = '\n';
 }
+/* line blockIdx.x of the (part, input index) order. Without part_dst the parts follow each other in `out` and in rec_index; with it
+   part p's lines start at out + part_dst[p] and its record indices at rec_index + part_dst[n_parts + p] (the caller's send buffer, in
+   which the parts of several batches stand behind each other per destination). rec_base is added to every index. */
 __global__ __launch_bounds__(PAFFY_NT) void k_split_copy(const uint8_t *in, uint32_t in_len, const uint32_t *sep_pos, const uint32_t *nl_idx, const uint64_t *sorted_key,
-                                                          const uint64_t *off, uint8_t *out) {
-    const uint32_t r = (uint32_t)sorted_key[blockIdx.x];
+                                                          const uint64_t *off, uint8_t *out, const int64_t *part_first, const int64_t *part_start, const int64_t *part_dst,
+                                                          uint32_t n_parts, int64_t *rec_index, int64_t rec_base) {
+    const uint64_t key = sorted_key[blockIdx.x];
+    const uint32_t r = (uint32_t)key, p = (uint32_t)(key >> 32);
     const uint32_t start = r == 0 ? 0u : sep_pos[nl_idx[r - 1]] + 1u, end = sep_pos[nl_idx[r]];
-    copy_line(in + start, (uint64_t)(end - start) + 1u, out + off[blockIdx.x], end >= in_len);
+    uint64_t at = off[blockIdx.x];
+    int64_t slot = (int64_t)blockIdx.x;
+    if (part_dst) {
+        at = (uint64_t)part_dst[p] + (at - (uint64_t)part_start[p]);
+        slot = part_dst[n_parts + p] + ((int64_t)blockIdx.x - part_first[p]);
+    }
+    if (rec_index && threadIdx.x == 0) rec_index[slot] = (int64_t)r + rec_base;
+    copy_line(in + start, (uint64_t)(end - start) + 1u, out + at, end >= in_len);
 }
 __global__ __launch_bounds__(PAFFY_NT) void k_scatter_lines(const uint8_t *src, const int64_t *src_off, const int64_t *dst_off, uint8_t *dst) {
     const uint64_t k = blockIdx.x;
@@ -1354,7 +1377,11 @@ static int index_restore(paffy_hip_ctx *c, const void *d_in, int64_t in_len, uin
     return 1;
 }
 
-int64_t paffy_hip_query_names(paffy_hip_ctx *c, const void *d_in, int64_t in_len, int64_t cap, uint64_t *hashes, int64_t *weights) {
+static void index_drop_all(paffy_hip_ctx *c) {
+    while (!c->kept_index.empty()) index_drop(c, c->kept_index.back().in);
+    c->indexed_in = nullptr;
+}
+static int64_t query_names_impl(paffy_hip_ctx *c, const void *d_in, int64_t in_len, int64_t cap, uint64_t *hashes, int64_t *weights, int64_t *records) {
     if (!c || !hashes || !weights || cap < 0) return PAFFY_E_ARG;
     if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
     if (in_len == 0) return 0;
@@ -1384,29 +1411,33 @@ int64_t paffy_hip_query_names(paffy_hip_ctx *c, const void *d_in, int64_t in_len
     uint32_t n_names = 0;
     if (cov_fetch(c, &n_names, scan + (n - 1), sizeof(uint32_t))) return PAFFY_E_HIP;
     if ((int64_t)n_names > cap) return PAFFY_E_CAPACITY;
-    if (ensure(c, S.pairs, sizeof(uint64_t) * (size_t)n_names) || ensure(c, S.pairs2, sizeof(uint64_t) * ((size_t)n_names + 1)) || ensure(c, S.bm_words, sizeof(uint64_t) * ((size_t)n + 1)) ||
+    if (ensure(c, S.pairs, sizeof(uint64_t) * (size_t)n_names) || ensure(c, S.pairs2, sizeof(uint64_t) * 2 * ((size_t)n_names + 1)) || ensure(c, S.bm_words, sizeof(uint64_t) * ((size_t)n + 1)) ||
         ensure(c, S.bm_off, sizeof(uint64_t) * ((size_t)n + 2)))
         return PAFFY_E_HIP;
     uint64_t *slen = static_cast<uint64_t *>(S.bm_words.p), *soff = static_cast<uint64_t *>(S.bm_off.p);
     LAUNCH(c, "k_run_lens", k_run_lens, dim3(g), dim3(PAFFY_NT), 0, static_cast<const uint32_t *>(sidx), static_cast<const uint64_t *>(len), n, slen);
     if (cov_excl_scan64(c, S, slen, soff, n)) return PAFFY_E_HIP;
     LAUNCH(c, "k_run_heads_out", k_run_heads_out, dim3(g), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(sorted), static_cast<const uint32_t *>(flags), static_cast<const uint32_t *>(scan),
-           static_cast<const uint64_t *>(soff), n, static_cast<uint64_t *>(S.pairs.p), static_cast<uint64_t *>(S.pairs2.p));
-    std::vector<uint64_t> starts((size_t)n_names + 1);
+           static_cast<const uint64_t *>(soff), n, static_cast<uint64_t *>(S.pairs.p), static_cast<uint64_t *>(S.pairs2.p), static_cast<uint64_t *>(S.pairs2.p) + n_names + 1);
+    std::vector<uint64_t> starts(2 * ((size_t)n_names + 1));
     HIPCHK(c, hipMemcpyAsync(hashes, S.pairs.p, sizeof(uint64_t) * (size_t)n_names, hipMemcpyDeviceToHost, c->stream));
-    if (cov_fetch(c, starts.data(), S.pairs2.p, sizeof(uint64_t) * ((size_t)n_names + 1))) return PAFFY_E_HIP;
+    if (cov_fetch(c, starts.data(), S.pairs2.p, sizeof(uint64_t) * 2 * ((size_t)n_names + 1))) return PAFFY_E_HIP;
     for (uint32_t k = 0; k < n_names; k++) weights[k] = (int64_t)(starts[k + 1] - starts[k]);
+    if (records)
+        for (uint32_t k = 0; k < n_names; k++) records[k] = (int64_t)(starts[(size_t)n_names + 1 + k + 1] - starts[(size_t)n_names + 1 + k]);
     return (int64_t)n_names;
 }
 
-int paffy_hip_split_by_owner(paffy_hip_ctx *c, const void *d_in, int64_t in_len, int32_t n_parts, const uint64_t *table_hash, const uint32_t *table_owner, int64_t n_table,
-                             void *d_out, int64_t out_cap, int64_t *part_bytes, int64_t *part_records, void *d_rec_index, int64_t rec_index_cap, int64_t *n_records) {
+static int split_impl0(paffy_hip_ctx *c, const void *d_in, int64_t in_len, int32_t n_parts, const uint64_t *table_hash, const uint32_t *table_owner, int64_t n_table,
+                       void *d_out, int64_t out_cap, const int64_t *part_dst, const int64_t *rec_dst, int64_t rec_base, int64_t *part_bytes, int64_t *part_records,
+                       void *d_rec_index, int64_t rec_index_cap, int64_t *n_records) {
     if (!c || n_parts < 1 || n_table < 0 || (n_table > 0 && (!table_hash || !table_owner)) || !part_bytes || !part_records || !n_records) return PAFFY_E_ARG;
     if (in_len < 0 || in_len >= (1ll << 31) - 64 || (in_len > 0 && !d_in) || (reinterpret_cast<uintptr_t>(d_in) & 15)) return PAFFY_E_ARG;
+    if ((part_dst != nullptr) != (rec_dst != nullptr)) return PAFFY_E_ARG;
     for (int32_t p = 0; p < n_parts; p++) part_bytes[p] = part_records[p] = 0;
     *n_records = 0;
     if (in_len == 0) return 0;
-    if (!d_out || out_cap < in_len + 1) return PAFFY_E_CAPACITY;
+    if (!d_out || (!part_dst && out_cap < in_len + 1)) return PAFFY_E_CAPACITY;
     CovState &S = cov_state(c);
     uint32_t n = 0;
     const uint8_t *in = static_cast<const uint8_t *>(d_in);
@@ -1420,11 +1451,11 @@ int paffy_hip_split_by_owner(paffy_hip_ctx *c, const void *d_in, int64_t in_len,
     c->indexed_in = nullptr;
     *n_records = n;
     if (n == 0) return 0;
-    if (d_rec_index && rec_index_cap < (int64_t)n) return PAFFY_E_CAPACITY;
+    if (d_rec_index && !part_dst && rec_index_cap < (int64_t)n) return PAFFY_E_CAPACITY;
     const uint32_t g = (n + PAFFY_NT - 1) / PAFFY_NT;
     if (ensure(c, S.k64a, sizeof(uint64_t) * ((size_t)n + 1)) || ensure(c, S.k64b, sizeof(uint64_t) * ((size_t)n + 1)) || ensure(c, S.name_hash, sizeof(uint64_t) * ((size_t)n + 1)) ||
         ensure(c, S.v32a, sizeof(uint32_t) * ((size_t)n + 1)) || ensure(c, S.bm_words, sizeof(uint64_t) * ((size_t)n + 1)) || ensure(c, S.bm_off, sizeof(uint64_t) * ((size_t)n + 2)) ||
-        ensure(c, S.pairs, (sizeof(uint64_t) + sizeof(uint32_t)) * ((size_t)n_table + 1)) || ensure(c, S.pairs2, sizeof(int64_t) * 2 * (size_t)n_parts))
+        ensure(c, S.pairs, (sizeof(uint64_t) + sizeof(uint32_t)) * ((size_t)n_table + 1)) || ensure(c, S.pairs2, sizeof(int64_t) * 4 * (size_t)n_parts))
         return PAFFY_E_HIP;
     uint64_t *hash = static_cast<uint64_t *>(S.name_hash.p), *len = static_cast<uint64_t *>(S.k64b.p), *key = static_cast<uint64_t *>(S.k64a.p), *skey = static_cast<uint64_t *>(S.bm_words.p);
     uint64_t *off = static_cast<uint64_t *>(S.bm_off.p);
@@ -1443,11 +1474,8 @@ int paffy_hip_split_by_owner(paffy_hip_ctx *c, const void *d_in, int64_t in_len,
     if (cov_excl_scan64(c, S, key, off, n)) return PAFFY_E_HIP;
     int64_t *d_tot = static_cast<int64_t *>(S.pairs2.p);
     HIPCHK(c, hipMemsetAsync(d_tot, 0xff, sizeof(int64_t) * 2 * (size_t)n_parts, c->stream));
-    if (ensure(c, S.out_len, sizeof(int64_t) * ((size_t)n + 1))) return PAFFY_E_HIP;
-    int64_t *d_idx = d_rec_index ? static_cast<int64_t *>(d_rec_index) : static_cast<int64_t *>(S.out_len.p);
-    LAUNCH(c, "k_part_bounds", k_part_bounds, dim3(g), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(skey), static_cast<const uint64_t *>(off), n, d_tot, d_tot + n_parts, d_idx);
-    LAUNCH(c, "k_split_copy", k_split_copy, dim3(n), dim3(PAFFY_NT), 0, in, (uint32_t)in_len, static_cast<const uint32_t *>(c->sep_pos.p), static_cast<const uint32_t *>(c->nl_idx.p),
-           static_cast<const uint64_t *>(skey), static_cast<const uint64_t *>(off), static_cast<uint8_t *>(d_out));
+    LAUNCH(c, "k_part_bounds", k_part_bounds, dim3(g), dim3(PAFFY_NT), 0, static_cast<const uint64_t *>(skey), static_cast<const uint64_t *>(off), n, d_tot, d_tot + n_parts);
+    /* the sizes of the parts first: a caller's destinations are checked against them before a byte is written */
     std::vector<int64_t> tot(2 * (size_t)n_parts);
     uint64_t all_bytes = 0;
     HIPCHK(c, hipMemcpyAsync(&all_bytes, off + n, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
@@ -1460,6 +1488,67 @@ int paffy_hip_split_by_owner(paffy_hip_ctx *c, const void *d_in, int64_t in_len,
         part_bytes[p] = next_start - start;
         next_first = first;
         next_start = start;
+    }
+    const int64_t *d_dst = nullptr;
+    if (part_dst) {
+        std::vector<int64_t> dst(2 * (size_t)n_parts);
+        for (int32_t p = 0; p < n_parts; p++) {
+            if (part_dst[p] < 0 || rec_dst[p] < 0 || part_dst[p] + part_bytes[p] > out_cap || (d_rec_index && rec_dst[p] + part_records[p] > rec_index_cap)) {
+                for (int32_t q = 0; q < n_parts; q++) part_bytes[q] = part_records[q] = 0;
+                return PAFFY_E_CAPACITY;
+            }
+            dst[(size_t)p] = part_dst[p];
+            dst[(size_t)n_parts + p] = rec_dst[p];
+        }
+        HIPCHK(c, hipMemcpyAsync(d_tot + 2 * n_parts, dst.data(), sizeof(int64_t) * 2 * (size_t)n_parts, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream)); /* `dst` is a local */
+        d_dst = d_tot + 2 * n_parts;
+    }
+    LAUNCH(c, "k_split_copy", k_split_copy, dim3(n), dim3(PAFFY_NT), 0, in, (uint32_t)in_len, static_cast<const uint32_t *>(c->sep_pos.p), static_cast<const uint32_t *>(c->nl_idx.p),
+           static_cast<const uint64_t *>(skey), static_cast<const uint64_t *>(off), static_cast<uint8_t *>(d_out), static_cast<const int64_t *>(d_tot),
+           static_cast<const int64_t *>(d_tot + n_parts), d_dst, (uint32_t)n_parts, static_cast<int64_t *>(d_rec_index), rec_base);
+    return 0;
+}
+
+/* A failing call leaves no kept index behind: whatever the caller does next starts from the text. */
+int64_t paffy_hip_query_names(paffy_hip_ctx *c, const void *d_in, int64_t in_len, int64_t cap, uint64_t *hashes, int64_t *weights) {
+    const int64_t n = query_names_impl(c, d_in, in_len, cap, hashes, weights, nullptr);
+    if (n < 0 && c) index_drop_all(c);
+    return n;
+}
+int64_t paffy_hip_query_names_counts(paffy_hip_ctx *c, const void *d_in, int64_t in_len, int64_t cap, uint64_t *hashes, int64_t *weights, int64_t *records) {
+    if (!records) return PAFFY_E_ARG;
+    const int64_t n = query_names_impl(c, d_in, in_len, cap, hashes, weights, records);
+    if (n < 0 && c) index_drop_all(c);
+    return n;
+}
+static int split_impl(paffy_hip_ctx *c, const void *d_in, int64_t in_len, int32_t n_parts, const uint64_t *table_hash, const uint32_t *table_owner, int64_t n_table,
+                      void *d_out, int64_t out_cap, const int64_t *part_dst, const int64_t *rec_dst, int64_t rec_base, int64_t *part_bytes, int64_t *part_records,
+                      void *d_rec_index, int64_t rec_index_cap, int64_t *n_records) {
+    const int rc = split_impl0(c, d_in, in_len, n_parts, table_hash, table_owner, n_table, d_out, out_cap, part_dst, rec_dst, rec_base, part_bytes, part_records, d_rec_index,
+                               rec_index_cap, n_records);
+    if (rc && c) index_drop_all(c);
+    return rc;
+}
+int paffy_hip_split_by_owner(paffy_hip_ctx *c, const void *d_in, int64_t in_len, int32_t n_parts, const uint64_t *table_hash, const uint32_t *table_owner, int64_t n_table,
+                             void *d_out, int64_t out_cap, int64_t *part_bytes, int64_t *part_records, void *d_rec_index, int64_t rec_index_cap, int64_t *n_records) {
+    return split_impl(c, d_in, in_len, n_parts, table_hash, table_owner, n_table, d_out, out_cap, nullptr, nullptr, 0, part_bytes, part_records, d_rec_index, rec_index_cap,
+                      n_records);
+}
+int paffy_hip_split_to(paffy_hip_ctx *c, const void *d_in, int64_t in_len, int32_t n_parts, const uint64_t *table_hash, const uint32_t *table_owner, int64_t n_table,
+                       void *d_out, int64_t out_cap, const int64_t *part_dst, const int64_t *rec_dst, int64_t rec_base, int64_t *part_bytes, int64_t *part_records,
+                       void *d_rec_index, int64_t rec_index_cap, int64_t *n_records) {
+    if (!part_dst || !rec_dst) return PAFFY_E_ARG;
+    return split_impl(c, d_in, in_len, n_parts, table_hash, table_owner, n_table, d_out, out_cap, part_dst, rec_dst, rec_base, part_bytes, part_records, d_rec_index,
+                      rec_index_cap, n_records);
+}
+int paffy_hip_drop_index(paffy_hip_ctx *c, const void *d_in) {
+    if (!c) return PAFFY_E_ARG;
+    if (d_in) {
+        index_drop(c, d_in);
+        if (c->indexed_in == d_in) c->indexed_in = nullptr;
+    } else {
+        index_drop_all(c);
     }
     return 0;
 }
@@ -1728,10 +1817,11 @@ struct paffy_hip_stream {
     StreamSlot slot[2];
     int fill = 0, drain = 0; /* slot the next chunk goes to, slot being read */
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
-    char *piece[2] = {nullptr, nullptr};
+    /* three output pieces: the one handed out, the one handed out before it (still the caller's until the next read) and the one in flight */
+    char *piece[3] = {nullptr, nullptr, nullptr};
     size_t piece_cap = 0;
-    hipEvent_t ev_piece[2] = {nullptr, nullptr};
-    int64_t piece_len[2] = {0, 0};
+    hipEvent_t ev_piece[3] = {nullptr, nullptr, nullptr};
+    int64_t piece_len[3] = {0, 0, 0};
     int64_t issued_at = 0; /* bytes of the draining chunk whose copy has been issued */
     int n_issued = 0, n_returned = 0;
 };
@@ -1748,9 +1838,10 @@ int paffy_hip_stream_open(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n
         StreamSlot &sl = s->slot[k];
         sl.h_cap = (size_t)chunk_bytes;
         ok = hipHostMalloc(reinterpret_cast<void **>(&sl.h_in), sl.h_cap + 64) == hipSuccess && hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&sl.ev_emit, hipEventDisableTiming) == hipSuccess &&
-             hipHostMalloc(reinterpret_cast<void **>(&s->piece[k]), (size_t)piece_bytes) == hipSuccess && hipEventCreateWithFlags(&s->ev_piece[k], hipEventDisableTiming) == hipSuccess;
+             hipEventCreateWithFlags(&sl.ev_emit, hipEventDisableTiming) == hipSuccess;
     }
+    for (int k = 0; k < 3 && ok; k++)
+        ok = hipHostMalloc(reinterpret_cast<void **>(&s->piece[k]), (size_t)piece_bytes) == hipSuccess && hipEventCreateWithFlags(&s->ev_piece[k], hipEventDisableTiming) == hipSuccess;
     s->piece_cap = (size_t)piece_bytes;
     if (!ok) {
         c->last_error = "paffy_hip_stream_open: pinned buffers / streams";
@@ -1771,6 +1862,8 @@ void paffy_hip_stream_close(paffy_hip_stream *s) {
         if (sl.d_out) (void)hipFree(sl.d_out);
         if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
         if (sl.ev_emit) (void)hipEventDestroy(sl.ev_emit);
+    }
+    for (int k = 0; k < 3; k++) {
         if (s->piece[k]) (void)hipHostFree(s->piece[k]);
         if (s->ev_piece[k]) (void)hipEventDestroy(s->ev_piece[k]);
     }
@@ -1834,8 +1927,9 @@ int paffy_hip_stream_submit(paffy_hip_stream *s, int64_t in_len, paffy_plan_info
     return 0;
 }
 
-/* the next piece of the oldest submitted chunk's output: *len bytes at *piece, valid until the call after next; *len = 0: that chunk
-   has been read completely (or nothing was submitted) */
+/* the next piece of the oldest submitted chunk's output: *len bytes at *piece, valid until the call after next (three pinned pieces
+   rotate: this call starts the copy that follows the piece it hands out, into the buffer handed out two calls ago); *len = 0: that
+   chunk has been read completely (or nothing was submitted) */
 int paffy_hip_stream_read(paffy_hip_stream *s, const char **piece, int64_t *len) {
     if (!s || !piece || !len) return PAFFY_E_ARG;
     paffy_hip_ctx *c = s->c;
@@ -1846,7 +1940,7 @@ int paffy_hip_stream_read(paffy_hip_stream *s, const char **piece, int64_t *len)
     if (s->n_issued == 0) HIPCHK(c, hipStreamWaitEvent(s->s_d2h, sl.ev_emit, 0)); /* first piece of this chunk */
     /* keep two copies in flight: the piece handed out now and the one after it */
     while (s->n_issued < s->n_returned + 2 && s->issued_at < sl.out_len) {
-        const int k = s->n_issued & 1;
+        const int k = s->n_issued % 3;
         const int64_t n = sl.out_len - s->issued_at < (int64_t)s->piece_cap ? sl.out_len - s->issued_at : (int64_t)s->piece_cap;
         HIPCHK(c, hipMemcpyAsync(s->piece[k], static_cast<char *>(sl.d_out) + s->issued_at, (size_t)n, hipMemcpyDeviceToHost, s->s_d2h));
         HIPCHK(c, hipEventRecord(s->ev_piece[k], s->s_d2h));
@@ -1861,7 +1955,7 @@ int paffy_hip_stream_read(paffy_hip_stream *s, const char **piece, int64_t *len)
         s->n_issued = s->n_returned = 0;
         return 0;
     }
-    const int k = s->n_returned & 1;
+    const int k = s->n_returned % 3;
     HIPCHK(c, hipEventSynchronize(s->ev_piece[k]));
     *piece = s->piece[k];
     *len = s->piece_len[k];
@@ -1891,6 +1985,7 @@ static int scan64(paffy_hip_ctx *c, const int64_t *in, uint64_t n, int64_t *out,
 int paffy_hip_bed_begin(paffy_hip_ctx *c, const paffy_bed_opts *opts) {
     if (!c || !opts) return PAFFY_E_ARG;
     c->planned = false;
+    index_drop_all(c);
     return cov_begin(c, opts->include_inverted ? 2 : 1);
 }
 int paffy_hip_bed_add(paffy_hip_ctx *c, const void *d_in, int64_t in_len) {

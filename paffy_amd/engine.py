@@ -113,8 +113,13 @@ def lib():
         L.paffy_hip_bed_run.argtypes = [vp, C.POINTER(BedOpts), C.POINTER(PlanInfo)]
         L.paffy_hip_query_names.restype = i64
         L.paffy_hip_query_names.argtypes = [vp, vp, i64, i64, C.POINTER(C.c_uint64), C.POINTER(i64)]
+        L.paffy_hip_query_names_counts.restype = i64
+        L.paffy_hip_query_names_counts.argtypes = [vp, vp, i64, i64, C.POINTER(C.c_uint64), C.POINTER(i64), C.POINTER(i64)]
         L.paffy_hip_split_by_owner.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), i64, vp, i64, C.POINTER(i64), C.POINTER(i64), vp, i64,
                                                C.POINTER(i64)]
+        L.paffy_hip_split_to.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), i64, vp, i64, C.POINTER(i64), C.POINTER(i64), i64, C.POINTER(i64),
+                                         C.POINTER(i64), vp, i64, C.POINTER(i64)]
+        L.paffy_hip_drop_index.argtypes = [vp, vp]
         L.paffy_hip_scatter_lines.argtypes = [vp, vp, vp, vp, i64, vp]
         L.paffy_hip_stream_open.argtypes = [vp, C.POINTER(Stage), i32, i64, i64, C.POINTER(vp)]
         L.paffy_hip_stream_input.restype = vp
@@ -240,6 +245,23 @@ class Engine:
             raise RuntimeError(f"paffy_hip_query_names failed ({n}): {lib().paffy_hip_last_error(self._ctx).decode()}")
         return {int(h[i]): int(w[i]) for i in range(n)}
 
+    def query_names_counts(self, d_in, in_len, cap=1 << 20):
+        """Distinct query names of a device batch as {hash: (bytes of its lines, number of its lines)}."""
+        cap0 = 4096  # the usual input has a few dozen sequences; the host arrays are kept and grown on demand
+        while True:
+            arrs = getattr(self, "_name_arrays", None)
+            if arrs is None or len(arrs[0]) < cap0:
+                arrs = self._name_arrays = ((C.c_uint64 * cap0)(), (C.c_int64 * cap0)(), (C.c_int64 * cap0)())
+            h, w, r = arrs
+            n = lib().paffy_hip_query_names_counts(self._ctx, C.c_void_p(d_in.data_ptr()), in_len, len(h), h, w, r)
+            if n == -4 and len(h) < cap:  # PAFFY_E_CAPACITY: more names than the arrays hold
+                cap0 = min(cap, len(h) * 16)
+                continue
+            break
+        if n < 0:
+            raise RuntimeError(f"paffy_hip_query_names_counts failed ({n}): {lib().paffy_hip_last_error(self._ctx).decode()}")
+        return {int(h[i]): (int(w[i]), int(r[i])) for i in range(n)}
+
     def split_by_owner(self, d_in, in_len, n_parts, owner_of):
         """Lines of a device batch regrouped by owner_of[hash of the query name] (input order inside a part). Returns (uint8 tensor,
         bytes per part, records per part, int64 tensor: batch index of every output line)."""
@@ -254,6 +276,26 @@ class Engine:
         self._check(lib().paffy_hip_split_by_owner(self._ctx, C.c_void_p(d_in.data_ptr()), in_len, n_parts, th, to, nt, C.c_void_p(out.data_ptr()), out.numel(), pb, pr,
                                                    C.c_void_p(idx.data_ptr()), idx.numel(), C.byref(nrec)), "paffy_hip_split_by_owner")
         return out, list(pb), list(pr), idx[: nrec.value]
+
+    def owner_arrays(self, owner_of):
+        """{name hash: part} as the two ctypes arrays the split calls take (ascending hashes), built once per partition."""
+        items = sorted(owner_of.items())
+        nt = len(items)
+        return (C.c_uint64 * max(1, nt))(*[k for k, _ in items]), (C.c_uint32 * max(1, nt))(*[v for _, v in items]), nt
+
+    def split_to(self, d_in, in_len, n_parts, owner_arrays, d_out, part_dst, d_rec_index, rec_dst, rec_base):
+        """split_by_owner straight into a send buffer: part p's lines go to d_out[part_dst[p]:], the global index (batch index +
+        rec_base) of every one of them to d_rec_index[rec_dst[p]:]. Returns (bytes per part, records per part, records of the batch)."""
+        th, to, nt = owner_arrays
+        pb, pr, nrec = (C.c_int64 * n_parts)(), (C.c_int64 * n_parts)(), C.c_int64()
+        pd, rd = (C.c_int64 * n_parts)(*part_dst), (C.c_int64 * n_parts)(*rec_dst)
+        self._check(lib().paffy_hip_split_to(self._ctx, C.c_void_p(d_in.data_ptr()), in_len, n_parts, th, to, nt, C.c_void_p(d_out.data_ptr()), d_out.numel(), pd, rd, rec_base,
+                                             pb, pr, C.c_void_p(d_rec_index.data_ptr()), d_rec_index.numel(), C.byref(nrec)), "paffy_hip_split_to")
+        return list(pb), list(pr), nrec.value
+
+    def drop_index(self, d_in=None):
+        """Forget the line index query_names kept for a batch that will not be split (None: for every batch)."""
+        lib().paffy_hip_drop_index(self._ctx, C.c_void_p(d_in.data_ptr()) if d_in is not None else None)
 
     def scatter_lines(self, d_src, src_off, dst_off, d_dst):
         """Line k = d_src[src_off[k] : src_off[k + 1]] to d_dst[dst_off[k]:] (int64 device tensors)."""

@@ -57,8 +57,13 @@ def gather_to_writer(dist, rank, world, local, sizes_by_batch, write, device="cp
 
     n_batches = len(sizes_by_batch)
     owner = [b % world for b in range(n_batches)]  # = batches_of_rank's round robin
+    # No tags: the nccl backend ignores them. A send is matched with a receive by ORDER per peer alone -- every sender posts its batches
+    # in ascending batch order and the writer posts its receives in ascending batch order, so the k-th send of rank r meets the k-th
+    # receive from rank r on any backend.
     if rank != writer:
-        reqs = [dist.isend(local[b].contiguous(), dst=writer, tag=b) for b in range(n_batches) if owner[b] == rank and sizes_by_batch[b] > 0]
+        mine = [b for b in range(n_batches) if owner[b] == rank and sizes_by_batch[b] > 0]
+        assert mine == sorted(mine)
+        reqs = [dist.isend(local[b].contiguous(), dst=writer) for b in mine]
         for r in reqs:
             r.wait()
         return
@@ -67,7 +72,7 @@ def gather_to_writer(dist, rank, world, local, sizes_by_batch, write, device="cp
     def post(b):
         if b < n_batches and owner[b] != writer and sizes_by_batch[b] > 0:
             buf = torch.empty(sizes_by_batch[b], dtype=torch.uint8, device=device)
-            pending[b] = (dist.irecv(buf, src=owner[b], tag=b), buf)
+            pending[b] = (dist.irecv(buf, src=owner[b]), buf)  # post() is called with ascending b: ascending per peer too
 
     for b in range(min(ahead, n_batches)):
         post(b)
@@ -154,6 +159,37 @@ def owner_table(weights, world):
     return contig_partition(weights, world)
 
 
+EXCHANGE_CHUNK = 256 << 20  # bytes per send / receive operation
+
+
+def _pairwise_exchange(dist, rank, world, src, send_counts, dst, recv_counts, chunk):
+    """dst <- what every rank holds for this rank in src (both flat, grouped by peer, counts in elements): the all-to-all as explicit
+    sends and receives per peer in pieces of at most `chunk` elements, the rank's own part as a plain copy. Over the nccl backend
+    these are RCCL send / recv pairs -- point-to-point over xGMI, which is what the fabric is. Why not all_to_all_single: one call
+    with several GB per peer came back without its bytes (tools/probes/rccl_a2a_sizes.py: wrong from 768 MiB on at world size 1)."""
+    so, ro = [0], [0]
+    for r in range(world):
+        so.append(so[-1] + int(send_counts[r]))
+        ro.append(ro[-1] + int(recv_counts[r]))
+    if send_counts[rank]:
+        dst[ro[rank]: ro[rank + 1]].copy_(src[so[rank]: so[rank + 1]])
+    rounds = max([0] + [(int(c) + chunk - 1) // chunk for r, c in enumerate(send_counts) if r != rank] +
+                 [(int(c) + chunk - 1) // chunk for r, c in enumerate(recv_counts) if r != rank])
+    for k in range(rounds):
+        ops = []
+        for step in range(1, world):  # peer order: everyone sends "to the right by step", receives "from the left by step"
+            to, frm = (rank + step) % world, (rank - step) % world
+            a, b = so[to] + k * chunk, min(so[to] + (k + 1) * chunk, so[to + 1])
+            if a < b:
+                ops.append(dist.P2POp(dist.isend, src[a:b], to))
+            a, b = ro[frm] + k * chunk, min(ro[frm] + (k + 1) * chunk, ro[frm + 1])
+            if a < b:
+                ops.append(dist.P2POp(dist.irecv, dst[a:b], frm))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+
 def exchange_lines(dist, send_buf, send_bytes, send_gidx, send_records, comm_device="cpu"):
     """The all-to-all of the partition. send_buf: uint8 tensor whose first sum(send_bytes) bytes are the lines grouped by destination
     rank; send_gidx: int64 tensor, the global input index of every line in the same order; send_bytes / send_records: per destination.
@@ -165,17 +201,21 @@ def exchange_lines(dist, send_buf, send_bytes, send_gidx, send_records, comm_dev
     if dist is None:
         n = int(send_bytes[0])
         return send_buf[:n], send_gidx[: int(send_records[0])], [n], [int(send_records[0])]
+    rank = dist.get_rank()
     sizes = torch.tensor([list(send_bytes), list(send_records)], dtype=torch.int64, device=comm_device).t().contiguous()  # [world, 2]
     got = torch.zeros_like(sizes)
-    dist.all_to_all_single(got, sizes)
+    dist.all_to_all_single(got, sizes)  # 16 bytes per peer
     recv_bytes, recv_records = [int(x) for x in got[:, 0].tolist()], [int(x) for x in got[:, 1].tolist()]
     src = _comm(send_buf[: sum(send_bytes)], comm_device)
-    recv_buf = torch.empty(sum(recv_bytes), dtype=torch.uint8, device=comm_device)
-    dist.all_to_all_single(recv_buf, src, recv_bytes, list(send_bytes))
+    recv_buf = torch.empty((sum(recv_bytes) + 15) // 16 * 16 + 16, dtype=torch.uint8, device=comm_device)
+    _pairwise_exchange(dist, rank, world, src, list(send_bytes), recv_buf, recv_bytes, EXCHANGE_CHUNK)
     gsrc = _comm(send_gidx[: sum(send_records)], comm_device)
     recv_gidx = torch.empty(sum(recv_records), dtype=torch.int64, device=comm_device)
-    dist.all_to_all_single(recv_gidx, gsrc, recv_records, list(send_records))
-    return recv_buf, recv_gidx, recv_bytes, recv_records
+    _pairwise_exchange(dist, rank, world, gsrc, list(send_records), recv_gidx, recv_records, EXCHANGE_CHUNK // 8)
+    return recv_buf[: sum(recv_bytes)], recv_gidx, recv_bytes, recv_records
+
+
+KEY_ROWS_PER_GATHER = 1 << 22  # 128 MiB of keys per rank and collective
 
 
 def gather_tile_keys(dist, keys, comm_device="cpu"):
@@ -190,14 +230,24 @@ def gather_tile_keys(dist, keys, comm_device="cpu"):
     n = torch.tensor([keys.shape[0]], dtype=torch.int64, device=comm_device)
     counts = torch.zeros(world, dtype=torch.int64, device=comm_device)
     dist.all_gather_into_tensor(counts, n)
-    cap = max(1, int(counts.max().item()))
-    mine = torch.zeros(cap, 4, dtype=torch.int64, device=comm_device)
-    mine[: keys.shape[0]] = keys
-    everyone = torch.zeros(world * cap, 4, dtype=torch.int64, device=comm_device)
-    dist.all_gather_into_tensor(everyone, mine)
-    everyone = everyone.reshape(world, cap, 4)
-    rows = [everyone[r, : int(counts[r].item())] for r in range(world)]
-    owner = [torch.full((int(counts[r].item()),), r, dtype=torch.int64, device=comm_device) for r in range(world)]
+    counts = [int(x) for x in counts.tolist()]
+    cap = max(1, max(counts))
+    rows = [torch.empty(counts[r], 4, dtype=torch.int64, device=comm_device) for r in range(world)]
+    step = KEY_ROWS_PER_GATHER  # rows of every rank per collective: bounded pieces instead of one multi-GB all-gather
+    mine = torch.zeros(min(cap, step), 4, dtype=torch.int64, device=comm_device)
+    everyone = torch.zeros(world * mine.shape[0], 4, dtype=torch.int64, device=comm_device)
+    for lo in range(0, cap, step):
+        k = min(step, cap - lo)
+        have = max(0, min(keys.shape[0] - lo, k))
+        if have:
+            mine[:have] = keys[lo: lo + have]
+        dist.all_gather_into_tensor(everyone[: world * k], mine[:k])
+        got = everyone[: world * k].reshape(world, k, 4)
+        for r in range(world):
+            m = max(0, min(counts[r] - lo, k))
+            if m:
+                rows[r][lo: lo + m] = got[r, :m]
+    owner = [torch.full((counts[r],), r, dtype=torch.int64, device=comm_device) for r in range(world)]
     return torch.cat(rows), torch.cat(owner)
 
 
@@ -244,9 +294,16 @@ def line_cuts(buf, max_bytes):
                 if hits.numel():
                     end = lo2 + int(hits[-1].item()) + 1
                     break
-                if lo2 == at:  # one line longer than max_bytes: take it whole
-                    fwd = (buf[end:] == 10).nonzero()
-                    end = end + int(fwd[0].item()) + 1 if fwd.numel() else n
+                if lo2 == at:  # one line longer than max_bytes: take it whole (forward through windows of 1 MiB, never a whole-buffer scan)
+                    hi = end
+                    while hi < n:
+                        hi2 = min(n, hi + (1 << 20))
+                        fwd = (buf[hi:hi2] == 10).nonzero()
+                        if fwd.numel():
+                            hi = hi + int(fwd[0].item()) + 1
+                            break
+                        hi = hi2
+                    end = hi
                     break
                 lo = lo2
         cuts.append((at, end))
@@ -255,49 +312,96 @@ def line_cuts(buf, max_bytes):
 
 
 class GpuTileWorker:
-    """The device side of a rank in tile_sharded(): everything through the C-ABI of libpaffy_hip (paffy_amd.Engine)."""
+    """The device side of a rank in tile_sharded(): everything through the C-ABI of libpaffy_hip (paffy_amd.Engine).
+
+    Memory: a rank never holds its share of the text more than twice. split() writes every batch's lines straight into ONE send
+    buffer (paffy_hip_split_to: no per-batch regrouped copy, no concatenation) and, when the caller hands its batches over
+    (`consume`), lets go of each batch as soon as it has been split; after the exchange the send buffer is dropped before tile() cuts
+    what was received into 16-byte aligned batches of at most batch_bytes, and the receive buffer is dropped once they are cut."""
 
     def __init__(self, eng, batch_bytes=(1 << 30) + (1 << 29)):
         self.eng, self.batch_bytes, self.keep = eng, batch_bytes, []
 
     def query_names(self, batches):
-        out = {}
+        """-> ({name hash: bytes of its lines} over all batches, [per batch: {name hash: (bytes, lines)}])"""
+        out, per_batch = {}, []
         for buf, nbytes in batches:
-            for h, w in self.eng.query_names(buf, nbytes).items():
+            names = self.eng.query_names_counts(buf, nbytes)
+            per_batch.append(names)
+            for h, (w, _) in names.items():
                 out[h] = out.get(h, 0) + w
-        self._last_named = batches[-1][0].data_ptr() if batches else None
-        return out
+        return out, per_batch
 
-    def split(self, batches, owner_of, world, first_record):
-        """-> (send buffer grouped by destination, bytes per destination, global input index of every line, records per destination)"""
+    def split(self, batches, owner_of, world, first_record, per_batch_names=None, consume=False):
+        """-> (send buffer grouped by destination, bytes per destination, global input index of every line, records per destination).
+        per_batch_names: what query_names returned for the same batches: the bytes and lines every batch sends to every destination
+        are known beforehand, so the send buffer and the index array are allocated once at their exact size and every batch's lines go
+        straight to their place (paffy_hip_split_to). consume: `batches` is emptied batch by batch -- the caller's last reference gone,
+        a batch is freed as soon as it has been split."""
         t = self.eng.torch
-        pieces, idx = [[] for _ in range(world)], [[] for _ in range(world)]
-        nbytes, nrec, base = [0] * world, [0] * world, first_record
-        for buf, n in batches:
-            out, pb, pr, ridx = self.eng.split_by_owner(buf, n, world, owner_of)
-            b0 = r0 = 0
+        dev = self.eng.device
+        if per_batch_names is None:
+            per_batch_names = [self.eng.query_names_counts(buf, nbytes) for buf, nbytes in batches]
+        n_batches = len(batches)
+        need_b = [[0] * world for _ in range(n_batches)]  # bytes / lines of batch b for destination d
+        need_r = [[0] * world for _ in range(n_batches)]
+        for b, names in enumerate(per_batch_names):
+            for h, (w, r) in names.items():
+                d = owner_of.get(h)
+                d = min(h % world if d is None else d, world - 1)
+                need_b[b][d] += w
+                need_r[b][d] += r
+        dest_bytes = [sum(need_b[b][d] for b in range(n_batches)) for d in range(world)]
+        dest_recs = [sum(need_r[b][d] for b in range(n_batches)) for d in range(world)]
+        total, total_r = sum(dest_bytes), sum(dest_recs)
+        send = t.empty((total + 15) // 16 * 16 + 16, dtype=t.uint8, device=dev)
+        gidx = t.empty(max(1, total_r), dtype=t.int64, device=dev)
+        at_b, at_r = [0] * world, [0] * world
+        for d in range(1, world):
+            at_b[d] = at_b[d - 1] + dest_bytes[d - 1]
+            at_r[d] = at_r[d - 1] + dest_recs[d - 1]
+        arrays = self.eng.owner_arrays(owner_of)
+        base = first_record
+        for b in range(n_batches):
+            buf, n = batches[0] if consume else batches[b]
+            pb, pr, nrec = self.eng.split_to(buf, n, world, arrays, send, at_b, gidx, at_r, base)
+            if pb != need_b[b] or pr != need_r[b]:
+                raise RuntimeError("split: a batch changed between query_names and split (bytes / lines per destination differ)")
             for d in range(world):
-                pieces[d].append(out[b0: b0 + pb[d]])
-                idx[d].append(ridx[r0: r0 + pr[d]] + base)
-                b0, r0 = b0 + pb[d], r0 + pr[d]
-                nbytes[d] += pb[d]
-                nrec[d] += pr[d]
-            base += int(ridx.numel())
-        flat = [p for d in range(world) for p in pieces[d]]
-        flat_i = [p for d in range(world) for p in idx[d]]
-        send = t.cat(flat) if flat else t.empty(0, dtype=t.uint8, device=self.eng.device)
-        gidx = t.cat(flat_i) if flat_i else t.empty(0, dtype=t.int64, device=self.eng.device)
-        return send, nbytes, gidx, nrec
+                at_b[d] += pb[d]
+                at_r[d] += pr[d]
+            base += nrec
+            if consume:
+                self.eng.sync()  # the copy kernel reads the batch
+                del buf
+                batches.pop(0)
+        return send[:total], dest_bytes, gidx[:total_r], dest_recs
 
     def tile(self, recv_buf):
-        """paffy tile over the lines this rank owns -> int64 [n, 5] per output line: chain_score, score, local record, bytes, level"""
+        """paffy tile over the lines this rank owns -> int64 [n, 5] per output line: chain_score, score, local record, bytes, level.
+        recv_buf is cut into 16-byte aligned batches; the caller should drop its reference to recv_buf before the call returns
+        control to code that allocates (tile_sharded passes a one-element list that is emptied here)."""
         t = self.eng.torch
-        recv = recv_buf.to(self.eng.device)
+        holder = recv_buf if isinstance(recv_buf, list) else [recv_buf]
+        recv = holder[0].to(self.eng.device)
         self.keep = []
-        for a, b in line_cuts(recv, self.batch_bytes):
-            piece = t.zeros((b - a + 15) // 16 * 16 + 16, dtype=t.uint8, device=self.eng.device)  # batches are 16-byte aligned
-            piece[: b - a] = recv[a:b]
-            self.keep.append((piece, b - a))
+        cuts = line_cuts(recv, self.batch_bytes)
+        n = int(recv.numel())
+        base = recv._base if recv._base is not None else recv
+        room = (n + 15) // 16 * 16
+        if len(cuts) == 1 and recv.data_ptr() % 16 == 0 and base.data_ptr() == recv.data_ptr() and base.numel() >= room:
+            if room > n:
+                base[n:room] = 0  # the library reads whole 16-byte chunks
+            self.keep.append((base, n))  # one batch, tiled where it was received
+        else:
+            for a, b in cuts:
+                piece = t.empty((b - a + 15) // 16 * 16 + 16, dtype=t.uint8, device=self.eng.device)  # batches are 16-byte aligned
+                piece[: b - a] = recv[a:b]
+                piece[b - a:] = 0
+                self.keep.append((piece, b - a))
+            if isinstance(recv_buf, list):
+                recv_buf.clear()
+        del recv, holder, base
         self.info = self.eng.tile_batches(self.keep)
         if self.info.error.code:
             raise RuntimeError(f"tile failed on this rank: code {self.info.error.code} at local record {self.info.error.record}")
@@ -314,10 +418,12 @@ class GpuTileWorker:
         self.eng.scatter_lines(src, src_off, dst_off, dst)
 
 
-def tile_sharded(worker, dist, rank, world, batches, first_record, comm_device="cpu"):
+def tile_sharded(worker, dist, rank, world, batches, first_record, comm_device="cpu", consume=False):
     """`paffy tile` over an input spread over the ranks (this rank holds `batches`, whose first record is global record
     first_record). Returns {"offsets": byte offset of every local output line in the ordered output (int64 tensor), "total": bytes
-    of the whole output, "keys": the worker's [n, 5] keys}; worker.emit() then gives the local lines."""
+    of the whole output, "keys": the worker's [n, 5] keys}; worker.emit() then gives the local lines.
+    consume: the list `batches` is emptied as its batches are split (hand over the only reference and a rank holds its share of the
+    text at most twice at any time: batches + send buffer, send + receive buffer, receive buffer + tile batches)."""
     import os
     import time
 
@@ -326,30 +432,44 @@ def tile_sharded(worker, dist, rank, world, batches, first_record, comm_device="
     timing, t0 = {}, time.perf_counter()
     trace = bool(os.environ.get("PAFFY_SHARD_TIMING"))
 
+    peak, live = [0], [0]
+
     def lap(name):
         nonlocal t0
         if trace:
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
+                free_b, total_b = torch.cuda.mem_get_info()
+                peak[0] = max(peak[0], total_b - free_b)
+                # live = in use minus what torch's caching allocator holds without a tensor in it
+                live[0] = max(live[0], total_b - free_b - (torch.cuda.memory_reserved() - torch.cuda.memory_allocated()))
             t1 = time.perf_counter()
             timing[name] = timing.get(name, 0.0) + (t1 - t0) * 1e3
             t0 = t1
 
-    weights = merge_name_weights(dist, worker.query_names(batches), comm_device)
+    local, per_batch = worker.query_names(batches)
+    weights = merge_name_weights(dist, local, comm_device)
     owner_of = owner_table(weights, world)
     lap("names_ms")
-    send, send_bytes, send_gidx, send_records = worker.split(batches, owner_of, world, first_record)
+    try:
+        send, send_bytes, send_gidx, send_records = worker.split(batches, owner_of, world, first_record, per_batch, consume)
+    except Exception:
+        worker.eng.drop_index()  # no kept index outlives a failed partition
+        raise
     lap("split_ms")
     recv, recv_gidx, _, _ = exchange_lines(dist, send, send_bytes, send_gidx, send_records, comm_device)
+    del send  # with ranks: the receive buffer holds this rank's lines now; without: recv is the send buffer itself
     lap("exchange_ms")
-    keys = worker.tile(recv)
+    holder = [recv]
+    del recv
+    keys = worker.tile(holder)
     lap("tile_ms")
     gidx = recv_gidx.to(keys.device)
     k4 = torch.stack([keys[:, 0], keys[:, 1], gidx[keys[:, 2]], keys[:, 3]], dim=1) if keys.shape[0] else torch.zeros(0, 4, dtype=torch.int64, device=keys.device)
     all_keys, owner = gather_tile_keys(dist, k4, comm_device)
     offsets, total = global_line_offsets(all_keys, owner, rank)
     lap("keys_ms")
-    return {"offsets": offsets, "total": total, "keys": keys, "owner_of": owner_of, "timing": timing}
+    return {"offsets": offsets, "total": total, "keys": keys, "owner_of": owner_of, "timing": timing, "hbm_peak": peak[0] or None, "hbm_live_peak": live[0] or None}
 
 
 def gather_ordered_output(worker, dist, rank, world, lines, line_bytes, offsets, total, comm_device="cpu", writer=0):

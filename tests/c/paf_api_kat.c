@@ -216,6 +216,22 @@ static void mismatches(void) {
     paf_encode_mismatches(p, q2, t2);
     CHECK(cigar_count(p->cigar) == 1 && op_is(p, 0, sequence_match, 6));
     paf_destruct(p);
+    /* a base edited IN PLACE between two calls (same pointers, same lengths) must be seen: the reference reads the caller's strings
+       on every call (impl/paf.c:752-757); the pair cached on the GPU is keyed by a hash over every byte, not a sample.
+       20 000 bases: a sample of 4 096 positions would step over base 7 777 */
+    enum { N = 20000 };
+    static char big_q[N + 1], big_t[N + 1];
+    for (int i = 0; i < N; i++) big_q[i] = big_t[i] = "ACGT"[(i * 7 + i / 13) & 3];
+    big_q[N] = big_t[N] = '\0';
+    p = make_paf("q", N, 0, N, true, "t", N, 0, N, N, N, 60, "20000M");
+    paf_encode_mismatches(p, big_q, big_t);
+    CHECK(cigar_count(p->cigar) == 1 && op_is(p, 0, sequence_match, N));
+    paf_destruct(p);
+    big_q[7777] = big_q[7777] == 'A' ? 'C' : 'A';
+    p = make_paf("q", N, 0, N, true, "t", N, 0, N, N, N, 60, "20000M");
+    paf_encode_mismatches(p, big_q, big_t);
+    CHECK(cigar_count(p->cigar) == 3 && op_is(p, 0, sequence_match, 7777) && op_is(p, 1, sequence_mismatch, 1) && op_is(p, 2, sequence_match, N - 7778));
+    paf_destruct(p);
 }
 
 /* paf_pretty_print (impl/paf.c:262-316): the answers are the columns derived by hand in tests/test_oracle_kat.py */

@@ -128,3 +128,31 @@ def test_one_large_group(eng):
     want, err, fresh = O.chain(data)
     assert err.code == 0 and fresh == 0
     assert eng.chain(data)[0] == want
+
+
+def test_groups_whose_names_share_a_hash_stay_apart(eng):
+    """impl/chaining.c:37-54 groups by strcmp of the names. Two query names with the same 64-bit FNV-1a hash (tools/fnv_collide.c)
+    give two records the same group hash; chained as one group they would link across the names."""
+    from paffy_amd import shard
+
+    with open(os.path.join(ROOT, "tests", "golden", "fnv_collision.txt")) as fh:
+        a, b, _ = fh.read().split()
+    assert a != b and shard.name_hash(a.encode()) == shard.name_hash(b.encode())
+    rng = random.Random(4)
+    recs = []
+    for k in range(60):  # collinear runs that alternate between the two names: a merged group would chain right through them
+        q = a if k % 2 == 0 else b
+        recs.append(line(q, 1000 * k, 1000 * k + 900, "t", 1000 * k, 1000 * k + 900, rng.randrange(50, 500)))
+    data = b"".join(recs)
+    want, err, fresh = O.chain(data, 10, 1, 100000, 1.0)
+    assert err.code == 0
+    got, info = eng.chain(data, 10, 1, 100000, 1.0)
+    assert info.error.code == 0
+    if fresh == 0:
+        assert got == want
+    # no chain holds both names
+    names_of = {}
+    for ln in got.splitlines():
+        cn = ln.split(b"\tcn:i:")[1].split(b"\t")[0]
+        names_of.setdefault(cn, set()).add(ln.split(b"\t", 1)[0])
+    assert all(len(v) == 1 for v in names_of.values()) and len(names_of) >= 2

@@ -101,3 +101,64 @@ def test_two_ranks_on_one_gpu_through_bench():
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["ordered_write"]["verified_against_one_process"] is True
     assert line["config"]["records_timed"] == 2 * 3000 * 2
+
+
+def test_split_to_fills_one_send_buffer(eng):
+    """paffy_hip_split_to: the parts of several batches land behind each other per destination in ONE buffer (what the all-to-all
+    sends), the global record indices likewise; a destination range that is too small is refused before anything is written."""
+    lines = [l.encode() for l in records(2000, contigs=9, seed=8)]
+    batches = [lines[:700], lines[700:1500], lines[1500:]]
+    bufs = [(eng.to_device(b"".join(b)), sum(len(x) for x in b)) for b in batches]
+    worker = shard.GpuTileWorker(eng)
+    names, per_batch = worker.query_names(bufs)
+    owner_of = shard.owner_table(names, 3)
+    held = list(bufs)
+    send, nbytes, gidx, nrec = worker.split(held, owner_of, 3, 1000, per_batch, consume=True)
+    eng.sync()
+    assert held == []  # handed over and let go
+    parts = [[] for _ in range(3)]
+    for i, ln in enumerate(lines):
+        parts[owner_of[shard.name_hash(shard.query_name(ln))]].append((1000 + i, ln))
+    assert nbytes == [sum(len(ln) for _, ln in p) for p in parts] and nrec == [len(p) for p in parts]
+    assert bytes(send.cpu().numpy().tobytes()) == b"".join(ln for p in parts for _, ln in p)
+    assert gidx.cpu().tolist() == [g for p in parts for g, _ in p]
+    # a destination one byte short: PAFFY_E_CAPACITY (-3), nothing kept behind
+    d_in, n = bufs[0]
+    arrays = eng.owner_arrays(owner_of)
+    small = torch.empty(64, dtype=torch.uint8, device=eng.device)
+    idx = torch.empty(4096, dtype=torch.int64, device=eng.device)
+    with pytest.raises(RuntimeError):
+        eng.split_to(d_in, n, 3, arrays, small, [0, 16, 32], idx, [0, 1000, 2000], 0)
+
+
+def test_kept_index_is_dropped_on_request(eng):
+    """query_names keeps the batch's line index for the split; a batch that is refilled instead must be re-indexed: drop_index (the
+    contract of include/paffy_hip.h)."""
+    lines = [l.encode() for l in records(300, contigs=4, seed=2)]
+    data = b"".join(lines)
+    d_in = eng.to_device(data)
+    eng.query_names(d_in, len(data))
+    other = b"".join(reversed(lines))  # same bytes in total, other line starts
+    assert len(other) == len(data)
+    d_in[: len(other)] = torch.frombuffer(bytearray(other), dtype=torch.uint8).to(eng.device)
+    eng.drop_index(d_in)
+    out, pb, pr, ridx = eng.split_by_owner(d_in, len(other), 1, {})
+    assert bytes(out[: pb[0]].cpu().numpy().tobytes()) == other
+
+
+def _bench(*flags):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_rccl_runs_at_world_size_one():
+    """The collectives of the N-rank path over RCCL (torch's nccl backend), executed for real at world size 1 (--force-dist): the
+    per-step all_gather_into_tensor of the stream commands on its side stream, and for tile the all-gathers of names and keys and the
+    uneven all_to_all_single of the lines on device tensors. Two ranks cannot share one GPU under RCCL, so this is as far as one GPU goes."""
+    line = _bench("--force-dist", "--workload", "cfg3", "--batch", "4096", "--steps", "3", "--warmup", "1", "--cpu-sample", "0")
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["ordered_write"]["total_bytes"] > 0
+    assert line["ordered_write"]["rank0_first_offsets"][0] == 0 and line["ordered_write"]["rank0_first_offsets"][1] > 0
+    line = _bench("--force-dist", "--workload", "cfg5", "--batch", "3000", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--verify")
+    assert line["n_gpus"] == 1 and line["ordered_write"]["verified_against_one_process"] is True

@@ -102,23 +102,33 @@ class OracleTileWorker:
         return [ln for buf, n in batches for ln in bytes(buf[:n].numpy().tobytes()).splitlines(keepends=True)]
 
     def query_names(self, batches):
-        w = {}
-        for ln in self._lines(batches):
-            h = shard.name_hash(shard.query_name(ln))
-            w[h] = w.get(h, 0) + len(ln)
-        return w
+        w, per_batch = {}, []
+        for batch in batches:
+            mine = {}
+            for ln in self._lines([batch]):
+                h = shard.name_hash(shard.query_name(ln))
+                mine[h] = mine.get(h, 0) + len(ln)
+                w[h] = w.get(h, 0) + len(ln)
+            per_batch.append(mine)
+        return w, per_batch
 
-    def split(self, batches, owner_of, world, first_record):
+    def split(self, batches, owner_of, world, first_record, per_batch_names=None, consume=False):
         parts = [[] for _ in range(world)]
         for i, ln in enumerate(self._lines(batches)):
             parts[owner_of[shard.name_hash(shard.query_name(ln))]].append((first_record + i, ln))
+        if consume:
+            del batches[:]
         send = b"".join(ln for p in parts for _, ln in p)
         gidx = torch.tensor([g for p in parts for g, _ in p], dtype=torch.int64)
         return (torch.frombuffer(bytearray(send), dtype=torch.uint8) if send else torch.empty(0, dtype=torch.uint8),
                 [sum(len(ln) for _, ln in p) for p in parts], gidx, [len(p) for p in parts])
 
     def tile(self, recv_buf):
-        data = bytes(recv_buf.numpy().tobytes())
+        if isinstance(recv_buf, list):  # tile_sharded hands over its only reference
+            held = recv_buf.pop()
+        else:
+            held = recv_buf
+        data = bytes(held.numpy().tobytes())
         self.out, err = O.tile(data)
         assert err.code == 0
         lines = data.splitlines(keepends=True)
@@ -166,7 +176,8 @@ def _tile_worker(rank, world, port, tmpdir):
     half = len(mine) // 2
     batches = [(torch.frombuffer(bytearray(b"".join(p)), dtype=torch.uint8), sum(len(x) for x in p)) for p in (mine[:half], mine[half:]) if p]
     worker = OracleTileWorker()
-    res = shard.tile_sharded(worker, dist, rank, world, batches, first, "cpu")
+    res = shard.tile_sharded(worker, dist, rank, world, batches, first, "cpu", consume=(rank == 0))
+    assert batches == [] if rank == 0 else len(batches) > 0  # a rank that hands its batches over gets the list back empty
     out = worker.emit()
     # every line's place is known: lines sum to the total, offsets ascend in the rank's own order
     assert int(res["keys"][:, 3].sum()) == out.numel()
