@@ -609,6 +609,7 @@ struct paffy_hip_ctx {
         DevBuf meta, sep_pos, nl_idx;
     };
     std::vector<KeptIndex> kept_index;
+    std::vector<KeptIndex> index_pool; /* buffers of dropped entries, reused by the next kept index (no hipMalloc / hipFree per batch) */
     DevBuf one_batch;               /* table with the single text pointer of a one-batch plan (dedupe / split_file lines) */
     /* what emit writes for a line plan (tile, dedupe): record order, levels, offsets */
     const uint8_t *const *line_batches = nullptr;
@@ -740,6 +741,12 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     cov_free(c);
     chain_free(c);
     while (!c->kept_index.empty()) index_drop(c, c->kept_index.back().in);
+    for (paffy_hip_ctx::KeptIndex &k : c->index_pool) {
+        if (k.meta.p) (void)hipFree(k.meta.p);
+        if (k.sep_pos.p) (void)hipFree(k.sep_pos.p);
+        if (k.nl_idx.p) (void)hipFree(k.nl_idx.p);
+    }
+    c->index_pool.clear();
     if (c->one_batch.p) (void)hipFree(c->one_batch.p);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
                       &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->seq_raw, &c->pretty_off, &c->pretty_out, &c->pretty_err, &c->host_in, &c->host_out, &c->rec_stats, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
@@ -1334,10 +1341,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_scatter_lines(const uint8_t *src, 
 static void index_drop(paffy_hip_ctx *c, const void *d_in) {
     for (size_t i = 0; i < c->kept_index.size(); i++)
         if (c->kept_index[i].in == d_in) {
-            paffy_hip_ctx::KeptIndex &k = c->kept_index[i];
-            if (k.meta.p) (void)hipFree(k.meta.p);
-            if (k.sep_pos.p) (void)hipFree(k.sep_pos.p);
-            if (k.nl_idx.p) (void)hipFree(k.nl_idx.p);
+            c->index_pool.push_back(c->kept_index[i]); /* the buffers stay allocated for the next batch */
             c->kept_index.erase(c->kept_index.begin() + (long)i);
             return;
         }
@@ -1346,6 +1350,10 @@ static int index_keep(paffy_hip_ctx *c, const void *d_in, int64_t in_len, uint32
     index_drop(c, d_in);
     if (c->kept_index.size() >= 64) return 0; /* a caller that never splits: stop keeping */
     paffy_hip_ctx::KeptIndex k;
+    if (!c->index_pool.empty()) {
+        k = c->index_pool.back();
+        c->index_pool.pop_back();
+    }
     k.in = d_in;
     k.len = in_len;
     k.n = n;

@@ -158,7 +158,14 @@ struct Shared { /* small workgroup-shared words */
 };
 
 __device__ __forceinline__ int op_code_of(uint32_t c) { /* impl/paf.c:96-103 */
-    return c == 'M' ? OP_M : c == 'I' ? OP_I : c == 'D' ? OP_D : c == '=' ? OP_EQ : c == 'X' ? OP_X : -1;
+    /* without branches (the compiler turns a chain of comparisons into a tree of divergent branches, ~80 instructions per call in the
+       parser's loop): bits 2..4 of the five letters differ -- '=' 7, 'D' 1, 'I' 2, 'M' 3, 'X' 6 -- so they index a nibble table of
+       the codes and a byte table of the letters themselves, against which c is checked */
+    const uint32_t h = (c >> 2) & 7u;
+    const uint32_t code = (0x34ff012fu >> (4u * h)) & 0xfu; /* h: 7 6 5 4 3 2 1 0 -> = X - - M I D - */
+    const uint32_t want = ((h & 4u ? 0x3d580000u : 0x4d494400u) >> (8u * (h & 3u))) & 0xffu;
+    const bool ok = (c == want) & (want != 0u);
+    return ok ? (int)code : -1;
 }
 __device__ __forceinline__ uint32_t op_char_of(int op) { /* impl/paf.c:372-379 */
     return op == OP_M ? 'M' : op == OP_I ? 'I' : op == OP_D ? 'D' : op == OP_EQ ? '=' : op == OP_X ? 'X' : 'N';
@@ -298,6 +305,7 @@ __device__ __forceinline__ uint32_t parse_cigar_lds(const uint8_t *in, uint32_t 
     }
     uint32_t n = 0;
     uint32_t sm = 0, sx = 0, sq = 0, st = 0, flags = 0; /* flags: 1 = a number of eight digits or more, 2 = not plain */
+    uint32_t bad_at = 0xffffffffu;                      /* smallest text offset of a letter outside MID=X this thread saw */
     for (uint32_t tb = a0; tb < end; tb += PARSE_LDS_TEXT) {
         uint4 h = make_uint4(0, 0, 0, 0);
         if (tb != a0 && tid < 2) h = reinterpret_cast<uint4 *>(txt + PARSE_LDS_TEXT)[tid]; /* the last 32 bytes become the halo */
@@ -324,30 +332,45 @@ __device__ __forceinline__ uint32_t parse_cigar_lds(const uint8_t *in, uint32_t 
         }
         uint32_t c1[1] = {(uint32_t)__popc(opmask)}, tot[1];
         block_excl_scan_u32<1>(c1, tot, bc); /* its barrier also publishes the staged text */
+        /* Two steps per round (round 3; one thread used to convert the numbers of its own 16 bytes in a loop over its letters -- as
+           many iterations as the densest 16 bytes of the wave hold letters, up to 16, for a mean of five ops per thread): first every
+           thread only leaves the LDS positions of its letters in the op store, at the ops' indices; then the threads take the ops of
+           the round in index order, one op per thread and step (ceil(ops / threads) steps, all lanes busy), read the position, convert
+           the number in front of it and put the op word where the position was -- and into the HBM mirror, coalesced. */
         uint32_t idx = n + c1[0];
         const uint32_t q0 = PAFFY_HALO + tid * 16u;
         while (opmask) {
             const uint32_t j = (uint32_t)__ffs((int)opmask) - 1u;
             opmask &= opmask - 1u;
-            uint32_t kk, c; /* the letter comes with the words the number is read from: no indexing into w[] by a variable */
-            const uint32_t len = number_before(txt, q0 + j, &kk, &c);
-            int code = op_code_of(c);
-            if (code < 0) {
-                atomicMin(&sh->err_pos, g + j);
-                code = 0;
-            }
-            if (kk >= 8u) flags |= 1u;
-            if (len == 0u || code > OP_D) flags |= 2u;
-            if (idx < cap) ops.p[idx] = (len << 3) | (uint32_t)code;
+            if (idx < cap) ops.p[idx] = q0 + j;
             idx++;
-            if (code == OP_M || code == OP_EQ) sm += len;
-            else sx += len;
-            if (code != OP_D) sq += len;
-            if (code != OP_I) st += len;
+        }
+        __syncthreads();
+        const uint32_t top = n + tot[0] < cap ? n + tot[0] : cap;
+        for (uint32_t i = n + tid; i < top; i += PAFFY_NT) {
+            const uint32_t pos = ops.p[i];
+            uint32_t kk, c; /* the letter comes with the words the number is read from */
+            const uint32_t len = number_before(txt, pos, &kk, &c);
+            int code = op_code_of(c);
+            const bool bad = code < 0; /* remembered per thread, reported once after the rounds: no atomic in the loop */
+            const uint32_t at = tb + (pos - PAFFY_HALO);
+            bad_at = bad && at < bad_at ? at : bad_at;
+            code = bad ? 0 : code;
+            flags |= (kk >= 8u ? 1u : 0u) | (((len == 0u) | (code > OP_D)) ? 2u : 0u);
+            const uint32_t word = (len << 3) | (uint32_t)code;
+            ops.p[i] = word;
+            if (i < ops.g_cap) ops.g[i] = word;
+            /* masks, not branches: code is 0..4 here (M I D = X) */
+            const uint32_t is_m = 0u - ((0x9u >> code) & 1u); /* M or = */
+            sm += len & is_m;
+            sx += len & ~is_m;
+            sq += len & (0u - (uint32_t)(code != OP_D));
+            st += len & (0u - (uint32_t)(code != OP_I));
         }
         n += tot[0];
     }
-    /* one collective: the four sums and the flags (a thread's own sums stay below 2^32: at most eight numbers of seven digits per round) */
+    if (bad_at != 0xffffffffu) atomicMin(&sh->err_pos, bad_at);
+    /* one collective: the four sums and the flags (a thread's own sums stay below 2^32: a thread converts at most 36 864 / 64 numbers of seven digits) */
     sums[0] = (int64_t)((uint64_t)sm | ((uint64_t)(flags & 1u) << 42) | ((uint64_t)((flags >> 1) & 1u) << 52));
     sums[1] = sx; sums[2] = sq; sums[3] = st;
     block_sum<4>(sums, bc);
@@ -357,8 +380,6 @@ __device__ __forceinline__ uint32_t parse_cigar_lds(const uint8_t *in, uint32_t 
     if ((packed >> 42) & 0x3ffull) return 0xffffffffu;
     *plain = ((packed >> 52) & 0x3ffull) == 0;
     *fits = n <= cap;
-    const uint32_t n_live = n < cap ? n : cap, n_copy = n_live < ops.g_cap ? n_live : ops.g_cap;
-    for (uint32_t i = tid; i < n_copy; i += PAFFY_NT) ops.g[i] = ops.p[i];
     __syncthreads(); /* the text area and the error word are free again */
     return n;
 }
