@@ -110,6 +110,43 @@ struct View {
             if (raw == lo + n - 1) len -= sub_hi;
         }
     }
+    /* get() for the 4-byte stores, 32-bit and without branches (the sweeps of the identity trim run once per op and thread: the
+       general form above costs ~30 instructions there, this one ~10): length and code of view index i */
+    __device__ __forceinline__ void get32(uint32_t i, uint32_t &len, uint32_t &op) const {
+        const uint32_t raw = rev ? lo + n - 1 - i : lo + i;
+        const uint32_t w = ops.p[raw];
+        uint32_t o = w & 7u;
+        o ^= swp ? ((0x6u >> o) & 1u) * 3u : 0u; /* I <-> D */
+        op = o;
+        len = (w >> 3) - (raw == lo ? (uint32_t)sub_lo : 0u) - (raw == lo + n - 1 ? (uint32_t)sub_hi : 0u);
+    }
+    /* sums of the match-type (M, =) and the other lengths of view indices [b, e): order and relabelling do not matter */
+    __device__ __forceinline__ void class_sums32(uint32_t b, uint32_t e, uint32_t &m, uint32_t &x) const {
+        uint32_t sm = 0, sx = 0;
+        if (e > b) {
+            const uint32_t r0 = rev ? lo + n - e : lo + b, r1 = r0 + (e - b); /* the same ops as raw indices [r0, r1) */
+            for (uint32_t r = r0; r < r1; r++) {
+                const uint32_t w = ops.p[r];
+                const uint32_t is_m = 0u - ((0x9u >> (w & 7u)) & 1u);
+                sm += (w >> 3) & is_m;
+                sx += (w >> 3) & ~is_m;
+            }
+            if ((sub_lo | sub_hi) != 0) { /* shortened end ops (fixed trim before this stage) */
+                if (r0 <= lo && lo < r1) {
+                    const uint32_t is_m = 0u - ((0x9u >> (ops.p[lo] & 7u)) & 1u);
+                    sm -= (uint32_t)sub_lo & is_m;
+                    sx -= (uint32_t)sub_lo & ~is_m;
+                }
+                if (r0 <= lo + n - 1 && lo + n - 1 < r1) {
+                    const uint32_t is_m = 0u - ((0x9u >> (ops.p[lo + n - 1] & 7u)) & 1u);
+                    sm -= (uint32_t)sub_hi & is_m;
+                    sx -= (uint32_t)sub_hi & ~is_m;
+                }
+            }
+        }
+        m = sm;
+        x = sx;
+    }
     /* split form of get(): issue the load early, decode when the value is needed */
     __device__ __forceinline__ uint32_t raw_index(uint32_t i) const { return rev ? lo + n - 1 - i : lo + i; }
     template <class RAW>
@@ -584,14 +621,8 @@ __device__ __forceinline__ void trim_prefix32(RecState &s, View<OPS> &v, float t
     const double thr = (double)thr_f, idd = (double)id_f;
     uint32_t b, e;
     sweep_bounds(v.n, b, e);
-    uint32_t c[2] = {0, 0}, tot[2];
-    for (uint32_t i = b; i < e; i++) {
-        int64_t len;
-        int op;
-        v.get(i, len, op);
-        if (op == OP_EQ || op == OP_M) c[0] += (uint32_t)len;
-        else c[1] += (uint32_t)len;
-    }
+    uint32_t c[2], tot[2];
+    v.class_sums32(b, e, c[0], c[1]);
     const uint32_t chunk_x = c[1];
     block_excl_scan_u32<2>(c, tot, bc);
     uint32_t cm = c[0], cx = c[1];
@@ -599,53 +630,47 @@ __device__ __forceinline__ void trim_prefix32(RecState &s, View<OPS> &v, float t
     const bool may_hit = e > b && !(c[0] > 0 && (double)c[0] >= thr * 1.00001 * (double)(c[0] + c[1] + chunk_x));
     if (may_hit)
         for (uint32_t i = b; i < e; i++) {
-            int64_t len;
-            int op;
-            v.get(i, len, op);
-            if (op == OP_EQ || op == OP_M) cm += (uint32_t)len;
-            else cx += (uint32_t)len;
+            uint32_t len, op;
+            v.get32(i, len, op);
+            const uint32_t is_m = 0u - ((0x9u >> op) & 1u);
+            cm += len & is_m;
+            cx += len & ~is_m;
             if (max_trim >= 0 && (int64_t)(cm + cx) > max_trim) break;
             if (ratio_f32_u32(cm, cm + cx) < thr) found = (int32_t)i;
         }
     const int32_t trim_idx = block_max_idx(found, bc);
     if (trim_idx < 0) return;
     if (trim_idx >= (int32_t)b && trim_idx < (int32_t)e) {
-        uint32_t am = c[0], ax = c[1];
-        for (uint32_t i = b; i <= (uint32_t)trim_idx; i++) {
-            int64_t len;
-            int op;
-            v.get(i, len, op);
-            if (op == OP_EQ || op == OP_M) am += (uint32_t)len;
-            else ax += (uint32_t)len;
-        }
-        sh->bcast[0] = am;
-        sh->bcast[1] = ax;
+        uint32_t am, ax;
+        v.class_sums32(b, (uint32_t)trim_idx + 1u, am, ax);
+        sh->bcast[0] = c[0] + am;
+        sh->bcast[1] = c[1] + ax;
     }
     __syncthreads();
     const uint32_t tm = (uint32_t)sh->bcast[0], tx = (uint32_t)sh->bcast[1];
     __syncthreads();
     uint32_t em = c[0], ex = c[1], best = 0xffffffffu;
     for (uint32_t i = b; i < e && (int32_t)i <= trim_idx; i++) {
-        int64_t len;
-        int op;
-        v.get(i, len, op);
+        uint32_t len, op;
+        v.get32(i, len, op);
         const uint32_t sm = tm - em, sx = tx - ex;
         if (best == 0xffffffffu && ratio_f32_u32(sm, sm + sx) >= idd) best = i;
-        if (op == OP_EQ || op == OP_M) em += (uint32_t)len;
-        else ex += (uint32_t)len;
+        const uint32_t is_m = 0u - ((0x9u >> op) & 1u);
+        em += len & is_m;
+        ex += len & ~is_m;
     }
     best = block_min_u32(best, bc);
     const uint32_t count = best != 0xffffffffu ? best : (uint32_t)trim_idx + 1u;
     if (count == 0) return;
     uint32_t d[4] = {0, 0, 0, 0};
     for (uint32_t i = b; i < e && i < count; i++) {
-        int64_t len;
-        int op;
-        v.get(i, len, op);
-        if (op != OP_I) d[0] += (uint32_t)len;
-        if (op != OP_D) d[1] += (uint32_t)len;
-        if (op == OP_EQ || op == OP_M) d[2] += (uint32_t)len;
-        else d[3] += (uint32_t)len;
+        uint32_t len, op;
+        v.get32(i, len, op);
+        const uint32_t is_m = 0u - ((0x9u >> op) & 1u);
+        d[0] += len & (0u - (uint32_t)(op != (uint32_t)OP_I));
+        d[1] += len & (0u - (uint32_t)(op != (uint32_t)OP_D));
+        d[2] += len & is_m;
+        d[3] += len & ~is_m;
     }
     block_sum_u32<4>(d, bc);
     s.ts += d[0];
@@ -3052,13 +3077,16 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
                 const uint32_t fixed = k.row_const + 2 * dq0 + 2 * dt0;
                 uint32_t b, e, a[2] = {0, 0};
                 sweep_bounds(v.n, b, e);
+                uint32_t extra = 0; /* digits of the lengths beyond the first, summed over the M ops */
                 for (uint32_t i = b; i < e; i++) {
                     const uint32_t w = ops.p[v.lo + i]; /* the order of the ops does not matter here */
-                    if ((w & 7u) == (uint32_t)OP_M) {
-                        a[0] += fixed + 3u * dec_len_u32(w >> 3);
-                        a[1]++;
-                    }
+                    const uint32_t is_m = (w & 7u) == (uint32_t)OP_M ? 1u : 0u, x = w >> 3;
+                    const uint32_t mk = 0u - is_m;
+                    a[1] += is_m;
+                    extra += mk & ((x >= 10u) + (x >= 100u) + (x >= 1000u) + (x >= 10000u));
+                    if (__any(x >= 100000u)) extra += mk & ((x >= 100000u) + (x >= 1000000u) + (x >= 10000000u) + (x >= 100000000u)); /* lengths stay below 2^29 */
                 }
+                a[0] = a[1] * (fixed + 3u) + 3u * extra;
                 block_sum_u32<2>(a, L.bc);
                 bytes = a[0];
                 rows = a[1];
