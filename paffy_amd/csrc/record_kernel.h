@@ -625,19 +625,41 @@ __device__ __forceinline__ void trim_prefix32(RecState &s, View<OPS> &v, float t
     v.class_sums32(b, e, c[0], c[1]);
     const uint32_t chunk_x = c[1];
     block_excl_scan_u32<2>(c, tot, bc);
-    uint32_t cm = c[0], cx = c[1];
+    const uint32_t lane = threadIdx.x & 63u;
     int32_t found = -1;
     const bool may_hit = e > b && !(c[0] > 0 && (double)c[0] >= thr * 1.00001 * (double)(c[0] + c[1] + chunk_x));
-    if (may_hit)
-        for (uint32_t i = b; i < e; i++) {
-            uint32_t len, op;
-            v.get32(i, len, op);
-            const uint32_t is_m = 0u - ((0x9u >> op) & 1u);
-            cm += len & is_m;
-            cx += len & ~is_m;
-            if (max_trim >= 0 && (int64_t)(cm + cx) > max_trim) break;
-            if (ratio_f32_u32(cm, cm + cx) < thr) found = (int32_t)i;
+    /* The chunks that may hold a hit (usually the first one or two of the record) are walked by the whole wave, one op per lane --
+       a thread walking its own chunk made the wave pay chunk-length iterations of a loop with a float division for one or two busy
+       lanes (round 3: that loop and the one below were most of the trim's time). The last index with cumulative <= max_trim and
+       prefix identity < threshold is wanted (impl/paf.c:820-838: the cumulative sums only grow, so "break once above max_trim"
+       excludes exactly the indices whose own cumulative sum is above it): chunks from the last one down, first hit wins. */
+    {
+        unsigned long long flagged = __ballot(may_hit);
+        while (flagged) {
+            const int t = 63 - __clzll((long long)flagged);
+            flagged &= ~(1ull << t);
+            const uint32_t cb = (uint32_t)__shfl((int)b, t), ce = (uint32_t)__shfl((int)e, t);
+            uint32_t pm = (uint32_t)__shfl((int)c[0], t), px = (uint32_t)__shfl((int)c[1], t);
+            int32_t hit = -1;
+            for (uint32_t p0 = cb; p0 < ce; p0 += 64u) {
+                const uint32_t i = p0 + lane;
+                uint32_t len = 0, op = 0;
+                if (i < ce) v.get32(i, len, op);
+                const uint32_t is_m = 0u - ((0x9u >> op) & 1u);
+                const uint32_t im = wave_incl_scan_u32(len & is_m), ix = wave_incl_scan_u32(len & ~is_m);
+                const uint32_t cm = pm + im, cx = px + ix;
+                const bool ok = i < ce && !(max_trim >= 0 && (int64_t)(cm + cx) > max_trim) && ratio_f32_u32(cm, cm + cx) < thr;
+                const unsigned long long hb = __ballot(ok);
+                if (hb) hit = (int32_t)(p0 + 63u - (uint32_t)__clzll((long long)hb));
+                pm += wave_last_u32(im);
+                px += wave_last_u32(ix);
+            }
+            if (hit >= 0) {
+                found = hit;
+                break;
+            }
         }
+    }
     const int32_t trim_idx = block_max_idx(found, bc);
     if (trim_idx < 0) return;
     if (trim_idx >= (int32_t)b && trim_idx < (int32_t)e) {
@@ -649,15 +671,38 @@ __device__ __forceinline__ void trim_prefix32(RecState &s, View<OPS> &v, float t
     __syncthreads();
     const uint32_t tm = (uint32_t)sh->bcast[0], tx = (uint32_t)sh->bcast[1];
     __syncthreads();
-    uint32_t em = c[0], ex = c[1], best = 0xffffffffu;
-    for (uint32_t i = b; i < e && (int32_t)i <= trim_idx; i++) {
-        uint32_t len, op;
-        v.get32(i, len, op);
-        const uint32_t sm = tm - em, sx = tx - ex;
-        if (best == 0xffffffffu && ratio_f32_u32(sm, sm + sx) >= idd) best = i;
-        const uint32_t is_m = 0u - ((0x9u >> op) & 1u);
-        em += len & is_m;
-        ex += len & ~is_m;
+    /* smallest index <= trim_idx whose suffix [i, trim_idx] has identity >= identity (impl/paf.c:879-890): the same way, chunks from
+       the first one up, first hit wins */
+    uint32_t best = 0xffffffffu;
+    {
+        unsigned long long flagged = __ballot(e > b && (int32_t)b <= trim_idx);
+        while (flagged) {
+            const int t = __ffsll((long long)flagged) - 1;
+            flagged &= flagged - 1ull;
+            const uint32_t cb = (uint32_t)__shfl((int)b, t);
+            uint32_t ce = (uint32_t)__shfl((int)e, t);
+            if ((int32_t)ce > trim_idx + 1) ce = (uint32_t)trim_idx + 1u;
+            uint32_t pm = (uint32_t)__shfl((int)c[0], t), px = (uint32_t)__shfl((int)c[1], t);
+            uint32_t hit = 0xffffffffu;
+            for (uint32_t p0 = cb; p0 < ce && hit == 0xffffffffu; p0 += 64u) {
+                const uint32_t i = p0 + lane;
+                uint32_t len = 0, op = 0;
+                if (i < ce) v.get32(i, len, op);
+                const uint32_t is_m = 0u - ((0x9u >> op) & 1u);
+                const uint32_t vm = len & is_m, vx = len & ~is_m;
+                const uint32_t im = wave_incl_scan_u32(vm), ix = wave_incl_scan_u32(vx);
+                const uint32_t sm = tm - (pm + im - vm), sx = tx - (px + ix - vx); /* sums of [i, trim_idx] */
+                const bool ok = i < ce && ratio_f32_u32(sm, sm + sx) >= idd;
+                const unsigned long long hb = __ballot(ok);
+                if (hb) hit = p0 + (uint32_t)__ffsll((long long)hb) - 1u;
+                pm += wave_last_u32(im);
+                px += wave_last_u32(ix);
+            }
+            if (hit != 0xffffffffu) {
+                best = hit;
+                break;
+            }
+        }
     }
     best = block_min_u32(best, bc);
     const uint32_t count = best != 0xffffffffu ? best : (uint32_t)trim_idx + 1u;
@@ -3137,8 +3182,8 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
     }
 #if defined(PAFFY_ABL) && PAFFY_ABL == 21
     PT_MARK(5)
-    if ((blockIdx.x & 8191u) == 77u && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == 1)
-        printf("rec %u ops %u: parse %llu invert+check %llu trim %llu check %llu shatter_size %llu plan %llu\n", blockIdx.x, n, pt_acc[0], pt_acc[1], pt_acc[2],
+    if ((blockIdx.x & 8191u) == 77u && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == (PAFFY_NWAVE == 1 ? 0 : 1))
+        printf("g%d rec %u ops %u: parse %llu invert+check %llu trim %llu check %llu shatter_size %llu plan %llu\n", PAFFY_NT, blockIdx.x, n, pt_acc[0], pt_acc[1], pt_acc[2],
                pt_acc[3], pt_acc[4], pt_acc[5]);
 #endif
     return true;
