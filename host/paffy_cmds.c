@@ -75,7 +75,7 @@ static int run_stream_cmd(const cmd_opts *o, const paffy_stage *stages, int n_st
     host_set_log_level(o->log_level);
     host_log_info("Input file string : %s\n", o->in_path ? o->in_path : "(stdin)");
     host_log_info("Output file string : %s\n", o->out_path ? o->out_path : "(stdout)");
-    FILE *in = o->in_path ? fopen(o->in_path, "r") : stdin;
+    FILE *in = host_open_input(o->in_path);
     if (!in) {
         fprintf(stderr, "paffy %s: cannot open %s\n", name, o->in_path);
         return 1;
@@ -231,7 +231,7 @@ int paffy_split_file_main(int argc, char *argv[]) {
     host_log_info("Output prefix : %s\n", prefix);
     host_log_info("Split by : %s\n", by_query ? "query" : "target");
     host_log_info("Min contig length : %lld\n", (long long)min_length);
-    FILE *in = in_path ? fopen(in_path, "r") : stdin;
+    FILE *in = host_open_input(in_path);
     if (!in) {
         fprintf(stderr, "paffy split_file: cannot open %s\n", in_path);
         return 1;
@@ -344,7 +344,7 @@ int paffy_tile_main(int argc, char *argv[]) {
     int rc = parse_opts(argc, argv, "tile", "Give every alignment a tile level along its query sequence", 0, &o);
     if (rc >= 0) return rc;
     host_set_log_level(o.log_level);
-    FILE *in = o.in_path ? fopen(o.in_path, "r") : stdin;
+    FILE *in = host_open_input(o.in_path);
     FILE *out = o.out_path ? fopen(o.out_path, "w") : stdout;
     if (!in || !out) {
         fprintf(stderr, "paffy tile: cannot open %s\n", !in ? o.in_path : o.out_path);
@@ -394,7 +394,7 @@ int paffy_chain_main(int argc, char *argv[]) {
     host_set_log_level(o.log_level);
     host_log_info("Input file string : %s\nOutput file string : %s\nMaximum gap length : %lld\nChain gap open : %lld\nChain gap extend : %lld\n", o.in_path, o.out_path,
                   (long long)c.max_gap_length, (long long)c.gap_open, (long long)c.gap_extend);
-    FILE *in = o.in_path ? fopen(o.in_path, "r") : stdin;
+    FILE *in = host_open_input(o.in_path);
     FILE *out = o.out_path ? fopen(o.out_path, "w") : stdout;
     if (!in || !out) {
         fprintf(stderr, "paffy chain: cannot open %s\n", !in ? o.in_path : o.out_path);
@@ -464,7 +464,7 @@ int paffy_view_main(int argc, char *argv[]) {
     host_set_alignment_rows(include_alignment && per_alignment); /* impl/paf_view.c:158-160: paf_pretty_print runs unless -t */
     const paffy_stage st[2] = {{PAFFY_ADD_MISMATCHES, 0.05f, 1.0f}, {PAFFY_STATS, 0.0f, 0.0f}};
     host_set_stats(1);
-    FILE *in = o.in_path ? fopen(o.in_path, "r") : stdin;
+    FILE *in = host_open_input(o.in_path);
     FILE *out = o.out_path ? fopen(o.out_path, "w") : stdout;
     if (!in || !out) {
         fprintf(stderr, "paffy view: cannot open %s\n", !in ? o.in_path : o.out_path);
@@ -536,7 +536,7 @@ int paffy_to_bed_main(int argc, char *argv[]) {
         }
     }
     host_set_log_level(o.log_level);
-    FILE *in = o.in_path ? fopen(o.in_path, "r") : stdin;
+    FILE *in = host_open_input(o.in_path);
     FILE *out = o.out_path ? fopen(o.out_path, "w") : stdout;
     if (!in || !out) {
         fprintf(stderr, "paffy to_bed: cannot open %s\n", !in ? o.in_path : o.out_path);

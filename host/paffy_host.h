@@ -25,6 +25,12 @@ int paffy_chain_main(int argc, char *argv[]);
 int paffy_view_main(int argc, char *argv[]);
 int paffy_to_bed_main(int argc, char *argv[]);
 
+/* The input of a command: `path` (NULL: stdin). Under the N-GPU launcher (host/paffy_launch.c) a worker reads only its byte range
+ * of the file: PAFFY_RANGE="first:end". */
+FILE *host_open_input(const char *path);
+/* The GPU this worker uses: PAFFY_DEVICE (set by the launcher), else the current device (-1). */
+int host_device(void);
+
 /* Log level shared by the drivers: 0 off, 1 info, 2 debug (set from -l/--logLevel). */
 void host_set_log_level(const char *s);
 void host_log_info(const char *fmt, ...);

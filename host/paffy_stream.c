@@ -10,7 +10,54 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include "paffy_host.h"
+
+/* ---- what the N-GPU launcher (host/paffy_launch.c) tells a worker through its environment ---- */
+int host_device(void) {
+    const char *e = getenv("PAFFY_DEVICE");
+    return e && *e ? atoi(e) : -1;
+}
+typedef struct {
+    int fd;
+    int64_t pos, end;
+} range_cookie;
+static ssize_t range_read(void *c, char *buf, size_t n) {
+    range_cookie *r = (range_cookie *)c;
+    const int64_t left = r->end - r->pos;
+    if (left <= 0) return 0;
+    if ((int64_t)n > left) n = (size_t)left;
+    const ssize_t got = pread(r->fd, buf, n, (off_t)r->pos);
+    if (got > 0) r->pos += got;
+    return got;
+}
+static int range_close(void *c) {
+    range_cookie *r = (range_cookie *)c;
+    close(r->fd);
+    free(r);
+    return 0;
+}
+FILE *host_open_input(const char *path) {
+    if (!path) return stdin;
+    const char *rg = getenv("PAFFY_RANGE");
+    long long a = 0, b = 0;
+    if (!rg || sscanf(rg, "%lld:%lld", &a, &b) != 2) return fopen(path, "r");
+    range_cookie *r = (range_cookie *)malloc(sizeof(range_cookie));
+    if (!r) return NULL;
+    r->fd = open(path, O_RDONLY);
+    r->pos = a;
+    r->end = b;
+    if (r->fd < 0) {
+        free(r);
+        return NULL;
+    }
+    cookie_io_functions_t io = {range_read, NULL, NULL, range_close};
+    FILE *fh = fopencookie(r, "r", io);
+    if (fh) setvbuf(fh, NULL, _IOFBF, 1 << 22);
+    return fh;
+}
 
 static int g_log_level = 0;
 static const char *const *g_seq_names, *const *g_seq_data;
@@ -289,7 +336,7 @@ static int pipelined_stream(paffy_hip_ctx *ctx, const paffy_stage *stages, int n
 
 int host_stream(const paffy_stage *stages, int n_stages, FILE *in, FILE *out) {
     paffy_hip_ctx *ctx = NULL;
-    if (paffy_hip_create(&ctx, -1) != 0) {
+    if (paffy_hip_create(&ctx, host_device()) != 0) {
         fprintf(stderr, "paffy: no usable GPU (this build has no CPU path)\n");
         return 1;
     }
@@ -399,7 +446,7 @@ static FILE *open_or_die(const char *path) {
 
 int host_split_file(FILE *in, const char *prefix, int by_query, int64_t min_length) {
     paffy_hip_ctx *ctx = NULL;
-    if (paffy_hip_create(&ctx, -1) != 0) {
+    if (paffy_hip_create(&ctx, host_device()) != 0) {
         fprintf(stderr, "paffy: no usable GPU (this build has no CPU path)\n");
         return 1;
     }
@@ -542,7 +589,7 @@ int host_chain(FILE *in, FILE *out, const paffy_chain_opts *opts) { return whole
  */
 static int whole_file(FILE *in, FILE *out, const paffy_bed_opts *bed, const paffy_chain_opts *chain) {
     paffy_hip_ctx *ctx = NULL;
-    if (paffy_hip_create(&ctx, -1) != 0) {
+    if (paffy_hip_create(&ctx, host_device()) != 0) {
         fprintf(stderr, "paffy: no usable GPU (this build has no CPU path)\n");
         return 1;
     }
@@ -624,6 +671,13 @@ static int whole_file(FILE *in, FILE *out, const paffy_bed_opts *bed, const paff
             int64_t *offs = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
             int64_t stage = (int64_t)256 << 20;
             if (!rows || !offs || paffy_hip_plan_rows(ctx, n + 1, rows, offs) != n) rc = 1;
+            if (!rc && getenv("PAFFY_ROWS_FILE")) { /* under the N-GPU launcher: the input record of every output line, for its merge */
+                FILE *rf = fopen(getenv("PAFFY_ROWS_FILE"), "w");
+                if (!rf || fwrite(rows, sizeof(uint32_t), (size_t)n, rf) != (size_t)n || fclose(rf) != 0) {
+                    fprintf(stderr, "paffy %s: cannot write %s\n", what, getenv("PAFFY_ROWS_FILE"));
+                    rc = 1;
+                }
+            }
             for (int64_t k = 0; !rc && k < n; k++)
                 if (offs[k + 1] - offs[k] > stage) stage = offs[k + 1] - offs[k];
             void *d_stage = NULL;
