@@ -162,7 +162,7 @@ def owner_table(weights, world):
 EXCHANGE_CHUNK = 256 << 20  # bytes per send / receive operation
 
 
-def _pairwise_exchange(dist, rank, world, src, send_counts, dst, recv_counts, chunk):
+def _pairwise_exchange(dist, rank, world, src, send_counts, dst, recv_counts, chunk, recv_offsets=None):
     """dst <- what every rank holds for this rank in src (both flat, grouped by peer, counts in elements): the all-to-all as explicit
     sends and receives per peer in pieces of at most `chunk` elements, the rank's own part as a plain copy. Over the nccl backend
     these are RCCL send / recv pairs -- point-to-point over xGMI, which is what the fabric is. Why not all_to_all_single: one call
@@ -171,8 +171,12 @@ def _pairwise_exchange(dist, rank, world, src, send_counts, dst, recv_counts, ch
     for r in range(world):
         so.append(so[-1] + int(send_counts[r]))
         ro.append(ro[-1] + int(recv_counts[r]))
+    re = ro[1:]  # where every peer's part ends in dst
+    if recv_offsets is not None:  # parts at given places (16-byte aligned segments) instead of back to back
+        ro = [int(x) for x in recv_offsets]
+        re = [ro[r] + int(recv_counts[r]) for r in range(world)]
     if send_counts[rank]:
-        dst[ro[rank]: ro[rank + 1]].copy_(src[so[rank]: so[rank + 1]])
+        dst[ro[rank]: re[rank]].copy_(src[so[rank]: so[rank + 1]])
     rounds = max([0] + [(int(c) + chunk - 1) // chunk for r, c in enumerate(send_counts) if r != rank] +
                  [(int(c) + chunk - 1) // chunk for r, c in enumerate(recv_counts) if r != rank])
     for k in range(rounds):
@@ -182,7 +186,7 @@ def _pairwise_exchange(dist, rank, world, src, send_counts, dst, recv_counts, ch
             a, b = so[to] + k * chunk, min(so[to] + (k + 1) * chunk, so[to + 1])
             if a < b:
                 ops.append(dist.P2POp(dist.isend, src[a:b], to))
-            a, b = ro[frm] + k * chunk, min(ro[frm] + (k + 1) * chunk, ro[frm + 1])
+            a, b = ro[frm] + k * chunk, min(ro[frm] + (k + 1) * chunk, re[frm])
             if a < b:
                 ops.append(dist.P2POp(dist.irecv, dst[a:b], frm))
         if ops:
@@ -190,29 +194,39 @@ def _pairwise_exchange(dist, rank, world, src, send_counts, dst, recv_counts, ch
                 req.wait()
 
 
-def exchange_lines(dist, send_buf, send_bytes, send_gidx, send_records, comm_device="cpu"):
-    """The all-to-all of the partition. send_buf: uint8 tensor whose first sum(send_bytes) bytes are the lines grouped by destination
-    rank; send_gidx: int64 tensor, the global input index of every line in the same order; send_bytes / send_records: per destination.
-    Returns (recv_buf uint8, recv_gidx int64, recv_bytes per source, recv_records per source): what this rank owns, grouped by
-    source rank -- and since every source sent its lines in input order and sources hold consecutive shares, in global input order."""
+def exchange_lines(dist, send_buf, send_bytes, send_gidx, send_records, comm_device="cpu", pieces=None):
+    """The all-to-all of the partition. send_buf: uint8 tensor holding the lines grouped by destination rank; send_gidx: int64
+    tensor, the global input index of every line in the same order; send_bytes / send_records: per destination.
+    Returns (recv_buf uint8, recv_gidx int64, pieces): what this rank owns -- the lines of every source rank as one segment of
+    recv_buf that starts at a multiple of 16 bytes, pieces = [(offset, bytes)] of the segments in source order. Every source sent its
+    lines in input order and sources hold consecutive shares, so the pieces one after the other are in global input order -- and each
+    is a whole number of lines at an aligned address: a text batch the library can take where it is, no copy.
+    Without ranks nothing moves: the send buffer and the pieces the splitter laid out come back."""
     import torch
 
     world = dist.get_world_size() if dist is not None else 1
     if dist is None:
         n = int(send_bytes[0])
-        return send_buf[:n], send_gidx[: int(send_records[0])], [n], [int(send_records[0])]
+        return send_buf, send_gidx[: int(send_records[0])], (pieces if pieces is not None else [(0, n)])
     rank = dist.get_rank()
     sizes = torch.tensor([list(send_bytes), list(send_records)], dtype=torch.int64, device=comm_device).t().contiguous()  # [world, 2]
     got = torch.zeros_like(sizes)
     dist.all_to_all_single(got, sizes)  # 16 bytes per peer
     recv_bytes, recv_records = [int(x) for x in got[:, 0].tolist()], [int(x) for x in got[:, 1].tolist()]
+    offs, at = [], 0
+    for r in range(world):
+        offs.append(at)
+        at += (recv_bytes[r] + 15) // 16 * 16
     src = _comm(send_buf[: sum(send_bytes)], comm_device)
-    recv_buf = torch.empty((sum(recv_bytes) + 15) // 16 * 16 + 16, dtype=torch.uint8, device=comm_device)
-    _pairwise_exchange(dist, rank, world, src, list(send_bytes), recv_buf, recv_bytes, EXCHANGE_CHUNK)
+    recv_buf = torch.empty(at + 16, dtype=torch.uint8, device=comm_device)
+    _pairwise_exchange(dist, rank, world, src, list(send_bytes), recv_buf, recv_bytes, EXCHANGE_CHUNK, offs)
+    for r in range(world):  # the few bytes between a segment's end and the next multiple of 16 are read with the segment's last chunk
+        if recv_bytes[r] % 16:
+            recv_buf[offs[r] + recv_bytes[r]: offs[r] + (recv_bytes[r] + 15) // 16 * 16] = 0
     gsrc = _comm(send_gidx[: sum(send_records)], comm_device)
     recv_gidx = torch.empty(sum(recv_records), dtype=torch.int64, device=comm_device)
     _pairwise_exchange(dist, rank, world, gsrc, list(send_records), recv_gidx, recv_records, EXCHANGE_CHUNK // 8)
-    return recv_buf[: sum(recv_bytes)], recv_gidx, recv_bytes, recv_records
+    return recv_buf, recv_gidx, [(offs[r], recv_bytes[r]) for r in range(world) if recv_bytes[r]]
 
 
 KEY_ROWS_PER_GATHER = 1 << 22  # 128 MiB of keys per rank and collective
@@ -353,7 +367,11 @@ class GpuTileWorker:
                 need_r[b][d] += r
         dest_bytes = [sum(need_b[b][d] for b in range(n_batches)) for d in range(world)]
         dest_recs = [sum(need_r[b][d] for b in range(n_batches)) for d in range(world)]
-        total, total_r = sum(dest_bytes), sum(dest_recs)
+        total_r = sum(dest_recs)
+        # One rank: nothing will be exchanged, so every batch's lines start at a multiple of 16 bytes in the buffer -- they are tiled
+        # right there as text batches (`pieces`). Several ranks: the parts of a destination stand back to back, as they are sent.
+        pad = (lambda x: (x + 15) // 16 * 16) if world == 1 else (lambda x: x)
+        total = sum(pad(need_b[b][d]) for b in range(n_batches) for d in range(world))
         send = t.empty((total + 15) // 16 * 16 + 16, dtype=t.uint8, device=dev)
         gidx = t.empty(max(1, total_r), dtype=t.int64, device=dev)
         at_b, at_r = [0] * world, [0] * world
@@ -362,46 +380,56 @@ class GpuTileWorker:
             at_r[d] = at_r[d - 1] + dest_recs[d - 1]
         arrays = self.eng.owner_arrays(owner_of)
         base = first_record
+        pieces = []
         for b in range(n_batches):
             buf, n = batches[0] if consume else batches[b]
             pb, pr, nrec = self.eng.split_to(buf, n, world, arrays, send, at_b, gidx, at_r, base)
             if pb != need_b[b] or pr != need_r[b]:
                 raise RuntimeError("split: a batch changed between query_names and split (bytes / lines per destination differ)")
+            if world == 1 and pb[0]:
+                pieces.append((at_b[0], pb[0]))
+                if pb[0] % 16:
+                    send[at_b[0] + pb[0]: at_b[0] + pad(pb[0])] = 0
             for d in range(world):
-                at_b[d] += pb[d]
+                at_b[d] += pad(pb[d])
                 at_r[d] += pr[d]
             base += nrec
             if consume:
                 self.eng.sync()  # the copy kernel reads the batch
                 del buf
                 batches.pop(0)
+        self.pieces = pieces if world == 1 else None
         return send[:total], dest_bytes, gidx[:total_r], dest_recs
 
-    def tile(self, recv_buf):
+    def tile(self, recv_buf, pieces=None):
         """paffy tile over the lines this rank owns -> int64 [n, 5] per output line: chain_score, score, local record, bytes, level.
-        recv_buf is cut into 16-byte aligned batches; the caller should drop its reference to recv_buf before the call returns
-        control to code that allocates (tile_sharded passes a one-element list that is emptied here)."""
+        pieces: [(offset, bytes)] -- whole lines starting at multiples of 16 bytes of recv_buf (what exchange_lines / split lay
+        out): they are tiled where they are; a piece too long for a batch, or a buffer without pieces, is cut at line ends into
+        16-byte aligned copies. recv_buf may be a one-element list (tile_sharded hands over its only reference)."""
         t = self.eng.torch
         holder = recv_buf if isinstance(recv_buf, list) else [recv_buf]
         recv = holder[0].to(self.eng.device)
+        if pieces is None:
+            pieces = [(0, int(recv.numel()))]
         self.keep = []
-        cuts = line_cuts(recv, self.batch_bytes)
-        n = int(recv.numel())
-        base = recv._base if recv._base is not None else recv
-        room = (n + 15) // 16 * 16
-        if len(cuts) == 1 and recv.data_ptr() % 16 == 0 and base.data_ptr() == recv.data_ptr() and base.numel() >= room:
-            if room > n:
-                base[n:room] = 0  # the library reads whole 16-byte chunks
-            self.keep.append((base, n))  # one batch, tiled where it was received
-        else:
-            for a, b in cuts:
+        in_place = recv.data_ptr() % 16 == 0
+        for off, n in pieces:
+            room = (n + 15) // 16 * 16
+            if n == 0:
+                continue
+            if in_place and off % 16 == 0 and n <= self.batch_bytes and off + room <= recv.numel():
+                self.keep.append((recv[off: off + room], n))  # where it was received
+                continue
+            part = recv[off: off + n]
+            for a, b in line_cuts(part, self.batch_bytes):
                 piece = t.empty((b - a + 15) // 16 * 16 + 16, dtype=t.uint8, device=self.eng.device)  # batches are 16-byte aligned
-                piece[: b - a] = recv[a:b]
+                piece[: b - a] = part[a:b]
                 piece[b - a:] = 0
                 self.keep.append((piece, b - a))
-            if isinstance(recv_buf, list):
-                recv_buf.clear()
-        del recv, holder, base
+        if isinstance(recv_buf, list):
+            recv_buf.clear()
+        self._recv = recv if any(x.data_ptr() >= recv.data_ptr() and x.data_ptr() < recv.data_ptr() + max(1, recv.numel()) for x, _ in self.keep) else None
+        del recv, holder
         self.info = self.eng.tile_batches(self.keep)
         if self.info.error.code:
             raise RuntimeError(f"tile failed on this rank: code {self.info.error.code} at local record {self.info.error.record}")
@@ -457,12 +485,12 @@ def tile_sharded(worker, dist, rank, world, batches, first_record, comm_device="
         worker.eng.drop_index()  # no kept index outlives a failed partition
         raise
     lap("split_ms")
-    recv, recv_gidx, _, _ = exchange_lines(dist, send, send_bytes, send_gidx, send_records, comm_device)
+    recv, recv_gidx, pieces = exchange_lines(dist, send, send_bytes, send_gidx, send_records, comm_device, getattr(worker, "pieces", None))
     del send  # with ranks: the receive buffer holds this rank's lines now; without: recv is the send buffer itself
     lap("exchange_ms")
     holder = [recv]
     del recv
-    keys = worker.tile(holder)
+    keys = worker.tile(holder, pieces)
     lap("tile_ms")
     gidx = recv_gidx.to(keys.device)
     k4 = torch.stack([keys[:, 0], keys[:, 1], gidx[keys[:, 2]], keys[:, 3]], dim=1) if keys.shape[0] else torch.zeros(0, 4, dtype=torch.int64, device=keys.device)

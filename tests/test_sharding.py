@@ -123,12 +123,13 @@ class OracleTileWorker:
         return (torch.frombuffer(bytearray(send), dtype=torch.uint8) if send else torch.empty(0, dtype=torch.uint8),
                 [sum(len(ln) for _, ln in p) for p in parts], gidx, [len(p) for p in parts])
 
-    def tile(self, recv_buf):
+    def tile(self, recv_buf, pieces=None):
         if isinstance(recv_buf, list):  # tile_sharded hands over its only reference
             held = recv_buf.pop()
         else:
             held = recv_buf
-        data = bytes(held.numpy().tobytes())
+        raw = bytes(held.numpy().tobytes())
+        data = raw if pieces is None else b"".join(raw[o: o + n] for o, n in pieces)  # segments start at multiples of 16 bytes
         self.out, err = O.tile(data)
         assert err.code == 0
         lines = data.splitlines(keepends=True)
