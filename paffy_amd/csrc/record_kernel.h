@@ -3439,8 +3439,16 @@ __global__ __launch_bounds__(64, PAFFY_ROWS_OCC) void k_emit_rows(KParams P) {
         w.pad_to(64);
     }
     __builtin_amdgcn_wave_barrier();
+#if defined(PAFFY_ABL) && PAFFY_ABL == 24 /* core clock against the 100 MHz wall clock inside the row kernel */
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+#endif
     shatter_emit_fast(s, v, k, reinterpret_cast<const u32x4 *>(A), reinterpret_cast<const u32x4 *>(B), reinterpret_cast<const u32x4 *>(C), 0u, v.n, 0ll, 0ll,
                       smem, P.out, (uint64_t)P.out_off[rec]);
+#if defined(PAFFY_ABL) && PAFFY_ABL == 24
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    if ((blockIdx.x & 16383u) == 99u && threadIdx.x == 0)
+        printf("block %u (%u ops): %llu core cycles, %llu wall ticks (100 MHz) -> %.0f MHz\n", blockIdx.x, v.n, c1 - c0, w1 - w0, (double)(c1 - c0) / (double)(w1 - w0) * 100.0);
+#endif
 }
 
 /*
