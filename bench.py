@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="stream workloads: contexts that take the batches in turn, each on its own HIP stream, so that the sizing pass of batch k + 1 runs beside "
                          "the writers of batch k (1 = one context, batches strictly one after the other)")
+    ap.add_argument("--tile-text-batch", type=int, default=200_000, help="cfg5: records per text batch handed to the library (each batch stays below 2 GiB)")
     ap.add_argument("--verify", action="store_true", help="cfg5: gather the ordered output of the last step on rank 0 and compare it with a one-process tile of the same records (small --batch only)")
     ap.add_argument("--rehearse", action="store_true",
                     help="plumbing rehearsal without a GPU: ranks, rendezvous, the per-step size exchange and the reductions run, the hot path does not (value is null)")
@@ -323,7 +324,7 @@ def bench_tile(args, wl, rank, world, dist, dev):
     eng = paffy_amd.Engine()
     worker = shard.GpuTileWorker(eng)
     comm = dev if (dist is None or args.dist_backend == "nccl") else "cpu"
-    per_batch = 200_000  # records per text batch: about 1.1 GB of text, below the 2 GiB of a batch
+    per_batch = args.tile_text_batch  # records per text batch (default 200 000: about 1.1 GB of text, below the 2 GiB of a batch)
 
     def share(step_no):
         first, n = shard.share_of_rank(rank, world, world * args.batch)

@@ -205,14 +205,20 @@ def exchange_lines(dist, send_buf, send_bytes, send_gidx, send_records, comm_dev
     import torch
 
     world = dist.get_world_size() if dist is not None else 1
-    if dist is None:
+    if dist is not None:
+        rank = dist.get_rank()
+        sizes = torch.tensor([list(send_bytes), list(send_records)], dtype=torch.int64, device=comm_device).t().contiguous()  # [world, 2]
+        got = torch.zeros_like(sizes)
+        dist.all_to_all_single(got, sizes)  # 16 bytes per peer
+        recv_bytes, recv_records = [int(x) for x in got[:, 0].tolist()], [int(x) for x in got[:, 1].tolist()]
+    if world == 1:
+        # One rank owns everything: the splitter laid every batch's lines out at a multiple of 16 bytes (`pieces`, with up to 15 bytes
+        # of padding between them -- the buffer is NOT sum(send_bytes) contiguous bytes), and a rank's own part never travels anyway.
+        # With a process group of one (bench.py --force-dist) the size exchange above still ran over the backend.
         n = int(send_bytes[0])
+        if dist is not None and (recv_bytes[0] != n or recv_records[0] != int(send_records[0])):
+            raise RuntimeError("exchange_lines: the size exchange of a one-rank group returned other sizes than were sent")
         return send_buf, send_gidx[: int(send_records[0])], (pieces if pieces is not None else [(0, n)])
-    rank = dist.get_rank()
-    sizes = torch.tensor([list(send_bytes), list(send_records)], dtype=torch.int64, device=comm_device).t().contiguous()  # [world, 2]
-    got = torch.zeros_like(sizes)
-    dist.all_to_all_single(got, sizes)  # 16 bytes per peer
-    recv_bytes, recv_records = [int(x) for x in got[:, 0].tolist()], [int(x) for x in got[:, 1].tolist()]
     offs, at = [], 0
     for r in range(world):
         offs.append(at)

@@ -113,6 +113,18 @@ class OracleTileWorker:
         return w, per_batch
 
     def split(self, batches, owner_of, world, first_record, per_batch_names=None, consume=False):
+        if world == 1 and getattr(self, "pad_pieces", False):
+            # what GpuTileWorker.split does for a single rank: every batch's lines start at a multiple of 16 bytes of the send buffer
+            # (zero padding between them) and are tiled where they are (`pieces`)
+            blob, self.pieces, n_lines, total = bytearray(), [], 0, 0
+            for buf, n in batches:
+                self.pieces.append((len(blob), n))
+                blob += bytes(buf[:n].numpy().tobytes()) + b"\0" * (-n % 16)
+                n_lines += bytes(buf[:n].numpy().tobytes()).count(b"\n")
+                total += n
+            if consume:
+                del batches[:]
+            return torch.frombuffer(blob + bytearray(16), dtype=torch.uint8), [total], torch.arange(first_record, first_record + n_lines, dtype=torch.int64), [n_lines]
         parts = [[] for _ in range(world)]
         for i, ln in enumerate(self._lines(batches)):
             parts[owner_of[shard.name_hash(shard.query_name(ln))]].append((first_record + i, ln))
@@ -217,3 +229,30 @@ def test_sharded_tile_single_rank_and_helpers():
         assert all(data[b - 1: b] == b"\n" for _, b in cuts)
         assert all(b - a <= mx or data[a:b].count(b"\n") == 1 for a, b in cuts)
     assert shard.share_of_rank(0, 3, 10) == (0, 4) and shard.share_of_rank(2, 3, 10) == (7, 3)
+
+
+def _one_rank_group(_rank, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    recs = [r.encode() for r in _tile_data(150)]
+    thirds = [recs[:50], recs[50:101], recs[101:]]
+    batches = [(torch.frombuffer(bytearray(b"".join(p)), dtype=torch.uint8), sum(len(x) for x in p)) for p in thirds]
+    assert any(n % 16 for _, n in batches[:-1])  # there is padding between the pieces
+    worker = OracleTileWorker()
+    worker.pad_pieces = True
+    res = shard.tile_sharded(worker, dist, 0, 1, batches, 0, "cpu", consume=True)
+    out = worker.emit()
+    whole = shard.gather_ordered_output(worker, dist, 0, 1, out, res["keys"][:, 3].contiguous(), res["offsets"], res["total"], "cpu")
+    with open(os.path.join(tmpdir, "tiled.paf"), "wb") as fh:
+        fh.write(bytes(whole.numpy().tobytes()))
+    dist.destroy_process_group()
+
+
+def test_one_rank_group_tiles_padded_pieces_in_place(tmp_path):
+    """A process group of ONE rank (bench.py --force-dist): the splitter's send buffer holds the batches as 16-byte aligned pieces with
+    padding between them; nothing travels, and the pieces -- not the buffer as one run of text -- are what is tiled. (Round 3: the
+    10 M-record cfg5 run over RCCL at world size 1 read the padded buffer as contiguous text and failed on its last record.)"""
+    mp.spawn(_one_rank_group, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    want, err = O.tile("".join(_tile_data(150)).encode())
+    assert err.code == 0
+    assert (tmp_path / "tiled.paf").read_bytes() == want
