@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="stream workloads: contexts that take the batches in turn, each on its own HIP stream, so that the sizing pass of batch k + 1 runs beside "
                          "the writers of batch k (1 = one context, batches strictly one after the other)")
+    ap.add_argument("--fresh-memory", action="store_true", help="cfg5: return torch's cached blocks to the driver between steps (outside the timed region)")
     ap.add_argument("--tile-text-batch", type=int, default=200_000, help="cfg5: records per text batch handed to the library (each batch stays below 2 GiB)")
     ap.add_argument("--verify", action="store_true", help="cfg5: gather the ordered output of the last step on rank 0 and compare it with a one-process tile of the same records (small --batch only)")
     ap.add_argument("--rehearse", action="store_true",
@@ -341,7 +342,10 @@ def bench_tile(args, wl, rank, world, dist, dev):
     eng.profile(False)
     elapsed, last, kernels, each = 0.0, None, {}, []
     for i in range(n_steps):
-        last = None  # the step before: its output and keys are let go before this step's input is generated
+        last = res = out = None  # the step before: its output, keys and text are let go before this step's input is generated
+        worker.release()
+        if args.fresh_memory:
+            torch.cuda.empty_cache()  # untimed: the step then allocates its buffers from the driver, as the first tile of a process does
         batches, first = share(i)
         if i == 0:
             head = bytes(batches[0][0][: min(batches[0][1], 4 << 20)].cpu().numpy().tobytes())

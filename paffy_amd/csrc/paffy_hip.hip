@@ -156,77 +156,141 @@ __device__ int64_t parse_i64_dev(const uint8_t *in, uint32_t p, uint32_t e) {
  * paf_parse, impl/paf.c:137-209: tokens are the non-empty gaps between consecutive separators of
  * the line (strtok_r collapses runs of tabs). Tag tokens shorter than 5 bytes are never
  * recognised (documented deviation: the reference reads past the token there).
+ *
+ * 32 lanes per record, one separator (= one token) per lane and round: a token's field number is the count of non-empty tokens in
+ * front of it (ballot + popcount), every lane parses its own token and drops the result into the record's RecMeta image in LDS, the
+ * image leaves as 36 coalesced words. The reference stops at the first token it aborts on (strand, tp): tokens behind the first
+ * failing one are ignored; of several tags of one kind the last one wins. (The one-lane-per-record version of rounds 1-2 needed 256
+ * registers -- one wave per SIMD -- and 0.16 ms per 131 072 records.)
  */
+#define HDR_GROUP 32u
 __global__ __launch_bounds__(PAFFY_NT) void k_header(const uint8_t *in, const uint32_t *sep_pos, const uint32_t *nl_idx, uint32_t n_lines,
                                                       RecMeta *meta, uint32_t *big_list, DevInfo *info, uint32_t lvl0_max) {
-    const uint32_t r = blockIdx.x * PAFFY_NT + threadIdx.x;
-    if (r >= n_lines) return;
-    const uint32_t s_end = nl_idx[r];
-    const uint32_t s_begin = r == 0 ? 0 : nl_idx[r - 1] + 1;
-    uint32_t tok = r == 0 ? 0 : sep_pos[nl_idx[r - 1]] + 1;
-    RecMeta m;
-    memset(&m, 0, sizeof(m));
-    m.tile_level = -1;
-    m.chain_id = -1;
-    m.chain_score = -1;
-    int field = 0;
-    for (uint32_t si = s_begin; si <= s_end && m.err == 0; si++) {
-        const uint32_t te = sep_pos[si];
-        const uint32_t t = tok;
-        tok = te + 1;
-        if (te == t) continue; /* empty token */
-        switch (field) {
-            case 0: m.qname_off = t; m.qname_len = te - t; break;
-            case 1: m.qlen = parse_i64_dev(in, t, te); break;
-            case 2: m.qs = parse_i64_dev(in, t, te); break;
-            case 3: m.qe = parse_i64_dev(in, t, te); break;
-            case 4: {
-                uint8_t c = in[t];
-                if (c != '+' && c != '-') {
-                    m.err = PAFFY_ERR_STRAND;
-                    m.err_aux = c;
+    constexpr uint32_t kWords = sizeof(RecMeta) / 4; /* 36 */
+    static_assert(sizeof(RecMeta) % 4 == 0 && kWords > 32 && kWords <= 64, "the image is written as two words per lane at most");
+    __shared__ __attribute__((aligned(16))) RecMeta image[PAFFY_NT / HDR_GROUP];
+    const uint32_t g = threadIdx.x / HDR_GROUP, gl = threadIdx.x % HDR_GROUP;
+    const uint32_t r = blockIdx.x * (PAFFY_NT / HDR_GROUP) + g;
+    const bool live = r < n_lines;
+    const uint32_t shift = (threadIdx.x & 32u); /* this group's half of the wave's 64-bit ballots */
+    RecMeta *m = &image[g];
+    uint32_t *mw = reinterpret_cast<uint32_t *>(m);
+    mw[gl] = 0;
+    if (gl + 32 < kWords) mw[32 + gl] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (gl == 0) {
+        m->tile_level = -1;
+        m->chain_id = -1;
+        m->chain_score = -1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t s_end = 0, s_begin = 1;
+    if (live) {
+        s_end = nl_idx[r];
+        s_begin = r == 0 ? 0 : nl_idx[r - 1] + 1;
+    }
+    uint32_t n_fields = 0; /* non-empty tokens taken so far (group-uniform) */
+    int32_t err = 0;       /* group-uniform */
+    for (uint32_t c = s_begin; c <= s_end && err == 0; c += HDR_GROUP) { /* s_end - s_begin < 2^31: no wrap */
+        const uint32_t si = c + gl;
+        const bool valid = live && si <= s_end && si >= c;
+        uint32_t te = 0, t = 0;
+        if (valid) {
+            te = sep_pos[si];
+            t = si == 0 ? 0u : sep_pos[si - 1] + 1u; /* the separator in front of a line's first token is the newline of the line before */
+        }
+        bool on = valid && te > t;
+        const uint32_t ne = (uint32_t)(__ballot(on) >> shift);
+        const uint32_t field = n_fields + (uint32_t)__popc(ne & ((1u << gl) - 1u));
+        /* what this token is */
+        int kind = -1; /* 0..5: tp AS cg tl cn s1 */
+        int32_t my_err = 0, my_aux = 0;
+        int64_t val = 0;
+        uint32_t v_off = 0;
+        uint8_t c0 = 0;
+        if (on) {
+            if (field < 12) {
+                if (field == 4) {
+                    c0 = in[t];
+                    if (c0 != '+' && c0 != '-') {
+                        my_err = PAFFY_ERR_STRAND;
+                        my_aux = c0;
+                    }
+                } else if (field != 0 && field != 5) {
+                    val = parse_i64_dev(in, t, te);
                 }
-                m.same_strand = c == '+';
-                break;
-            }
-            case 5: m.tname_off = t; m.tname_len = te - t; break;
-            case 6: m.tlen = parse_i64_dev(in, t, te); break;
-            case 7: m.ts = parse_i64_dev(in, t, te); break;
-            case 8: m.te = parse_i64_dev(in, t, te); break;
-            case 9: m.nmatch = parse_i64_dev(in, t, te); break;
-            case 10: m.nbases = parse_i64_dev(in, t, te); break;
-            case 11: m.mapq = parse_i64_dev(in, t, te); break;
-            default: {
-                if (te - t < 5 || in[t + 2] != ':' || in[t + 4] != ':') break;
+            } else if (te - t >= 5 && in[t + 2] == ':' && in[t + 4] == ':') {
                 const uint8_t t0 = in[t], t1 = in[t + 1];
-                const uint32_t v = t + 5;
+                v_off = t + 5;
                 if (t0 == 't' && t1 == 'p') {
-                    m.type = v < te ? in[v] : 0;
-                    if (m.type != 'P' && m.type != 'S' && m.type != 'I') {
-                        m.err = PAFFY_ERR_TP_ASSERT;
-                        m.err_aux = m.type;
+                    kind = 0;
+                    c0 = v_off < te ? in[v_off] : 0;
+                    if (c0 != 'P' && c0 != 'S' && c0 != 'I') {
+                        my_err = PAFFY_ERR_TP_ASSERT;
+                        my_aux = c0;
                     }
                 } else if (t0 == 'A' && t1 == 'S') {
-                    m.score = parse_i64_dev(in, v, te);
+                    kind = 1;
                 } else if (t0 == 'c' && t1 == 'g') {
-                    m.has_cg = 1; /* last cg tag wins (impl/paf.c:193-198) */
-                    m.cg_off = v;
-                    m.cg_len = te - v;
+                    kind = 2;
                 } else if (t0 == 't' && t1 == 'l') {
-                    m.tile_level = parse_i64_dev(in, v, te);
+                    kind = 3;
                 } else if (t0 == 'c' && t1 == 'n') {
-                    m.chain_id = parse_i64_dev(in, v, te);
+                    kind = 4;
                 } else if (t0 == 's' && t1 == '1') {
-                    m.chain_score = parse_i64_dev(in, v, te);
+                    kind = 5;
                 }
+                if (kind == 1 || kind >= 3) val = parse_i64_dev(in, v_off, te);
             }
         }
-        field++;
+        /* the reference never sees a token behind the first one it aborts on */
+        const uint32_t em = (uint32_t)(__ballot(my_err != 0) >> shift);
+        if (em) {
+            const uint32_t first = (uint32_t)__ffs((int)em) - 1u;
+            on = on && gl <= first;
+            err = __shfl(my_err, (int)(first + shift), 64);
+            const int32_t aux = __shfl(my_aux, (int)(first + shift), 64);
+            if (gl == first) {
+                m->err = err;
+                m->err_aux = aux;
+            }
+        }
+        const uint32_t taken = (uint32_t)(__ballot(on) >> shift);
+        n_fields += (uint32_t)__popc(taken);
+        if (on && field < 12) {
+            switch (field) {
+                case 0: m->qname_off = t; m->qname_len = te - t; break;
+                case 4: m->same_strand = c0 == '+'; break;
+                case 5: m->tname_off = t; m->tname_len = te - t; break;
+                default: (&m->qlen)[field <= 3 ? field - 1 : field - 3] = val; break; /* qlen qs qe | tlen ts te nmatch nbases mapq */
+            }
+        }
+        /* of several tags of one kind the last one wins: the highest lane writes */
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const uint32_t km = (uint32_t)(__ballot(on && kind == k) >> shift);
+            if (km && gl == 31u - (uint32_t)__clz((int)km)) {
+                if (k == 0) m->type = c0;
+                else if (k == 1) m->score = val;
+                else if (k == 2) { m->has_cg = 1; m->cg_off = v_off; m->cg_len = te - v_off; } /* impl/paf.c:193-198 */
+                else if (k == 3) m->tile_level = val;
+                else if (k == 4) m->chain_id = val;
+                else m->chain_score = val;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    if (m.err == 0 && field < 12) m.err = PAFFY_ERR_FEW_FIELDS;
-    meta[r] = m;
+    if (!live) return;
+    if (err == 0 && n_fields < 12) {
+        err = PAFFY_ERR_FEW_FIELDS;
+        if (gl == 0) m->err = err;
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t *dst = reinterpret_cast<uint32_t *>(meta + r);
+    dst[gl] = mw[gl];
+    if (gl + 32 < kWords) dst[32 + gl] = mw[32 + gl];
     /* long cigars go straight to the sizing launch with the bigger LDS store (runs beside the main one) */
-    if (m.err == 0 && (m.cg_len >> 1) > lvl0_max) big_list[atomicAdd(&info->b_count[0], 1u)] = r;
+    if (gl == 0 && err == 0 && (m->cg_len >> 1) > lvl0_max) big_list[atomicAdd(&info->b_count[0], 1u)] = r;
 }
 
 /* ------------------------------------------------------------------ */
@@ -695,6 +759,19 @@ static void prof_collect(paffy_hip_ctx *c) {
 
 extern "C" {
 
+/* Experiments only: extra dynamic LDS per workgroup of the row writer (0), the one-wave sizing launch (1) and the four-wave sizing launch (2)
+   of the lean pipes, from PAFFY_DBG_LDS_PAD="emit,size64,size256" (bytes) -- lowers a kernel's occupancy so that two contexts' kernels can be
+   resident on a CU at the same time (bench.py --pipeline 2). */
+static size_t dbg_lds_pad(int which) {
+    static long pad[3] = {-1, 0, 0};
+    if (pad[0] < 0) {
+        pad[0] = 0;
+        const char *e = getenv("PAFFY_DBG_LDS_PAD");
+        if (e) sscanf(e, "%ld,%ld,%ld", &pad[0], &pad[1], &pad[2]);
+        for (int k = 0; k < 3; k++) pad[k] = pad[k] < 0 ? 0 : pad[k] & ~15l;
+    }
+    return (size_t)pad[which];
+}
 int paffy_hip_create(paffy_hip_ctx **out, int device) {
     if (!out) return PAFFY_E_ARG;
     if (device >= 0 && hipSetDevice(device) != hipSuccess) return PAFFY_E_HIP;
@@ -714,10 +791,12 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_walk<true>), hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(CovWalkLds));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cov_walk<false>), hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(CovWalkLds));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_LEAN>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_LEAN>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES + dbg_lds_pad(2));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_ADD>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds<PAFFY_MASK_SEL>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds_long<PAFFY_MASK_PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds_long<PAFFY_MASK_SEL>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds_long<PAFFY_MASK_ADD>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds_long<PAFFY_MASK_ALL>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_size_lds_long<PAFFY_MASK_LEAN>), hipFuncAttributeMaxDynamicSharedMemorySize, PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG));
@@ -816,7 +895,7 @@ static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, ui
     LAUNCH(c, "k_sep_write", k_sep_write, dim3(n_tiles), dim3(PAFFY_NT), 0, in, len, static_cast<const uint2 *>(c->tile_counts.p),
            static_cast<uint32_t *>(c->sep_pos.p), static_cast<uint32_t *>(c->nl_idx.p));
     if (n_lines > 0)
-        LAUNCH(c, "k_header", k_header, dim3((n_lines + PAFFY_NT - 1) / PAFFY_NT), dim3(PAFFY_NT), 0, in,
+        LAUNCH(c, "k_header", k_header, dim3((n_lines + PAFFY_NT / HDR_GROUP - 1) / (PAFFY_NT / HDR_GROUP)), dim3(PAFFY_NT), 0, in,
                static_cast<const uint32_t *>(c->sep_pos.p), static_cast<const uint32_t *>(c->nl_idx.p), n_lines,
                static_cast<RecMeta *>(c->meta.p), static_cast<uint32_t *>(c->b_list.p), static_cast<DevInfo *>(c->info.p), lvl0_max);
 
@@ -851,6 +930,8 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     for (int32_t i = 0; i < n_stages; i++) lean = lean && ((PAFFY_MASK_LEAN >> stages[i].kind) & 1u);
     bool lean_add = !lean; /* the lean kinds and add_mismatches: its own instantiation (the encoder wants the registers) */
     for (int32_t i = 0; i < n_stages; i++) lean_add = lean_add && ((PAFFY_MASK_ADD >> stages[i].kind) & 1u);
+    bool sel = !lean && !lean_add; /* the lean kinds with filter / trim -f / stats / check */
+    for (int32_t i = 0; i < n_stages; i++) sel = sel && ((PAFFY_MASK_SEL >> stages[i].kind) & 1u);
     bool plain = !lean; /* no stage of the kinds that came with the encoder: the instantiation without them */
     for (int32_t i = 0; i < n_stages; i++) plain = plain && ((PAFFY_MASK_PLAIN >> stages[i].kind) & 1u);
     c->planned = false;
@@ -962,6 +1043,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
                 k1.level = 1;
                 if (lean) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_LEAN>, dim3(768), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_MID), c->side, k1);
                 else if (lean_add) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_ADD>, dim3(768), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_MID), c->side, k1);
+                else if (sel) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_SEL>, dim3(768), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_MID), c->side, k1);
                 else if (plain) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_PLAIN>, dim3(768), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_MID), c->side, k1);
                 else hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_ALL>, dim3(768), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_MID), c->side, k1);
                 k1.ops_cap = PAFFY_OPS_CAP_BIG;
@@ -969,6 +1051,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
                 k1.level = 2;
                 if (lean) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_LEAN>, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), c->side, k1);
                 else if (lean_add) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_ADD>, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), c->side, k1);
+                else if (sel) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_SEL>, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), c->side, k1);
                 else if (plain) hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_PLAIN>, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), c->side, k1);
                 else hipLaunchKernelGGL(k_size_lds_long<PAFFY_MASK_ALL>, dim3(256), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES_FOR(PAFFY_OPS_CAP_BIG), c->side, k1);
                 HIPCHK(c, hipGetLastError());
@@ -982,13 +1065,15 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
                 KParams kw = kp;
                 kw.ops_cap = wave_cap_env;
                 const size_t wlds = (size_t)wave_cap_env * 4 + PAFFY_HALO + 64 * 16 + 64 * 8 + 64;
-                if (lean) LAUNCH(c, "k_size_wave", g64::k_size_lds<PAFFY_MASK_LEAN>, dim3(n_lines), dim3(64), wlds, kw);
+                if (lean) LAUNCH(c, "k_size_wave", g64::k_size_lds<PAFFY_MASK_LEAN>, dim3(n_lines), dim3(64), wlds + dbg_lds_pad(1), kw);
                 else if (lean_add) LAUNCH(c, "k_size_wave", g64::k_size_lds<PAFFY_MASK_ADD>, dim3(n_lines), dim3(64), wlds, kw);
+                else if (sel) LAUNCH(c, "k_size_wave", g64::k_size_lds<PAFFY_MASK_SEL>, dim3(n_lines), dim3(64), wlds, kw);
                 else if (plain) LAUNCH(c, "k_size_wave", g64::k_size_lds<PAFFY_MASK_PLAIN>, dim3(n_lines), dim3(64), wlds, kw);
                 else LAUNCH(c, "k_size_wave", g64::k_size_lds<PAFFY_MASK_ALL>, dim3(n_lines), dim3(64), wlds, kw);
             }
-            if (lean) LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_LEAN>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
+            if (lean) LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_LEAN>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES + dbg_lds_pad(2), kp);
             else if (lean_add) LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_ADD>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
+            else if (sel) LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_SEL>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             else if (plain) LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_PLAIN>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             else LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_ALL>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); /* join */
@@ -1735,7 +1820,7 @@ int paffy_hip_emit(paffy_hip_ctx *c, void *d_out, int64_t out_cap) {
     kp.out = static_cast<uint8_t *>(d_out);
     const bool shatter = kp.n_stages > 0 && kp.stages[kp.n_stages - 1].kind == PAFFY_SHATTER;
     if (shatter) {
-        LAUNCH(c, "k_emit_rows", k_emit_rows, dim3(kp.n_rec), dim3(64), PAFFY_ROWS_LDS_BYTES, kp);
+        LAUNCH(c, "k_emit_rows", k_emit_rows, dim3(kp.n_rec), dim3(64), PAFFY_ROWS_LDS_BYTES + dbg_lds_pad(0), kp);
         if (c->h_info->g_count > 0) LAUNCH(c, "k_emit_lds", k_emit_lds<true>, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
         if (c->h_info->w_count > 0) LAUNCH(c, "k_arena_emit", k_arena_emit<true>, dim3(2048), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
     } else {

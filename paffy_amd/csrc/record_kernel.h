@@ -2883,6 +2883,9 @@ __device__ __forceinline__ void load_state(const RecMeta &m, RecState &s) {
 #define PAFFY_MASK_ADD (PAFFY_MASK_LEAN | (1u << PAFFY_ADD_MISMATCHES))
 /* everything but the mismatch encoder, the stats sums and the trim by count: the pipes of filter, fixed trim, add_mismatches -a */
 #define PAFFY_MASK_PLAIN (PAFFY_MASK_ALL & ~((1u << PAFFY_ADD_MISMATCHES) | (1u << PAFFY_STATS) | (1u << PAFFY_TRIM_ENDS)))
+/* the selecting / measuring commands around the lean kinds (`filter`, `trim -f`, `view -s`, a bare paf_check): an instantiation of their own keeps
+   them free of the spills that the op-array rebuilding stages (remove_mismatches) bring into the general build */
+#define PAFFY_MASK_SEL (PAFFY_MASK_LEAN | (1u << PAFFY_FILTER) | (1u << PAFFY_TRIM_FIXED) | (1u << PAFFY_CHECK) | (1u << PAFFY_STATS))
 #define STAGE_ON(kind) ((MASK >> (kind)) & 1u)
 template <class OPS, uint32_t MASK = PAFFY_MASK_ALL>
 __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS &ops, uint32_t cap, const RecLds &L, uint32_t klass,
@@ -3077,11 +3080,12 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
             const int64_t ins = s.has_cigar ? all - v.tt : 0, del = s.has_cigar ? all - v.tq : 0;
             const double identity = ratio_f32(mm, mm + (mx - ins - del));
             const double identity_with_gaps = ratio_f32(mm, all);
-            const paffy_filter &f = P.filter;
-            const bool pass = s.score >= f.min_alignment_score && s.chain_score >= f.min_chain_score &&
-                              (f.max_tile_level == -1 || s.tile_level <= f.max_tile_level) && identity >= f.min_identity &&
-                              identity_with_gaps >= f.min_identity_with_gaps;
-            if (pass == (f.invert != 0)) { /* dropped: no output, later stages never see the record */
+            /* field by field: a reference to the struct inside the kernel arguments makes the compiler keep a private copy (36 bytes of scratch per lane) */
+            const int64_t f_as = P.filter.min_alignment_score, f_cs = P.filter.min_chain_score, f_tl = P.filter.max_tile_level;
+            const double f_id = P.filter.min_identity, f_idg = P.filter.min_identity_with_gaps;
+            const bool f_inv = P.filter.invert != 0;
+            const bool pass = s.score >= f_as && s.chain_score >= f_cs && (f_tl == -1 || s.tile_level <= f_tl) && identity >= f_id && identity_with_gaps >= f_idg;
+            if (pass == f_inv) { /* dropped: no output, later stages never see the record */
                 if (threadIdx.x == 0) {
                     RecPlan *dp = static_cast<RecPlan *>(P.rec_plan) + rec;
                     P.status[rec] = klass << 16;

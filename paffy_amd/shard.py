@@ -162,6 +162,19 @@ def owner_table(weights, world):
 EXCHANGE_CHUNK = 256 << 20  # bytes per send / receive operation
 
 
+def big_buffer_bytes(n):
+    """Size to allocate for a buffer that must hold n bytes of a rank's share (send, receive and output buffers): rounded up to 1/64 of
+    its size in 2 MiB units. A second tile of an input of about the same size (another step of the bench, another file of a pipeline)
+    then asks torch's caching allocator for the very block it let go -- a buffer a few kilobytes larger than the cached one cannot
+    use it, and with a share of 54 GB per buffer the allocator then has to return everything it caches to the driver and allocate
+    again (1.5 s per step in the 10 M-record run of round 3)."""
+    n = int(n)
+    if n < (64 << 20):
+        return n
+    unit = max(2 << 20, (n >> 6) >> 21 << 21)
+    return (n + unit - 1) // unit * unit
+
+
 def _pairwise_exchange(dist, rank, world, src, send_counts, dst, recv_counts, chunk, recv_offsets=None):
     """dst <- what every rank holds for this rank in src (both flat, grouped by peer, counts in elements): the all-to-all as explicit
     sends and receives per peer in pieces of at most `chunk` elements, the rank's own part as a plain copy. Over the nccl backend
@@ -224,7 +237,7 @@ def exchange_lines(dist, send_buf, send_bytes, send_gidx, send_records, comm_dev
         offs.append(at)
         at += (recv_bytes[r] + 15) // 16 * 16
     src = _comm(send_buf[: sum(send_bytes)], comm_device)
-    recv_buf = torch.empty(at + 16, dtype=torch.uint8, device=comm_device)
+    recv_buf = torch.empty(big_buffer_bytes(at + 16), dtype=torch.uint8, device=comm_device)
     _pairwise_exchange(dist, rank, world, src, list(send_bytes), recv_buf, recv_bytes, EXCHANGE_CHUNK, offs)
     for r in range(world):  # the few bytes between a segment's end and the next multiple of 16 are read with the segment's last chunk
         if recv_bytes[r] % 16:
@@ -341,9 +354,17 @@ class GpuTileWorker:
 
     def __init__(self, eng, batch_bytes=(1 << 30) + (1 << 29)):
         self.eng, self.batch_bytes, self.keep = eng, batch_bytes, []
+        self._recv = self.pieces = None
+
+    def release(self):
+        """Let go of the text of the last tile (the received lines stay referenced until then: emit() reads them)."""
+        self.keep = []
+        self._recv = None
+        self.pieces = None
 
     def query_names(self, batches):
         """-> ({name hash: bytes of its lines} over all batches, [per batch: {name hash: (bytes, lines)}])"""
+        self.release()  # a new input: the text of the tile before it is no longer needed (it would stand beside the new send buffer)
         out, per_batch = {}, []
         for buf, nbytes in batches:
             names = self.eng.query_names_counts(buf, nbytes)
@@ -378,7 +399,7 @@ class GpuTileWorker:
         # right there as text batches (`pieces`). Several ranks: the parts of a destination stand back to back, as they are sent.
         pad = (lambda x: (x + 15) // 16 * 16) if world == 1 else (lambda x: x)
         total = sum(pad(need_b[b][d]) for b in range(n_batches) for d in range(world))
-        send = t.empty((total + 15) // 16 * 16 + 16, dtype=t.uint8, device=dev)
+        send = t.empty(big_buffer_bytes((total + 15) // 16 * 16 + 16), dtype=t.uint8, device=dev)
         gidx = t.empty(max(1, total_r), dtype=t.int64, device=dev)
         at_b, at_r = [0] * world, [0] * world
         for d in range(1, world):
@@ -443,7 +464,7 @@ class GpuTileWorker:
 
     def emit(self):
         """-> uint8 tensor with this rank's output lines in its output order"""
-        out = self.eng.alloc_out(self.info.out_bytes)
+        out = self.eng.alloc_out(big_buffer_bytes(self.info.out_bytes))
         if self.info.out_bytes:
             self.eng.emit(out)
         return out[: self.info.out_bytes]
