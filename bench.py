@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="stream workloads: contexts that take the batches in turn, each on its own HIP stream, so that the sizing pass of batch k + 1 runs beside "
                          "the writers of batch k (1 = one context, batches strictly one after the other)")
-    ap.add_argument("--fresh-memory", action="store_true", help="cfg5: return torch's cached blocks to the driver between steps (outside the timed region)")
+    ap.add_argument("--keep-cache", action="store_true", help="cfg5: do not return torch's cached blocks to the driver between steps (experiments only)")
     ap.add_argument("--tile-text-batch", type=int, default=200_000, help="cfg5: records per text batch handed to the library (each batch stays below 2 GiB)")
     ap.add_argument("--verify", action="store_true", help="cfg5: gather the ordered output of the last step on rank 0 and compare it with a one-process tile of the same records (small --batch only)")
     ap.add_argument("--rehearse", action="store_true",
@@ -344,8 +344,11 @@ def bench_tile(args, wl, rank, world, dist, dev):
     for i in range(n_steps):
         last = res = out = None  # the step before: its output, keys and text are let go before this step's input is generated
         worker.release()
-        if args.fresh_memory:
-            torch.cuda.empty_cache()  # untimed: the step then allocates its buffers from the driver, as the first tile of a process does
+        if not args.keep_cache:
+            # untimed: torch's cached blocks go back to the driver, so the step allocates its buffers as the first tile of a process does.
+            # (Left cached, the blocks of the step before fit this step's slightly different sizes only by luck; with a share of 54 GB per
+            # buffer the allocator then frees and re-allocates everything inside the timed region: 2.3 s instead of 0.73 s per step.)
+            torch.cuda.empty_cache()
         batches, first = share(i)
         if i == 0:
             head = bytes(batches[0][0][: min(batches[0][1], 4 << 20)].cpu().numpy().tobytes())

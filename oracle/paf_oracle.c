@@ -923,6 +923,11 @@ static int loc_cmp(const rec *a, int64_t a_te, int64_t a_qe, int64_t a_ptr, cons
     return i;
 }
 
+/* Tests only: 0 restates the search WITHOUT the walk from a fresh iterator (no candidate at all when no active chain sorts <= the key):
+   what the GPU does on those inputs, see DESIGN 5. The default (1) is the reference as read. */
+static int g_chain_fresh_walk = 1;
+void po_set_chain_fresh_walk(int on) { g_chain_fresh_walk = on; }
+
 static int64_t chain_gap_cost(int64_t dq, int64_t dt, int64_t gap_open, int64_t gap_extend) { /* impl/paf_chain.c:36-45 */
     return dq + dt == 0 ? 0 : gap_open + gap_extend * (dq + dt);
 }
@@ -969,7 +974,7 @@ static void chain_one_strand(rec *recs, int64_t *list, int64_t n, int64_t gap_op
             else hi = mid;
         }
         int fresh = lo == 0;
-        int64_t it = fresh ? n_act - 1 : lo - 1; /* fresh iterator: getPrevious gives the last element (libavl avl_t_prev) */
+        int64_t it = fresh ? (g_chain_fresh_walk ? n_act - 1 : -1) : lo - 1; /* fresh iterator: getPrevious gives the last element (libavl avl_t_prev) */
         for (; it >= 0; it--) {
             ochain *pc = &ch[act[it]];
             const rec *pp = &recs[pc->rec];

@@ -462,6 +462,19 @@ class GpuTileWorker:
             raise RuntimeError(f"tile failed on this rank: code {self.info.error.code} at local record {self.info.error.record}")
         return self.eng.tile_keys(self.info.n_rows)
 
+    def tile_direct(self, batches, consume=False):
+        """paffy tile over text batches [(uint8 tensor, bytes)] as they are (16-byte aligned, whole lines, below 2 GiB each): what a
+        single rank does, no partition. Same return value as tile(). consume: the list is emptied (the worker holds the batches until
+        the lines have been written -- the text is read where it is)."""
+        self.release()
+        self.keep = [(buf, n) for buf, n in batches if n]
+        if consume:
+            del batches[:]
+        self.info = self.eng.tile_batches(self.keep)
+        if self.info.error.code:
+            raise RuntimeError(f"tile failed on this rank: code {self.info.error.code} at local record {self.info.error.record}")
+        return self.eng.tile_keys(self.info.n_rows)
+
     def emit(self):
         """-> uint8 tensor with this rank's output lines in its output order"""
         out = self.eng.alloc_out(big_buffer_bytes(self.info.out_bytes))
@@ -502,6 +515,16 @@ def tile_sharded(worker, dist, rank, world, batches, first_record, comm_device="
             timing[name] = timing.get(name, 0.0) + (t1 - t0) * 1e3
             t0 = t1
 
+    if world == 1 and hasattr(worker, "tile_direct"):
+        # One rank owns every query sequence: there is nothing to partition, the batches are tiled where they are (the reference's
+        # single process, impl/paf_tile.c:156-178). The key exchange and the offsets below are the N-rank code with N = 1.
+        keys = worker.tile_direct(batches, consume)
+        lap("tile_ms")
+        k4 = torch.stack([keys[:, 0], keys[:, 1], keys[:, 2] + first_record, keys[:, 3]], dim=1) if keys.shape[0] else torch.zeros(0, 4, dtype=torch.int64, device=keys.device)
+        all_keys, owner = gather_tile_keys(dist, k4, comm_device)
+        offsets, total = global_line_offsets(all_keys, owner, rank)
+        lap("keys_ms")
+        return {"offsets": offsets, "total": total, "keys": keys, "owner_of": None, "timing": timing, "hbm_peak": peak[0] or None, "hbm_live_peak": live[0] or None}
     local, per_batch = worker.query_names(batches)
     weights = merge_name_weights(dist, local, comm_device)
     owner_of = owner_table(weights, world)

@@ -188,8 +188,13 @@ def pretty_print(line, query_seq, target_seq, include_alignment=True):
     return rc, _take(out, n)
 
 
-def chain(data, gap_open=5000, gap_extend=1, max_gap=1000000, trim=1.0):
-    """`paffy chain` (impl/paf_chain.c defaults). Returns (output, error, fresh_hits)."""
+def chain(data, gap_open=5000, gap_extend=1, max_gap=1000000, trim=1.0, fresh_walk=True):
+    """`paffy chain` (impl/paf_chain.c defaults). Returns (output, error, fresh_hits). fresh_walk=False: the search without the walk from
+    a fresh iterator (impl/chaining.c:74-76) -- the GPU's behaviour on the inputs where that walk sees a candidate."""
     out, n, fresh, err = C.c_void_p(), C.c_int64(), C.c_int64(), Error()
-    lib().po_chain(data, len(data), gap_open, gap_extend, max_gap, trim, C.byref(out), C.byref(n), C.byref(fresh), C.byref(err))
+    lib().po_set_chain_fresh_walk(1 if fresh_walk else 0)
+    try:
+        lib().po_chain(data, len(data), gap_open, gap_extend, max_gap, trim, C.byref(out), C.byref(n), C.byref(fresh), C.byref(err))
+    finally:
+        lib().po_set_chain_fresh_walk(1)
     return _take(out, n), err, fresh.value

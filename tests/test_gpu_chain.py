@@ -72,12 +72,31 @@ def test_random_sets_match_the_oracle(eng, seed, kw):
         data = collinear_set(rng, n, exact=0.0 if seed % 2 else 0.3, score_hi=50 if seed == 6 else 20000)
         want, err, fresh = O.chain(data, **kw)
         assert err.code == 0
-        if fresh:
-            continue  # the reference's fresh-iterator walk saw a candidate: an address tie, not restated on the GPU
         got, info = eng.chain(data, **kw)
+        if fresh:
+            # the reference's fresh-iterator walk saw a candidate (an exactly abutting alignment that stands later in the input): the GPU
+            # applies the "largest active chain <= key" rule without that walk -- DESIGN 5; what it writes is pinned all the same
+            want2, err2, _ = O.chain(data, fresh_walk=False, **kw)
+            assert err2.code == 0 and got == want2, (seed, n)
+            continue
         assert got == want, (seed, n)
         compared += 1
     assert compared >= 3
+
+
+def test_abutting_alignment_later_in_the_input(eng):
+    """The one place where `paffy chain` here is known to differ from the reference as read: B abuts A exactly on both sequences
+    and stands BEFORE A in the input. The reference's search for the largest active chain <= (B.ts, B.qs, &B) finds none (A's address is
+    higher), takes a fresh sonLib iterator and -- libavl's avl_t_prev on a fresh traverser gives the LAST element -- walks the whole set
+    from its top: A is chained to B (s1 200). The GPU keeps to the <= rule: two chains of one record. With A first in the input both agree."""
+    a, b = line("q", 0, 100, "t", 0, 100, 100), line("q", 100, 200, "t", 100, 200, 100)
+    want, err, fresh = O.chain(b + a, trim=0.0)
+    assert err.code == 0 and fresh == 1 and want.count(b"s1:i:200") == 2
+    want_gpu, _, _ = O.chain(b + a, trim=0.0, fresh_walk=False)
+    got, _ = eng.chain(b + a, trim=0.0)
+    assert got == want_gpu and got.count(b"s1:i:100") == 2
+    want, err, fresh = O.chain(a + b, trim=0.0)
+    assert fresh == 0 and eng.chain(a + b, trim=0.0)[0] == want and want.count(b"s1:i:200") == 2
 
 
 def test_batches_cli_and_errors(eng, tmp_path):

@@ -343,3 +343,20 @@ def test_dedupe_known_answer():
     assert err.code == 0 and out.splitlines() == [written(x) for x in (a, a_minus, a_inv)]
     out, err = O.dedupe(data, check_inverse=True)
     assert err.code == 0 and out.splitlines() == [written(x) for x in (a, a_minus)]
+
+
+def test_chain_fresh_iterator_walk_is_the_only_switchable_part():
+    """impl/chaining.c:74-76: when no active chain sorts <= the key the reference walks the set from a fresh iterator (libavl: from its
+    last element). The oracle restates that walk and counts its candidates; with the walk switched off (what the GPU implements,
+    DESIGN 5) the same input gives two chains of one record instead of one chain of two. Inputs without such candidates do not depend
+    on the switch."""
+    def ln(qs, qe, ts, te):
+        return f"q\t1000\t{qs}\t{qe}\t+\tt\t1000\t{ts}\t{te}\t{qe - qs}\t{qe - qs}\t60\tAS:i:100\tcg:Z:{qe - qs}M\n".encode()
+    a, b = ln(0, 100, 0, 100), ln(100, 200, 100, 200)
+    out, err, fresh = O.chain(b + a, trim=0.0)
+    assert err.code == 0 and fresh == 1 and out.count(b"cn:i:0\ts1:i:200") == 2
+    out2, err2, fresh2 = O.chain(b + a, trim=0.0, fresh_walk=False)
+    assert err2.code == 0 and fresh2 == 0 and out2.count(b"s1:i:100") == 2 and b"cn:i:1" in out2
+    for fw in (True, False):  # A first: the ordinary search finds it
+        out3, _, fresh3 = O.chain(a + b, trim=0.0, fresh_walk=fw)
+        assert fresh3 == 0 and out3.count(b"s1:i:200") == 2
