@@ -275,6 +275,7 @@ def main():
                 cpu = cpu_baseline(eng, wl, stages, args.cpu_sample)
                 cpu_all = cpu_baseline_all_cores(eng, wl, stages, max(1024, args.cpu_sample // 8))
                 e2e = end_to_end(eng, stages, batches[:2], args.batch)
+                e2e["link"] = pcie_probe(dev)
         line = {
             "metric": "PAF records/sec (shatter+invert+trim pipe); % HBM roofline at 1/2/4/8 GPU",
             "value": round(records / elapsed, 1),
@@ -718,6 +719,33 @@ def end_to_end(eng, stages, batches, batch_records):
     dt = time.perf_counter() - t0
     return {"value": round(records / dt, 1), "unit": "records/s", "sample": f"{len(chunks)} batches of {batch_records} records as host bytes: "
             f"{sum(len(c) for c in chunks)} B over PCIe in, {out_bytes} B out, {dt:.2f} s", "GBps_out": round(out_bytes / dt / 1e9, 2)}
+
+
+def pcie_probe(dev, mib=256, reps=4):
+    """What the link of THIS box gives a plain pinned copy, each direction alone (the end_to_end leg is bounded by the D2H figure: its
+    output is 23 times its input): 256 MiB pinned <-> device, the best of `reps` copies, timed with events on the current stream."""
+    import torch
+
+    n = mib << 20
+    host = torch.empty(n, dtype=torch.uint8).pin_memory()
+    devb = torch.empty(n, dtype=torch.uint8, device=dev)
+    out = {}
+    for name, dst, src in (("h2d_GBps", devb, host), ("d2h_GBps", host, devb)):
+        best = 0.0
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dst.copy_(src, non_blocking=True)
+            e1.record()
+            e1.synchronize()
+            best = max(best, n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        out[name] = round(best, 2)
+    out["copy_MiB"] = mib
+    try:
+        out["host_cpus"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        out["host_cpus"] = os.cpu_count()
+    return out
 
 
 def cpu_baseline_tile(eng, wl, n):
