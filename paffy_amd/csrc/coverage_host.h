@@ -158,7 +158,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_line_emit(const uint8_t *const *ba
     uint8_t *o = out + (out_off[k] - base_off);
     RecState s;
     tile_state(m, level[order[k]], s);
-    const uint32_t hl = header_len(s, false) + (m.has_cg ? 6u : 0u), cl = m.has_cg ? m.cg_len : 0;
+    const uint32_t hl = header_len_wave(s, false) + (m.has_cg ? 6u : 0u), cl = m.has_cg ? m.cg_len : 0;
     const bool direct = hl > 3 * PAFFY_TMPL_MAX; /* header longer than the LDS staging: built in place */
     {
         Piece w{direct ? o : hdr, 0, direct ? hl : 3 * PAFFY_TMPL_MAX, false};

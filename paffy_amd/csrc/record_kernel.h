@@ -2647,22 +2647,94 @@ __device__ __forceinline__ void shatter_emit_direct(const KParams &P, const RecS
 }
 
 /* Header of paf_write_to_buffer up to (and including) "\tcg:Z:" -- impl/paf.c:317-368. */
+/*
+ * The line in front of the cigar (paf_write, impl/paf.c:317-368), one ITEM per lane (round 3): the twelve fields, the five optional
+ * tags, the cigar's tag name and the newline are nineteen items; lane k turns item k into text -- one decimal conversion per lane
+ * instead of twelve to seventeen wave-uniform ones, each computed by all 64 lanes (about 2 000 instructions per record: a third of the
+ * one-wave line writer's time on cfg3 records, most of the tile writer's) --, a wave scan of the lengths places the items, every lane
+ * drops its bytes, the two names are copied by all lanes.
+ */
+struct HeaderItem {
+    int64_t val;      /* numeric items */
+    uint64_t pre;     /* up to seven bytes in front of the number: the tab, a tag's name */
+    uint32_t plen;
+    uint32_t name_len; /* items 0 and 5: the query / target name follows the prefix */
+    bool numeric, present;
+};
+__device__ constexpr uint64_t header_tag6(char a, char b, char t) {
+    return 0x09ull | ((uint64_t)(uint8_t)a << 8) | ((uint64_t)(uint8_t)b << 16) | ((uint64_t)':' << 24) | ((uint64_t)(uint8_t)t << 32) | ((uint64_t)':' << 40);
+}
+__device__ __forceinline__ HeaderItem header_item(const RecState &s, bool newline, uint32_t k) {
+    HeaderItem it;
+    it.val = 0; it.pre = '\t'; it.plen = 1; it.name_len = 0; it.numeric = true; it.present = k < 12;
+    const int64_t f[12] = {0, s.qlen, s.qs, s.qe, 0, 0, s.tlen, s.ts, s.te, s.nmatch, s.nbases, s.mapq};
+#pragma unroll
+    for (uint32_t j = 1; j < 12; j++)
+        if (k == j) it.val = f[j];
+    if (k == 0) { it.numeric = false; it.plen = 0; it.name_len = s.qn_len; }
+    if (k == 4) { it.numeric = false; it.pre = (uint64_t)'\t' | ((uint64_t)(s.same ? '+' : '-') << 8); it.plen = 2; }
+    if (k == 5) { it.numeric = false; it.name_len = s.tn_len; }
+    if (k == 12) { /* impl/paf.c:343-348 */
+        uint32_t t = s.type;
+        if (t == 0) t = s.tile_level > 1 ? 'S' : 'P';
+        it.present = s.type != 0 || s.tile_level != -1;
+        it.numeric = false;
+        it.pre = header_tag6('t', 'p', 'A') | ((uint64_t)t << 48);
+        it.plen = 7;
+    }
+    if (k == 13) { it.present = s.score != 2147483647ll; it.pre = header_tag6('A', 'S', 'i'); it.plen = 6; it.val = s.score; } /* INT_MAX guard, impl/paf.c:349 */
+    if (k == 14) { it.present = s.tile_level != -1; it.pre = header_tag6('t', 'l', 'i'); it.plen = 6; it.val = s.tile_level; }
+    if (k == 15) { it.present = s.chain_id != -1; it.pre = header_tag6('c', 'n', 'i'); it.plen = 6; it.val = s.chain_id; }
+    if (k == 16) { it.present = s.chain_score != -1; it.pre = header_tag6('s', '1', 'i'); it.plen = 6; it.val = s.chain_score; }
+    if (k == 17) { it.present = s.has_cigar; it.numeric = false; it.pre = header_tag6('c', 'g', 'Z'); it.plen = 6; }
+    if (k == 18) { it.present = newline; it.numeric = false; it.pre = '\n'; }
+    return it;
+}
+__device__ __forceinline__ void header_put(uint8_t *p, uint32_t cap, uint32_t at, uint64_t w, uint32_t n) { /* n <= 8 bytes of w at p[at ..) */
+#pragma unroll
+    for (uint32_t b = 0; b < 8; b++)
+        if (b < n && at + b < cap) p[at + b] = (uint8_t)(w >> (8 * b));
+}
 __device__ __forceinline__ void build_header(Piece &w, const RecState &s, const uint8_t *in, bool newline) {
-    w.name(in, s.qn_off, s.qn_len);
-    w.ch('\t'); w.num(s.qlen);
-    w.ch('\t'); w.num(s.qs);
-    w.ch('\t'); w.num(s.qe);
-    w.ch('\t'); w.ch(s.same ? '+' : '-');
-    w.ch('\t'); w.name(in, s.tn_off, s.tn_len);
-    w.ch('\t'); w.num(s.tlen);
-    w.ch('\t'); w.num(s.ts);
-    w.ch('\t'); w.num(s.te);
-    w.ch('\t'); w.num(s.nmatch);
-    w.ch('\t'); w.num(s.nbases);
-    w.ch('\t'); w.num(s.mapq);
-    piece_tags(w, s, s.chain_score);
-    if (s.has_cigar) w.str("\tcg:Z:", 6);
-    if (newline) w.ch('\n');
+    const uint32_t lane = threadIdx.x & 63u;
+    const HeaderItem it = header_item(s, newline, lane);
+    DecText d;
+    dec_text(it.val, d);
+    const uint32_t len = it.present ? it.plen + it.name_len + (it.numeric ? text_len(d) : 0u) : 0u;
+    const uint32_t inc = wave_incl_scan_u32(len), total = wave_last_u32(inc);
+    const uint32_t at0 = w.n + inc - len;
+    if (w.n + total > w.cap) w.over = true;
+    if (it.present) {
+        uint32_t at = at0;
+        header_put(w.p, w.cap, at, it.pre, it.plen);
+        at += it.plen;
+        if (it.numeric) {
+            if (d.neg_separate) {
+                header_put(w.p, w.cap, at, '-', 1);
+                at += 1;
+            }
+            header_put(w.p, w.cap, at, d.top, d.ntop);
+            at += d.ntop;
+            if (d.groups == 2) {
+                header_put(w.p, w.cap, at, ascii8(d.g1), 8);
+                at += 8;
+            }
+            if (d.groups >= 1) header_put(w.p, w.cap, at, ascii8(d.g0), 8);
+        }
+    }
+    /* the names, by all lanes: the query name opens the line, the target name follows item 5's tab */
+    const uint32_t t_at = w.n + (uint32_t)__shfl((int)(inc - len), 5) + 1u;
+    for (uint32_t i = lane; i < s.qn_len; i += 64)
+        if (w.n + i < w.cap) w.p[w.n + i] = in[s.qn_off + i];
+    for (uint32_t i = lane; i < s.tn_len; i += 64)
+        if (t_at + i < w.cap) w.p[t_at + i] = in[s.tn_off + i];
+    w.n += total;
+}
+/* the same items' lengths, one per lane: for the callers that are whole waves */
+__device__ __forceinline__ uint32_t header_len_wave(const RecState &s, bool newline) {
+    const HeaderItem it = header_item(s, newline, threadIdx.x & 63u);
+    const uint32_t len = it.present ? it.plen + it.name_len + (it.numeric ? (uint32_t)dec_len(it.val) : 0u) : 0u;
+    return wave_last_u32(wave_incl_scan_u32(len));
 }
 __device__ uint32_t header_len(const RecState &s, bool newline) {
     uint32_t n = s.qn_len + s.tn_len + 12 + dec_len(s.qlen) + dec_len(s.qs) + dec_len(s.qe) + dec_len(s.tlen) + dec_len(s.ts) +
@@ -2700,6 +2772,82 @@ __device__ __forceinline__ int64_t cigar_text_len(const View<OPS> &v, RecPlan *p
  * the sizing pass) and streams it through its own LDS ring in windows of WRITE_PER ops per lane, with
  * no workgroup barrier; wave 0 first sends the header in 1 KiB windows.
  */
+/*
+ * Cigar text of the one-wave line writer, one op per lane and step (round 3). The funnel below gives every lane sixteen consecutive
+ * ops and a 64-bit accumulator: three sweeps over them, a store decision per op -- about 130 instructions per op and lane, 1.8 ms for
+ * the 1.2 GB of a cfg4 batch. Here the 64 lanes take 64 consecutive ops: length and letter become at most five characters (lengths
+ * below 10^4: one 4-digit BCD conversion), an inclusive scan of the character counts places them, and the characters are dropped at
+ * their bytes of the ring with ds_write_b8 -- the one LDS store that runs at full rate at any byte address. Sixteen steps make a
+ * window (the op words of all of them are requested together, then waited for once); the window leaves through the emitter as before.
+ * Returns the first op it did not write: a window with a length of five digits or more is left to the funnel.
+ */
+#define TEXT_STEPS 16u
+template <bool WRAP>
+__device__ __forceinline__ uint32_t text_window_steps(const View<OpsGlobal> &v, uint32_t i, uint32_t w, const uint32_t (&raw)[TEXT_STEPS], uint8_t *ring, uint32_t pos_r) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t done = 0; /* bytes of the steps before (wave-uniform) */
+    const uint32_t steps = (w + 63u) >> 6;
+#pragma unroll
+    for (uint32_t st = 0; st < TEXT_STEPS; st++) {
+        if (st >= steps) continue; /* wave-uniform; no break: the loop must unroll for raw[] to stay in registers */
+        const uint32_t j = i + 64u * st + lane;
+        const bool has = j < i + w;
+        const uint32_t r = v.raw_index(j);
+        uint32_t op = raw[st] & 7u;
+        op ^= v.swp ? ((0x6u >> op) & 1u) * 3u : 0u; /* I <-> D */
+        const uint32_t x = (raw[st] >> 3) - (r == v.lo ? (uint32_t)v.sub_lo : 0u) - (r == v.lo + v.n - 1 ? (uint32_t)v.sub_hi : 0u);
+        const uint32_t nd = 1u + (x >= 10u) + (x >= 100u) + (x >= 1000u);
+        const uint32_t digits = (bcd4(x) + 0x30303030u) >> (8u * (4u - nd)); /* most significant digit in byte 0 */
+        const uint32_t letter = op < 4u ? (0x3d44494du >> (8u * op)) & 0xffu : (op == 4u ? (uint32_t)'X' : (uint32_t)'N'); /* M I D = X, impl/paf.c:372-379 */
+        const bool nl = has && j + 1u == v.n; /* the record's last op takes the newline along */
+        const uint32_t n = has ? nd + 1u + (nl ? 1u : 0u) : 0u;
+        const uint32_t inc = wave_incl_scan_u32(n);
+        uint32_t a = pos_r + done + inc - n;
+        if (WRAP && a >= PAFFY_WAVE_RING) a -= PAFFY_WAVE_RING;
+        done += wave_last_u32(inc);
+        if (has) {
+#define TEXT_PUT(k, val)                                                      \
+    {                                                                         \
+        uint32_t a_ = a + (k);                                                \
+        if (WRAP && a_ >= PAFFY_WAVE_RING) a_ -= PAFFY_WAVE_RING;             \
+        ring[a_] = (uint8_t)(val);                                            \
+    }
+            TEXT_PUT(0u, digits)
+            if (nd > 1u) TEXT_PUT(1u, digits >> 8)
+            if (nd > 2u) TEXT_PUT(2u, digits >> 16)
+            if (nd > 3u) TEXT_PUT(3u, digits >> 24)
+            TEXT_PUT(nd, letter)
+            if (nl) TEXT_PUT(nd + 1u, '\n')
+#undef TEXT_PUT
+        }
+    }
+    return done;
+}
+template <class EM>
+__device__ __forceinline__ uint32_t cigar_text_fast(const View<OpsGlobal> &v, uint32_t wb, uint32_t we, EM &em) {
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t i = wb;
+    while (i < we) {
+        const uint32_t w = we - i < 64u * TEXT_STEPS ? we - i : 64u * TEXT_STEPS;
+        uint32_t raw[TEXT_STEPS];
+        bool short_lens = true;
+#pragma unroll
+        for (uint32_t st = 0; st < TEXT_STEPS; st++) {
+            const uint32_t j = i + 64u * st + lane;
+            raw[st] = j < i + w ? v.ops.raw(v.raw_index(j)) : 0u;
+        }
+#pragma unroll
+        for (uint32_t st = 0; st < TEXT_STEPS; st++) short_lens = short_lens && (raw[st] >> 3) < 10000u; /* the ends' cuts only shorten */
+        if (!__all(short_lens)) break;
+        uint32_t bytes;
+        if (em.pos_r + 6u * w + 8u <= PAFFY_WAVE_RING) bytes = text_window_steps<false>(v, i, w, raw, em.ring, em.pos_r);
+        else bytes = text_window_steps<true>(v, i, w, raw, em.ring, em.pos_r);
+        em.commit(bytes); /* its wave barrier orders the byte stores before the flush's reads */
+        i += w;
+    }
+    return i;
+}
+
 #define WRITE_PER 16u
 template <class OPS>
 __device__ __forceinline__ void write_emit_range(const View<OPS> &v, uint32_t wb, uint32_t we, bool with_header, const uint64_t *H, uint32_t lenH,
@@ -2729,6 +2877,9 @@ __device__ __forceinline__ void write_emit_range(const View<OPS> &v, uint32_t wb
     const uint32_t cap_bytes = PAFFY_WAVE_RING - 32;
     const uint32_t w_full = 64 * WRITE_PER, w_safe = cap_bytes / 21; /* an op prints as at most 20 + 1 bytes */
     uint32_t i = wb, w_try = w_full;
+#ifndef PAFFY_NO_TEXT_FAST
+    if constexpr (std::is_same<OPS, OpsGlobal>::value) i = cigar_text_fast(v, wb, we, em); /* what it leaves (a length of five digits or more) follows below */
+#endif
     while (i < we) {
         const uint32_t w = we - i < w_try ? we - i : w_try;
         const uint32_t per = (w + 63) / 64;
@@ -3150,7 +3301,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
         }
     } else {
         const bool nl_in_header = !(s.has_cigar && v.n > 0);
-        const uint32_t lenH = header_len(s, nl_in_header);
+        const uint32_t lenH = header_len(s, nl_in_header); /* not header_len_wave: its items cost the mismatch encoder's build eleven registers (and a wave per SIMD) */
         direct = lenH > 3 * PAFFY_TMPL_MAX; /* header too long for the LDS staging: built straight in HBM */
         line_kernel = OPS::kNarrow && lenH + 8 <= PAFFY_TMPL_MAX && v.n <= PAFFY_ROWS_MAX_OPS; /* written by k_emit_line */
         bytes = lenH;
@@ -3256,7 +3407,7 @@ __device__ __forceinline__ void emit_record(const KParams &P, uint32_t rec, cons
         shatter_emit(s, v, k, pieces, pl, L.ring, P.out, (uint64_t)P.out_off[rec]);
     } else {
         const bool nl_in_header = !(s.has_cigar && v.n > 0);
-        const uint32_t lenH = header_len(s, nl_in_header);
+        const uint32_t lenH = header_len_wave(s, nl_in_header);
         const bool direct = (pl.flags & 32u) != 0;
         if (threadIdx.x < 64) { /* wave 0 builds the header: in LDS, or straight in the output when it is too long */
             Piece w{direct ? P.out + P.out_off[rec] : (uint8_t *)L.pieces, 0, direct ? lenH : 3 * PAFFY_TMPL_MAX, false};
@@ -3481,7 +3632,7 @@ __global__ __launch_bounds__(64, PAFFY_EMIT_OCC) void k_emit_line(KParams P) {
     v.lo = pl.lo; v.rev = pl.flags & 1u; v.swp = (pl.flags & 2u) != 0;
     v.sub_lo = pl.sub_lo; v.sub_hi = pl.sub_hi;
     const bool nl_in_header = !(s.has_cigar && v.n > 0);
-    const uint32_t lenH = header_len(s, nl_in_header);
+    const uint32_t lenH = header_len_wave(s, nl_in_header);
     uint64_t *H = reinterpret_cast<uint64_t *>(smem + PAFFY_WAVE_RING);
     {
         Piece w{(uint8_t *)H, 0, PAFFY_TMPL_MAX, false};
