@@ -3546,6 +3546,60 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_EMIT_OCC) void k_emit_lds(KParams P
  * 10^11, ops in the HBM mirror). The per-record preparation runs once instead of once per wave of a workgroup,
  * there is no barrier at all, and the kernel carries none of the general paths.
  */
+/*
+ * The three constant pieces of a record's rows (paf_shatter2 + paf_write, impl/paf.c:600-627, 317-368) for the one-wave row kernel, 64 zero
+ * filled bytes each at p, p + 64, p + 128 -- one item per lane like build_header: thirteen items, one decimal conversion per lane
+ * (the Piece form converted the three to five numbers one after the other, each in all 64 lanes). Pieces are at most 48 bytes here.
+ */
+__device__ __forceinline__ void row_pieces_lanes(uint8_t *p, const RecState &s, const uint8_t *in) {
+    const uint32_t k = threadIdx.x & 63u;
+    if (k < 12) reinterpret_cast<uint4 *>(p)[k] = make_uint4(0, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier(); /* a wave's LDS operations execute in order */
+    HeaderItem it;
+    it.val = 0; it.pre = '\t'; it.plen = 1; it.name_len = 0; it.numeric = false; it.present = k < 13;
+    if (k == 0) { it.plen = 0; it.name_len = s.qn_len; }
+    if (k == 1) { it.numeric = true; it.val = s.qlen; }
+    if (k == 3) { it.pre = (uint64_t)'\t' | ((uint64_t)(s.same ? '+' : '-') << 8) | ((uint64_t)'\t' << 16); it.plen = 3; it.name_len = s.tn_len; }
+    if (k == 4) { it.numeric = true; it.val = s.tlen; }
+    if (k == 6) { it.numeric = true; it.val = s.mapq; }
+    if (k >= 7 && k <= 11) { /* the tags of header_item(), children carry s1:i:0 (calloc, impl/paf.c:601) */
+        RecState c = s;
+        c.chain_score = 0;
+        it = header_item(c, false, k + 5u);
+    }
+    if (k == 12) { it.pre = header_tag6('c', 'g', 'Z'); it.plen = 6; }
+    DecText d;
+    dec_text(it.val, d);
+    const uint32_t len = it.present ? it.plen + it.name_len + (it.numeric ? text_len(d) : 0u) : 0u;
+    const uint32_t inc = wave_incl_scan_u32(len), ex = inc - len;
+    const uint32_t seg = k < 3 ? 0u : (k < 6 ? 1u : 2u);
+    const uint32_t seg_first = seg == 0 ? 0u : (seg == 1 ? 3u : 6u);
+    const uint32_t at0 = ex - (uint32_t)__shfl((int)ex, (int)seg_first);
+    uint8_t *q = p + 64u * seg;
+    if (it.present) {
+        uint32_t at = at0;
+        header_put(q, 64, at, it.pre, it.plen);
+        at += it.plen;
+        if (it.numeric) {
+            if (d.neg_separate) {
+                header_put(q, 64, at, '-', 1);
+                at += 1;
+            }
+            header_put(q, 64, at, d.top, d.ntop);
+            at += d.ntop;
+            if (d.groups == 2) {
+                header_put(q, 64, at, ascii8(d.g1), 8);
+                at += 8;
+            }
+            if (d.groups >= 1) header_put(q, 64, at, ascii8(d.g0), 8);
+        }
+    }
+    const uint32_t t_at = (uint32_t)__shfl((int)at0, 3) + 3u; /* the target name follows "\t+\t" */
+    for (uint32_t i = k; i < s.qn_len; i += 64)
+        if (i < 64) p[i] = in[s.qn_off + i];
+    for (uint32_t i = k; i < s.tn_len; i += 64)
+        if (t_at + i < 64) p[64 + t_at + i] = in[s.tn_off + i];
+}
 #define PAFFY_ROWS_LDS_BYTES (PAFFY_WAVE_RING + 3 * 64 + 64)
 #ifndef PAFFY_ROWS_OCC
 #define PAFFY_ROWS_OCC 4
@@ -3573,26 +3627,7 @@ __global__ __launch_bounds__(64, PAFFY_ROWS_OCC) void k_emit_rows(KParams P) {
     ShatterConst k;
     shatter_consts(s, k);
     uint8_t *A = smem + PAFFY_WAVE_RING, *B = A + 64, *C = B + 64;
-    {
-        Piece w{A, 0, 64, false};
-        w.name(P.in, s.qn_off, s.qn_len);
-        w.ch('\t'); w.num(s.qlen); w.ch('\t');
-        w.pad_to(64);
-    }
-    {
-        Piece w{B, 0, 64, false};
-        w.ch('\t'); w.ch(s.same ? '+' : '-'); w.ch('\t');
-        w.name(P.in, s.tn_off, s.tn_len);
-        w.ch('\t'); w.num(s.tlen); w.ch('\t');
-        w.pad_to(64);
-    }
-    {
-        Piece w{C, 0, 64, false};
-        w.ch('\t'); w.num(s.mapq);
-        piece_tags(w, s, 0);
-        w.str("\tcg:Z:", 6);
-        w.pad_to(64);
-    }
+    row_pieces_lanes(A, s, P.in); /* A = qname \t qlen \t | B = \t strand \t tname \t tlen \t | C = \t mapq tags \tcg:Z: -- 64 bytes each, zero filled */
     __builtin_amdgcn_wave_barrier();
 #if defined(PAFFY_ABL) && PAFFY_ABL == 24 /* core clock against the 100 MHz wall clock inside the row kernel */
     const unsigned long long c0 = clock64(), w0 = wall_clock64();
