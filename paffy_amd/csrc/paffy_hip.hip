@@ -131,6 +131,111 @@ __global__ __launch_bounds__(PAFFY_NT) void k_sep_write(const uint8_t *in, uint3
     }
 }
 
+/*
+ * The separator index in ONE pass over the text (round 3; k_sep_count / k_scan_tiles / k_sep_write above read it twice and are kept for
+ * the first batch of a context, whose separator density is not known yet). A workgroup takes the next 64 KiB tile from a ticket
+ * counter, keeps the tab / newline masks of its sixteen rounds in registers (two 16-bit masks per round and thread), turns the counts
+ * into positions inside the tile with ONE workgroup scan (the per-round counts are laid out in LDS in text order, every thread sums
+ * sixteen consecutive entries; the two-pass version ran a workgroup scan per round), learns the number of separators and lines in
+ * front of its tile by decoupled look-back over the tiles' published counts (a tile publishes its own counts at once and the running
+ * totals as soon as it knows them; tiles are handed out in dispatch order, so a tile only ever waits for tiles that are running), and
+ * writes the positions. Capacities are the caller's guess: nothing is written past them, the totals tell the host whether to repeat.
+ */
+#define SEP_AGG (1ull << 62)
+#define SEP_INC (2ull << 62)
+__device__ __forceinline__ unsigned long long sep_pack(uint32_t seps, uint32_t lines) { return (unsigned long long)seps | ((unsigned long long)lines << 31); }
+__global__ __launch_bounds__(PAFFY_NT) void k_sep_index(const uint8_t *in, uint32_t in_len, uint32_t n_tiles, unsigned long long *state, uint32_t *sep_pos,
+                                                         uint32_t cap_seps, uint32_t *nl_idx, uint32_t cap_lines, DevInfo *info) {
+    __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
+    __shared__ uint32_t pref[16][PAFFY_NT]; /* per round and thread: separators | newlines << 16 -- first the counts, then the exclusive prefix inside the tile */
+    __shared__ uint32_t s_tile, s_base[2];
+    BlockComm scratch{scratch_mem, 0};
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(reinterpret_cast<unsigned int *>(state), 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile, tile0 = tile * SEP_TILE;
+    unsigned long long *status = state + 1;
+    uint32_t m[16];
+#pragma unroll
+    for (uint32_t it = 0; it < 16; it++) {
+        uint32_t a, b;
+        sep_masks(in, in_len, tile0 + it * (PAFFY_NT * 16u) + tid * 16u, a, b);
+        m[it] = a | (b << 16);
+        pref[it][tid] = (uint32_t)__popc(a) | ((uint32_t)__popc(b) << 16);
+    }
+    __syncthreads();
+    /* entries in text order: e = round * 256 + thread; this thread sums entries [16 tid, 16 tid + 16) (at most 256 per field: no carry) */
+    const uint32_t r_j = tid >> 4, t_j = (tid & 15u) * 16u;
+    uint32_t loc[16], run = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+        loc[k] = run;
+        run += pref[r_j][t_j + k];
+    }
+    uint32_t v[2] = {run & 0xffffu, run >> 16}, tot[2];
+    block_excl_scan_u32<2>(v, tot, scratch);
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) pref[r_j][t_j + k] = (v[0] + (loc[k] & 0xffffu)) | ((v[1] + (loc[k] >> 16)) << 16); /* below 65 536 each */
+    /* a final line without '\n' still is a record (impl/paf.c:213): virtual newline at in_len */
+    const bool virt = tile == n_tiles - 1 && in_len > 0 && in[in_len - 1] != '\n';
+    const uint32_t t_seps = tot[0] + (virt ? 1u : 0u), t_lines = tot[1] + (virt ? 1u : 0u);
+    if (wave == 0) {
+        uint32_t e_seps = 0, e_lines = 0;
+        if (tile > 0) {
+            if (lane == 0) __hip_atomic_store(&status[tile], SEP_AGG | sep_pack(t_seps, t_lines), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t look = (int64_t)tile - 1;
+            for (;;) {
+                const int64_t idx = look - (int64_t)lane;
+                unsigned long long sv = SEP_INC; /* in front of tile 0: nothing */
+                if (idx >= 0) sv = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__any((sv >> 62) == 0)) continue; /* a tile in the window has not published yet: it is running, ask again */
+                const unsigned long long inc = __ballot((sv >> 62) == 2);
+                const uint32_t first = inc ? (uint32_t)__ffsll((long long)inc) - 1u : 63u; /* nearest tile that knows its running totals */
+                const bool use = lane <= first;
+                uint32_t a = use ? (uint32_t)(sv & 0x7fffffffull) : 0u, b = use ? (uint32_t)((sv >> 31) & 0x7fffffffull) : 0u;
+                a = wave_last_u32(wave_incl_scan_u32(a));
+                b = wave_last_u32(wave_incl_scan_u32(b));
+                e_seps += a;
+                e_lines += b;
+                if (inc) break;
+                look -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&status[tile], SEP_INC | sep_pack(e_seps + t_seps, e_lines + t_lines), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base[0] = e_seps;
+            s_base[1] = e_lines;
+            if (tile == n_tiles - 1) {
+                info->n_seps = e_seps + t_seps;
+                info->n_lines = e_lines + t_lines;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t e_seps = s_base[0], e_lines = s_base[1];
+#pragma unroll
+    for (uint32_t it = 0; it < 16; it++) {
+        uint32_t a = m[it] & 0xffffu;
+        const uint32_t b = m[it] >> 16, g = tile0 + it * (PAFFY_NT * 16u) + tid * 16u, pp = pref[it][tid];
+        uint32_t si = e_seps + (pp & 0xffffu), li = e_lines + (pp >> 16);
+        while (a) {
+            const int j = __ffs((int)a) - 1;
+            a &= a - 1;
+            if (si < cap_seps) sep_pos[si] = g + j;
+            if (b & (1u << j)) {
+                if (li < cap_lines) nl_idx[li] = si;
+                li++;
+            }
+            si++;
+        }
+    }
+    if (virt && tid == 0) {
+        const uint32_t si = e_seps + tot[0], li = e_lines + tot[1];
+        if (si < cap_seps) sep_pos[si] = in_len;
+        if (li < cap_lines) nl_idx[li] = si;
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /* header fields                                                        */
 /* ------------------------------------------------------------------ */
@@ -639,6 +744,7 @@ struct paffy_hip_ctx {
     hipStream_t side = nullptr; /* sizing launches of the long-cigar records run here, beside the main launch */
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string last_error;
+    double sep_guess_per_mib = 0, line_guess_per_mib = 0; /* separators / lines per MiB of the last batch indexed: sizes the one-pass index of the next */
     DevBuf tile_counts, sep_pos, nl_idx, meta, out_len, out_rows, status, err_aux, n_ops, arena_off, out_off, w_list, b_list, b_list1, arena, info, synth_sizes, rec_plan, ops_mirror, seq_blob, seq_table, seq_names, seq_name_off, rec_qseq, rec_tseq, seq_comp;
     int32_t n_seqs = 0;
     DevBuf synth4_contigs, synth4_q, synth4_t; /* cfg4 workload tables (paffy_hip_synth4_setup) */
@@ -866,16 +972,44 @@ static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, ui
     memset(&zero, 0, sizeof(zero));
     zero.first_err_key = ~0ull;
     HIPCHK(c, hipMemcpyAsync(c->info.p, &zero, sizeof(zero), hipMemcpyHostToDevice, c->stream));
-    if (ensure(c, c->tile_counts, sizeof(uint2) * n_tiles)) return PAFFY_E_HIP;
-    LAUNCH(c, "k_sep_count", k_sep_count, dim3(n_tiles), dim3(PAFFY_NT), 0, in, len, static_cast<uint2 *>(c->tile_counts.p));
-    LAUNCH(c, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(PAFFY_NT), 0, static_cast<uint2 *>(c->tile_counts.p), n_tiles,
-           static_cast<DevInfo *>(c->info.p));
-    if (fetch_info(c)) return PAFFY_E_HIP;
-    const uint32_t n_seps = c->h_info->n_seps, n_lines = c->h_info->n_lines;
+    /* One pass (k_sep_index) when the separator density of this context's batches is known from the batch before: the index buffers are
+       sized by that guess, the kernel writes nothing past them and reports the true counts; a batch that needs more is indexed again
+       with exact sizes. The first batch of a context (no guess) takes the two-pass form, which sizes the buffers exactly. */
+    uint32_t n_seps = 0, n_lines = 0;
+    bool indexed = false;
+    if (c->sep_guess_per_mib > 0 && !getenv("PAFFY_TWO_PASS_INDEX")) {
+        const double mib = (double)len / (1 << 20) + 1.0;
+        const size_t want_seps = (size_t)(c->sep_guess_per_mib * mib * 1.25) + 4096, want_lines = (size_t)(c->line_guess_per_mib * mib * 1.25) + 4096;
+        if (ensure(c, c->sep_pos, sizeof(uint32_t) * (want_seps + 1)) || ensure(c, c->nl_idx, sizeof(uint32_t) * (want_lines + 1)) ||
+            ensure(c, c->tile_counts, sizeof(unsigned long long) * ((size_t)n_tiles + 1)))
+            return PAFFY_E_HIP;
+        const uint32_t cap_seps = (uint32_t)std::min<size_t>(c->sep_pos.cap / sizeof(uint32_t), 0x7fffffffu), cap_lines = (uint32_t)std::min<size_t>(c->nl_idx.cap / sizeof(uint32_t), 0x7fffffffu);
+        HIPCHK(c, hipMemsetAsync(c->tile_counts.p, 0, sizeof(unsigned long long) * ((size_t)n_tiles + 1), c->stream));
+        LAUNCH(c, "k_sep_index", k_sep_index, dim3(n_tiles), dim3(PAFFY_NT), 0, in, len, n_tiles, static_cast<unsigned long long *>(c->tile_counts.p),
+               static_cast<uint32_t *>(c->sep_pos.p), cap_seps, static_cast<uint32_t *>(c->nl_idx.p), cap_lines, static_cast<DevInfo *>(c->info.p));
+        if (fetch_info(c)) return PAFFY_E_HIP;
+        n_seps = c->h_info->n_seps;
+        n_lines = c->h_info->n_lines;
+        indexed = n_seps <= cap_seps && n_lines <= cap_lines; /* otherwise: denser than the guess, once more below with exact sizes */
+    }
+    if (!indexed) {
+        if (ensure(c, c->tile_counts, sizeof(uint2) * n_tiles)) return PAFFY_E_HIP;
+        LAUNCH(c, "k_sep_count", k_sep_count, dim3(n_tiles), dim3(PAFFY_NT), 0, in, len, static_cast<uint2 *>(c->tile_counts.p));
+        LAUNCH(c, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(PAFFY_NT), 0, static_cast<uint2 *>(c->tile_counts.p), n_tiles,
+               static_cast<DevInfo *>(c->info.p));
+        if (fetch_info(c)) return PAFFY_E_HIP;
+        n_seps = c->h_info->n_seps;
+        n_lines = c->h_info->n_lines;
+        if (ensure(c, c->sep_pos, sizeof(uint32_t) * (size_t)(n_seps + 1))) return PAFFY_E_HIP;
+        if (ensure(c, c->nl_idx, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+    }
     *n_lines_out = n_lines;
+    {
+        const double mib = (double)len / (1 << 20) + 1.0;
+        c->sep_guess_per_mib = (double)n_seps / mib + 1.0;
+        c->line_guess_per_mib = (double)n_lines / mib + 1.0;
+    }
 
-    if (ensure(c, c->sep_pos, sizeof(uint32_t) * (size_t)(n_seps + 1))) return PAFFY_E_HIP;
-    if (ensure(c, c->nl_idx, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->meta, sizeof(RecMeta) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->b_list, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
     if (ensure(c, c->out_len, sizeof(int64_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
@@ -892,8 +1026,9 @@ static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, ui
     if (ensure(c, c->ops_mirror, sizeof(uint32_t) * ((size_t)len / 2 + 64))) return PAFFY_E_HIP;
     if (c->arena.cap == 0 && ensure(c, c->arena, (size_t)8 << 20)) return PAFFY_E_HIP;
 
-    LAUNCH(c, "k_sep_write", k_sep_write, dim3(n_tiles), dim3(PAFFY_NT), 0, in, len, static_cast<const uint2 *>(c->tile_counts.p),
-           static_cast<uint32_t *>(c->sep_pos.p), static_cast<uint32_t *>(c->nl_idx.p));
+    if (!indexed)
+        LAUNCH(c, "k_sep_write", k_sep_write, dim3(n_tiles), dim3(PAFFY_NT), 0, in, len, static_cast<const uint2 *>(c->tile_counts.p),
+               static_cast<uint32_t *>(c->sep_pos.p), static_cast<uint32_t *>(c->nl_idx.p));
     if (n_lines > 0)
         LAUNCH(c, "k_header", k_header, dim3((n_lines + PAFFY_NT / HDR_GROUP - 1) / (PAFFY_NT / HDR_GROUP)), dim3(PAFFY_NT), 0, in,
                static_cast<const uint32_t *>(c->sep_pos.p), static_cast<const uint32_t *>(c->nl_idx.p), n_lines,
