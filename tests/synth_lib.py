@@ -67,13 +67,21 @@ class Synth4:
         lib().psynth4_generate(self._h, r0, n, buf, total, threads)
         return buf.raw
 
-    def genomes(self):
-        """{name: bytes} for hs.chr1.. (query) and pt.chr1.. (target)."""
-        out = {}
-        for g, prefix in ((0, "hs.chr"), (1, "pt.chr")):
-            for c in range(self.n_contigs):
-                n = lib().psynth4_contig_len(self._h, g, c)
-                buf = C.create_string_buffer(n)
-                lib().psynth4_genome(self._h, g, c, buf)
-                out[f"{prefix}{c + 1}"] = buf.raw
-        return out
+    def genomes(self, threads=1):
+        """{name: bytes} for hs.chr1.. (query) and pt.chr1.. (target). threads > 1: the contigs are generated side by side (the C calls
+        release the GIL; a 250 Mb contig takes about 1.4 s on one core, the two 3.6 Gb genomes of cfg4 about 40 s)."""
+        jobs = [(g, c, f"{prefix}{c + 1}") for g, prefix in ((0, "hs.chr"), (1, "pt.chr")) for c in range(self.n_contigs)]
+
+        def one(job):
+            g, c, name = job
+            n = lib().psynth4_contig_len(self._h, g, c)
+            buf = (C.c_char * n)()
+            lib().psynth4_genome(self._h, g, c, buf)
+            return name, bytes(memoryview(buf))
+
+        if threads > 1:
+            from concurrent.futures import ThreadPoolExecutor
+
+            with ThreadPoolExecutor(threads) as pool:
+                return dict(pool.map(one, jobs))
+        return dict(one(j) for j in jobs)
