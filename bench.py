@@ -411,7 +411,7 @@ def bench_tile(args, wl, rank, world, dist, dev):
             dom = max(kernels, key=lambda k: kernels[k][0])
             ach = per_step / (step_ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": f"all kernels of one step on one rank (dominant: {dom})", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "step_kernels_ms": round(step_ms, 4), "dominant_kernel": dom,
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tile_step_traffic(args, kernels), "step_kernels_ms": round(step_ms, 4), "dominant_kernel": dom,
                         "dominant_avg_kernel_ms": round(kernels[dom][0] / max(1, kernels[dom][1]), 4), "algorithmic_bytes_per_launch": int(per_step),
                         "note": "algorithmic bytes = input lines + output lines + 4 B per aligned base (SURVEY 8d counts the counter of every aligned base as 2 B read + 2 B "
                                 "written in HBM; here a slice's counters live in LDS while its records are walked, so the walk itself moves one bit per base)"}
@@ -611,6 +611,22 @@ def rehearse(args):
     return 0 if ok else 1
 
 
+def tile_step_traffic(args, kernels):
+    """HBM bytes of one tile step: every kernel's measured bytes per launch (profiles/*traffic*.json of this workload and batch size) times
+    its launches per step. None when no such pass is committed or it misses one of the step's heavy kernels."""
+    label = {"k_tile_emit": "k_line_emit"}  # launch labels that differ from the kernel's name
+    total, seen = 0.0, False
+    for name, (ms, launches) in kernels.items():
+        t = measured_traffic(args, label.get(name, name))
+        if t is None:
+            if ms >= 1.0 * max(1, args.steps):  # a kernel of a millisecond or more per step without a figure: no total
+                return None
+            continue
+        seen = True
+        total += t * launches / max(1, args.steps)
+    return int(total) if seen else None
+
+
 def measured_traffic(args, kernel):
     """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process;
     tools/traffic_collect.py writes the files): the newest profiles/*traffic*.json taken on this workload and batch size."""
@@ -740,6 +756,29 @@ def pcie_probe(dev, mib=256, reps=4):
             e1.synchronize()
             best = max(best, n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
         out[name] = round(best, 2)
+    # the same D2H copy while the GPU is busy: a stream of HBM-saturating element-wise kernels on the current stream, the copies on a side
+    # stream. A box whose runtime moves pinned copies with its copy engines keeps (most of) the idle rate; where the copies are shader
+    # kernels they queue behind the compute -- which is what the end_to_end leg, whose copies run beside the row writer, then sees.
+    try:
+        busy = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize()
+        for _ in range(40):
+            busy.add_(1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(side):
+            e0.record()
+            for _ in range(2):
+                host.copy_(devb, non_blocking=True)
+            e1.record()
+        for _ in range(40):
+            busy.add_(1)
+        e1.synchronize()
+        out["d2h_GBps_gpu_busy"] = round(2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9, 2)
+        torch.cuda.synchronize()
+        del busy
+    except RuntimeError:
+        out["d2h_GBps_gpu_busy"] = None
     out["copy_MiB"] = mib
     try:
         out["host_cpus"] = len(os.sched_getaffinity(0))

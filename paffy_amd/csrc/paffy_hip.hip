@@ -147,7 +147,11 @@ __device__ __forceinline__ unsigned long long sep_pack(uint32_t seps, uint32_t l
 __global__ __launch_bounds__(PAFFY_NT) void k_sep_index(const uint8_t *in, uint32_t in_len, uint32_t n_tiles, unsigned long long *state, uint32_t *sep_pos,
                                                          uint32_t cap_seps, uint32_t *nl_idx, uint32_t cap_lines, DevInfo *info) {
     __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
-    __shared__ uint32_t pref[16][PAFFY_NT]; /* per round and thread: separators | newlines << 16 -- first the counts, then the exclusive prefix inside the tile */
+    /* per round and thread, in text order (entry e = round * 256 + thread): separators | newlines << 16 -- first the counts, then the
+       exclusive prefix inside the tile. One spare word per sixteen entries: a thread's sixteen consecutive entries are then 17 words from
+       its neighbour's, not 16 (sixteen lanes on four banks) */
+    __shared__ uint32_t pref[16 * PAFFY_NT + PAFFY_NT];
+#define SEP_PREF(e) pref[(e) + ((e) >> 4)]
     __shared__ uint32_t s_tile, s_base[2];
     BlockComm scratch{scratch_mem, 0};
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -161,21 +165,20 @@ __global__ __launch_bounds__(PAFFY_NT) void k_sep_index(const uint8_t *in, uint3
         uint32_t a, b;
         sep_masks(in, in_len, tile0 + it * (PAFFY_NT * 16u) + tid * 16u, a, b);
         m[it] = a | (b << 16);
-        pref[it][tid] = (uint32_t)__popc(a) | ((uint32_t)__popc(b) << 16);
+        SEP_PREF(it * PAFFY_NT + tid) = (uint32_t)__popc(a) | ((uint32_t)__popc(b) << 16);
     }
     __syncthreads();
     /* entries in text order: e = round * 256 + thread; this thread sums entries [16 tid, 16 tid + 16) (at most 256 per field: no carry) */
-    const uint32_t r_j = tid >> 4, t_j = (tid & 15u) * 16u;
     uint32_t loc[16], run = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 16; k++) {
         loc[k] = run;
-        run += pref[r_j][t_j + k];
+        run += pref[17u * tid + k]; /* = SEP_PREF(16 tid + k) */
     }
     uint32_t v[2] = {run & 0xffffu, run >> 16}, tot[2];
     block_excl_scan_u32<2>(v, tot, scratch);
 #pragma unroll
-    for (uint32_t k = 0; k < 16; k++) pref[r_j][t_j + k] = (v[0] + (loc[k] & 0xffffu)) | ((v[1] + (loc[k] >> 16)) << 16); /* below 65 536 each */
+    for (uint32_t k = 0; k < 16; k++) pref[17u * tid + k] = (v[0] + (loc[k] & 0xffffu)) | ((v[1] + (loc[k] >> 16)) << 16); /* below 65 536 each */
     /* a final line without '\n' still is a record (impl/paf.c:213): virtual newline at in_len */
     const bool virt = tile == n_tiles - 1 && in_len > 0 && in[in_len - 1] != '\n';
     const uint32_t t_seps = tot[0] + (virt ? 1u : 0u), t_lines = tot[1] + (virt ? 1u : 0u);
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_sep_index(const uint8_t *in, uint3
 #pragma unroll
     for (uint32_t it = 0; it < 16; it++) {
         uint32_t a = m[it] & 0xffffu;
-        const uint32_t b = m[it] >> 16, g = tile0 + it * (PAFFY_NT * 16u) + tid * 16u, pp = pref[it][tid];
+        const uint32_t b = m[it] >> 16, g = tile0 + it * (PAFFY_NT * 16u) + tid * 16u, pp = SEP_PREF(it * PAFFY_NT + tid);
         uint32_t si = e_seps + (pp & 0xffffu), li = e_lines + (pp >> 16);
         while (a) {
             const int j = __ffs((int)a) - 1;
@@ -234,6 +237,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_sep_index(const uint8_t *in, uint3
         if (si < cap_seps) sep_pos[si] = in_len;
         if (li < cap_lines) nl_idx[li] = si;
     }
+#undef SEP_PREF
 }
 
 /* ------------------------------------------------------------------ */

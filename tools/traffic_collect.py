@@ -21,9 +21,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("out")
     ap.add_argument("--workload", default="cfg3")
-    ap.add_argument("--batch", type=int, default=131072)
+    ap.add_argument("--batch", type=int, default=None, help="records per step (default: what bench.py uses for the workload: 131072, cfg5 2000000)")
     ap.add_argument("--steps", type=int, default=6)
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 2_000_000 if args.workload == "cfg5" else 131072
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.environ.setdefault("TMPDIR", "/tmp")
     sums, launches = {}, {}
