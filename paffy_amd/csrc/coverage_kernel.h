@@ -215,26 +215,42 @@ __global__ __launch_bounds__(PAFFY_NT) void k_cov_bitmap(CovParams P, int null_c
             serial = true;
             break;
         }
-        /* pass 1: my ops -> LDS, my sums */
-        int64_t sums[2] = {0, 0}, tots[2]; /* bases along the walked sequence, aligned bases */
+        /* pass 1, in two steps (round 3, as the sizing parser: a thread used to convert the numbers of its own 16 bytes in a loop over
+           its letters -- as many iterations as the densest 16 bytes of the wave hold letters): first every thread leaves the LDS
+           positions of its letters in the op list, at the ops' indices; then the round's ops are dealt out evenly, a run of consecutive
+           ops per thread -- the same run it walks again in pass 2 -- and converted where they stand */
         {
             uint32_t idx = cnt[0], mk = opmask;
             while (mk) {
                 const uint32_t j = (uint32_t)__ffs((int)mk) - 1u;
                 mk &= mk - 1u;
-                const uint32_t c = (w[j >> 2] >> ((j & 3u) * 8u)) & 0xffu;
+                ops[idx++] = PAFFY_HALO + tid * 16u + j;
+            }
+        }
+        __syncthreads();
+        const uint32_t n_round = ctot[0], per = (n_round + PAFFY_NT - 1u) / PAFFY_NT;
+        const uint32_t i0 = tid * per < n_round ? tid * per : n_round, i1 = i0 + per < n_round ? i0 + per : n_round;
+        int64_t sums[2] = {0, 0}, tots[2]; /* bases along the walked sequence, aligned bases */
+        {
+            uint32_t bad_at = 0xffffffffu, long_num = 0;
+            for (uint32_t i = i0; i < i1; i++) {
+                const uint32_t pos = (uint32_t)ops[i];
+                const uint32_t c = txt[pos];
                 int code = cov_op_code(c);
                 if (code < 0) {
-                    atomicMin(&sh->err_pos, g + j);
+                    const uint32_t at = tb + (pos - PAFFY_HALO);
+                    bad_at = at < bad_at ? at : bad_at;
                     code = OP_D;
                 }
                 uint32_t k;
-                const uint32_t len = number_before(txt, PAFFY_HALO + tid * 16u + j, &k);
-                if (k >= 8u) atomicOr(&sh->flags, 1u); /* eight digits or more: the serial path decides */
-                ops[idx++] = ((uint64_t)len << 8) | (uint64_t)code;
+                const uint32_t len = number_before(txt, pos, &k);
+                long_num |= k >= 8u ? 1u : 0u; /* eight digits or more: the serial path decides */
+                ops[i] = ((uint64_t)len << 8) | (uint64_t)code;
                 if (code != S.skip_op) sums[0] += len;
                 if (code == OP_M || code == OP_EQ || code == OP_X) sums[1] += len;
             }
+            if (bad_at != 0xffffffffu) atomicMin(&sh->err_pos, bad_at);
+            if (long_num) atomicOr(&sh->flags, 1u);
         }
         block_excl_scan<2>(sums, tots, bc);
         if (sh->flags & 1u) { /* uniform: written before the scan's barrier */
@@ -254,7 +270,6 @@ __global__ __launch_bounds__(PAFFY_NT) void k_cov_bitmap(CovParams P, int null_c
         /* pass 2: my ops again, from LDS, with their positions */
         if (any) {
             int64_t p = cur + sums[0];
-            const uint32_t i0 = cnt[0], i1 = cnt[0] + (uint32_t)__popc(opmask);
             for (uint32_t i = i0; i < i1; i++) {
                 const uint64_t o = ops[i];
                 const int code = (int)(o & 0xffu);

@@ -500,11 +500,18 @@ class Engine:
     def stream_host(self, stages, chunks, sink=None):
         """Push host chunks (bytes objects of whole lines) through paffy_hip_stream_*: pinned staging, H2D / kernels / D2H
         overlapped. sink(piece_bytes) gets the output pieces in order (default: they are only counted). Returns (records, output bytes)."""
+        import time
+
         L = lib()
         arr = (Stage * max(1, len(stages)))(*stages)
         st = C.c_void_p()
         cap0 = max(4096, max((len(c) for c in chunks), default=4096))
+        t_open = time.perf_counter()
         self._check(L.paffy_hip_stream_open(self._ctx, arr, len(stages), cap0, 64 << 20, C.byref(st)), "paffy_hip_stream_open")
+        # where the time of the call went: opening the stream pins its host buffers (two input slots, three output pieces) and allocates the
+        # device buffers -- once per process in the CLI, and seconds on some hosts; the host's copy of a chunk into its pinned slot
+        self.stream_seconds = {"open": time.perf_counter() - t_open, "input_copy": 0.0, "run": 0.0, "close": 0.0}
+        t_run = time.perf_counter()
         records = out_bytes = 0
 
         def drain():
@@ -525,7 +532,9 @@ class Engine:
                 buf = L.paffy_hip_stream_input(st, len(chunk), 0, C.byref(cap))
                 if not buf:
                     raise RuntimeError("paffy_hip_stream_input: no free slot")
+                t_in = time.perf_counter()
                 C.memmove(buf, chunk, len(chunk))
+                self.stream_seconds["input_copy"] += time.perf_counter() - t_in
                 info = PlanInfo()
                 self._check(L.paffy_hip_stream_submit(st, len(chunk), C.byref(info)), "paffy_hip_stream_submit")
                 if info.error.code:
@@ -536,8 +545,11 @@ class Engine:
                 pending = True
             if pending:
                 drain()
+            self.stream_seconds["run"] = time.perf_counter() - t_run
         finally:
+            t_close = time.perf_counter()
             L.paffy_hip_stream_close(st)
+            self.stream_seconds["close"] = time.perf_counter() - t_close
         return records, out_bytes
 
     # ---- per-kernel HIP-event timing ----
