@@ -29,7 +29,9 @@
 #define COV_WORDS (COV_SLICE / 32u)       /* bitmap words per slice */
 #define COV_NT 512                        /* threads of a slice workgroup: words tid and tid + 512 of the slice are this thread's */
 #define COV_NWAVE (COV_NT / 64)
-#define COV_HIST_W 256u                   /* levels the LDS histogram tells apart (index = level mod 256) */
+#ifndef COV_HIST_W
+#define COV_HIST_W 256u
+#endif                   /* levels the LDS histogram tells apart (index = level mod 256) */
 #define COV_BIAS 32769u                   /* LDS counters hold count + 32769: the clamped 16-bit add then stops at count 32766 (impl/paf.c:700) */
 
 #define COV_TEXT 4096u   /* cigar bytes per round of the bitmap kernel (256 threads x 16) */
@@ -587,7 +589,12 @@ __global__ __launch_bounds__(COV_NT, 4) void k_cov_walk(CovParams P, uint16_t *b
             }
             uint32_t *flat = &L.hist[j & 1u][0][0]; /* the buffer as COV_COPIES * COV_HIST_W / 2 plain counters */
             const uint32_t width = COV_COPIES * (COV_HIST_W / 2);
-            for (uint32_t i = tid; i < width; i += COV_NT) flat[i] = 0;
+            /* the WHOLE buffer goes back to zero, spare words included: a copy starts every COV_HIST_ROW words, so the walk above left this
+               entry's (aliased) levels in words up to COV_COPIES * COV_HIST_ROW. Rounds 2-3 cleared `width` words only: the last 28 words of
+               the last copy kept the counts and entry j + 2 read them as levels 100..127 (mod 128) of its own -- found by the soak at
+               445-fold coverage (tests/golden/fuzz/tile_r3_fail.paf), where an entry's levels first spread over more than COV_HIST_W */
+            const uint32_t whole = COV_COPIES * COV_HIST_ROW;
+            for (uint32_t i = tid; i < whole; i += COV_NT) flat[i] = 0;
             __syncthreads();
             const unsigned long long off = L.bcast;
             const bool room = off + n <= P.arena_cap;
@@ -598,7 +605,7 @@ __global__ __launch_bounds__(COV_NT, 4) void k_cov_walk(CovParams P, uint16_t *b
                     if (room) P.arena[off + (base - mn) + i] = (uint16_t)flat[i];
                 }
                 __syncthreads();
-                for (uint32_t i = tid; i < width; i += COV_NT) flat[i] = 0;
+                for (uint32_t i = tid; i < whole; i += COV_NT) flat[i] = 0;
                 __syncthreads();
             }
         }

@@ -138,6 +138,28 @@ def test_slices_piles_and_wide_level_spreads(eng):
     assert got.splitlines()[-1].split(b"\ttl:i:")[1].split(b"\t")[0] == b"4200"
 
 
+def test_records_behind_a_record_whose_levels_overflow_the_lds_histogram(eng):
+    """Round 3, found by the soak (tools/fuzz_gpu.py tile): a record whose new counts spread over more than the 256 levels of the LDS
+    histogram is re-histogrammed window by window, and that path cleared 1 024 of the buffer's 1 056 words -- the record two places
+    later in the same slice then read the stale words as levels 100..127 (mod 128) of its own and got a median one to four levels low.
+    The fixture is the input the soak failed on (1 500 records on one 70 000-base contig, 445-fold coverage, 28 wrong levels between
+    228 and 279); the constructed case puts many small records behind a wide one on a 300-step staircase."""
+    with open(os.path.join(GOLDEN, "fuzz", "tile_r3_fail.paf"), "rb") as fh:
+        data = fh.read()
+    got, info = check(eng, data)
+    assert info.n_rows == 1500
+    rng = random.Random(11)
+    stairs = [f"st\t100000\t{10 * k}\t{10 * k + 20000}\t+\tt\t9000000\t0\t20000\t20000\t20000\t60\tAS:i:{5000 - k}\tcg:Z:20000M\n" for k in range(300)]
+    stairs.append("st\t100000\t0\t24000\t-\tt\t9000000\t0\t24000\t24000\t24000\t60\tAS:i:1000\tcg:Z:24000M\n")  # meets levels 2 .. 301
+    for m in range(400):  # behind it, in the same slice: small records all over the staircase, the wide one in between again
+        a = rng.randrange(0, 22000)
+        n = rng.choice([8, 40, 300, 1500])
+        stairs.append(f"st\t100000\t{a}\t{a + n}\t{rng.choice('+-')}\tt\t9000000\t5\t{5 + n}\t{n}\t{n}\t60\tAS:i:{900 - m}\tcg:Z:{n}M\n")
+        if m % 50 == 49:
+            stairs.append(f"st\t100000\t0\t24000\t+\tt\t9000000\t0\t24000\t24000\t24000\t60\tAS:i:{900 - m}\tcg:Z:24000M\n")
+    check(eng, "".join(stairs).encode())
+
+
 def test_counters_saturate_at_32766(eng):
     """impl/paf.c:700: a counter stops at INT16_MAX - 1, and so do the levels."""
     one = b"deep\t10\t2\t4\t+\tt\t10\t0\t2\t2\t2\t60\tcg:Z:2M\n"
