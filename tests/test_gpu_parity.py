@@ -169,6 +169,41 @@ def test_edges(eng):
         check(eng, PIPES[name], tiny, name)
 
 
+def test_header_lines_of_many_tokens(eng):
+    """The header kernel takes 32 separators of a line per round (round 3): lines with dozens of tags, the recognised ones spread over
+    several rounds and repeated (the last one of a kind wins), runs of tabs inside and between rounds, a bad tp / strand token in the
+    second round (tokens behind it are ignored), short tokens, a cg tag that is not the last token."""
+    import random
+
+    rng = random.Random(3)
+    junk = ["NM:i:%d" % i for i in range(40)] + ["de:f:0.01", "zd:Z:x", "ab", "x", "tp:B:P", "AS:f:1.0", "s1:Z:9", ""]
+    lines = []
+    for k in range(300):
+        toks = [rng.choice(junk) for _ in range(rng.choice([0, 5, 19, 20, 21, 31, 32, 33, 64, 90]))]
+        for kind in ("AS:i:%d", "tl:i:%d", "cn:i:%d", "s1:i:%d"):
+            for _ in range(rng.choice([0, 1, 2, 3])):
+                toks.insert(rng.randrange(len(toks) + 1), kind % rng.randrange(-5, 500))
+        if rng.random() < 0.6:
+            toks.insert(rng.randrange(len(toks) + 1), "tp:A:" + rng.choice("PSI"))
+        cigs = ["cg:Z:5M"] * rng.choice([1, 1, 2]) + (["cg:Z:2M1I2M1D1M"] if rng.random() < 0.3 else [])
+        for c in cigs:
+            toks.insert(rng.randrange(len(toks) + 1), c)
+        last_cg = next(t for t in reversed(toks) if t.startswith("cg:Z:"))  # the last cg tag is the record's cigar (impl/paf.c:193-198)
+        qe, te = (6, 6) if last_cg == "cg:Z:2M1I2M1D1M" else (5, 5)
+        head = ["q%d" % k, "100", "0", str(qe), rng.choice("+-"), "t", "100", "0", str(te), "5", "5", "60"]
+        sep = lambda: "\t" * rng.choice([1, 1, 1, 2, 3])  # noqa: E731
+        line = head[0]
+        for t in head[1:] + toks:
+            line += sep() + t
+        lines.append(line.encode() + b"\n")
+    data = b"".join(lines)
+    for name in ("pass", "invert", "shatter"):
+        check(eng, PIPES[name], data, name)
+    # a token the reference aborts on, in the second round of its line: everything in front is written, the codes agree
+    bad_tp = b"q\t100\t0\t5\t+\tt\t100\t0\t5\t5\t5\t60\t" + b"\t".join(b"NM:i:%d" % i for i in range(30)) + b"\ttp:A:X\tAS:i:7\tcg:Z:5M\n"
+    check(eng, PIPES["pass"], lines[0] + lines[1] + bad_tp + lines[2], "bad tp in round 2")
+
+
 def test_one_pass_separator_index_follows_the_density(eng):
     """Round 3: from the second batch of a context on the separator index is ONE pass over the text whose buffers are sized by the batch
     before (k_sep_index: tile tickets, decoupled look-back); a denser batch is indexed again with exact sizes. One engine, batches of
