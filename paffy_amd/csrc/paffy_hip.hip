@@ -2526,7 +2526,12 @@ int paffy_hip_parse_host(paffy_hip_ctx *c, const char *h_in, int64_t in_len, paf
                         for (uint32_t i = 0; i < plan[r].n; i++) oo[at++] = (((uint64_t)((int64_t)src[i] >> 8)) & 0x00ffffffffffffffull) | ((src[i] & 0xffull) << 56);
                     } else {
                         const uint32_t *src = mirror.data() + (m.cg_off >> 1);
-                        for (uint32_t i = 0; i < plan[r].n; i++) oo[at++] = (uint64_t)(src[i] >> 3) | ((uint64_t)(src[i] & 7u) << 56);
+                        const uint16_t *src16 = reinterpret_cast<const uint16_t *>(src);
+                        const bool half = (plan[r].flags & 0x60000u) == 0x40000u; /* 2-byte words (every length below 8192): emit_ops_half() */
+                        for (uint32_t i = 0; i < plan[r].n; i++) {
+                            const uint32_t w = half ? (uint32_t)src16[i] : src[i];
+                            oo[at++] = (uint64_t)(w >> 3) | ((uint64_t)(w & 7u) << 56);
+                        }
                     }
                 }
             }

@@ -65,10 +65,12 @@ __device__ __forceinline__ int64_t pretty_columns(const PrettyParams &P, const R
     const bool rev = (pl.flags & 1u) != 0, wide = (P.status[rec] >> 16) == KLASS_ARENA;
     const uint64_t *ops8 = P.arena + P.arena_off[rec];
     const uint32_t *ops4 = (pl.flags & 0x20000u) ? reinterpret_cast<const uint32_t *>(P.arena + P.arena_off[rec]) : P.ops_mirror + (m.cg_off >> 1);
+    const bool half = (pl.flags & 0x60000u) == 0x40000u; /* the mirror holds 2-byte words (record_kernel.h: emit_ops_half) */
     int64_t part = 0;
     for (uint32_t i = threadIdx.x; i < pl.n; i += PRETTY_NT) {
         const uint32_t raw = rev ? pl.lo + pl.n - 1 - i : pl.lo + i;
-        int64_t len = wide ? (int64_t)ops8[raw] >> 8 : (int64_t)(ops4[raw] >> 3);
+        const uint32_t w4 = half ? (uint32_t) reinterpret_cast<const uint16_t *>(ops4)[raw] : ops4[raw];
+        int64_t len = wide ? (int64_t)ops8[raw] >> 8 : (int64_t)(w4 >> 3);
         if (raw == pl.lo) len -= pl.sub_lo;
         if (raw == pl.lo + pl.n - 1) len -= pl.sub_hi;
         part += len;
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(PRETTY_NT) void k_pretty_rows(PrettyParams P) {
     const bool wide = (P.status[rec] >> 16) == KLASS_ARENA; /* 8-byte ops in the arena */
     const uint64_t *ops8 = P.arena + P.arena_off[rec];
     const uint32_t *ops4 = (pl.flags & 0x20000u) ? reinterpret_cast<const uint32_t *>(P.arena + P.arena_off[rec]) : P.ops_mirror + (m.cg_off >> 1);
+    const bool half = (pl.flags & 0x60000u) == 0x40000u; /* the mirror holds 2-byte words (record_kernel.h: emit_ops_half) */
     /* the width of the last window needs the number of columns: one pass over the ops first */
     const int64_t cols_total = pretty_columns(P, m, pl, rec, tmp);
     uint8_t *out = P.out + P.row_off[blockIdx.x];
@@ -128,8 +131,9 @@ __global__ __launch_bounds__(PRETTY_NT) void k_pretty_rows(PrettyParams P) {
                 len = (int64_t)ops8[raw] >> 8;
                 op = (int)(ops8[raw] & 0xffu);
             } else {
-                len = (int64_t)(ops4[raw] >> 3);
-                op = (int)(ops4[raw] & 7u);
+                const uint32_t w4 = half ? (uint32_t) reinterpret_cast<const uint16_t *>(ops4)[raw] : ops4[raw];
+                len = (int64_t)(w4 >> 3);
+                op = (int)(w4 & 7u);
             }
             if (swp) op ^= (int)((0x6u >> op) & 1u) * 3;
             if (raw == pl.lo) len -= pl.sub_lo;

@@ -49,15 +49,16 @@ struct OpsLds { /* 4-byte ops in LDS (len << 3 | op, len < 2^29), mirrored to HB
 };
 struct OpsGlobal { /* the HBM mirror, read by the emit pass */
     const uint32_t *p;
+    bool half; /* round 3: the ops of this record are 2-byte words (len << 3 | op with every length below 8192), at the same base address */
     static constexpr bool kNarrow = true;
     typedef uint32_t raw_t;
-    __device__ __forceinline__ raw_t raw(uint32_t i) const { return p[i]; }
+    __device__ __forceinline__ raw_t raw(uint32_t i) const { return half ? (raw_t) reinterpret_cast<const uint16_t *>(p)[i] : p[i]; }
     static __device__ __forceinline__ void decode(raw_t w, int64_t &len, int &op) {
         op = (int)(w & 7u);
         len = (int64_t)(w >> 3);
     }
     __device__ __forceinline__ void get(uint32_t i, int64_t &len, int &op) const {
-        uint32_t w = p[i];
+        const uint32_t w = raw(i);
         op = (int)(w & 7u);
         len = (int64_t)(w >> 3);
     }
@@ -113,6 +114,7 @@ struct View {
     /* get() for the 4-byte stores, 32-bit and without branches (the sweeps of the identity trim run once per op and thread: the
        general form above costs ~30 instructions there, this one ~10): length and code of view index i */
     __device__ __forceinline__ void get32(uint32_t i, uint32_t &len, uint32_t &op) const {
+        static_assert(!std::is_same<OPS, OpsGlobal>::value, "the mirror may hold 2-byte words: read it through raw()");
         const uint32_t raw = rev ? lo + n - 1 - i : lo + i;
         const uint32_t w = ops.p[raw];
         uint32_t o = w & 7u;
@@ -122,6 +124,7 @@ struct View {
     }
     /* sums of the match-type (M, =) and the other lengths of view indices [b, e): order and relabelling do not matter */
     __device__ __forceinline__ void class_sums32(uint32_t b, uint32_t e, uint32_t &m, uint32_t &x) const {
+        static_assert(!std::is_same<OPS, OpsGlobal>::value, "the mirror may hold 2-byte words: read it through raw()");
         uint32_t sm = 0, sx = 0;
         if (e > b) {
             const uint32_t r0 = rev ? lo + n - e : lo + b, r1 = r0 + (e - b); /* the same ops as raw indices [r0, r1) */
@@ -331,7 +334,7 @@ __device__ __forceinline__ uint32_t parse_cigar(const uint8_t *in, uint32_t cg_o
  */
 #define PARSE_LDS_TEXT (16u * PAFFY_NT) /* bytes per round */
 __device__ __forceinline__ uint32_t parse_cigar_lds(const uint8_t *in, uint32_t cg_off, uint32_t cg_len, const OpsLds &ops, uint32_t cap, uint8_t *txt, BlockComm &bc,
-                                                    Shared *sh, bool *fits, uint32_t *err_pos, int64_t (&sums)[4], bool *plain) {
+                                                    Shared *sh, bool *fits, uint32_t *err_pos, int64_t (&sums)[4], bool *plain, bool *mirror16) {
     const uint32_t tid = threadIdx.x;
     const uint32_t end = cg_off + cg_len;
     const uint32_t a0 = cg_off & ~15u;
@@ -396,7 +399,10 @@ __device__ __forceinline__ uint32_t parse_cigar_lds(const uint8_t *in, uint32_t 
             flags |= (kk >= 8u ? 1u : 0u) | (((len == 0u) | (code > OP_D)) ? 2u : 0u);
             const uint32_t word = (len << 3) | (uint32_t)code;
             ops.p[i] = word;
-            if (i < ops.g_cap) ops.g[i] = word;
+            /* the mirror in 2-byte words (round 3: half the bytes written here and read by the writers); a length of 8192 or more
+               anywhere in the record and the mirror is written again below, in 4-byte words */
+            if (i < ops.g_cap) reinterpret_cast<uint16_t *>(ops.g)[i] = (uint16_t)word;
+            flags |= word > 0xffffu ? 4u : 0u;
             /* masks, not branches: code is 0..4 here (M I D = X) */
             const uint32_t is_m = 0u - ((0x9u >> code) & 1u); /* M or = */
             sm += len & is_m;
@@ -409,14 +415,22 @@ __device__ __forceinline__ uint32_t parse_cigar_lds(const uint8_t *in, uint32_t 
     if (bad_at != 0xffffffffu) atomicMin(&sh->err_pos, bad_at);
     /* one collective: the four sums and the flags (a thread's own sums stay below 2^32: a thread converts at most 36 864 / 64 numbers of seven digits) */
     sums[0] = (int64_t)((uint64_t)sm | ((uint64_t)(flags & 1u) << 42) | ((uint64_t)((flags >> 1) & 1u) << 52));
-    sums[1] = sx; sums[2] = sq; sums[3] = st;
+    sums[1] = (int64_t)((uint64_t)sx | ((uint64_t)((flags >> 2) & 1u) << 42)); /* sums stay below 2^42: 36 864 lengths of seven digits */
+    sums[2] = sq; sums[3] = st;
     block_sum<4>(sums, bc);
-    const uint64_t packed = (uint64_t)sums[0];
+    const uint64_t packed = (uint64_t)sums[0], packed1 = (uint64_t)sums[1];
     sums[0] = (int64_t)(packed & ((1ull << 42) - 1ull));
+    sums[1] = (int64_t)(packed1 & ((1ull << 42) - 1ull));
     *err_pos = sh->err_pos; /* written before the barrier of the collective */
     if ((packed >> 42) & 0x3ffull) return 0xffffffffu;
     *plain = ((packed >> 52) & 0x3ffull) == 0;
     *fits = n <= cap;
+    const bool wide = ((packed1 >> 42) & 0x3ffull) != 0;
+    *mirror16 = !wide;
+    if (wide && n <= cap) { /* every op is still in LDS: the mirror once more, as 4-byte words (behind the collective's barrier: the 2-byte stores are done) */
+        const uint32_t top = n < ops.g_cap ? n : ops.g_cap;
+        for (uint32_t i = tid; i < top; i += PAFFY_NT) ops.g[i] = ops.p[i];
+    }
     __syncthreads(); /* the text area and the error word are free again */
     return n;
 }
@@ -2407,8 +2421,13 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
     {                                                                                                                \
         dst = 0;                                                                                                     \
         if ((idx) < we) {                                                                                            \
-            const uint32_t *ptr_ = v.ops.p + v.raw_index(idx);                                                       \
-            asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr_) : "memory");                       \
+            if (v.ops.half) { /* wave-uniform: 2-byte words, zero-extended by the load */                            \
+                const uint16_t *ptr_ = reinterpret_cast<const uint16_t *>(v.ops.p) + v.raw_index(idx);               \
+                asm volatile("global_load_ushort %0, %1, off" : "=v"(dst) : "v"(ptr_) : "memory");                  \
+            } else {                                                                                                 \
+                const uint32_t *ptr_ = v.ops.p + v.raw_index(idx);                                                   \
+                asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr_) : "memory");                   \
+            }                                                                                                        \
         }                                                                                                            \
     }
     PT_DECL
@@ -3053,14 +3072,18 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
     int64_t parse_sums[4] = {0, 0, 0, 0};
     bool have_sums = false;
     bool parse_plain = false; /* parsed here and every op is M / I / D with a length >= 1 */
+    bool mirror16 = false;    /* the HBM mirror of this record holds 2-byte words */
     if (s.has_cigar) {
         bool fits;
         uint32_t err_pos;
         uint32_t r;
         r = 0xffffffffu;
         if constexpr (std::is_same<OPS, OpsLds>::value) {
-            r = parse_cigar_lds(P.in, m.cg_off, m.cg_len, ops, cap, L.ring, L.bc, L.sh, &fits, &err_pos, parse_sums, &parse_plain);
-            if (r == 0xffffffffu) parse_plain = false;
+            r = parse_cigar_lds(P.in, m.cg_off, m.cg_len, ops, cap, L.ring, L.bc, L.sh, &fits, &err_pos, parse_sums, &parse_plain, &mirror16);
+            if (r == 0xffffffffu) {
+                parse_plain = false;
+                mirror16 = false; /* the general parser below writes the mirror again, in 4-byte words */
+            }
         }
         if (r == 0xffffffffu) r = parse_cigar(P.in, m.cg_off, m.cg_len, ops, cap, L.ring, L.bc, L.sh, &fits, &err_pos, parse_sums);
         have_sums = true;
@@ -3121,6 +3144,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
             rc = check_record(s, v, L.bc); /* paf_check alone, impl/paf.c:427-461 */
         } else if (STAGE_ON(PAFFY_REMOVE_MISMATCHES) && st.kind == PAFFY_REMOVE_MISMATCHES) {
             parse_plain = false; /* the op array is rebuilt */
+            mirror16 = false;    /* ... in 4-byte words (MirrorDst) */
             if (s.has_cigar) {
                 bool narrow_ok = true;
                 uint32_t n2;
@@ -3327,7 +3351,7 @@ __device__ __forceinline__ bool size_record(const KParams &P, uint32_t rec, OPS 
         plan->lo = v.lo; plan->n = v.n;
         plan->flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | (s.has_cigar ? 8u : 0u) | ((uint32_t)s.type << 8) |
                       (shatter ? 16u : 0u) | (direct ? 32u : 0u) | (rows_kernel ? 64u : 0u) | (line_kernel ? 0x10000u : 0u) |
-                      (ops_in_arena ? 0x20000u : 0u);
+                      (ops_in_arena ? 0x20000u : 0u) | (mirror16 && !ops_in_arena ? 0x40000u : 0u);
         if (ops_in_arena) P.arena_off[rec] = arena_block;
         plan->chunk = ((v.n + PAFFY_NT - 1) / PAFFY_NT) | 1u; /* = sweep_bounds() */
 #if PAFFY_NWAVE == 1
@@ -3454,6 +3478,7 @@ __device__ __forceinline__ uint32_t mirror_index(const RecMeta &m) { return m.cg
 __device__ __forceinline__ const uint32_t *emit_ops_of(const KParams &P, uint32_t rec, const RecMeta &m, const RecPlan &pl) {
     return (pl.flags & 0x20000u) ? reinterpret_cast<const uint32_t *>(P.arena + P.arena_off[rec]) : P.ops_mirror + mirror_index(m);
 }
+__device__ __forceinline__ bool emit_ops_half(const RecPlan &pl) { return (pl.flags & 0x60000u) == 0x40000u; } /* the mirror, in 2-byte words */
 
 /*
  * Sizing, LDS class: one workgroup per record, ops parsed from the text into LDS (and mirrored).
@@ -3530,7 +3555,7 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_EMIT_OCC) void k_emit_lds(KParams P
     if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return; /* nothing at or after the first failure */
     if ((P.status[rec] >> 16) != KLASS_LDS) return;
     if (static_cast<const RecPlan *>(P.rec_plan)[rec].flags & (SHATTER ? 64u : 0x10000u)) return; /* k_emit_rows / k_emit_line has it */
-    OpsGlobal ops{emit_ops_of(P, rec, P.meta[rec], static_cast<const RecPlan *>(P.rec_plan)[rec])};
+    OpsGlobal ops{emit_ops_of(P, rec, P.meta[rec], static_cast<const RecPlan *>(P.rec_plan)[rec]), emit_ops_half(static_cast<const RecPlan *>(P.rec_plan)[rec])};
 #if defined(PAFFY_ABL) && PAFFY_ABL == 22
     const unsigned long long c0 = clock64(), w0 = wall_clock64();
 #endif
@@ -3619,7 +3644,7 @@ __global__ __launch_bounds__(64, PAFFY_ROWS_OCC) void k_emit_rows(KParams P) {
     s.qs = pl.qs; s.qe = pl.qe; s.ts = pl.ts; s.te = pl.te;
     s.has_cigar = (pl.flags & 8u) != 0;
     s.type = (uint8_t)(pl.flags >> 8);
-    OpsGlobal ops{emit_ops_of(P, rec, m, pl)};
+    OpsGlobal ops{emit_ops_of(P, rec, m, pl), emit_ops_half(pl)};
     View<OpsGlobal> v;
     v.reset(ops, pl.n);
     v.lo = pl.lo; v.rev = pl.flags & 1u; v.swp = (pl.flags & 2u) != 0;
@@ -3661,7 +3686,7 @@ __global__ __launch_bounds__(64, PAFFY_EMIT_OCC) void k_emit_line(KParams P) {
     s.qs = pl.qs; s.qe = pl.qe; s.ts = pl.ts; s.te = pl.te;
     s.has_cigar = (pl.flags & 8u) != 0;
     s.type = (uint8_t)(pl.flags >> 8);
-    OpsGlobal ops{emit_ops_of(P, rec, m, pl)};
+    OpsGlobal ops{emit_ops_of(P, rec, m, pl), emit_ops_half(pl)};
     View<OpsGlobal> v;
     v.reset(ops, pl.n);
     v.lo = pl.lo; v.rev = pl.flags & 1u; v.swp = (pl.flags & 2u) != 0;

@@ -59,7 +59,8 @@ struct RecPlan {
     uint32_t lo, n;
     uint32_t flags; /* bit0 rev, bit1 swp, bit2 query/target swapped, bit3 has_cigar, bit4 shatter, bit5 direct, bit6 k_emit_rows,
                        bit7 dropped by a filter, bits 8-15 type, bit16 k_emit_line,
-                       bit17 the 4-byte ops live in the arena block arena_off[rec] (rebuilt by add_mismatches), not in the mirror */
+                       bit17 the 4-byte ops live in the arena block arena_off[rec] (rebuilt by add_mismatches), not in the mirror,
+                       bit18 the mirror holds 2-byte words (every length below 8192) */
     uint32_t chunk; /* ops per lane in the sizing sweep: wave w owns view ops [64*w*chunk, 64*(w+1)*chunk) */
     /* shatter: query / target bases consumed and output bytes produced before each wave's range */
     int64_t wq[4], wt[4], wo[4]; /* four waves: the emit workgroups; a one-wave sizing workgroup fills entry 0 and zeroes the rest */
@@ -81,7 +82,7 @@ struct KParams {
     uint32_t *n_ops;
     uint64_t *arena_off;
     void *rec_plan; /* RecPlan[n_rec] */
-    uint32_t *ops_mirror; /* 4-byte ops of LDS-class records, indexed from cg_off / 2 */
+    uint32_t *ops_mirror; /* ops of LDS-class records from word cg_off / 2 on: 2-byte words (len << 3 | op) when every length of the record is below 8192 (RecPlan flag bit 18), else 4-byte words */
     /* add_mismatches: sequences in HBM and, per record, the index of its query / target sequence (-1: absent) */
     const uint8_t *seq_base; /* upper-cased when loaded (every comparison is of toupper'ed bases, impl/paf.c:752-757) */
     const uint8_t *seq_comp; /* the same bytes complemented (A<->T, C<->G): what the - strand compares, read backwards */
