@@ -799,6 +799,8 @@ struct paffy_hip_ctx {
     paffy_plan_info plan;
     /* profiling */
     bool profile = false;
+    std::string profile_only; /* when not empty: only launches of this kernel are bracketed (paffy_hip_profile_only) */
+    std::vector<hipEvent_t> event_pool;
     std::vector<ProfEntry> prof;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
     std::vector<std::string> name_store;
@@ -844,23 +846,35 @@ static void prof_collect(paffy_hip_ctx *c) {
         (void)hipEventElapsedTime(&ms, p.second.first, p.second.second);
         c->prof[p.first].ms += ms;
         c->prof[p.first].launches += 1;
-        (void)hipEventDestroy(p.second.first);
-        (void)hipEventDestroy(p.second.second);
+        c->event_pool.push_back(p.second.first);
+        c->event_pool.push_back(p.second.second);
     }
     c->pending.clear();
 }
+static hipEvent_t prof_event(paffy_hip_ctx *c) {
+    hipEvent_t e = nullptr;
+    if (!c->event_pool.empty()) {
+        e = c->event_pool.back();
+        c->event_pool.pop_back();
+    } else {
+        (void)hipEventCreate(&e);
+    }
+    return e;
+}
+static bool prof_wants(const paffy_hip_ctx *c, const char *name) { return c->profile && (c->profile_only.empty() || c->profile_only == name); }
 
 /* launch wrapper: optional HIP events on the context's stream around each kernel */
 #define LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                                  \
     do {                                                                                    \
         hipEvent_t e0_ = nullptr, e1_ = nullptr;                                            \
-        if ((ctx)->profile) {                                                               \
-            (void)hipEventCreate(&e0_);                                                           \
-            (void)hipEventCreate(&e1_);                                                           \
+        const bool prof_ = prof_wants(ctx, name);                                           \
+        if (prof_) {                                                                        \
+            e0_ = prof_event(ctx);                                                          \
+            e1_ = prof_event(ctx);                                                          \
             (void)hipEventRecord(e0_, (ctx)->stream);                                             \
         }                                                                                   \
         hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);         \
-        if ((ctx)->profile) {                                                               \
+        if (prof_) {                                                                        \
             (void)hipEventRecord(e1_, (ctx)->stream);                                             \
             (ctx)->pending.push_back({prof_slot(ctx, name), {e0_, e1_}});                   \
         }                                                                                   \
@@ -927,6 +941,8 @@ static void chain_free(paffy_hip_ctx *c);
 void paffy_hip_destroy(paffy_hip_ctx *c) {
     if (!c) return;
     prof_collect(c);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    c->event_pool.clear();
     cov_free(c);
     chain_free(c);
     while (!c->kept_index.empty()) index_drop(c, c->kept_index.back().in);
@@ -2668,6 +2684,11 @@ const char *paffy_hip_error_string(int32_t code) {
 int paffy_hip_profile_enable(paffy_hip_ctx *c, int on) {
     if (!c) return PAFFY_E_ARG;
     c->profile = on != 0;
+    return 0;
+}
+int paffy_hip_profile_only(paffy_hip_ctx *c, const char *kernel) {
+    if (!c) return PAFFY_E_ARG;
+    c->profile_only = kernel ? kernel : "";
     return 0;
 }
 int paffy_hip_profile_reset(paffy_hip_ctx *c) {

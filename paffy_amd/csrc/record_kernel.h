@@ -346,15 +346,19 @@ __device__ __forceinline__ uint32_t parse_cigar_lds(const uint8_t *in, uint32_t 
     uint32_t n = 0;
     uint32_t sm = 0, sx = 0, sq = 0, st = 0, flags = 0; /* flags: 1 = a number of eight digits or more, 2 = not plain */
     uint32_t bad_at = 0xffffffffu;                      /* smallest text offset of a letter outside MID=X this thread saw */
+    /* the text of a round is requested a round ahead: a round of 16 bytes per thread is short next to the latency of its load */
+    uint4 v_ahead = make_uint4(0, 0, 0, 0);
+    if (a0 + tid * 16 < end) v_ahead = *reinterpret_cast<const uint4 *>(in + a0 + tid * 16);
     for (uint32_t tb = a0; tb < end; tb += PARSE_LDS_TEXT) {
         uint4 h = make_uint4(0, 0, 0, 0);
         if (tb != a0 && tid < 2) h = reinterpret_cast<uint4 *>(txt + PARSE_LDS_TEXT)[tid]; /* the last 32 bytes become the halo */
         __syncthreads();
         if (tb != a0 && tid < 2) reinterpret_cast<uint4 *>(txt)[tid] = h;
         const uint32_t g = tb + tid * 16;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (g < end) v = *reinterpret_cast<const uint4 *>(in + g);
+        const uint4 v = v_ahead;
         reinterpret_cast<uint4 *>(txt + PAFFY_HALO)[tid] = v;
+        v_ahead = make_uint4(0, 0, 0, 0);
+        if (g + PARSE_LDS_TEXT < end) v_ahead = *reinterpret_cast<const uint4 *>(in + g + PARSE_LDS_TEXT);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint32_t opmask = 0;
 #pragma unroll
@@ -2167,33 +2171,37 @@ __device__ __forceinline__ void store_rest_then(uint8_t *p, uint64_t rest_lo, ui
  * window is issued after the sizing arithmetic of the next one (stage()/flush() are separate), so that
  * a wave does not sit on the LDS queue behind its own stores.
  */
+#define PAFFY_FLUSH_GRAN 128u /* bytes: a window leaves for HBM in whole granules (cache lines), the rest is carried */
 struct WaveLinear {
     uint8_t *buf, *out;
     uint64_t begin, base; /* wave-uniform */
-    uint32_t phase;       /* bytes of the buffer already holding output (< 16) */
+    uint32_t phase;       /* bytes of the buffer already holding output (< PAFFY_FLUSH_GRAN) */
     uint32_t pending;     /* bytes staged behind `phase` and not flushed yet */
     __device__ __forceinline__ void start(uint8_t *b, uint8_t *o, uint64_t off) {
         buf = b;
         out = o;
         begin = off;
-        base = off & ~15ull;
-        phase = (uint32_t)(off & 15u);
+        base = off & ~(uint64_t)(PAFFY_FLUSH_GRAN - 1u);
+        phase = (uint32_t)(off & (PAFFY_FLUSH_GRAN - 1u));
         pending = 0;
     }
     /* buffer offset at which the next window's rows start (valid before the pending flush has run) */
-    __device__ __forceinline__ uint32_t next_phase() const { return (phase + pending) & 15u; }
+    __device__ __forceinline__ uint32_t next_phase() const { return (phase + pending) & (PAFFY_FLUSH_GRAN - 1u); }
     __device__ __forceinline__ void stage(uint32_t bytes) { pending = bytes; }
-    /* push the staged window's whole 16-byte chunks to HBM */
+    /* push the staged window's whole granules to HBM (tools/probes/rowstore_global.hip: a flush that ends on a cache-line boundary
+       instead of any 16-byte boundary is worth 7 % of the write rate: no line is written in two halves by two store instructions
+       that are a whole window's arithmetic apart) */
     __device__ __forceinline__ void flush() {
         if (pending == 0) return;
         __builtin_amdgcn_wave_barrier();
         const uint32_t lane = threadIdx.x & 63;
-        const uint32_t total = phase + pending, nch = total >> 4;
+        const uint32_t total = phase + pending, nch = (total / PAFFY_FLUSH_GRAN) * (PAFFY_FLUSH_GRAN / 16u);
         uint8_t *dst = out + base; /* wave-uniform: scalar base, 32-bit lane offsets */
         uint32_t first = 0;
-        if (base < begin && nch > 0) { /* first chunk of the range: the bytes below `begin` belong to the previous wave or record */
-            if (lane >= (uint32_t)(begin - base) && lane < 16) dst[lane] = buf[lane];
-            first = 1;
+        if (base < begin && nch > 0) { /* first granule of the range: the bytes below `begin` belong to the previous wave or record */
+            const uint32_t head = (uint32_t)(begin - base);
+            first = (head + 15u) >> 4;
+            if (lane >= (head & 15u) && lane < 16 && (head & 15u)) dst[(head & ~15u) + lane] = buf[(head & ~15u) + lane];
         }
         for (uint32_t ch = first + lane; ch < nch; ch += 256) { /* four chunks per step: the LDS reads fly together, one wait */
             const uint32_t c1 = ch + 64, c2 = ch + 128, c3 = ch + 192;
@@ -2206,9 +2214,13 @@ struct WaveLinear {
             if (c2 < nch) *reinterpret_cast<uint4 *>(dst + 16 * c2) = v2;
             if (c3 < nch) *reinterpret_cast<uint4 *>(dst + 16 * c3) = v3;
         }
-        if ((total & 15u) && nch > 0 && lane == 0) *reinterpret_cast<uint4 *>(buf) = *reinterpret_cast<const uint4 *>(buf + 16 * nch);
+        const uint32_t rest = total - 16u * nch; /* < PAFFY_FLUSH_GRAN: carried to the front (nch >= 8, so the chunks read and written are apart) */
+        if (nch > 0 && 16u * lane < rest) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(buf + 16 * (nch + lane));
+            *reinterpret_cast<uint4 *>(buf + 16 * lane) = t;
+        }
         base += 16ull * nch;
-        phase = total & 15u;
+        phase = rest;
         pending = 0;
 #if defined(PAFFY_STORE_WINDOW)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PAFFY_STORE_WINDOW) : "memory");
@@ -2218,7 +2230,8 @@ struct WaveLinear {
     __device__ __forceinline__ void finish() {
         flush();
         const uint32_t lane = threadIdx.x & 63;
-        if (lane < phase && base + lane >= begin) out[base + lane] = buf[lane];
+        for (uint32_t b = lane; b < phase; b += 64)
+            if (base + b >= begin) out[base + b] = buf[b];
     }
 };
 
@@ -2369,7 +2382,7 @@ __device__ __forceinline__ bool shatter_fast_ok(const RecState &s, const Shatter
        and the cigar's sums equal the spans, so window sums fit 32 bits when the spans do */
     /* the bases of the digit arithmetic are the record's own coordinates: they must be sane themselves (shatter does not
        check its parent: a record with target_start -1 whose first op is a deletion still has valid rows) */
-    return k.lenA >= 16 && s.qlen < 100000000000ll && s.tlen < 100000000000ll && s.qs >= 0 && s.qs <= s.qe && s.qe <= s.qlen && s.ts >= 0 &&
+    return k.lenA >= 16 && k.row_max <= PAFFY_WAVE_RING - 48u - PAFFY_FLUSH_GRAN && s.qlen < 100000000000ll && s.tlen < 100000000000ll && s.qs >= 0 && s.qs <= s.qe && s.qe <= s.qlen && s.ts >= 0 &&
            s.ts <= s.te && s.te <= s.tlen && s.qe - s.qs < 0x7f000000ll && s.te - s.ts < 0x7f000000ll;
 }
 
@@ -2397,8 +2410,8 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
     DigitBase bq, bt;
     bq.set(s.same ? (uint64_t)(s.qs + cq0) : (uint64_t)(s.qe - cq0));
     bt.set((uint64_t)(s.ts + ct0));
-    const uint32_t cap_bytes = PAFFY_WAVE_RING - 48;
-    const uint32_t rows_cap = cap_bytes / k.row_max; /* >= 1, checked by the sizing pass */
+    const uint32_t cap_bytes = PAFFY_WAVE_RING - 48 - PAFFY_FLUSH_GRAN; /* a carried rest of up to a granule in front */
+    const uint32_t rows_cap = cap_bytes / k.row_max; /* >= 1: shatter_fast_ok */
     const uint32_t w_safe = rows_cap < 128 ? rows_cap : 128;
     const uint32_t w_full = 2 * rows_cap < 128 ? 2 * rows_cap : 128;
     uint32_t i = wb, w_try = w_full;

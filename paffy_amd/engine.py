@@ -139,6 +139,7 @@ def lib():
         L.paffy_hip_last_error.argtypes = [vp]
         L.paffy_hip_profile_enable.argtypes = [vp, C.c_int]
         L.paffy_hip_profile_reset.argtypes = [vp]
+        L.paffy_hip_profile_only.argtypes = [vp, C.c_char_p]
         L.paffy_hip_profile_read.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(i64), C.c_int]
         L.paffy_hip_synth.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64)]
         L.paffy_hip_synth_contigs.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64)]
@@ -553,7 +554,9 @@ class Engine:
         return records, out_bytes
 
     # ---- per-kernel HIP-event timing ----
-    def profile(self, on=True):
+    def profile(self, on=True, only=None):
+        """HIP events around every kernel launch, or around the launches of the kernel `only` alone."""
+        lib().paffy_hip_profile_only(self._ctx, only.encode() if only else None)
         lib().paffy_hip_profile_enable(self._ctx, 1 if on else 0)
         lib().paffy_hip_profile_reset(self._ctx)
 
