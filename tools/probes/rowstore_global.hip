@@ -45,12 +45,13 @@ __global__ __launch_bounds__(256, 4) void k(uint8_t *out, const uint64_t *rec_of
     uint64_t done = 0;
     for (uint32_t r0 = 0; r0 < ROWS; r0 += 64) {
         const uint32_t row = r0 + lane;
-        const uint32_t len = row < ROWS ? row_len(rec, row) : 0u;
+        const uint32_t len = row < ROWS ? (V == 7 ? 127u : row_len(rec, row)) : 0u;
         uint32_t total;
-        const uint32_t off = wave_excl_scan(len, lane, total);
+        const uint32_t off = V == 7 ? lane * 127u : wave_excl_scan(len, lane, total);
+        if (V == 7) total = (ROWS - r0 < 64u ? ROWS - r0 : 64u) * 127u;
         u32x4 v = {row * 0x01010101u, len * 0x01010101u, rec, lane * 0x03030303u};
-        if (V == 0 || V == 3 || V == 4 || V == 5) {
-            if (len && V != 4) {
+        if (V == 0 || V == 3 || V == 4 || V == 5 || V == 6 || V == 7) {
+            if (len && V != 4 && V != 6 && V != 7) {
                 const uint32_t a = win_a + carry + off;
 #pragma unroll
                 for (int j = 8; j >= 0; j--) {
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(256, 4) void k(uint8_t *out, const uint64_t *rec_of
             const uint32_t chunks = (have / FA) * (FA / 16);
             if (V != 5) {
                 for (uint32_t c = lane; c < chunks; c += 64) {
-                    u32x4 t = *reinterpret_cast<const u32x4 *>(win + c * 16);
+                    u32x4 t = v;
+                    if (V != 6 && V != 7) t = *reinterpret_cast<const u32x4 *>(win + c * 16);
                     uint8_t *to = flush_to + c * 16;
                     if (NT == 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(to), "v"(t) : "memory");
                     else if (NT == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(to), "v"(t) : "memory");
@@ -85,9 +87,11 @@ __global__ __launch_bounds__(256, 4) void k(uint8_t *out, const uint64_t *rec_of
             }
             const uint32_t rest = have - chunks * 16;
             u32x4 tail = {0, 0, 0, 0};
-            if (lane * 16 < rest) tail = *reinterpret_cast<const u32x4 *>(win + chunks * 16 + lane * 16);
-            __builtin_amdgcn_wave_barrier();
-            if (lane * 16 < rest) *reinterpret_cast<u32x4 *>(win + lane * 16) = tail;
+            if (V != 6 && V != 7) {
+                if (lane * 16 < rest) tail = *reinterpret_cast<const u32x4 *>(win + chunks * 16 + lane * 16);
+                __builtin_amdgcn_wave_barrier();
+                if (lane * 16 < rest) *reinterpret_cast<u32x4 *>(win + lane * 16) = tail;
+            }
             flush_to += chunks * 16;
             carry = rest;
         } else if (V == 1) {
@@ -246,16 +250,10 @@ int main() {
     hipMalloc(&woff, 4ull * n * (NWIN + 1));
     k_win<<<n / 256, 256>>>(woff, n);
     run<0>(d, off, n, (double)total, "V0 LDS window, byte-aligned ds_write_b128, flush in 16 B granules");
-    run<0, 128>(d, off, n, (double)total, "V0 flush in 128 B granules");
-    run<4>(d, off, n, (double)total, "V4 flush only (no piece stores), 16 B granules");
     run<4, 128>(d, off, n, (double)total, "V4 flush only, 128 B granules");
-    run2<1, 0>(d, off, woff, n, (double)total, "W1 one wave per record, windows on their own, flush only");
-    run2<2, 0>(d, off, woff, n, (double)total, "W2 two waves per record, flush only");
-    run2<4, 0>(d, off, woff, n, (double)total, "W4 four waves per record, flush only");
-    run2<8, 0>(d, off, woff, n, (double)total, "W8 eight waves per record, flush only");
-    run2<16, 0>(d, off, woff, n, (double)total, "W16 sixteen waves per record, flush only");
-    run2<1, 1>(d, off, woff, n, (double)total, "W1 with piece stores");
-    run2<4, 1>(d, off, woff, n, (double)total, "W4 with piece stores");
-    run2<16, 1>(d, off, woff, n, (double)total, "W16 with piece stores");
+    run<6, 128>(d, off, n, (double)total, "V6 flush only from registers (no LDS read), 128 B granules");
+    run<6, 16>(d, off, n, (double)total, "V6 flush only from registers, 16 B granules");
+    run<7, 128>(d, off, n, (double)total, "V7 like V6, rows of 127 bytes (no hash, no scan), 128 B granules");
+    run<5>(d, off, n, (double)total, "V5 piece stores only (no global stores)");
     return 0;
 }
