@@ -71,3 +71,91 @@ def test_batch_properties(eng):
     ok = same(c, int(ic.out_bytes), f, int(jf.out_bytes))
     fused_rows = int(jf.n_rows)
     assert ok and fused_rows <= n_m
+
+
+def first_lines_bytes(text, n_lines):
+    """byte length of the first n_lines lines of a device text"""
+    import torch
+
+    nl = torch.nonzero(text == 10).flatten()
+    return int(nl[n_lines - 1]) + 1
+
+
+def test_full_batch_cfg3(eng):
+    """One whole bench batch (131 072 records of the cfg3 stream, 16.7 GB of rows): the fused pipe equals its stages chained through
+    device text, every row is well formed, and the rows of the first 4 096 records do not depend on what else is in the batch."""
+    import paffy_amd as P
+
+    n = 131072
+    buf, nbytes = eng.synth(0x5EED0003, 2048, 0, n)
+    pipe = [P.stage(P.INVERT), P.stage(P.TRIM_IDENTITY), P.stage(P.SHATTER)]
+    f, jf = run_dev(eng, pipe, buf, nbytes)
+    nf = int(jf.out_bytes)
+    rows = int(jf.n_rows)
+    o = f[:nf]
+    n_nl = int((o == 10).sum())
+    holes = int((o == 0).sum())
+    tabs = int((o == 9).sum())
+    bad_before_nl = int(((o[1:] == 10) & (o[:-1] != ord("M"))).sum())
+    assert n_nl == rows and holes == 0 and tabs == 15 * rows and bad_before_nl == 0
+    del o
+    a, ia = run_dev(eng, [P.stage(P.INVERT)], buf, nbytes)
+    b, ib = run_dev(eng, [P.stage(P.TRIM_IDENTITY)], a, int(ia.out_bytes))
+    del a
+    c, ic = run_dev(eng, [P.stage(P.SHATTER)], b, int(ib.out_bytes))
+    del b
+    ok = same(c, int(ic.out_bytes), f, nf)
+    assert ok
+    del c
+    head = first_lines_bytes(buf[:nbytes], 4096)
+    h, jh = run_dev(eng, pipe, buf, head)
+    nh = int(jh.out_bytes)
+    recs = int(jh.n_records)
+    ok = nh <= nf and same(h, nh, f, nh)
+    assert recs == 4096 and ok
+    del h, f
+    import torch
+
+    torch.cuda.empty_cache()
+
+
+def test_full_batch_cfg4():
+    """One whole bench batch of the add_mismatches workload (131 072 records on 2 x 3.6 Gb of device-generated sequence):
+    =/X runs put back together give the cigar the record came with, every aligned column is accounted for, and the lines of the
+    first 4 096 records do not depend on what else is in the batch."""
+    import torch
+
+    import paffy_amd as P
+
+    torch.cuda.empty_cache()  # the slabs of the tests before: the library allocates with hipMalloc, beside torch's cache
+    e = P.Engine()
+    try:
+        e.synth4_setup(0x5EED0004, 2048)
+        n = 131072
+        buf, nbytes = e.synth4(0, n)
+        add, ja = run_dev(e, [P.stage(P.ADD_MISMATCHES)], buf, nbytes)
+        na = int(ja.out_bytes)
+        o = add[:na]
+        lines = int((o == 10).sum())
+        m_left = int((o == ord("M")).sum())  # the names and the tags that are written hold no M: every M op became = / X runs
+        eq_x = int(((o == ord("=")) | (o == ord("X"))).sum())
+        assert lines == n and m_left == 0 and eq_x > 0
+        del o
+        back, jb = run_dev(e, [P.stage(P.REMOVE_MISMATCHES)], add, na)
+        plain, jp = run_dev(e, [P.stage(P.REMOVE_MISMATCHES)], buf, nbytes)
+        ok = same(back, int(jb.out_bytes), plain, int(jp.out_bytes))
+        assert ok
+        del back, plain
+        fused, jf = run_dev(e, [P.stage(P.ADD_MISMATCHES), P.stage(P.REMOVE_MISMATCHES)], buf, nbytes)
+        plain, jp = run_dev(e, [P.stage(P.REMOVE_MISMATCHES)], buf, nbytes)
+        ok = same(fused, int(jf.out_bytes), plain, int(jp.out_bytes))
+        assert ok
+        del fused, plain
+        head = first_lines_bytes(buf[:nbytes], 4096)
+        h, jh = run_dev(e, [P.stage(P.ADD_MISMATCHES)], buf, head)
+        nh = int(jh.out_bytes)
+        ok = nh <= na and same(h, nh, add, nh)
+        assert ok
+    finally:
+        e.close()
+        torch.cuda.empty_cache()
