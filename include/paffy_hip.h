@@ -200,7 +200,9 @@ int paffy_hip_emit_lines(paffy_hip_ctx *ctx, int64_t first, int64_t n, void *d_o
  * batch or in an earlier batch of the same context since the last paffy_hip_dedupe_reset -- has the same query name,
  * target name, strand and four coordinates (with check_inverse: or equals it with query and target swapped; paf_check
  * then runs on the record, as in the reference). Kept records are written in input order with the cigar text verbatim.
- * Keys are compared as 128-bit hashes of those fields (two independent 64-bit hashes). Followed by paffy_hip_emit().
+ * Keys are compared as 128-bit hashes of those fields (two independent 64-bit hashes). The selection runs on the device (sort by key,
+ * first of every run, binary searches in the sorted keys of the earlier batches); the context's memory lives in HBM, 16 bytes per
+ * record written. Followed by paffy_hip_emit().
  */
 int paffy_hip_dedupe_plan(paffy_hip_ctx *ctx, const void *d_in, int64_t in_len, int check_inverse, paffy_plan_info *info);
 int paffy_hip_dedupe_reset(paffy_hip_ctx *ctx);

@@ -755,7 +755,7 @@ struct paffy_hip_ctx {
     psynth4_cfg synth4_cfg = {0, 0, 0, 0, 0};
     paffy_filter filter = {-1, -1, -1.0, -1.0, -1, 0};
     DevBuf dedupe_keys;
-    std::unordered_set<std::string> dedupe_seen; /* 16-byte keys of the records written so far */
+    struct DedupeState *dedupe = nullptr; /* dedupe_host.h: keys of the records written so far (sorted, on the device) and scratch */
     DevBuf scan_part, emit_order, order_cnt, tile_keys, tile_order, tile_rank, tile_coff, tile_cbase, tile_cov, tile_level, tile_len, tile_items, tile_slots, tile_parts;
     bool plan_is_tile = false;
     bool plan_is_bed = false; /* paffy to_bed: emit writes the run lines */
@@ -934,6 +934,7 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
 }
 
 static void cov_free(paffy_hip_ctx *c); /* coverage_host.h state */
+static void dedupe_free(paffy_hip_ctx *c); /* dedupe_host.h state */
 static void index_drop(paffy_hip_ctx *c, const void *d_in);
 static void index_drop_all(paffy_hip_ctx *c);
 static void chain_free(paffy_hip_ctx *c);
@@ -959,6 +960,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
                       &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts, &c->scan_part, &c->dedupe_keys, &c->emit_order, &c->order_cnt};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    dedupe_free(c);
     delete c->bed_params;
     if (c->h_info) (void)hipHostFree(c->h_info);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -1307,6 +1309,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
 } /* extern "C" */
 
 #include "coverage_host.h"
+#include "dedupe_host.h"
 #include "chain_host.h"
 #include "pretty_kernel.h"
 
@@ -1837,7 +1840,7 @@ int64_t paffy_hip_tile_keys(paffy_hip_ctx *c, int64_t cap_lines, void *d_keys) {
 
 int paffy_hip_dedupe_reset(paffy_hip_ctx *c) {
     if (!c) return PAFFY_E_ARG;
-    c->dedupe_seen.clear();
+    if (c->dedupe) c->dedupe->seen_n = 0;
     return 0;
 }
 
@@ -1874,47 +1877,30 @@ int paffy_hip_dedupe_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, in
     if (ensure(c, c->tile_len, sizeof(int64_t) * (size_t)(n + 2))) return PAFFY_E_HIP;
     LAUNCH(c, "k_dedupe_keys", k_dedupe_keys, dim3(grid), dim3(PAFFY_NT), 0, in, static_cast<const RecMeta *>(c->meta.p), n,
            static_cast<DedupeKey *>(c->dedupe_keys.p), static_cast<int64_t *>(c->tile_level.p));
-    std::vector<DedupeKey> keys(n);
-    HIPCHK(c, hipMemcpyAsync(keys.data(), c->dedupe_keys.p, sizeof(DedupeKey) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    /* the reference's loop, record by record (impl/paf_dedupe.c:117-143): first seen wins */
-    std::vector<uint32_t> kept;
-    kept.reserve(n);
-    for (uint32_t i = 0; i < n; i++) {
-        const DedupeKey &k = keys[i];
+    /* the reference's loop, record by record (impl/paf_dedupe.c:117-143): first seen wins -- on the device, dedupe_host.h */
+    if (!c->dedupe) c->dedupe = new DedupeState();
+    uint32_t nk = 0, first_bad = n;
+    {
+        int rc = dedupe_select(c, *c->dedupe, static_cast<const DedupeKey *>(c->dedupe_keys.p), n, check_inverse, static_cast<uint32_t *>(c->tile_order.p), &nk, &first_bad);
+        if (rc) return rc;
+    }
+    if (first_bad < n) { /* the record that ends the run: a parse error, or paf_check (impl/paf_dedupe.c:126) */
+        DedupeKey k;
+        HIPCHK(c, hipMemcpy(&k, static_cast<const DedupeKey *>(c->dedupe_keys.p) + first_bad, sizeof(k), hipMemcpyDeviceToHost));
+        c->plan.error.record = first_bad;
         if (k.err) {
             c->plan.error.code = k.err;
             c->plan.error.stage = -1;
-            c->plan.error.record = i;
             RecMeta m;
-            HIPCHK(c, hipMemcpy(&m, static_cast<RecMeta *>(c->meta.p) + i, sizeof(m), hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(&m, static_cast<RecMeta *>(c->meta.p) + first_bad, sizeof(m), hipMemcpyDeviceToHost));
             c->plan.error.aux = m.err_aux;
-            break;
-        }
-        if (check_inverse == PAFFY_DEDUPE_KEEP_ALL) {
-            kept.push_back(i);
-            continue;
-        }
-        std::string key(reinterpret_cast<const char *>(&k.a), 16);
-        bool found = c->dedupe_seen.count(key) != 0;
-        if (!found && check_inverse == 1) {
-            found = c->dedupe_seen.count(std::string(reinterpret_cast<const char *>(&k.ia), 16)) != 0;
-            if (k.check) { /* paf_check(paf), impl/paf_dedupe.c:126 */
-                c->plan.error.code = k.check;
-                c->plan.error.stage = 0;
-                c->plan.error.record = i;
-                break;
-            }
-        }
-        if (!found) {
-            c->dedupe_seen.insert(std::move(key));
-            kept.push_back(i);
+        } else {
+            c->plan.error.code = k.check;
+            c->plan.error.stage = 0;
         }
     }
-    const uint32_t nk = (uint32_t)kept.size();
     int64_t total = 0;
     if (nk > 0) {
-        HIPCHK(c, hipMemcpyAsync(c->tile_order.p, kept.data(), sizeof(uint32_t) * (size_t)nk, hipMemcpyHostToDevice, c->stream));
         int64_t *lens = static_cast<int64_t *>(c->tile_len.p);
         LAUNCH(c, "k_line_size", k_line_size, dim3((nk + 1 + PAFFY_NT - 1) / PAFFY_NT), dim3(PAFFY_NT), 0, static_cast<const RecMeta *>(c->meta.p),
                static_cast<const uint32_t *>(c->tile_order.p), static_cast<const int64_t *>(c->tile_level.p), (uint64_t)nk, reinterpret_cast<uint64_t *>(lens));
@@ -1922,7 +1908,7 @@ int paffy_hip_dedupe_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, in
         HIPCHK(c, hipMemcpyAsync(&total, lens + nk, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         if (ensure(c, c->one_batch, sizeof(void *))) return PAFFY_E_HIP;
         HIPCHK(c, hipMemcpyAsync(c->one_batch.p, &in, sizeof(void *), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream)); /* `kept` must outlive the copy */
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     if (c->profile) prof_collect(c);
     c->plan.out_bytes = total;

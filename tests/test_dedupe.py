@@ -80,6 +80,65 @@ def test_gpu_dedupe_matches_oracle(human_chimp):
 
 
 @pytest.mark.gpu
+def test_gpu_dedupe_random_streams():
+    """Random streams with many repeats, swapped twins and records that fail paf_check (reached or not, depending on what was written
+    before them), in one batch and cut into random batches through one context: output, error code and failing record as the oracle's loop."""
+    import paffy_amd
+
+    eng = paffy_amd.Engine()
+    for seed in range(12):
+        rng = random.Random(100 + seed)
+        pool = []
+        for k in range(60):
+            qn, tn = b"q%d" % rng.randrange(6), b"t%d" % rng.randrange(6)
+            ql, tl = 1000, 2000
+            qs, ts = rng.randrange(0, 900), rng.randrange(0, 1900)
+            ln = rng.randrange(1, 90)
+            strand = rng.choice([b"+", b"-"])
+            pool.append(b"\t".join([qn, b"%d" % ql, b"%d" % qs, b"%d" % (qs + ln), strand, tn, b"%d" % tl, b"%d" % ts, b"%d" % (ts + ln), b"%d" % ln, b"%d" % ln, b"60",
+                                     b"cg:Z:%dM" % ln]) + b"\n")
+        bad = []  # coordinates paf_check rejects; they parse
+        for k in range(3):
+            bad.append(b"qb%d\t50\t10\t4\t+\ttb\t200\t0\t3\t3\t3\t60\tcg:Z:3M\n" % k)
+        n = rng.choice([50, 400, 3000])
+        p_bad = rng.choice([0.0, 0.002, 0.02])
+        lines = []
+        for _ in range(n):
+            l = rng.choice(pool)
+            r = rng.random()
+            if r < p_bad:
+                l = rng.choice(bad)
+            if rng.random() < 0.35:
+                f = l.rstrip(b"\n").split(b"\t")
+                f[0], f[5] = f[5], f[0]
+                f[1], f[6] = f[6], f[1]
+                f[2], f[7] = f[7], f[2]
+                f[3], f[8] = f[8], f[3]
+                l = b"\t".join(f) + b"\n"
+            lines.append(l)
+        data = b"".join(lines)
+        for inv in (False, True):
+            want, werr = O.dedupe(data, inv)
+            got, info = eng.dedupe(data, inv, raise_on_error=False)
+            assert info.error.code == werr.code and got == want, (seed, inv)
+            if werr.code:
+                assert info.error.record == werr.record, (seed, inv)
+            # the same stream in random batches through one context
+            cuts = sorted(rng.sample(range(1, n), min(n - 1, rng.randrange(1, 6))))
+            parts = [b"".join(lines[a:b]) for a, b in zip([0] + cuts, cuts + [n])]
+            outs, base, code, rec = [], 0, 0, 0
+            for i, part in enumerate(parts):
+                o, inf = eng.dedupe(part, inv, reset=(i == 0), raise_on_error=False)
+                outs.append(o)
+                if inf.error.code:
+                    code, rec = inf.error.code, base + inf.error.record
+                    break
+                base += part.count(b"\n")
+            assert b"".join(outs) == want and code == werr.code and (not code or rec == werr.record), (seed, inv, cuts)
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_cli_dedupe(human_chimp):
     rng = random.Random(10)
     data = build_dupes(rng, human_chimp[:100000], 1500)
