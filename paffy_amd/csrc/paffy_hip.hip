@@ -606,6 +606,29 @@ __global__ __launch_bounds__(PAFFY_NT) void k_dedupe_keys(const uint8_t *in, con
     level[r] = m.tile_level;
 }
 
+/* PAFFY_STATS: the batch's six sums from the records' (rec_stats[6 n], zero for records that stopped in front of the stage) */
+__global__ __launch_bounds__(PAFFY_NT) void k_stats_reduce(const int64_t *rec_stats, uint32_t n, unsigned long long *sums) {
+    __shared__ unsigned long long part[PAFFY_NT / 64][6];
+    unsigned long long a[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * PAFFY_NT + threadIdx.x; i < n; i += gridDim.x * PAFFY_NT) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) a[k] += (unsigned long long)rec_stats[6ull * i + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        for (int d = 32; d; d >>= 1) a[k] += __shfl_down(a[k], d, 64);
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        for (int k = 0; k < 6; k++) part[wave][k] = a[k];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        unsigned long long t = 0;
+        for (uint32_t w = 0; w < PAFFY_NT / 64; w++) t += part[w][threadIdx.x];
+        if (t) atomicAdd(&sums[threadIdx.x], t);
+    }
+}
+
 __device__ __forceinline__ void tile_state(const RecMeta &m, int64_t level, RecState &s) {
     load_state(m, s);
     s.has_cigar = false; /* the cigar is written verbatim from the text, impl/paf.c:381-385 */
@@ -1235,6 +1258,9 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             else LAUNCH(c, "k_size_lds", k_size_lds<PAFFY_MASK_ALL>, dim3(n_lines), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0)); /* join */
             LAUNCH(c, "k_arena_size", k_arena_size, dim3(2048), dim3(PAFFY_NT), PAFFY_SIZE_LDS_BYTES, kp);
+            if (kp.rec_stats)
+                LAUNCH(c, "k_stats_reduce", k_stats_reduce, dim3(std::min<uint32_t>(512u, (n_lines + PAFFY_NT - 1) / PAFFY_NT)), dim3(PAFFY_NT), 0, kp.rec_stats, n_lines,
+                       static_cast<DevInfo *>(c->info.p)->stats);
             /* the scan rides along: one host synchronisation per plan in the usual case (the arena was big enough) */
             {
                 const uint32_t n_blocks = (n_lines + SCAN_BLOCK - 1) / SCAN_BLOCK;

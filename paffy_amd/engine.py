@@ -478,7 +478,7 @@ class Engine:
         return out, info
 
     def plan_stats(self):
-        """Sums of the STATS stages of the last plan: (matches, mismatches, inserts, deletes, insert bases, delete bases)."""
+        """Sums of the STATS stage of the last plan (the last one, should a pipe hold several): (matches, mismatches, inserts, deletes, insert bases, delete bases)."""
         out = (C.c_int64 * 6)()
         self._check(lib().paffy_hip_plan_stats(self._ctx, out), "paffy_hip_plan_stats")
         return tuple(out)
