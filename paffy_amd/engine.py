@@ -508,7 +508,7 @@ class Engine:
         st = C.c_void_p()
         cap0 = max(4096, max((len(c) for c in chunks), default=4096))
         t_open = time.perf_counter()
-        self._check(L.paffy_hip_stream_open(self._ctx, arr, len(stages), cap0, 64 << 20, C.byref(st)), "paffy_hip_stream_open")
+        self._check(L.paffy_hip_stream_open(self._ctx, arr, len(stages), cap0, getattr(self, "stream_piece_bytes", 64 << 20), C.byref(st)), "paffy_hip_stream_open")
         # where the time of the call went: opening the stream pins its host buffers (two input slots, three output pieces) and allocates the
         # device buffers -- once per process in the CLI, and seconds on some hosts; the host's copy of a chunk into its pinned slot
         self.stream_seconds = {"open": time.perf_counter() - t_open, "input_copy": 0.0, "run": 0.0, "close": 0.0}
