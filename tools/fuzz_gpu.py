@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak test (GPU box): random records through random pipes, HIP path vs the CPU oracle, for a time budget.
-usage: python tools/fuzz_gpu.py [seconds] [seed] [pipe|tile|mism|bed|chain]   -- prints the first mismatch (and saves it under gpurun_out/) or a summary."""
+usage: python tools/fuzz_gpu.py [seconds] [seed] [pipe|tile|mism|bed|chain|dedupe]   -- prints the first mismatch (and saves it under gpurun_out/) or a summary."""
 import hashlib
 import os
 import random
@@ -203,6 +203,55 @@ def fuzz_chain(eng, rng, budget):
     print(f"chain fuzz ok: {rounds} rounds ({skipped} of them inputs with an address tie, compared with the oracle without the fresh-iterator walk)")
 
 
+def fuzz_dedupe(eng, rng, budget):
+    """paffy dedupe [-a]: streams drawn from a small pool of records (repeats, swapped twins, near misses, records that fail paf_check
+    or do not parse), whole and cut into random batches through one context, against the oracle's loop."""
+    t0, rounds = time.time(), 0
+    while time.time() - t0 < budget:
+        pool = []
+        for _ in range(rng.choice([3, 20, 120])):
+            qn, tn = "q%d" % rng.randrange(rng.choice([1, 5, 40])), "t%d" % rng.randrange(rng.choice([1, 5, 40]))
+            qs, ts, ln = rng.randrange(0, 900), rng.randrange(0, 1900), rng.randrange(1, 90)
+            pool.append("\t".join([qn, "1000", str(qs), str(qs + ln), rng.choice("+-"), tn, "2000", str(ts), str(ts + ln), str(ln), str(ln), "60",
+                                   rng.choice(["cg:Z:%dM" % ln, "AS:i:7\tcg:Z:%dM" % ln, "tp:A:P\tcg:Z:3S"])]) + "\n")
+        bad = ["qb%d\t50\t10\t4\t+\ttb\t200\t0\t3\t3\t3\t60\tcg:Z:3M\n" % k for k in range(3)] + ["qz\t50\t1\n"]
+        n = rng.choice([1, 2, 50, 400, 3000, 20000])
+        p_bad = rng.choice([0.0, 0.0, 0.001, 0.02])
+        lines = []
+        for _ in range(n):
+            l = rng.choice(bad[:3] if rng.random() < 0.9 else bad) if rng.random() < p_bad else rng.choice(pool)
+            f = l.rstrip("\n").split("\t")
+            if len(f) > 8 and rng.random() < 0.35:
+                f[0], f[5] = f[5], f[0]
+                f[1], f[6] = f[6], f[1]
+                f[2], f[7] = f[7], f[2]
+                f[3], f[8] = f[8], f[3]
+            elif len(f) > 8 and rng.random() < 0.1:
+                f[3] = str(int(f[3]) + 1)
+            lines.append(("\t".join(f) + "\n").encode())
+        data = b"".join(lines)
+        for inv in (False, True):
+            want, werr = O.dedupe(data, inv)
+            got, info = eng.dedupe(data, inv, raise_on_error=False)
+            ok = info.error.code == werr.code and got == want and (not werr.code or info.error.record == werr.record)
+            cuts = sorted(rng.sample(range(1, n), min(n - 1, rng.randrange(0, 6)))) if n > 1 else []
+            outs, base, code, rec = [], 0, 0, 0
+            for i, (a, b) in enumerate(zip([0] + cuts, cuts + [n])):
+                o, inf = eng.dedupe(b"".join(lines[a:b]), inv, reset=(i == 0), raise_on_error=False)
+                outs.append(o)
+                if inf.error.code:
+                    code, rec = inf.error.code, a + inf.error.record
+                    break
+            ok = ok and b"".join(outs) == want and code == werr.code and (not code or rec == werr.record)
+            if not ok:
+                with open(os.path.join(ROOT, "gpurun_out", "fuzz_dedupe_fail.paf"), "wb") as fh:
+                    fh.write(data)
+                print("DEDUPE MISMATCH", inv, cuts, (info.error.code, info.error.record), (werr.code, werr.record), len(got), len(want))
+                sys.exit(1)
+        rounds += 1
+    print(f"dedupe fuzz ok: {rounds} rounds")
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -218,6 +267,8 @@ def main():
         return fuzz_mismatches(eng, rng, budget)
     if mode == "chain":
         return fuzz_chain(eng, rng, budget)
+    if mode == "dedupe":
+        return fuzz_dedupe(eng, rng, budget)
     kinds = [O.INVERT, O.TRIM_IDENTITY, O.TRIM_FIXED, O.REMOVE_MISMATCHES, O.PASS, O.FILTER]
     t0, rounds, nbytes = time.time(), 0, 0
     while time.time() - t0 < budget:
