@@ -1930,8 +1930,15 @@ int paffy_hip_dedupe_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, in
         int64_t *lens = static_cast<int64_t *>(c->tile_len.p);
         LAUNCH(c, "k_line_size", k_line_size, dim3((nk + 1 + PAFFY_NT - 1) / PAFFY_NT), dim3(PAFFY_NT), 0, static_cast<const RecMeta *>(c->meta.p),
                static_cast<const uint32_t *>(c->tile_order.p), static_cast<const int64_t *>(c->tile_level.p), (uint64_t)nk, reinterpret_cast<uint64_t *>(lens));
-        LAUNCH(c, "k_scan_i64", k_scan_i64, dim3(1), dim3(PAFFY_NT), 0, lens, nk, static_cast<int64_t *>(c->out_off.p), lens + nk);
-        HIPCHK(c, hipMemcpyAsync(&total, lens + nk, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        { /* offsets of the lines: exclusive scan of nk + 1 lengths (the last one zero, k_line_size), so that entry nk is the total */
+            if (ensure(c, c->out_off, sizeof(int64_t) * ((size_t)nk + 1))) return PAFFY_E_HIP;
+            DedupeState &D = *c->dedupe;
+            size_t bytes = 0;
+            RPCHK(c, rocprim::exclusive_scan(nullptr, bytes, lens, static_cast<int64_t *>(c->out_off.p), (int64_t)0, (size_t)nk + 1, rocprim::plus<int64_t>(), c->stream));
+            if (ensure(c, D.tmp, bytes + 16)) return PAFFY_E_HIP;
+            RPCHK(c, rocprim::exclusive_scan(D.tmp.p, bytes, lens, static_cast<int64_t *>(c->out_off.p), (int64_t)0, (size_t)nk + 1, rocprim::plus<int64_t>(), c->stream));
+        }
+        HIPCHK(c, hipMemcpyAsync(&total, static_cast<int64_t *>(c->out_off.p) + nk, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         if (ensure(c, c->one_batch, sizeof(void *))) return PAFFY_E_HIP;
         HIPCHK(c, hipMemcpyAsync(c->one_batch.p, &in, sizeof(void *), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
