@@ -245,7 +245,19 @@ static int cov_add(paffy_hip_ctx *c, const void *d_in, int64_t in_len, bool with
 
 static size_t cov_bitmap_budget_words() {
     const char *e = getenv("PAFFY_COV_BITMAP_MB");
-    long mb = e ? atol(e) : 4096;
+    long mb = e ? atol(e) : 0;
+    if (!e) { /* 32 GiB when the GPU has the room (a quarter of what is free at most): every chunk loads and saves the counters of the slices
+                 it touches, so fewer, larger chunks move less (cfg5 at 2 M records per step: 3 chunks at 4 GiB, 110.2 ms; 1 chunk, 106.6 ms;
+                 at 10 M records: 623 ms at 4 GiB, 548 at 16, 521 at 32, 520 at 64) */
+        size_t free_b = 0, total_b = 0;
+        mb = 4096;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const long quarter = (long)(free_b >> 22);
+            mb = quarter > 32768 ? 32768 : (quarter < 256 ? 256 : quarter);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (mb < 1) mb = 1;
     return (size_t)mb << 18; /* 32-bit words */
 }
