@@ -243,6 +243,10 @@ static int cov_add(paffy_hip_ctx *c, const void *d_in, int64_t in_len, bool with
     return 0;
 }
 
+static uint32_t cov_wave_bytes() { /* experiments: PAFFY_COV_WAVE_BYTES=0 sends every entry to the four-wave shape */
+    static const uint32_t v = getenv("PAFFY_COV_WAVE_BYTES") ? (uint32_t)atol(getenv("PAFFY_COV_WAVE_BYTES")) : 9000u;
+    return v;
+}
 static size_t cov_bitmap_budget_words() {
     const char *e = getenv("PAFFY_COV_BITMAP_MB");
     long mb = e ? atol(e) : 0;
@@ -484,7 +488,9 @@ static int cov_run(paffy_hip_ctx *c, int mode, paffy_error *err) {
         P.e1 = e1;
         P.bitmap = static_cast<uint32_t *>(S.bitmap.p);
         P.bm_base = w_e0;
-        LAUNCH(c, "k_cov_bitmap", k_cov_bitmap, dim3(e1 - e0), dim3(PAFFY_NT), COV_BM_LDS_BYTES, P, mode == 0 ? 1 : 0);
+        /* short cigars one wave per entry, the rest four (COV_WAVE_BYTES: the longest cigar of the one-wave shape) */
+        LAUNCH(c, "k_cov_bitmap_wave", k_cov_bitmap<CovGroup64>, dim3(e1 - e0), dim3(64), COV_BM_LDS_BYTES_OF(CovGroup64), P, mode == 0 ? 1 : 0, 0u, cov_wave_bytes());
+        LAUNCH(c, "k_cov_bitmap", k_cov_bitmap<CovGroup256>, dim3(e1 - e0), dim3(256), COV_BM_LDS_BYTES_OF(CovGroup256), P, mode == 0 ? 1 : 0, cov_wave_bytes() + 1u, 0xffffffffu);
         if (n_p > 0) {
             const uint32_t np = (uint32_t)n_p, g_p = (np + PAFFY_NT - 1) / PAFFY_NT;
             if (ensure(c, S.pairs, sizeof(uint64_t) * (size_t)(n_p + 1))) return PAFFY_E_HIP;

@@ -140,21 +140,47 @@ __device__ __forceinline__ CovWalkSide cov_side(const RecMeta &m, uint32_t side)
  * the record's first failing check in the reference's order: cigar_parse (impl/paf.c:102), then the position asserts and the end
  * assert of increase_alignment_level_counts (impl/paf.c:698,708).
  */
-#define COV_BM_LDS_BYTES (PAFFY_HALO + COV_TEXT + COV_TEXT / 2 * 8 + COV_WIN * 4 + 64 * 8 + 64)
-__global__ __launch_bounds__(PAFFY_NT) void k_cov_bitmap(CovParams P, int null_cigar_is_error) {
+/* The kernel in two workgroup shapes, like the sizing pass of the record kernels (round 3, last session): one wave per entry for the short
+   cigars -- no barrier costs anything, twenty entries in flight per CU -- and four waves for the rest; an entry belongs to the shape
+   whose byte range [lo_bytes, hi_bytes] holds its cigar (entries without a cigar and lines that did not parse: the four-wave shape). */
+struct CovGroup64 {
+    static constexpr uint32_t NT = 64, TEXT = 64 * 16, WIN = 512; /* 16 384 bases of bitmap staged per round of at most 512 ops */
+    typedef g64::BlockComm Comm;
+    typedef g64::Shared Sh;
+    template <int K>
+    static __device__ __forceinline__ void scan_u32(uint32_t (&v)[K], uint32_t (&t)[K], Comm &bc) { g64::block_excl_scan_u32<K>(v, t, bc); }
+    template <int K>
+    static __device__ __forceinline__ void scan_i64(int64_t (&v)[K], int64_t (&t)[K], Comm &bc) { g64::block_excl_scan<K>(v, t, bc); }
+};
+struct CovGroup256 {
+    static constexpr uint32_t NT = 256, TEXT = COV_TEXT, WIN = COV_WIN;
+    typedef g256::BlockComm Comm;
+    typedef g256::Shared Sh;
+    template <int K>
+    static __device__ __forceinline__ void scan_u32(uint32_t (&v)[K], uint32_t (&t)[K], Comm &bc) { g256::block_excl_scan_u32<K>(v, t, bc); }
+    template <int K>
+    static __device__ __forceinline__ void scan_i64(int64_t (&v)[K], int64_t (&t)[K], Comm &bc) { g256::block_excl_scan<K>(v, t, bc); }
+};
+#define COV_BM_LDS_BYTES_OF(G) (PAFFY_HALO + G::TEXT + G::TEXT / 2 * 8 + G::WIN * 4 + 64 * 8 + 64)
+template <class G>
+__global__ __launch_bounds__(G::NT) void k_cov_bitmap(CovParams P, int null_cigar_is_error, uint32_t lo_bytes, uint32_t hi_bytes) {
     extern __shared__ uint4 smem4[];
     uint8_t *smem = reinterpret_cast<uint8_t *>(smem4);
     uint8_t *txt = smem;                                                        /* halo + tile */
-    uint64_t *ops = reinterpret_cast<uint64_t *>(smem + PAFFY_HALO + COV_TEXT); /* len << 8 | op, at most COV_TEXT / 2 per round */
-    uint32_t *win = reinterpret_cast<uint32_t *>(smem + PAFFY_HALO + COV_TEXT + COV_TEXT / 2 * 8);
-    BlockComm bc;
-    bc.scratch = reinterpret_cast<int64_t *>(smem + PAFFY_HALO + COV_TEXT + COV_TEXT / 2 * 8 + COV_WIN * 4);
+    uint64_t *ops = reinterpret_cast<uint64_t *>(smem + PAFFY_HALO + G::TEXT); /* len << 8 | op, at most TEXT / 2 per round */
+    uint32_t *win = reinterpret_cast<uint32_t *>(smem + PAFFY_HALO + G::TEXT + G::TEXT / 2 * 8);
+    typename G::Comm bc;
+    bc.scratch = reinterpret_cast<int64_t *>(smem + PAFFY_HALO + G::TEXT + G::TEXT / 2 * 8 + G::WIN * 4);
     bc.flip = 0;
-    Shared *sh = reinterpret_cast<Shared *>(reinterpret_cast<uint8_t *>(bc.scratch) + 64 * 8);
+    typename G::Sh *sh = reinterpret_cast<typename G::Sh *>(reinterpret_cast<uint8_t *>(bc.scratch) + 64 * 8);
     const uint32_t tid = threadIdx.x;
     const uint32_t e = P.e0 + blockIdx.x;
     const CovEntry E = P.entries[e];
     const RecMeta &m = P.meta[E.rec];
+    {
+        const uint32_t route = (m.err || !m.has_cg) ? 0xffffffffu : m.cg_len; /* no cigar to read: the four-wave shape's few lines */
+        if (route < lo_bytes || route > hi_bytes) return;                     /* the other shape's entry (workgroup-uniform) */
+    }
     const uint8_t *in = P.batch_in[m.pad1];
     const CovWalkSide S = cov_side(m, E.side);
     uint32_t *bm = P.bitmap + (E.bm_off - P.bm_base);
@@ -184,10 +210,10 @@ __global__ __launch_bounds__(PAFFY_NT) void k_cov_bitmap(CovParams P, int null_c
     int64_t cur = S.start; /* position of the next op on the walked sequence */
     int64_t aligned = 0;
     bool serial = false;
-    for (uint32_t tb = a0; tb < end && !serial; tb += COV_TEXT) {
+    for (uint32_t tb = a0; tb < end && !serial; tb += G::TEXT) {
         /* stage the tile; the last 32 bytes of the tile before it become the halo */
         uint4 h = make_uint4(0, 0, 0, 0);
-        if (tb != a0 && tid < 2) h = reinterpret_cast<uint4 *>(txt + COV_TEXT)[tid];
+        if (tb != a0 && tid < 2) h = reinterpret_cast<uint4 *>(txt + G::TEXT)[tid];
         __syncthreads();
         if (tb != a0 && tid < 2) reinterpret_cast<uint4 *>(txt)[tid] = h;
         const uint32_t g = tb + tid * 16;
@@ -212,8 +238,8 @@ __global__ __launch_bounds__(PAFFY_NT) void k_cov_bitmap(CovParams P, int null_c
             opmask &= valid;
         }
         uint32_t cnt[1] = {(uint32_t)__popc(opmask)}, ctot[1];
-        block_excl_scan_u32<1>(cnt, ctot, bc); /* also orders the staging stores before the reads below */
-        if (ctot[0] > COV_TEXT / 2) { /* more ops than the LDS list holds (ops without digits): the serial path */
+        G::template scan_u32<1>(cnt, ctot, bc); /* also orders the staging stores before the reads below */
+        if (ctot[0] > G::TEXT / 2) { /* more ops than the LDS list holds (ops without digits): the serial path */
             serial = true;
             break;
         }
@@ -230,7 +256,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_cov_bitmap(CovParams P, int null_c
             }
         }
         __syncthreads();
-        const uint32_t n_round = ctot[0], per = (n_round + PAFFY_NT - 1u) / PAFFY_NT;
+        const uint32_t n_round = ctot[0], per = (n_round + G::NT - 1u) / G::NT;
         const uint32_t i0 = tid * per < n_round ? tid * per : n_round, i1 = i0 + per < n_round ? i0 + per : n_round;
         int64_t sums[2] = {0, 0}, tots[2]; /* bases along the walked sequence, aligned bases */
         {
@@ -254,7 +280,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_cov_bitmap(CovParams P, int null_c
             if (bad_at != 0xffffffffu) atomicMin(&sh->err_pos, bad_at);
             if (long_num) atomicOr(&sh->flags, 1u);
         }
-        block_excl_scan<2>(sums, tots, bc);
+        G::template scan_i64<2>(sums, tots, bc);
         if (sh->flags & 1u) { /* uniform: written before the scan's barrier */
             serial = true;
             break;
@@ -265,9 +291,9 @@ __global__ __launch_bounds__(PAFFY_NT) void k_cov_bitmap(CovParams P, int null_c
         const bool any = c_hi > c_lo && tots[1] > 0;
         const int64_t ww0 = c_lo >> 5;
         const uint64_t n_w = any ? (uint64_t)(((c_hi - 1) >> 5) - ww0 + 1) : 0;
-        const bool in_lds = n_w <= COV_WIN;
+        const bool in_lds = n_w <= G::WIN;
         if (any && in_lds)
-            for (uint32_t i = tid; i < (uint32_t)n_w; i += PAFFY_NT) win[i] = 0;
+            for (uint32_t i = tid; i < (uint32_t)n_w; i += G::NT) win[i] = 0;
         __syncthreads();
         /* pass 2: my ops again, from LDS, with their positions */
         if (any) {
@@ -295,7 +321,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_cov_bitmap(CovParams P, int null_c
         __syncthreads();
         if (any && in_lds) { /* window -> HBM: its first and last word may be shared with the rounds before and after */
             const uint64_t gw = (uint64_t)(ww0 - w0);
-            for (uint32_t i = tid; i < (uint32_t)n_w; i += PAFFY_NT) {
+            for (uint32_t i = tid; i < (uint32_t)n_w; i += G::NT) {
                 const uint32_t x = win[i];
                 if (i == 0 || i + 1 == (uint32_t)n_w) {
                     if (x) atomicOr(&bm[gw + i], x);

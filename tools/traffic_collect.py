@@ -51,6 +51,7 @@ def main():
                         name = "k_size_wave"  # the one-wave build, launched under this name (bench.py's kernel_ms key)
                     name = re.sub(r"^(k_size_lds(?:_long)?)<.*>$", r"\1", name)
                     name = re.sub(r"^(k_cov_walk)<.*>$", r"\1", name)
+                    name = {"k_cov_bitmap<CovGroup64>": "k_cov_bitmap_wave", "k_cov_bitmap<CovGroup256>": "k_cov_bitmap"}.get(name, name)
                     sums.setdefault(name, {}).setdefault(counter, 0.0)
                     sums[name][counter] += float(row["Counter_Value"])
                     launches.setdefault(name, {}).setdefault(counter, 0)
