@@ -288,6 +288,10 @@ char *paffy_hip_stream_input(paffy_hip_stream *stream, int64_t want, int64_t kee
 int paffy_hip_stream_submit(paffy_hip_stream *stream, int64_t in_len, paffy_plan_info *info);
 int paffy_hip_stream_read(paffy_hip_stream *stream, const char **piece, int64_t *len);
 void paffy_hip_stream_close(paffy_hip_stream *stream);
+/* A closed stream leaves the device buffers of its two slots (input text, output) with the context; the context's next stream takes them
+   again instead of allocating (a hipMalloc of the tens of GB a slot's output needs takes 16 ms most of the time and seconds right behind
+   the hipFree of the stream before). paffy_hip_stream_trim frees them; paffy_hip_destroy does too. */
+int paffy_hip_stream_trim(paffy_hip_ctx *ctx);
 
 /*
  * Sums of the PAFFY_STATS stages of the last plan, in the argument order of paf_stats_calc (impl/paf.c:236-260): matches (M and =

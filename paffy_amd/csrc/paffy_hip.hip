@@ -822,6 +822,11 @@ struct paffy_hip_ctx {
     paffy_plan_info plan;
     /* profiling */
     bool profile = false;
+    /* device buffers of the two slots of a closed stream (paffy_hip_stream_close), taken again by the next paffy_hip_stream_open: a
+       hipMalloc of the tens of GB a slot's output needs takes 16 ms most of the time and 0.5-2.6 s right behind the hipFree of the stream
+       before (tools/probes/d2h_pieces.py) */
+    void *kept_slot_buf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; /* [slot][0 = input, 1 = output] */
+    size_t kept_slot_cap[2][2] = {{0, 0}, {0, 0}};
     std::string profile_only; /* when not empty: only launches of this kernel are bracketed (paffy_hip_profile_only) */
     std::vector<hipEvent_t> event_pool;
     std::vector<ProfEntry> prof;
@@ -984,6 +989,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     dedupe_free(c);
+    (void)paffy_hip_stream_trim(c);
     delete c->bed_params;
     if (c->h_info) (void)hipHostFree(c->h_info);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -2093,6 +2099,17 @@ struct paffy_hip_stream {
     int n_issued = 0, n_returned = 0;
 };
 
+int paffy_hip_stream_trim(paffy_hip_ctx *c) {
+    if (!c) return PAFFY_E_ARG;
+    for (int k = 0; k < 2; k++)
+        for (int b = 0; b < 2; b++) {
+            if (c->kept_slot_buf[k][b]) (void)hipFree(c->kept_slot_buf[k][b]);
+            c->kept_slot_buf[k][b] = nullptr;
+            c->kept_slot_cap[k][b] = 0;
+        }
+    return 0;
+}
+
 int paffy_hip_stream_open(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages, int64_t chunk_bytes, int64_t piece_bytes, paffy_hip_stream **out) {
     if (!c || !out || n_stages < 0 || n_stages > PAFFY_MAX_STAGES || (n_stages > 0 && !stages) || chunk_bytes < 4096 || chunk_bytes >= (1ll << 31) - 64 || piece_bytes < 4096)
         return PAFFY_E_ARG;
@@ -2101,6 +2118,13 @@ int paffy_hip_stream_open(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n
     s->n_stages = n_stages;
     for (int32_t i = 0; i < n_stages; i++) s->stages[i] = stages[i];
     bool ok = hipStreamCreateWithFlags(&s->s_h2d, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&s->s_d2h, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 2; k++) { /* the device buffers the stream before left with the context */
+        StreamSlot &sl = s->slot[k];
+        sl.d_in = c->kept_slot_buf[k][0]; sl.d_in_cap = c->kept_slot_cap[k][0];
+        sl.d_out = c->kept_slot_buf[k][1]; sl.d_out_cap = c->kept_slot_cap[k][1];
+        c->kept_slot_buf[k][0] = c->kept_slot_buf[k][1] = nullptr;
+        c->kept_slot_cap[k][0] = c->kept_slot_cap[k][1] = 0;
+    }
     for (int k = 0; k < 2 && ok; k++) {
         StreamSlot &sl = s->slot[k];
         sl.h_cap = (size_t)chunk_bytes;
@@ -2125,8 +2149,18 @@ void paffy_hip_stream_close(paffy_hip_stream *s) {
     for (int k = 0; k < 2; k++) {
         StreamSlot &sl = s->slot[k];
         if (sl.h_in) (void)hipHostFree(sl.h_in);
-        if (sl.d_in) (void)hipFree(sl.d_in);
-        if (sl.d_out) (void)hipFree(sl.d_out);
+        /* the device buffers stay with the context for its next stream (freed by paffy_hip_destroy or paffy_hip_stream_trim) */
+        void *bufs[2] = {sl.d_in, sl.d_out};
+        const size_t caps[2] = {sl.d_in_cap, sl.d_out_cap};
+        for (int b = 0; b < 2; b++) {
+            if (!bufs[b]) continue;
+            if (s->c && !s->c->kept_slot_buf[k][b]) {
+                s->c->kept_slot_buf[k][b] = bufs[b];
+                s->c->kept_slot_cap[k][b] = caps[b];
+            } else {
+                (void)hipFree(bufs[b]);
+            }
+        }
         if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
         if (sl.ev_emit) (void)hipEventDestroy(sl.ev_emit);
     }
@@ -2205,8 +2239,9 @@ int paffy_hip_stream_read(paffy_hip_stream *s, const char **piece, int64_t *len)
     StreamSlot &sl = s->slot[s->drain];
     if (!sl.busy) return 0;
     if (s->n_issued == 0) HIPCHK(c, hipStreamWaitEvent(s->s_d2h, sl.ev_emit, 0)); /* first piece of this chunk */
-    /* keep two copies in flight: the piece handed out now and the one after it */
-    while (s->n_issued < s->n_returned + 2 && s->issued_at < sl.out_len) {
+    /* keep two copies in flight: the piece handed out now and the one after it (PAFFY_D2H_INFLIGHT: experiments) */
+    static const int in_flight = getenv("PAFFY_D2H_INFLIGHT") ? atoi(getenv("PAFFY_D2H_INFLIGHT")) : 2;
+    while (s->n_issued < s->n_returned + (in_flight < 1 ? 1 : in_flight > 2 ? 2 : in_flight) && s->issued_at < sl.out_len) {
         const int k = s->n_issued % 3;
         const int64_t n = sl.out_len - s->issued_at < (int64_t)s->piece_cap ? sl.out_len - s->issued_at : (int64_t)s->piece_cap;
         HIPCHK(c, hipMemcpyAsync(s->piece[k], static_cast<char *>(sl.d_out) + s->issued_at, (size_t)n, hipMemcpyDeviceToHost, s->s_d2h));

@@ -140,6 +140,7 @@ def lib():
         L.paffy_hip_profile_enable.argtypes = [vp, C.c_int]
         L.paffy_hip_profile_reset.argtypes = [vp]
         L.paffy_hip_profile_only.argtypes = [vp, C.c_char_p]
+        L.paffy_hip_stream_trim.argtypes = [vp]
         L.paffy_hip_profile_read.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(i64), C.c_int]
         L.paffy_hip_synth.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64)]
         L.paffy_hip_synth_contigs.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64)]
