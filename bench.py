@@ -762,9 +762,9 @@ def end_to_end(eng, stages, batches, batch_records):
     """The PCIe-inclusive rate (reported beside `value`, never as it): the same batches as host bytes through the streaming
     runtime of the CLI (paffy_hip_stream_*: pinned staging, H2D / kernels / D2H overlapped), output pieces landing in host memory."""
     chunks = [bytes(buf[:nbytes].cpu().numpy().tobytes()) for buf, nbytes, _ in batches]
-    eng.stream_host(stages, chunks[:1])  # buffers allocated, kernels loaded
-    # three runs, the best one reported and all of them listed: on a shared host a run is either quiet (49 GB/s of output on a 57 GB/s
-    # link) or slow from its first piece to its last (9-20 GB/s), whatever the runtime does (DESIGN 4.2, tools/probes/d2h_pieces.py)
+    eng.stream_host(stages, chunks)  # both slots' buffers allocated (they stay with the context), kernels loaded
+    # three runs, the best one reported and all of them listed (a run whose stream had to allocate a slot's output buffer used to take
+    # seconds in that hipMalloc; the buffers now stay with the context between streams: DESIGN 4.2, tools/probes/d2h_pieces.py)
     runs = []
     for _ in range(3):
         t0 = time.perf_counter()
