@@ -31,6 +31,7 @@
 
 #define SEP_TILE 65536u /* bytes per workgroup in the separator passes */
 #define WAVE_OPS_CAP 2048u   /* op store of the one-wave sizing kernel: 8 KiB, sixteen workgroups per CU */
+#define LVL0_LONG_BYTES 20000u /* cigars up to this length start at the first store level once a batch has shown that none of them overflows it */
 #define WAVE_MAX_BYTES 6000u /* cigars up to this length go there (about 1950 ops at 3.08 bytes per op; the few denser ones are redone by the four-wave build) */
 
 /* ------------------------------------------------------------------ */
@@ -822,6 +823,7 @@ struct paffy_hip_ctx {
     paffy_plan_info plan;
     /* profiling */
     bool profile = false;
+    bool lvl0_long_ok = false, lvl0_long_off = false; /* the longer first store level: shown safe by the batch before / overflowed once */
     /* device buffers of the two slots of a closed stream (paffy_hip_stream_close), taken again by the next paffy_hip_stream_open: a
        hipMalloc of the tens of GB a slot's output needs takes 16 ms most of the time and 0.5-2.6 s right behind the hipFree of the stream
        before (tools/probes/d2h_pieces.py) */
@@ -1144,7 +1146,16 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             if (stages[i].kind == PAFFY_ADD_MISMATCHES) return true;
         return false;
     }();
-    const uint32_t lvl0_max = add_not_last ? PAFFY_OPS_CAP * 5 / 8 : PAFFY_OPS_CAP;
+    /* Cigars of more than 2 x lvl0_max bytes start at the second store level (k_header queues them), whose 64 KB of ops leave a CU two
+       workgroups: on cfg3 / cfg4 the 7 % of the records there cost as much kernel time as all the others. Two bytes per op is the bound
+       that can never overflow the first level's 8 192-op store, but a cigar of the usual density (2.5-3 bytes per op) fits it up to about
+       LVL0_LONG_BYTES. So a context starts with the safe bound and lets the second level count the records that would have overflowed the
+       longer one (DevInfo::lvl0_probe_dense); a batch without any switches the following batches to the longer first level (cfg4 12.23 ->
+       11.72 ms per step, cfg3 -1.2 to -1.6 %), and the first record that does overflow there (it goes to the arena class: slow, correct)
+       switches the context back for good. PAFFY_LVL0_BYTES overrides the length (0: never). */
+    static const uint32_t lvl0_long_bytes = getenv("PAFFY_LVL0_BYTES") ? (uint32_t)atol(getenv("PAFFY_LVL0_BYTES")) : LVL0_LONG_BYTES;
+    const bool lvl0_long = !add_not_last && c->lvl0_long_ok && lvl0_long_bytes > 2u * PAFFY_OPS_CAP;
+    const uint32_t lvl0_max = add_not_last ? PAFFY_OPS_CAP * 5 / 8 : (lvl0_long ? lvl0_long_bytes / 2u : PAFFY_OPS_CAP);
     /* records with at most this many cigar bytes (about WAVE_OPS_CAP ops at three bytes per op) are sized one wave per record; denser
        cigars of that length overflow the wave's store and are redone by the four-wave build. add_mismatches rebuilds the op array: when
        a stage follows it the new array must fit the store, so only pipes that end with it take the one-wave build. */
@@ -1156,6 +1167,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
         if (rc) return rc;
     }
     kp.lvl0_max = lvl0_max;
+    kp.lvl0_long_bytes = (!add_not_last && !lvl0_long && !c->lvl0_long_off && lvl0_long_bytes > 2u * PAFFY_OPS_CAP) ? lvl0_long_bytes : 0u;
 
     kp.in = in;
     kp.in_len = len;
@@ -1288,7 +1300,15 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
                 kp.emit_order = static_cast<const uint32_t *>(c->emit_order.p);
             }
             if (fetch_info(c)) return PAFFY_E_HIP;
-            if (c->h_info->arena_used <= kp.arena_cap) break;
+            if (c->h_info->arena_used <= kp.arena_cap) {
+                if (lvl0_long && c->h_info->lvl0_over > 0) { /* denser cigars than the longer first level takes: back to the safe bound, for good */
+                    c->lvl0_long_ok = false;
+                    c->lvl0_long_off = true;
+                } else if (kp.lvl0_long_bytes) { /* the safe bound was in force and the second level kept count */
+                    c->lvl0_long_ok = c->h_info->lvl0_probe_dense == 0;
+                }
+                break;
+            }
             /* arena too small: grow to the demand seen so far and redo the sizing pass */
             /* a record that found no room stopped asking, so the demand seen is a lower bound: at least double what there was */
             size_t need = (size_t)c->h_info->arena_used * 8 * 2;

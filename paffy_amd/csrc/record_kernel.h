@@ -3509,6 +3509,12 @@ __device__ __forceinline__ void size_lds_one(const KParams &P, uint32_t rec, uin
     if (threadIdx.x == 0) P.n_ops[rec] = to_four ? 0xffffffffu : 0u;
     if (to_four) return;
 #endif
+#if PAFFY_NWAVE == 4
+    if (threadIdx.x == 0 && need == 0) {
+        if (P.level == 0 && !ok && n_ops > P.ops_cap) atomicAdd(&P.info->lvl0_over, 1u); /* denser than the longer first level assumed */
+        if (P.level == 1 && P.lvl0_long_bytes && m.cg_len <= P.lvl0_long_bytes && n_ops > PAFFY_OPS_CAP) atomicAdd(&P.info->lvl0_probe_dense, 1u);
+    }
+#endif
     if (!ok && threadIdx.x == 0) {
         P.out_len[rec] = 0;
         P.out_rows[rec] = 0;

@@ -51,6 +51,9 @@ struct DevInfo {
     uint32_t internal;  /* internal-limit flags (must stay 0) */
     uint32_t g_count;   /* LDS-class shatter records left to the general row kernel (not eligible for k_emit_rows) */
     unsigned long long stats[6]; /* PAFFY_STATS: matches, mismatches, inserts, deletes, insert bases, delete bases */
+    /* the longer first store level (paffy_hip.hip: lvl0_long): records whose ops overflowed the first-level store although their cigar was
+       short enough to start there, and -- while the safe bound is in force -- records of the second level that would have */
+    uint32_t lvl0_over, lvl0_probe_dense;
 };
 
 /* What the stage list left of a record; written by the sizing pass, read by the emit pass. */
@@ -101,6 +104,7 @@ struct KParams {
     uint32_t next_cap;   /* store of the next level (0: none, overflow goes to the arena) */
     uint32_t level;      /* 0: whole batch; 1, 2: walk b_list[level - 1] */
     uint32_t lvl0_max;   /* records with more than this many cigar bytes / 2 start at level 1 (k_header queued them) */
+    uint32_t lvl0_long_bytes; /* the cigar length the longer first level would take (0: none): level 1 counts what would have overflowed it */
     DevInfo *info;
     paffy_filter filter; /* thresholds of PAFFY_FILTER stages */
     const uint32_t *emit_order; /* records by descending output size (coarse): the one-wave-per-record writers start the long ones first */

@@ -170,3 +170,30 @@ def test_trim_ends_stage_equals_paf_trim_ends():
             checked += len(ok)
     assert checked > 200
     eng.close()
+
+
+def test_longer_first_store_level_and_its_way_back():
+    """A context sizes cigars of up to 20 000 bytes at the first store level once a batch has shown that none of them holds more ops than
+    that store (8 192); a cigar that then does (two bytes per op) goes through the arena class -- same bytes as the oracle's -- and the
+    context returns to the safe bound. Every batch of the sequence is compared with the oracle."""
+    import paffy_amd
+
+    rng = random.Random(77)
+    eng = paffy_amd.Engine()
+    pipe_g = [paffy_amd.stage(paffy_amd.INVERT), paffy_amd.stage(paffy_amd.TRIM_IDENTITY), paffy_amd.stage(paffy_amd.SHATTER)]
+    pipe_o = [O.stage(O.INVERT), O.stage(O.TRIM_IDENTITY), O.stage(O.SHATTER)]
+
+    def usual(n):  # three-digit lengths: 4 bytes per op, cigars of 17 000 - 19 000 bytes among them (4 300 - 4 700 ops)
+        return "".join(make_record(rng, f"q{k}", f"t{k % 3}", 10**9, 10**9, rng.choice([40, 900, 4300, 4700]), rng.choice("+-"), [100, 250, 999]) for k in range(n))
+
+    def dense(n_ops):  # one-digit lengths: 2 bytes per op
+        return make_record(rng, "qd", "td", 10**9, 10**9, n_ops, "+", [1, 2, 9])
+
+    batches = [usual(40), usual(40), usual(20) + dense(9500) + usual(20), usual(40), dense(9000) + usual(10), usual(30)]
+    for i, text in enumerate(batches):
+        data = text.encode()
+        want, werr = O.run(pipe_o, data)
+        got, info = eng.run(pipe_g, data, raise_on_error=False)
+        assert info.error.code == werr.code == 0, i
+        assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest(), i
+    eng.close()
