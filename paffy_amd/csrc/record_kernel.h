@@ -1896,7 +1896,8 @@ __device__ __forceinline__ int shatter_size(const RecState &s, const View<OPS> &
  * flushes). No workgroup barrier anywhere.
  */
 #ifndef PAFFY_ROWS_MAX_OPS
-#define PAFFY_ROWS_MAX_OPS 16384u /* one wave formats at most this many ops (128 windows) on its own */
+#define PAFFY_ROWS_MAX_OPS 32768u /* one wave formats at most this many ops (256 windows) on its own; 16 384 until the last session of round 3: the
+                                     four-wave writers of the records in between cost cfg4 2.6 % and cfg3 1-2 % of a step */
 #endif
 #ifndef PAFFY_WAVE_RING
 #define PAFFY_WAVE_RING 9216u
