@@ -11,7 +11,7 @@
  * Distributions (integer only):
  *   E(x)      ~ -log2(U) in 16.16 fixed point from the leading-zero count of a 64-bit draw and
  *               a linear mantissa; scaled(m, x) = floor(m * E(x) * ln2) is ~exponential, mean m.
- *   #M ops k  = 1 + scaled((mean_ops+1)/2 - 1), capped at min(8*mean_k, 25000);  ops = 2k-1
+ *   #M ops k  = exponential body + a heavy tail, capped at 2^19 (psynth_num_match_ops);  ops = 2k-1
  *   M length  = 1 + scaled(39)   indel length = 1 + scaled(2)   I vs D: one bit
  */
 #ifndef PAF_SYNTH_CORE_H_
@@ -60,12 +60,23 @@ PSYNTH_HD static inline int64_t psynth_contig_len(uint64_t seed, int genome, uin
     return 50000000ll + (int64_t)(psynth_mix(seed ^ (0xC0117100ull + (uint64_t)genome * 4096 + c)) % 200000001ull);
 }
 
+/*
+ * Number of M ops of a record (ops = 2k - 1). Round 4: the op count has its heavy tail again ("heavy tail capped at 2^20").
+ * The reference's fixture (tests/human_chimp.paf: mean 1 785 ops) has 5 % of its records above six times the mean and its longest at
+ * 11.6 times; an exponential alone has 0.25 % and, in 207 records, nothing above 7. So: fifteen records in sixteen come from an
+ * exponential body of mean 81/128 mean_k, one in sixteen is a tail record of k = 4 mean_k + Exp(5/2 mean_k) -- 2.8 % of the records
+ * above 6 x the mean, 0.8 % above 9 x, the longest of 207 at about 10 x, the longest of a 10 M-record stream at about 37 x (76 k ops at
+ * mean 2 048) -- and the overall mean stays mean_k (15/16 * 81/128 + 1/16 * 6.5 = 0.9995). Cap: 2^19 M ops = 2^20 - 1 ops.
+ * (Rounds 1-3: one exponential of mean mean_k capped at 8 mean_k -- no cfg3 record above 16 383 ops.)
+ */
 PSYNTH_HD static inline uint32_t psynth_num_match_ops(const psynth_cfg *c, uint64_t rkey) {
-    uint64_t mean_k = ((uint64_t)c->mean_ops + 1) / 2;
-    uint64_t k = 1 + psynth_scaled(mean_k ? mean_k - 1 : 0, psynth_rnd(rkey, 0));
-    uint64_t cap = 8 * mean_k;
-    if (cap > 25000) cap = 25000;
-    if (cap < 1) cap = 1;
+    const uint64_t mean_k = ((uint64_t)c->mean_ops + 1) / 2;
+    const uint64_t x = psynth_rnd(rkey, 0);
+    uint64_t k;
+    if ((psynth_rnd(rkey, 14) & 15u) == 0) k = 4 * mean_k + psynth_scaled((5 * mean_k) >> 1, x);
+    else k = 1 + psynth_scaled(mean_k ? ((mean_k - 1) * 81) >> 7 : 0, x);
+    const uint64_t cap = 1ull << 19;
+    if (k < 1) k = 1;
     return (uint32_t)(k > cap ? cap : k);
 }
 

@@ -77,3 +77,18 @@ def test_synth_cfg4_records_lie_on_homologous_bases():
         xx = sum(int(x) for l in lines for x in re.findall(rb"(\d+)X", l))
         assert 0.97 < eq / (eq + xx) < 0.99
     assert O.run([O.stage(O.ADD_MISMATCHES), O.stage(O.REMOVE_MISMATCHES)], a, seqs)[0] == O.run([O.stage(O.PASS)], a)[0]
+
+
+def test_synth_op_counts_have_the_heavy_tail():
+    """the op count has a heavy tail capped at 2^20 (the reference's fixture: 5 % of the records above six times the mean, the
+    longest at 11.6 times). The generator's mixture keeps the configured mean and puts about 2.8 % of the records above six times it."""
+    data = synth_lib.generate(0x5EED0003, 2048, 0, 40000, threads=4)
+    n = []
+    for line in data.splitlines():
+        cg = line[line.rindex(b"cg:Z:") + 5:]
+        n.append(cg.count(b"M") + cg.count(b"I") + cg.count(b"D"))
+    mean = sum(n) / len(n)
+    assert 1950 < mean < 2250
+    above6 = sum(1 for x in n if x > 6 * 2048) / len(n)
+    assert 0.02 < above6 < 0.04
+    assert max(n) > 16 * 2048 and max(n) < (1 << 20)
