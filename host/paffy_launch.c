@@ -24,6 +24,7 @@
 #define _GNU_SOURCE
 #include <errno.h>
 #include <fcntl.h>
+#include <getopt.h>
 #include <limits.h>
 #include <signal.h>
 #include <stdint.h>
@@ -39,16 +40,37 @@
 #define MAX_RANKS 64
 
 static char g_worker[PATH_MAX];
-static char g_tmpdir[PATH_MAX];
+static char g_tmpdir[PATH_MAX];  /* where the private spool directory is made */
+static char g_spooldir[PATH_MAX]; /* mkdtemp(<tmpdir>/paffy.XXXXXX), mode 0700: nobody else can plant a link under a name we open */
 static char g_spool[MAX_RANKS][4][PATH_MAX]; /* per rank: input, output, rows, index */
 static char g_stdin_spool[PATH_MAX];
 static int g_n = 0;
+static volatile pid_t g_pids[MAX_RANKS]; /* workers that are running (0: none) */
 
 static void cleanup(void) {
     for (int r = 0; r < g_n; r++)
         for (int k = 0; k < 4; k++)
             if (g_spool[r][k][0]) unlink(g_spool[r][k]);
     if (g_stdin_spool[0]) unlink(g_stdin_spool);
+    if (g_spooldir[0]) rmdir(g_spooldir);
+}
+
+/* SIGINT / SIGTERM / SIGHUP: the workers go with us and the spools (RAM-backed under /dev/shm) are removed */
+static void on_signal(int sig) {
+    for (int r = 0; r < MAX_RANKS; r++)
+        if (g_pids[r] > 0) kill(g_pids[r], SIGTERM);
+    cleanup(); /* unlink / rmdir only: async-signal-safe */
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
+static int make_spooldir(void) {
+    snprintf(g_spooldir, sizeof(g_spooldir), "%s/paffy.XXXXXX", g_tmpdir);
+    if (!mkdtemp(g_spooldir)) {
+        g_spooldir[0] = 0;
+        return -1;
+    }
+    return 0;
 }
 
 static void find_worker(void) {
@@ -83,36 +105,68 @@ static int is_stream_cmd(const char *c) {
     return !strcmp(c, "invert") || !strcmp(c, "trim") || !strcmp(c, "shatter") || !strcmp(c, "add_mismatches") || !strcmp(c, "filter");
 }
 
-/* value of option -<s> / --<lng> in argv[2..]; *at / *n_args: where it stands and how many argv entries it takes (0: absent) */
-static const char *find_opt(int argc, char **argv, char s, const char *lng, int *at, int *n_args) {
-    *at = 0;
-    *n_args = 0;
-    const size_t ll = strlen(lng);
-    const char *val = NULL;
-    for (int i = 2; i < argc; i++) {
-        const char *a = argv[i];
-        if (!strcmp(a, "--")) break;
-        if (a[0] == '-' && a[1] == '-' && !strncmp(a + 2, lng, ll) && (a[2 + ll] == 0 || a[2 + ll] == '=')) {
-            if (a[2 + ll] == '=') {
-                val = a + 3 + ll; *at = i; *n_args = 1;
-            } else if (i + 1 < argc) {
-                val = argv[i + 1]; *at = i; *n_args = 2; i++;
-            }
-        } else if (a[0] == '-' && a[1] == s) {
-            if (a[2]) {
-                val = a + 2; *at = i; *n_args = 1;
-            } else if (i + 1 < argc) {
-                val = argv[i + 1]; *at = i; *n_args = 2; i++;
-            }
-        }
-    }
-    return val;
-}
+/*
+ * The command line of a sharded command, parsed the way the worker will parse it: getopt_long with the subcommand's own option string
+ * and long options (/root/reference/impl/paf_invert.c:41-76, paf_trim.c:45-100, paf_add_mismatches.c:40-85, paf_filter.c:50-115,
+ * paf_tile.c:100-150) -- clustered short flags (`trim -fi in.paf`), abbreviated long options (`--input x`), an option's value that
+ * looks like an option (`-l -i`) all mean here what they mean there. The worker's command line is rebuilt from the parse: every
+ * option but -i / -o as the worker would have seen it, then the positional arguments, then our own -i / -o. Anything getopt_long
+ * rejects, and -h, leaves the command to a single worker (which prints what the reference prints).
+ */
+typedef struct {
+    const char *in_path, *out_path;
+    char *opts[256]; /* "-x" or "-x", "value" */
+    int n_opts;
+    char **pos; /* positional arguments (in argv order) */
+    int n_pos;
+    int ok;
+} CmdLine;
 
-static int wants_help(int argc, char **argv) {
-    for (int i = 2; i < argc; i++)
-        if (!strcmp(argv[i], "-h") || !strcmp(argv[i], "--help")) return 1;
-    return 0;
+static const struct option k_common[] = {{"logLevel", required_argument, 0, 'l'}, {"inputFile", required_argument, 0, 'i'}, {"outputFile", required_argument, 0, 'o'},
+                                         {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+static const struct option k_trim[] = {{"logLevel", required_argument, 0, 'l'}, {"inputFile", required_argument, 0, 'i'}, {"outputFile", required_argument, 0, 'o'},
+                                       {"help", no_argument, 0, 'h'}, {"trimFraction", required_argument, 0, 't'}, {"trimIdentity", required_argument, 0, 'r'},
+                                       {"fixedTrim", no_argument, 0, 'f'}, {0, 0, 0, 0}};
+static const struct option k_add[] = {{"logLevel", required_argument, 0, 'l'}, {"inputFile", required_argument, 0, 'i'}, {"outputFile", required_argument, 0, 'o'},
+                                      {"removeMismatches", no_argument, 0, 'a'}, {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+static const struct option k_filter[] = {{"logLevel", required_argument, 0, 'l'}, {"inputFile", required_argument, 0, 'i'}, {"outputFile", required_argument, 0, 'o'},
+                                         {"minChainScore", required_argument, 0, 's'}, {"minAlignmentScore", required_argument, 0, 't'},
+                                         {"minIdentity", required_argument, 0, 'u'}, {"minIdentityWithGaps", required_argument, 0, 'v'},
+                                         {"maxTileLevel", required_argument, 0, 'w'}, {"invert", no_argument, 0, 'x'}, {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+
+static void parse_cmdline(int argc, char **argv, CmdLine *cl) {
+    memset(cl, 0, sizeof(*cl));
+    const char *cmd = argv[1];
+    const char *optstring = "l:i:o:h";
+    const struct option *lopts = k_common;
+    if (!strcmp(cmd, "trim")) { optstring = "l:i:o:ht:r:f"; lopts = k_trim; }
+    else if (!strcmp(cmd, "add_mismatches")) { optstring = "l:i:o:ha"; lopts = k_add; }
+    else if (!strcmp(cmd, "filter")) { optstring = "l:i:o:s:t:u:v:w:xh"; lopts = k_filter; }
+    /* getopt_long permutes the array it is given: a copy of argv[1..] (argv[1], the subcommand, stands where the program name would) */
+    char **v = (char **)calloc((size_t)argc + 1, sizeof(char *));
+    for (int i = 1; i < argc; i++) v[i - 1] = argv[i];
+    const int vc = argc - 1;
+    static char flag[64][3];
+    int n_flag = 0;
+    opterr = 0;
+    optind = 1;
+    cl->ok = 1;
+    for (;;) {
+        int idx = 0;
+        const int key = getopt_long(vc, v, optstring, lopts, &idx);
+        if (key == -1) break;
+        if (key == '?' || key == ':' || key == 'h' || cl->n_opts + 2 >= (int)(sizeof(cl->opts) / sizeof(cl->opts[0])) || n_flag >= 64) {
+            cl->ok = 0;
+            break;
+        }
+        if (key == 'i') { cl->in_path = optarg; continue; }
+        if (key == 'o') { cl->out_path = optarg; continue; }
+        flag[n_flag][0] = '-'; flag[n_flag][1] = (char)key; flag[n_flag][2] = 0;
+        cl->opts[cl->n_opts++] = flag[n_flag++];
+        if (optarg) cl->opts[cl->n_opts++] = optarg;
+    }
+    cl->pos = v + optind; /* what getopt_long moved behind the options */
+    cl->n_pos = cl->ok ? vc - optind : 0;
 }
 
 static int copy_fd(int from, int to) {
@@ -135,20 +189,19 @@ static int copy_fd(int from, int to) {
     }
 }
 
-/* argv of worker r: the command line without its -i / -o, then ours */
-static char **worker_argv(int argc, char **argv, int in_at, int in_n, int out_at, int out_n, const char *in_path, const char *out_path) {
-    char **v = (char **)calloc((size_t)argc + 6, sizeof(char *));
+/* argv of a worker: the subcommand, the options as parsed (without -i / -o), the positional arguments behind "--", then our -i / -o */
+static char **worker_argv(const char *cmd, const CmdLine *cl, const char *in_path, const char *out_path) {
+    char **v = (char **)calloc((size_t)cl->n_opts + (size_t)cl->n_pos + 9, sizeof(char *));
     int k = 0;
     v[k++] = g_worker;
-    for (int i = 1; i < argc; i++) {
-        if (in_n && i >= in_at && i < in_at + in_n) continue;
-        if (out_n && i >= out_at && i < out_at + out_n) continue;
-        v[k++] = argv[i];
-    }
+    v[k++] = (char *)cmd;
+    for (int i = 0; i < cl->n_opts; i++) v[k++] = cl->opts[i];
     v[k++] = (char *)"-i";
     v[k++] = (char *)in_path;
     v[k++] = (char *)"-o";
     v[k++] = (char *)out_path;
+    if (cl->n_pos) v[k++] = (char *)"--";
+    for (int i = 0; i < cl->n_pos; i++) v[k++] = cl->pos[i];
     v[k] = NULL;
     return v;
 }
@@ -186,11 +239,11 @@ static int status_of(int st) {
 
 /* ---------------- stream commands ---------------- */
 
-static int run_stream(int argc, char **argv, int n, int one_device, const char *in_path, int in_at, int in_n, const char *out_path, int out_at, int out_n) {
+static int run_stream(const char *cmd, const CmdLine *cl, int n, int one_device, const char *in_path, const char *out_path) {
     int fd = open(in_path, O_RDONLY);
     struct stat sb;
     if (fd < 0 || fstat(fd, &sb) != 0) {
-        fprintf(stderr, "paffy %s: cannot open %s\n", argv[1], in_path);
+        fprintf(stderr, "paffy %s: cannot open %s\n", cmd, in_path);
         return 1;
     }
     const int64_t size = (int64_t)sb.st_size;
@@ -217,29 +270,33 @@ static int run_stream(int argc, char **argv, int n, int one_device, const char *
     close(fd);
     pid_t pids[MAX_RANKS];
     for (int r = 0; r < n; r++) {
-        snprintf(g_spool[r][1], PATH_MAX, "%s/paffy.%d.%d.out", g_tmpdir, (int)getpid(), r);
+        snprintf(g_spool[r][1], PATH_MAX, "%s/%d.out", g_spooldir, r);
         char range[64];
         snprintf(range, sizeof(range), "%lld:%lld", (long long)cut[r], (long long)cut[r + 1]);
-        char **wv = worker_argv(argc, argv, in_at, in_n, out_at, out_n, in_path, g_spool[r][1]);
+        char **wv = worker_argv(cmd, cl, in_path, g_spool[r][1]);
         pids[r] = spawn(wv, r, n, one_device, range, NULL);
         free(wv);
         if (pids[r] < 0) {
             fprintf(stderr, "paffy: fork failed\n");
             for (int q = 0; q < r; q++) kill(pids[q], SIGTERM);
+            for (int q = 0; q < r; q++) waitpid(pids[q], NULL, 0);
             return 1;
         }
+        g_pids[r] = pids[r];
     }
     int out_fd = out_path ? open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0666) : 1;
     if (out_fd < 0) {
-        fprintf(stderr, "paffy %s: cannot open %s\n", argv[1], out_path);
+        fprintf(stderr, "paffy %s: cannot open %s\n", cmd, out_path);
         for (int q = 0; q < n; q++) kill(pids[q], SIGTERM);
+        for (int q = 0; q < n; q++) waitpid(pids[q], NULL, 0);
         return 1;
     }
     int rc = 0;
     for (int r = 0; r < n; r++) { /* in rank order: the output of worker r follows that of worker r - 1 */
         int st = 0;
         while (waitpid(pids[r], &st, 0) < 0 && errno == EINTR) {}
-        int sfd = open(g_spool[r][1], O_RDONLY);
+        g_pids[r] = 0;
+        int sfd = open(g_spool[r][1], O_RDONLY | O_NOFOLLOW);
         if (sfd >= 0) {
             if (copy_fd(sfd, out_fd) != 0) rc = 1;
             close(sfd);
@@ -247,7 +304,10 @@ static int run_stream(int argc, char **argv, int n, int one_device, const char *
         const int failed = WIFSIGNALED(st) || WEXITSTATUS(st) != 0;
         if (failed) { /* the records before the failing one are out; nothing after them is written */
             for (int q = r + 1; q < n; q++) kill(pids[q], SIGTERM);
-            for (int q = r + 1; q < n; q++) waitpid(pids[q], NULL, 0);
+            for (int q = r + 1; q < n; q++) {
+                waitpid(pids[q], NULL, 0);
+                g_pids[q] = 0;
+            }
             if (out_fd != 1) close(out_fd);
             return status_of(st);
         }
@@ -368,7 +428,7 @@ static const void *map_file(const char *path, size_t *len) {
     return p == MAP_FAILED ? NULL : p;
 }
 
-static int run_tile(int argc, char **argv, int n, int one_device, const char *in_path, int in_at, int in_n, const char *out_path, int out_at, int out_n) {
+static int run_tile(const CmdLine *cl, int n, int one_device, const char *in_path, const char *out_path) {
     size_t in_len = 0;
     const char *in = (const char *)map_file(in_path, &in_len);
     if (!in) {
@@ -406,9 +466,9 @@ static int run_tile(int argc, char **argv, int n, int one_device, const char *in
     FILE *fin[MAX_RANKS], *fidx[MAX_RANKS];
     for (int r = 0; r < n; r++) {
         const char *ext[4] = {"in", "out", "rows", "idx"};
-        for (int k = 0; k < 4; k++) snprintf(g_spool[r][k], PATH_MAX, "%s/paffy.%d.%d.%s", g_tmpdir, (int)getpid(), r, ext[k]);
-        fin[r] = fopen(g_spool[r][0], "w");
-        fidx[r] = fopen(g_spool[r][3], "w");
+        for (int k = 0; k < 4; k++) snprintf(g_spool[r][k], PATH_MAX, "%s/%d.%s", g_spooldir, r, ext[k]);
+        fin[r] = fopen(g_spool[r][0], "wx"); /* O_EXCL: inside our own 0700 directory nothing can be there */
+        fidx[r] = fopen(g_spool[r][3], "wx");
         if (!fin[r] || !fidx[r]) {
             fprintf(stderr, "paffy tile: cannot write under %s\n", g_tmpdir);
             return 1;
@@ -416,6 +476,7 @@ static int run_tile(int argc, char **argv, int n, int one_device, const char *in
         setvbuf(fin[r], NULL, _IOFBF, 1 << 22);
     }
     uint64_t line_no = 0;
+    int64_t spooled[MAX_RANKS] = {0}; /* lines routed to each worker */
     for (const char *p = in, *end = in + in_len; p < end; line_no++) {
         const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
         const char *le = nl ? nl + 1 : end;
@@ -425,6 +486,7 @@ static int run_tile(int argc, char **argv, int n, int one_device, const char *in
         fwrite(p, 1, (size_t)(le - p), fin[r]);
         if (!nl) fputc('\n', fin[r]); /* a last line without its newline is a record all the same (impl/paf.c:213) */
         fwrite(&line_no, sizeof(line_no), 1, fidx[r]);
+        spooled[r]++;
         p = le;
     }
     int werr = 0;
@@ -435,17 +497,32 @@ static int run_tile(int argc, char **argv, int n, int one_device, const char *in
         fprintf(stderr, "paffy tile: writing the spools under %s failed\n", g_tmpdir);
         return 1;
     }
-    /* the workers */
+    /* the workers: one per GPU that has lines to tile. Fewer query names than GPUs (one per-contig split of the input is the reference's
+       own workflow, tests/paf_pipeline_test.sh:42-67) or an empty input leave workers without a line: they are not started, and the
+       merge below has nothing to take from them -- the reference writes an empty output and exits 0 for an empty input */
     pid_t pids[MAX_RANKS];
     for (int r = 0; r < n; r++) {
-        char **wv = worker_argv(argc, argv, in_at, in_n, out_at, out_n, g_spool[r][0], g_spool[r][1]);
+        pids[r] = 0;
+        if (spooled[r] == 0) continue;
+        char **wv = worker_argv("tile", cl, g_spool[r][0], g_spool[r][1]);
         pids[r] = spawn(wv, r, n, one_device, NULL, g_spool[r][2]);
         free(wv);
+        if (pids[r] < 0) {
+            fprintf(stderr, "paffy: fork failed\n");
+            for (int q = 0; q < r; q++)
+                if (pids[q] > 0) kill(pids[q], SIGTERM);
+            for (int q = 0; q < r; q++)
+                if (pids[q] > 0) waitpid(pids[q], NULL, 0);
+            return 1;
+        }
+        g_pids[r] = pids[r];
     }
     int bad_st = 0, any_bad = 0;
     for (int r = 0; r < n; r++) {
+        if (pids[r] <= 0) continue;
         int st = 0;
         while (waitpid(pids[r], &st, 0) < 0 && errno == EINTR) {}
+        g_pids[r] = 0;
         if (!any_bad && (WIFSIGNALED(st) || WEXITSTATUS(st) != 0)) {
             any_bad = 1;
             bad_st = st;
@@ -457,9 +534,14 @@ static int run_tile(int argc, char **argv, int n, int one_device, const char *in
     memset(cur, 0, sizeof(cur));
     for (int r = 0; r < n; r++) {
         Cursor *c = &cur[r];
+        if (pids[r] <= 0) continue; /* no lines, no worker: line_end stays NULL */
         c->out = (const char *)map_file(g_spool[r][1], &c->out_len);
         c->rows = (const uint32_t *)map_file(g_spool[r][2], &c->rows_len);
         c->idx = (const uint64_t *)map_file(g_spool[r][3], &c->idx_len);
+        if (c->out && c->out_len == 0 && !c->rows) { /* a worker that ended well and wrote nothing had nothing to list either */
+            c->rows = (const uint32_t *)"";
+            c->rows_len = 0;
+        }
         if (!c->out || !c->rows || !c->idx) {
             fprintf(stderr, "paffy tile: worker %d left no output\n", r);
             return 1;
@@ -504,7 +586,13 @@ int main(int argc, char **argv) {
     const char *g = getenv("PAFFY_GPUS");
     int n = g ? atoi(g) : 1;
     if (n > MAX_RANKS) n = MAX_RANKS;
-    const int shard = n > 1 && argc >= 2 && !wants_help(argc, argv) && (is_stream_cmd(argv[1]) || !strcmp(argv[1], "tile"));
+    int shard = n > 1 && argc >= 2 && (is_stream_cmd(argv[1]) || !strcmp(argv[1], "tile"));
+    CmdLine cl;
+    memset(&cl, 0, sizeof(cl));
+    if (shard) {
+        parse_cmdline(argc, argv, &cl);
+        shard = cl.ok; /* -h, or something getopt_long would reject: the one worker says what the reference says */
+    }
     if (!shard) { /* one GPU (or a command that does not shard): this process becomes the worker; it has not touched a GPU */
         argv[0] = g_worker;
         execv(g_worker, argv);
@@ -512,15 +600,25 @@ int main(int argc, char **argv) {
         return 127;
     }
     find_tmpdir();
+    if (make_spooldir() != 0) {
+        fprintf(stderr, "paffy: cannot make a spool directory under %s\n", g_tmpdir);
+        return 1;
+    }
     g_n = n;
     atexit(cleanup);
+    {
+        struct sigaction sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.sa_handler = on_signal;
+        sigaction(SIGINT, &sa, NULL);
+        sigaction(SIGTERM, &sa, NULL);
+        sigaction(SIGHUP, &sa, NULL);
+    }
     const int one_device = getenv("PAFFY_ONE_DEVICE") && atoi(getenv("PAFFY_ONE_DEVICE")) != 0;
-    int in_at, in_n, out_at, out_n;
-    const char *in_path = find_opt(argc, argv, 'i', "inputFile", &in_at, &in_n);
-    const char *out_path = find_opt(argc, argv, 'o', "outputFile", &out_at, &out_n);
+    const char *in_path = cl.in_path, *out_path = cl.out_path;
     if (!in_path) { /* stdin: to a spool file first, the workers read ranges of it */
-        snprintf(g_stdin_spool, sizeof(g_stdin_spool), "%s/paffy.%d.stdin", g_tmpdir, (int)getpid());
-        int fd = open(g_stdin_spool, O_WRONLY | O_CREAT | O_TRUNC, 0600);
+        snprintf(g_stdin_spool, sizeof(g_stdin_spool), "%s/stdin", g_spooldir);
+        int fd = open(g_stdin_spool, O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
         if (fd < 0 || copy_fd(0, fd) != 0) {
             fprintf(stderr, "paffy: cannot spool the input under %s\n", g_tmpdir);
             return 1;
@@ -528,6 +626,6 @@ int main(int argc, char **argv) {
         close(fd);
         in_path = g_stdin_spool;
     }
-    if (!strcmp(argv[1], "tile")) return run_tile(argc, argv, n, one_device, in_path, in_at, in_n, out_path, out_at, out_n);
-    return run_stream(argc, argv, n, one_device, in_path, in_at, in_n, out_path, out_at, out_n);
+    if (!strcmp(argv[1], "tile")) return run_tile(&cl, n, one_device, in_path, out_path);
+    return run_stream(argv[1], &cl, n, one_device, in_path, out_path);
 }

@@ -654,6 +654,13 @@ static int whole_file(FILE *in, FILE *out, const paffy_bed_opts *bed, const paff
         rc = 1;
     }
     if (!rc && info.error.code) die_like_reference(&info.error, 0);
+    if (!rc && info.out_bytes <= 0 && !bed && !chain && getenv("PAFFY_ROWS_FILE")) { /* under the N-GPU launcher: no output line, an empty list */
+        FILE *rf = fopen(getenv("PAFFY_ROWS_FILE"), "w");
+        if (!rf || fclose(rf) != 0) {
+            fprintf(stderr, "paffy %s: cannot write %s\n", what, getenv("PAFFY_ROWS_FILE"));
+            rc = 1;
+        }
+    }
     if (!rc && info.out_bytes > 0) {
         if (bed) { /* the runs: one buffer */
             void *d_out = NULL;

@@ -1,0 +1,625 @@
+/*
+ * flat_kernel.h -- the sizing pass of the lean pipes (invert / identity trim / shatter / pass) without an op store per record (round 4).
+ *
+ * The record kernels (record_kernel.h) give every record a workgroup that holds the record's ops in LDS: a record costs a cold prologue
+ * whatever its length (half of a typical cfg3 record's time), a long record needs a store of its own size (three LDS levels, then an
+ * arena in HBM), and the 6 % of the records above 8 192 ops -- 41 % of the ops of the heavy-tailed stream of SURVEY 8d -- run at one or
+ * two workgroups per CU. Here the work is cut differently:
+ *
+ *   k_flat_parse   cigar_parse (impl/paf.c:70-111) over CHUNKS of cigar text, whatever record they belong to: a wave takes four 1 KiB
+ *                  tiles of one record's cigar ("pieces": a record's cigar cut at the 1 KiB boundaries of the batch text), finds the op
+ *                  letters, converts the numbers in front of them, writes the ops as 2-byte words into the record's mirror (the
+ *                  layout the writers already read) and leaves one 32-byte summary per piece: ops, bases by kind, rows and digits of
+ *                  the M ops, text offset. Where a chunk's ops start inside its record's mirror comes from the non-digit counts per
+ *                  1 KiB tile that the separator index leaves behind (k_sep_index reads those bytes anyway). Any length of record
+ *                  is just more chunks; every wave has the same work.
+ *   k_flat_size    one wave per record, on the summaries: totals, paf_check (impl/paf.c:427-461), the identity trim
+ *                  (impl/paf.c:811-953) with the pieces as the chunks of its pruned searches -- only the pieces that can hold a hit
+ *                  are walked, op by op, from the mirror --, the rows and bytes of paf_shatter (impl/paf.c:600-663) or the length of
+ *                  the written line (impl/paf.c:317-389) from the summaries of the window that is left.
+ *
+ * What the flat pass does not take -- numbers of five digits or more or with leading zeros, lengths of 8 192 or more, zero lengths,
+ * characters outside MID=X, a failing check, rows whose digit counts change inside the record, pieces longer than the writers' LDS
+ * staging, sums beyond 31 bits, any error at all -- it leaves to the record kernels (flat_done[rec] = 0), which run afterwards over
+ * exactly those records; errors are reported there, by the code that has always reported them.
+ */
+#ifndef PAFFY_FLAT_KERNEL_H_
+#define PAFFY_FLAT_KERNEL_H_
+
+#define FLAT_TILE 1024u
+#define FLAT_TILE_SHIFT 10u
+#define FLAT_CHUNK_PIECES 4u /* pieces (1 KiB of cigar text each) per parse work item */
+#define FLAT_P_CAP 512u      /* op letters a 1 KiB piece of a regular cigar can hold (two bytes per op at least) */
+#define FLAT_F_IRREG 1u      /* the piece holds something the flat pass leaves to the record kernels */
+#define FLAT_F_NONPLAIN 2u   /* the piece holds = or X ops (paf_shatter asserts on them, impl/paf.c:649-651) */
+
+/* Summary of one piece as k_flat_parse leaves it; k_flat_size turns the seven sums into inclusive prefix sums over the record's pieces,
+   in place, for the records of more than 64 pieces. */
+struct PieceSum {
+    uint32_t cnt;      /* ops whose letter lies in the piece; as parsed: | flags << 16 */
+    uint32_t m, x;     /* bases of M and = ops; of X, I and D ops (the matches / mismatches of impl/paf.c:823-828) */
+    uint32_t ins, del; /* bases of I ops, of D ops */
+    uint32_t rows;     /* M ops */
+    uint32_t extra;    /* digits of the M ops' lengths beyond the first */
+    uint32_t text_end; /* offset from the cigar's first byte just behind the last op letter at or before the end of the piece */
+};
+static_assert(sizeof(PieceSum) == 32, "two 16-byte stores");
+
+struct FlatParams {
+    const uint8_t *in;
+    uint32_t in_len;
+    const RecMeta *meta;
+    const uint2 *flat_rec;     /* per record: first piece, first chunk */
+    const uint32_t *chunk_rec; /* per chunk: its record */
+    const uint16_t *nd;        /* per 1 KiB tile of the text: bytes that are not digits */
+    PieceSum *sums;
+    uint32_t *ops_mirror;
+    DevInfo *info;
+};
+
+__device__ __forceinline__ uint32_t nondigit16(const uint4 &v) { /* bit j: byte j of the 16 is not an ASCII digit */
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint32_t nd = nondigit4(w[j]) >> 7;
+        nd = (nd | (nd >> 7) | (nd >> 14) | (nd >> 21)) & 0xfu;
+        m |= nd << (4 * j);
+    }
+    return m;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return wave_last_u32(wave_incl_scan_u32(v)); }
+
+/* bytes of LDS per wave: 16 bytes in front of the tile (the text before it), the tile, the positions of its op letters */
+#define FLAT_PARSE_LDS (16u + FLAT_TILE + 2u * FLAT_P_CAP)
+#define FLAT_PARSE_WAVES 4u
+__global__ __launch_bounds__(64 * FLAT_PARSE_WAVES) void k_flat_parse(FlatParams F) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[FLAT_PARSE_WAVES][FLAT_PARSE_LDS];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint8_t *T = smem[wave];
+    uint16_t *Pl = reinterpret_cast<uint16_t *>(T + 16u + FLAT_TILE);
+    const uint32_t n_chunks = (uint32_t)(F.info->flat_alloc & 0xffffffffull);
+    const uint32_t n_waves = gridDim.x * FLAT_PARSE_WAVES;
+    for (uint32_t c = blockIdx.x * FLAT_PARSE_WAVES + wave; c < n_chunks; c += n_waves) {
+        const uint32_t rec = F.chunk_rec[c];
+        const uint32_t cg_off = F.meta[rec].cg_off, cg_end = cg_off + F.meta[rec].cg_len;
+        const uint2 fr = F.flat_rec[rec];
+        const uint32_t tile_first = cg_off >> FLAT_TILE_SHIFT;
+        const uint32_t np = ((cg_end - 1u) >> FLAT_TILE_SHIFT) - tile_first + 1u;
+        const uint32_t p0 = (c - fr.y) * FLAT_CHUNK_PIECES, p1 = p0 + FLAT_CHUNK_PIECES < np ? p0 + FLAT_CHUNK_PIECES : np;
+        uint32_t tile = tile_first + p0;
+        /* the 16 bytes in front of the chunk's first tile */
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            uint4 h = make_uint4(0, 0, 0, 0);
+            if (tile > 0) h = *reinterpret_cast<const uint4 *>(F.in + ((size_t)tile << FLAT_TILE_SHIFT) - 16u);
+            *reinterpret_cast<uint4 *>(T) = h;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t n = 0;        /* ops of the record in front of the current tile */
+        int32_t prev;          /* the last op letter in front of the tile, relative to the tile's first byte (negative) */
+        uint32_t text_end = 0; /* offset from cg_off just behind that letter */
+        if (p0 == 0) {
+            prev = (int32_t)cg_off - 1 - (int32_t)(tile << FLAT_TILE_SHIFT);
+        } else {
+            /* ops in front of the chunk: the letters of the record's first, partial tile and the non-digit bytes of the whole tiles
+               between it and the chunk (inside a cigar the flat pass keeps, every byte that is not a digit is an op letter) */
+            uint32_t cnt = 0;
+            {
+                const uint32_t g = (tile_first << FLAT_TILE_SHIFT) + lane * 16u;
+                uint4 v = make_uint4(0x30303030u, 0x30303030u, 0x30303030u, 0x30303030u);
+                if (g < F.in_len) v = *reinterpret_cast<const uint4 *>(F.in + g);
+                const uint32_t lo_b = cg_off > g ? (cg_off - g < 16u ? cg_off - g : 16u) : 0u;
+                cnt = (uint32_t)__popc(nondigit16(v) & 0xffffu & ~((1u << lo_b) - 1u));
+            }
+            for (uint32_t t = tile_first + 1u + lane; t < tile; t += 64u) cnt += F.nd[t];
+            n = wave_sum_u32(cnt);
+            const uint4 h = *reinterpret_cast<const uint4 *>(T);
+            const uint32_t hm = nondigit16(h);
+            prev = hm ? (int32_t)(31 - __clz((int)hm)) - 16 : -17; /* no letter within 16 bytes: the first number of the chunk counts as too long */
+            text_end = (uint32_t)((int32_t)(tile << FLAT_TILE_SHIFT) + prev + 1 - (int32_t)cg_off);
+        }
+        uint16_t *dst = reinterpret_cast<uint16_t *>(F.ops_mirror + (cg_off >> 1));
+        for (uint32_t p = p0; p < p1; p++, tile++) {
+            const uint32_t t0 = tile << FLAT_TILE_SHIFT, g = t0 + lane * 16u;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (g < F.in_len) v = *reinterpret_cast<const uint4 *>(F.in + g);
+            *reinterpret_cast<uint4 *>(T + 16u + lane * 16u) = v;
+            const uint32_t ndm = nondigit16(v);
+            const uint32_t lo_b = cg_off > g ? (cg_off - g < 16u ? cg_off - g : 16u) : 0u;
+            const uint32_t hi_b = cg_end < g + 16u ? (cg_end > g ? cg_end - g : 0u) : 16u;
+            uint32_t opmask = ndm & (hi_b >= 16u ? 0xffffu : ((1u << hi_b) - 1u)) & ~((1u << lo_b) - 1u);
+            /* a cigar that ends in digits: the reference's switch sees the NUL (impl/paf.c:96-103) */
+            uint32_t bad = (hi_b > lo_b && g + hi_b == cg_end && !((ndm >> (hi_b - 1u)) & 1u)) ? 1u : 0u;
+            const uint32_t cnt = (uint32_t)__popc(opmask), inc = wave_incl_scan_u32(cnt), total = wave_last_u32(inc);
+            uint32_t rank = inc - cnt;
+            while (opmask) {
+                const uint32_t j = (uint32_t)__ffs((int)opmask) - 1u;
+                opmask &= opmask - 1u;
+                if (rank < FLAT_P_CAP) Pl[rank] = (uint16_t)(lane * 16u + j);
+                rank++;
+            }
+            if (total > FLAT_P_CAP) bad = 1u; /* op letters side by side: lengths without digits */
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t top = total < FLAT_P_CAP ? total : FLAT_P_CAP;
+            /* per lane at most eight ops of at most 8 191 bases: two 16-bit sums per register */
+            uint32_t acc_mx = 0, acc_id = 0, acc_re = 0, nonplain = 0;
+            for (uint32_t i = lane; i < top; i += 64u) {
+                const int32_t pos = (int32_t)Pl[i];
+                const int32_t before = i ? (int32_t)Pl[i - 1u] : prev;
+                const uint32_t k = (uint32_t)(pos - before - 1); /* digits in front of the letter */
+                /* the four bytes in front of the letter and the letter itself: two aligned words of the staged text */
+                const uint32_t a = 16u + (uint32_t)pos - 4u, sh = a & 3u;
+                const uint32_t *wp = reinterpret_cast<const uint32_t *>(T + (a - sh));
+                const uint32_t d0 = wp[0], d1 = wp[1];
+                const uint32_t hi = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                const uint32_t ch = (d1 >> (8u * sh)) & 0xffu;
+                const uint32_t kk = k < 4u ? k : 4u;
+                const uint32_t x = kk ? ((hi ^ 0x30303030u) & (0xffffffffu << (32u - 8u * kk))) : 0u;
+                const uint32_t len = swar4(x);
+                int code = op_code_of(ch);
+                const bool lead0 = kk >= 2u && ((hi >> (8u * (4u - kk))) & 0xffu) == (uint32_t)'0';
+                /* what the flat pass keeps: one to four digits without a leading zero, 1 <= length < 8192, a letter of MID=X */
+                bad |= ((k - 1u > 3u) | (len - 1u >= 8191u) | lead0 | (code < 0)) ? 1u : 0u;
+                code = code < 0 ? 0 : code;
+                dst[n + i] = (uint16_t)((len << 3) | (uint32_t)code);
+                const uint32_t l16 = len & 0xffffu;
+                acc_mx += l16 << (((0x16u >> code) & 1u) << 4);                                     /* M = | X I D */
+                acc_id += (code == OP_I ? l16 : 0u) + (code == OP_D ? l16 << 16 : 0u);              /* I | D */
+                acc_re += code == OP_M ? 1u + ((kk - 1u) << 16) : 0u;                               /* rows | digits beyond the first */
+                nonplain |= code > OP_D ? 1u : 0u;
+            }
+            const uint32_t s_m = wave_sum_u32(acc_mx & 0xffffu), s_x = wave_sum_u32(acc_mx >> 16);
+            const uint32_t s_i = wave_sum_u32(acc_id & 0xffffu), s_d = wave_sum_u32(acc_id >> 16);
+            const uint32_t s_r = wave_sum_u32(acc_re & 0xffffu), s_e = wave_sum_u32(acc_re >> 16);
+            const uint32_t flags = (__any(bad != 0) ? FLAT_F_IRREG : 0u) | (__any(nonplain != 0) ? FLAT_F_NONPLAIN : 0u);
+            if (total) {
+                const int32_t last = (int32_t)Pl[top - 1u];
+                text_end = t0 + (uint32_t)last + 1u - cg_off;
+                prev = last - (int32_t)FLAT_TILE;
+            } else {
+                prev -= (int32_t)FLAT_TILE;
+                if (prev < -64) prev = -64;
+            }
+            if (lane == 0) {
+                uint4 *o = reinterpret_cast<uint4 *>(F.sums + fr.x + p);
+                o[0] = make_uint4(total | (flags << 16), s_m, s_x, s_i);
+                o[1] = make_uint4(s_d, s_r, s_e, text_end);
+            }
+            n += total;
+            /* the tile's last 16 bytes are the next tile's front */
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 63u) *reinterpret_cast<uint4 *>(T) = v;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------------------ */
+
+struct FlatSizeParams {
+    KParams P;
+    const uint2 *flat_rec;
+    PieceSum *sums;
+    uint8_t *flat_done;
+};
+
+/* prefix sums at a boundary between raw ops of a record (wave-uniform) */
+struct FlatPre {
+    uint32_t cnt, m, x, ins, del, rows, extra, text;
+};
+__device__ __forceinline__ FlatPre flat_sub(const FlatPre &a, const FlatPre &b) {
+    FlatPre r;
+    r.cnt = a.cnt - b.cnt; r.m = a.m - b.m; r.x = a.x - b.x; r.ins = a.ins - b.ins; r.del = a.del - b.del;
+    r.rows = a.rows - b.rows; r.extra = a.extra - b.extra; r.text = a.text - b.text;
+    return r;
+}
+/* a word another lane of this wave has just stored: read past the L1 */
+__device__ __forceinline__ uint32_t flat_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint32_t lane_val(uint32_t x, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)l); }
+
+/* One record's pieces: their inclusive prefix sums, lane p = piece p for records of at most 64 pieces, in HBM (scanned in place) for longer ones. */
+struct FlatRec {
+    const PieceSum *ps;
+    uint32_t np, n_ops;
+    bool in_regs;
+    FlatPre inc; /* in_regs: lane p holds the sums of pieces [0, p] */
+    const uint16_t *ops;
+    bool want_text;
+
+    __device__ __forceinline__ FlatPre piece_prefix(uint32_t j) const { /* pieces [0, j) */
+        FlatPre r;
+        r.cnt = r.m = r.x = r.ins = r.del = r.rows = r.extra = r.text = 0;
+        if (j == 0) return r;
+        if (in_regs) {
+            const uint32_t l = j - 1u;
+            r.cnt = lane_val(inc.cnt, l); r.m = lane_val(inc.m, l); r.x = lane_val(inc.x, l); r.ins = lane_val(inc.ins, l);
+            r.del = lane_val(inc.del, l); r.rows = lane_val(inc.rows, l); r.extra = lane_val(inc.extra, l); r.text = lane_val(inc.text, l);
+        } else {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(ps + (j - 1u));
+            r.cnt = uni(flat_ld(q)); r.m = uni(flat_ld(q + 1)); r.x = uni(flat_ld(q + 2)); r.ins = uni(flat_ld(q + 3));
+            r.del = uni(flat_ld(q + 4)); r.rows = uni(flat_ld(q + 5)); r.extra = uni(flat_ld(q + 6)); r.text = uni(flat_ld(q + 7));
+        }
+        return r;
+    }
+    /* the piece that holds raw op r (r < n_ops): the number of pieces that end at or before it */
+    __device__ __forceinline__ uint32_t piece_of(uint32_t r) const {
+        if (in_regs) {
+            const uint32_t lane = threadIdx.x & 63u;
+            return (uint32_t)__popcll(__ballot(lane < np && inc.cnt <= r));
+        }
+        uint32_t lo = 0, hi = np; /* first piece whose inclusive count is above r */
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (uni(flat_ld(&ps[mid].cnt)) <= r) lo = mid + 1u;
+            else hi = mid;
+        }
+        return lo;
+    }
+    /* sums of raw ops [0, r) */
+    __device__ __forceinline__ FlatPre raw_prefix(uint32_t r) const {
+        if (r >= n_ops) return piece_prefix(np);
+        const uint32_t pc = piece_of(r);
+        FlatPre a = piece_prefix(pc);
+        if (a.cnt == r) return a;
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t sm = 0, sx = 0, si = 0, sd = 0, sr = 0, se = 0, st = 0;
+        for (uint32_t i = a.cnt + lane; i < r; i += 64u) {
+            const uint32_t w = ops[i], len = w >> 3, code = w & 7u;
+            const uint32_t is_m = 0u - ((0x9u >> code) & 1u);
+            const uint32_t dg = (len >= 10u) + (len >= 100u) + (len >= 1000u);
+            sm += len & is_m;
+            sx += len & ~is_m;
+            si += code == (uint32_t)OP_I ? len : 0u;
+            sd += code == (uint32_t)OP_D ? len : 0u;
+            sr += code == (uint32_t)OP_M ? 1u : 0u;
+            se += code == (uint32_t)OP_M ? dg : 0u;
+            st += dg + 2u;
+        }
+        a.m += wave_sum_u32(sm); a.x += wave_sum_u32(sx); a.ins += wave_sum_u32(si); a.del += wave_sum_u32(sd);
+        a.rows += wave_sum_u32(sr); a.extra += wave_sum_u32(se);
+        if (want_text) a.text += wave_sum_u32(st);
+        a.cnt = r;
+        return a;
+    }
+};
+
+/* The window of raw ops a record's view is, with the prefix sums at its two ends. */
+struct FlatView {
+    uint32_t lo, n;
+    bool rev, swp;
+    FlatPre wlo, whi;
+    __device__ __forceinline__ uint32_t tm() const { return whi.m - wlo.m; }
+    __device__ __forceinline__ uint32_t tx() const { return whi.x - wlo.x; }
+    __device__ __forceinline__ uint32_t ins_v() const { return swp ? whi.del - wlo.del : whi.ins - wlo.ins; } /* I <-> D under an invert */
+    __device__ __forceinline__ uint32_t del_v() const { return swp ? whi.ins - wlo.ins : whi.del - wlo.del; }
+    __device__ __forceinline__ int64_t tq() const { return (int64_t)tm() + (int64_t)tx() - (int64_t)del_v(); }
+    __device__ __forceinline__ int64_t tt() const { return (int64_t)tm() + (int64_t)tx() - (int64_t)ins_v(); }
+};
+
+__device__ __forceinline__ int flat_check(const RecState &s, const FlatView &v) { /* paf_check, impl/paf.c:427-461 */
+    if (s.qs < 0 || s.qs >= s.qlen) return PAFFY_ERR_CHECK_QSTART;
+    if (s.qs > s.qe || s.qe > s.qlen) return PAFFY_ERR_CHECK_QEND;
+    if (s.ts < 0 || s.ts >= s.tlen) return PAFFY_ERR_CHECK_TSTART;
+    if (s.ts > s.te || s.te > s.tlen) return PAFFY_ERR_CHECK_TEND;
+    if (v.tq() != s.qe - s.qs) return PAFFY_ERR_CHECK_CIGAR_Q;
+    if (v.tt() != s.te - s.ts) return PAFFY_ERR_CHECK_CIGAR_T;
+    return 0;
+}
+
+/*
+ * paf_trim_unreliable_prefix + paf_trim_upto (impl/paf.c:842-904) on the front of the view; the same searches as trim_prefix32 of
+ * record_kernel.h with the record's pieces as the chunks: a piece whose best-case prefix identity clears the threshold by 1e-5 cannot
+ * hold a hit (float32 conversions and the divide are off by less than 2e-7 relative) and is not looked at, the others are walked by
+ * the wave, one op per lane, from the mirror.
+ */
+__device__ __forceinline__ void flat_trim_prefix(const FlatRec &R, RecState &s, FlatView &v, float thr_f, float id_f, int64_t max_trim) {
+    const double thr = (double)thr_f, idd = (double)id_f;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w_end = v.lo + v.n;
+    const uint32_t nb = (R.np + 63u) >> 6;
+    /* last view index with cumulative <= max_trim and prefix identity < threshold (impl/paf.c:820-838): pieces in descending view order */
+    int32_t trim_idx = -1;
+    uint32_t hit_m = 0, hit_x = 0;
+    for (uint32_t bi = 0; bi < nb && trim_idx < 0; bi++) {
+        const uint32_t b = v.rev ? bi : nb - 1u - bi;
+        const uint32_t p = b * 64u + lane;
+        /* prefix sums at the piece's two ends, clipped to the window */
+        uint32_t a_cnt = 0, a_m = 0, a_x = 0, b_cnt = 0, b_m = 0, b_x = 0;
+        if (p < R.np) {
+            if (R.in_regs) {
+                b_cnt = R.inc.cnt; b_m = R.inc.m; b_x = R.inc.x;
+            } else {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(R.ps + p);
+                b_cnt = flat_ld(q); b_m = flat_ld(q + 1); b_x = flat_ld(q + 2);
+            }
+        }
+        if (R.in_regs) {
+            a_cnt = dpp_mov_u32<0x138, 0xf, 0xf>(b_cnt); a_m = dpp_mov_u32<0x138, 0xf, 0xf>(b_m); a_x = dpp_mov_u32<0x138, 0xf, 0xf>(b_x); /* wave_shr:1, lane 0 receives 0 */
+        } else if (p > 0 && p < R.np) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(R.ps + (p - 1u));
+            a_cnt = flat_ld(q); a_m = flat_ld(q + 1); a_x = flat_ld(q + 2);
+        }
+        if (a_cnt < v.lo) { a_cnt = v.lo; a_m = v.wlo.m; a_x = v.wlo.x; }
+        if (a_cnt > w_end) { a_cnt = w_end; a_m = v.whi.m; a_x = v.whi.x; }
+        if (b_cnt < v.lo) { b_cnt = v.lo; b_m = v.wlo.m; b_x = v.wlo.x; }
+        if (b_cnt > w_end) { b_cnt = w_end; b_m = v.whi.m; b_x = v.whi.x; }
+        const bool live = p < R.np && b_cnt > a_cnt;
+        /* cumulative sums in front of the piece, in view order */
+        const uint32_t c_m = v.rev ? v.whi.m - b_m : a_m - v.wlo.m, c_x = v.rev ? v.whi.x - b_x : a_x - v.wlo.x;
+        const uint32_t chunk_x = b_x - a_x;
+        const bool may_hit = live && !(c_m > 0 && (double)c_m >= thr * 1.00001 * (double)(c_m + c_x + chunk_x)) &&
+                             !(max_trim >= 0 && (int64_t)c_m + (int64_t)c_x > max_trim);
+        unsigned long long flagged = __ballot(may_hit);
+        while (flagged) {
+            /* descending view order: the highest piece of a forward view, the lowest of a reversed one */
+            const uint32_t t = v.rev ? (uint32_t)__ffsll((long long)flagged) - 1u : 63u - (uint32_t)__clzll((long long)flagged);
+            flagged &= ~(1ull << t);
+            const uint32_t ra = lane_val(a_cnt, t), rb = lane_val(b_cnt, t);
+            uint32_t pm = lane_val(c_m, t), px = lane_val(c_x, t);
+            const uint32_t vb = v.rev ? w_end - rb : ra - v.lo, ve = v.rev ? w_end - ra : rb - v.lo; /* view indices of the piece's ops */
+            int32_t hit = -1;
+            for (uint32_t i0 = vb; i0 < ve; i0 += 64u) {
+                const uint32_t i = i0 + lane;
+                uint32_t len = 0, code = 0;
+                if (i < ve) {
+                    const uint32_t w = R.ops[v.rev ? w_end - 1u - i : v.lo + i];
+                    len = w >> 3;
+                    code = w & 7u;
+                }
+                const uint32_t is_m = 0u - ((0x9u >> code) & 1u);
+                const uint32_t im = wave_incl_scan_u32(len & is_m), ix = wave_incl_scan_u32(len & ~is_m);
+                const uint32_t cm = pm + im, cx = px + ix;
+                const bool ok = i < ve && !(max_trim >= 0 && (int64_t)(cm + cx) > max_trim) && ratio_f32_u32(cm, cm + cx) < thr;
+                const unsigned long long hb = __ballot(ok);
+                if (hb) {
+                    const uint32_t hl = 63u - (uint32_t)__clzll((long long)hb);
+                    hit = (int32_t)(i0 + hl);
+                    hit_m = lane_val(cm, hl);
+                    hit_x = lane_val(cx, hl);
+                }
+                pm += wave_last_u32(im);
+                px += wave_last_u32(ix);
+            }
+            if (hit >= 0) {
+                trim_idx = hit;
+                break;
+            }
+        }
+    }
+    if (trim_idx < 0) return;
+    /* smallest view index <= trim_idx whose suffix [i, trim_idx] has identity >= identity (impl/paf.c:879-890): ops in view order from the front */
+    uint32_t best = 0xffffffffu;
+    {
+        uint32_t pm = 0, px = 0;
+        for (uint32_t i0 = 0; i0 <= (uint32_t)trim_idx && best == 0xffffffffu; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            uint32_t len = 0, code = 0;
+            if (i <= (uint32_t)trim_idx) {
+                const uint32_t w = R.ops[v.rev ? w_end - 1u - i : v.lo + i];
+                len = w >> 3;
+                code = w & 7u;
+            }
+            const uint32_t is_m = 0u - ((0x9u >> code) & 1u);
+            const uint32_t vm = len & is_m, vx = len & ~is_m;
+            const uint32_t im = wave_incl_scan_u32(vm), ix = wave_incl_scan_u32(vx);
+            const uint32_t sm = hit_m - (pm + im - vm), sx = hit_x - (px + ix - vx); /* sums of [i, trim_idx] */
+            const bool ok = i <= (uint32_t)trim_idx && ratio_f32_u32(sm, sm + sx) >= idd;
+            const unsigned long long hb = __ballot(ok);
+            if (hb) best = i0 + (uint32_t)__ffsll((long long)hb) - 1u;
+            pm += wave_last_u32(im);
+            px += wave_last_u32(ix);
+        }
+    }
+    const uint32_t count = best != 0xffffffffu ? best : (uint32_t)trim_idx + 1u;
+    if (count == 0) return;
+    /* paf_trim_upto: the coordinates move over the dropped ops (impl/paf.c:842-861) */
+    const FlatView old = v;
+    if (!v.rev) {
+        v.lo += count;
+        v.wlo = R.raw_prefix(v.lo);
+    } else {
+        v.whi = R.raw_prefix(v.lo + v.n - count);
+    }
+    v.n -= count;
+    const int64_t d_t = old.tt() - v.tt(), d_q = old.tq() - v.tq();
+    s.ts += d_t;
+    if (s.same) s.qs += d_q;
+    else s.qe -= d_q;
+}
+
+/* what the record kernels take instead: nothing is written for the record but its mark */
+__device__ __forceinline__ void flat_leave(const FlatSizeParams &F, uint32_t rec) {
+    if ((threadIdx.x & 63u) == 0) {
+        F.flat_done[rec] = 0;
+        F.P.out_len[rec] = 0;
+        F.P.out_rows[rec] = 0;
+        F.P.status[rec] = 0;
+        atomicAdd(&F.P.info->flat_legacy, 1u);
+    }
+}
+
+#define FLAT_SIZE_WAVES 4u
+__global__ __launch_bounds__(64 * FLAT_SIZE_WAVES) void k_flat_size(FlatSizeParams F) {
+    const KParams &P = F.P;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t rec = blockIdx.x * FLAT_SIZE_WAVES + (threadIdx.x >> 6);
+    if (rec >= P.n_rec) return;
+    const RecMeta &m = P.meta[rec];
+    if (m.err || !m.has_cg || m.cg_len == 0) return flat_leave(F, rec);
+    const uint32_t cg_off = m.cg_off, cg_end = cg_off + m.cg_len;
+    const uint2 fr = F.flat_rec[rec];
+    FlatRec R;
+    R.np = ((cg_end - 1u) >> FLAT_TILE_SHIFT) - (cg_off >> FLAT_TILE_SHIFT) + 1u;
+    R.ps = F.sums + fr.x;
+    R.ops = reinterpret_cast<const uint16_t *>(P.ops_mirror + (cg_off >> 1));
+    R.in_regs = R.np <= 64u;
+    const bool shatter_last = P.n_stages > 0 && P.stages[P.n_stages - 1].kind == PAFFY_SHATTER;
+    R.want_text = !shatter_last;
+    /* the pieces' sums become inclusive prefix sums: in registers for a record of at most 64 pieces, in place in HBM for a longer one */
+    uint32_t flags = 0;
+    unsigned long long tot_m = 0, tot_x = 0;
+    {
+        FlatPre carry;
+        carry.cnt = carry.m = carry.x = carry.ins = carry.del = carry.rows = carry.extra = carry.text = 0;
+        const uint32_t nb = (R.np + 63u) >> 6;
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint32_t p = b * 64u + lane;
+            uint4 qa = make_uint4(0, 0, 0, 0), qb = make_uint4(0, 0, 0, 0);
+            if (p < R.np) {
+                qa = reinterpret_cast<const uint4 *>(R.ps + p)[0];
+                qb = reinterpret_cast<const uint4 *>(R.ps + p)[1];
+            }
+            flags |= qa.x >> 16;
+            FlatPre inc;
+            inc.cnt = carry.cnt + wave_incl_scan_u32(qa.x & 0xffffu);
+            inc.m = carry.m + wave_incl_scan_u32(qa.y);
+            inc.x = carry.x + wave_incl_scan_u32(qa.z);
+            inc.ins = carry.ins + wave_incl_scan_u32(qa.w);
+            inc.del = carry.del + wave_incl_scan_u32(qb.x);
+            inc.rows = carry.rows + wave_incl_scan_u32(qb.y);
+            inc.extra = carry.extra + wave_incl_scan_u32(qb.z);
+            inc.text = qb.w; /* cumulative as parsed */
+            tot_m += wave_sum_u32(qa.y); /* a block's own sums stay below 2^32 (64 pieces of 512 ops of 8 191 bases) */
+            tot_x += wave_sum_u32(qa.z);
+            if (R.in_regs) {
+                R.inc = inc;
+            } else if (p < R.np) {
+                uint4 *o = reinterpret_cast<uint4 *>(F.sums + fr.x + p);
+                o[0] = make_uint4(inc.cnt, inc.m, inc.x, inc.ins);
+                o[1] = make_uint4(inc.del, inc.rows, inc.extra, inc.text);
+            }
+            carry.cnt = lane_val(inc.cnt, 63); carry.m = lane_val(inc.m, 63); carry.x = lane_val(inc.x, 63); carry.ins = lane_val(inc.ins, 63);
+            carry.del = lane_val(inc.del, 63); carry.rows = lane_val(inc.rows, 63); carry.extra = lane_val(inc.extra, 63);
+        }
+        R.n_ops = carry.cnt;
+    }
+    flags = (__any((flags & FLAT_F_IRREG) != 0) ? FLAT_F_IRREG : 0u) | (__any((flags & FLAT_F_NONPLAIN) != 0) ? FLAT_F_NONPLAIN : 0u);
+    if ((flags & FLAT_F_IRREG) || R.n_ops == 0 || tot_m + tot_x >= 0x7fffffffull || P.nocheck_mask) return flat_leave(F, rec);
+    if (!R.in_regs) __threadfence(); /* the scanned sums are read back below by this wave (other lanes' stores): past the L1, flat_ld() */
+    RecState s;
+    load_state(m, s);
+    FlatView v;
+    v.lo = 0; v.n = R.n_ops; v.rev = false; v.swp = false;
+    v.wlo = R.piece_prefix(0);
+    v.whi = R.piece_prefix(R.np);
+    bool swapped = false, shatter = false, checked = false;
+    for (int32_t si = 0; si < P.n_stages; si++) {
+        const paffy_stage st = P.stages[si];
+        if (si > 0) { /* what `paf_write | paf_parse` between two processes does to the record */
+            if (v.n == 0) return flat_leave(F, rec);
+            if (s.type == 0 && s.tile_level != -1) s.type = s.tile_level > 1 ? 'S' : 'P';
+        }
+        int rc = 0;
+        if (st.kind == PAFFY_INVERT) {
+            invert_state(s);
+            v.swp = !v.swp;
+            if (!s.same) v.rev = !v.rev;
+            swapped = !swapped;
+            rc = flat_check(s, v);
+        } else if (st.kind == PAFFY_TRIM_IDENTITY) { /* paf_trim_unreliable_tails, impl/paf.c:906-953 */
+            const uint32_t mm = v.tm(), mx = v.tx();
+            const double identity = ratio_f32((int64_t)mm, (int64_t)mm + (int64_t)mx);
+            const double thr = __dsub_rn(identity, __dmul_rn(identity, (double)st.p0));
+            const int64_t max_trim = __float2ll_rz(__fmul_rn(__ll2float_rn((int64_t)mm + (int64_t)mx), st.p1));
+            const float thr_f = __double2float_rn(thr), id_f = __double2float_rn(identity);
+            const uint32_t n_before = v.n;
+#pragma unroll 1
+            for (int pass = 0; pass < 2; pass++) {
+                if (pass == 1) {
+                    if (s.same && v.n == n_before) break;
+                    invert_state(s);
+                    v.swp = !v.swp;
+                    if (!s.same) v.rev = !v.rev;
+                }
+                flat_trim_prefix(R, s, v, thr_f, id_f, max_trim);
+                if (pass == 1) {
+                    invert_state(s);
+                    v.swp = !v.swp;
+                    if (!s.same) v.rev = !v.rev;
+                }
+            }
+            const uint32_t m2 = v.tm(), x2 = v.tx();
+            const double final_identity = ratio_f32((int64_t)m2, (int64_t)m2 + (int64_t)x2);
+            rc = final_identity >= identity ? 0 : PAFFY_ERR_TRIM_IDENTITY_ASSERT;
+            if (!rc) rc = flat_check(s, v);
+        } else if (st.kind == PAFFY_SHATTER) {
+            shatter = true;
+            break;
+        } else if (st.kind != PAFFY_PASS) {
+            return flat_leave(F, rec);
+        }
+        if (rc) return flat_leave(F, rec);
+        checked = st.kind != PAFFY_PASS;
+    }
+    RecPlan *plan = static_cast<RecPlan *>(P.rec_plan) + rec;
+    int64_t bytes, rows;
+    bool rows_kernel = false, line_kernel = false;
+    uint32_t chunk = ((v.n + 63u) / 64u) | 1u;
+    int64_t wq[4] = {0, 0, 0, 0}, wt[4] = {0, 0, 0, 0}, wo[4] = {0, 0, 0, 0};
+    const FlatPre win = flat_sub(v.whi, v.wlo);
+    if (shatter) {
+        if (v.n == 0 || (flags & FLAT_F_NONPLAIN)) return flat_leave(F, rec);
+        if (!checked && flat_check(s, v)) return flat_leave(F, rec); /* every row of a record that passes paf_check passes its own (impl/paf.c:624) */
+        ShatterConst k;
+        shatter_consts(s, k);
+        const uint32_t dq0 = (uint32_t)dec_len(s.qs), dt0 = (uint32_t)dec_len(s.ts);
+        if (!shatter_fits(k) || !shatter_fast_ok(s, k) || k.lenA > 48 || k.lenB > 48 || k.lenC > 48 || dq0 != (uint32_t)dec_len(s.qe) ||
+            dt0 != (uint32_t)dec_len(s.te) || s.qe - s.qs >= 0x7fffffffll || s.te - s.ts >= 0x7fffffffll)
+            return flat_leave(F, rec);
+        /* start and end coordinates print with the same number of digits: a row's size depends on its length only */
+        const uint32_t fixed = k.row_const + 2u * dq0 + 2u * dt0;
+        rows = win.rows;
+        bytes = (int64_t)win.rows * (int64_t)(fixed + 3u) + 3ll * (int64_t)win.extra;
+        rows_kernel = v.n <= PAFFY_ROWS_MAX_OPS;
+        if (!rows_kernel) { /* the four-wave writer: bases consumed and bytes written in front of each wave's share of the view */
+            chunk = ((v.n + 255u) / 256u) | 1u;
+            for (uint32_t w = 1; w < 4; w++) {
+                const uint64_t at64 = 64ull * w * chunk;
+                const uint32_t at = at64 < v.n ? (uint32_t)at64 : v.n;
+                const FlatPre e = v.rev ? flat_sub(v.whi, R.raw_prefix(v.lo + v.n - at)) : flat_sub(R.raw_prefix(v.lo + at), v.wlo);
+                wq[w] = (int64_t)e.m + e.x - (v.swp ? e.ins : e.del);
+                wt[w] = (int64_t)e.m + e.x - (v.swp ? e.del : e.ins);
+                wo[w] = (int64_t)e.rows * (int64_t)(fixed + 3u) + 3ll * (int64_t)e.extra;
+            }
+        }
+    } else {
+        if (v.n == 0) return flat_leave(F, rec);
+        const uint32_t lenH = header_len(s, false);
+        if (lenH > 3 * PAFFY_TMPL_MAX) return flat_leave(F, rec);
+        line_kernel = lenH + 8 <= PAFFY_TMPL_MAX && v.n <= PAFFY_ROWS_MAX_OPS;
+        bytes = (int64_t)lenH + (int64_t)win.text + 1;
+        rows = 1;
+        if (!line_kernel) {
+            chunk = ((v.n + 255u) / 256u) | 1u;
+            for (uint32_t w = 1; w < 4; w++) {
+                const uint64_t at64 = 64ull * w * chunk;
+                const uint32_t at = at64 < v.n ? (uint32_t)at64 : v.n;
+                const FlatPre e = v.rev ? flat_sub(v.whi, R.raw_prefix(v.lo + v.n - at)) : flat_sub(R.raw_prefix(v.lo + at), v.wlo);
+                wo[w] = (int64_t)e.text;
+            }
+        }
+    }
+    if (lane == 0) {
+        if (shatter ? !rows_kernel : !line_kernel) atomicAdd(&P.info->g_count, 1u);
+        F.flat_done[rec] = 1;
+        P.status[rec] = (uint32_t)KLASS_LDS << 16;
+        P.err_aux[rec] = 0;
+        P.n_ops[rec] = 0;
+        P.out_len[rec] = bytes;
+        P.out_rows[rec] = rows;
+        plan->qs = s.qs; plan->qe = s.qe; plan->ts = s.ts; plan->te = s.te; plan->sub_lo = 0; plan->sub_hi = 0;
+        plan->lo = v.lo; plan->n = v.n;
+        plan->flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | 8u | ((uint32_t)s.type << 8) | (shatter ? 16u : 0u) |
+                      (rows_kernel ? 64u : 0u) | (line_kernel ? 0x10000u : 0u) | 0x40000u;
+        plan->chunk = chunk;
+        for (int w = 0; w < 4; w++) {
+            plan->wq[w] = wq[w];
+            plan->wt[w] = wt[w];
+            plan->wo[w] = wo[w];
+        }
+    }
+}
+
+#endif

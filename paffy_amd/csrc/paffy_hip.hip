@@ -26,6 +26,7 @@
 #include "../../include/paffy_hip.h"
 #include "paf_synth_core.h"
 #include "record_groups.h"
+#include "flat_kernel.h"
 #include "coverage_kernel.h"
 #include "bed_kernel.h"
 
@@ -38,11 +39,15 @@
 /* separators                                                           */
 /* ------------------------------------------------------------------ */
 
-__device__ __forceinline__ void sep_masks(const uint8_t *in, uint32_t in_len, uint32_t g, uint32_t &tabs_nl, uint32_t &nl) {
-    /* 16 bytes at g (multiple of 16): bit j of tabs_nl set for '\t' or '\n', of nl for '\n' */
+template <bool ND = false>
+__device__ __forceinline__ void sep_masks(const uint8_t *in, uint32_t in_len, uint32_t g, uint32_t &tabs_nl, uint32_t &nl, uint32_t *nondigits = nullptr) {
+    /* 16 bytes at g (multiple of 16): bit j of tabs_nl set for '\t' or '\n', of nl for '\n'; ND: *nondigits = bytes that are not ASCII digits
+       (the flat sizing pass, flat_kernel.h, places a chunk's ops inside its record with the counts per 1 KiB tile) */
     tabs_nl = nl = 0;
+    if (ND) *nondigits = 0;
     if (g >= in_len) return;
     uint4 v = *reinterpret_cast<const uint4 *>(in + g);
+    if (ND) *nondigits = (uint32_t)__popc(nondigit16(v));
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int k = 0; k < 4; k++) { /* four bytes at a time: a byte equals the pattern where the xor has a zero byte */
@@ -57,16 +62,18 @@ __device__ __forceinline__ void sep_masks(const uint8_t *in, uint32_t in_len, ui
     }
 }
 
-__global__ __launch_bounds__(PAFFY_NT) void k_sep_count(const uint8_t *in, uint32_t in_len, uint2 *tile_counts) {
+__global__ __launch_bounds__(PAFFY_NT) void k_sep_count(const uint8_t *in, uint32_t in_len, uint2 *tile_counts, uint16_t *nd) {
     __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
     BlockComm scratch{scratch_mem, 0};
     const uint32_t tile0 = blockIdx.x * SEP_TILE;
     int64_t acc[2] = {0, 0};
     for (uint32_t off = threadIdx.x * 16; off < SEP_TILE; off += PAFFY_NT * 16) {
-        uint32_t a, b;
-        sep_masks(in, in_len, tile0 + off, a, b);
+        uint32_t a, b, c;
+        sep_masks<true>(in, in_len, tile0 + off, a, b, &c);
         acc[0] += __popc(a);
         acc[1] += __popc(b);
+        c = wave_sum_u32(c); /* a wave's 64 x 16 bytes are one 1 KiB tile */
+        if ((threadIdx.x & 63u) == 0 && nd && tile0 + off < in_len) nd[(tile0 + off) >> FLAT_TILE_SHIFT] = (uint16_t)c;
     }
     block_sum<2>(acc, scratch);
     if (threadIdx.x == 0) {
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(PAFFY_NT) void k_sep_write(const uint8_t *in, uint3
 #define SEP_INC (2ull << 62)
 __device__ __forceinline__ unsigned long long sep_pack(uint32_t seps, uint32_t lines) { return (unsigned long long)seps | ((unsigned long long)lines << 31); }
 __global__ __launch_bounds__(PAFFY_NT) void k_sep_index(const uint8_t *in, uint32_t in_len, uint32_t n_tiles, unsigned long long *state, uint32_t *sep_pos,
-                                                         uint32_t cap_seps, uint32_t *nl_idx, uint32_t cap_lines, DevInfo *info) {
+                                                         uint32_t cap_seps, uint32_t *nl_idx, uint32_t cap_lines, DevInfo *info, uint16_t *nd) {
     __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
     /* per round and thread, in text order (entry e = round * 256 + thread): separators | newlines << 16 -- first the counts, then the
        exclusive prefix inside the tile. One spare word per sixteen entries: a thread's sixteen consecutive entries are then 17 words from
@@ -163,8 +170,10 @@ __global__ __launch_bounds__(PAFFY_NT) void k_sep_index(const uint8_t *in, uint3
     uint32_t m[16];
 #pragma unroll
     for (uint32_t it = 0; it < 16; it++) {
-        uint32_t a, b;
-        sep_masks(in, in_len, tile0 + it * (PAFFY_NT * 16u) + tid * 16u, a, b);
+        uint32_t a, b, c;
+        sep_masks<true>(in, in_len, tile0 + it * (PAFFY_NT * 16u) + tid * 16u, a, b, &c);
+        c = wave_sum_u32(c); /* a wave's 64 x 16 bytes are one 1 KiB tile */
+        if (lane == 0 && nd && tile0 + it * (PAFFY_NT * 16u) + tid * 16u < in_len) nd[(tile0 + it * (PAFFY_NT * 16u) + tid * 16u) >> FLAT_TILE_SHIFT] = (uint16_t)c;
         m[it] = a | (b << 16);
         SEP_PREF(it * PAFFY_NT + tid) = (uint32_t)__popc(a) | ((uint32_t)__popc(b) << 16);
     }
@@ -275,7 +284,7 @@ __device__ int64_t parse_i64_dev(const uint8_t *in, uint32_t p, uint32_t e) {
  */
 #define HDR_GROUP 32u
 __global__ __launch_bounds__(PAFFY_NT) void k_header(const uint8_t *in, const uint32_t *sep_pos, const uint32_t *nl_idx, uint32_t n_lines,
-                                                      RecMeta *meta, uint32_t *big_list, DevInfo *info, uint32_t lvl0_max) {
+                                                      RecMeta *meta, uint32_t *big_list, DevInfo *info, uint32_t lvl0_max, uint2 *flat_rec, uint32_t *chunk_rec) {
     constexpr uint32_t kWords = sizeof(RecMeta) / 4; /* 36 */
     static_assert(sizeof(RecMeta) % 4 == 0 && kWords > 32 && kWords <= 64, "the image is written as two words per lane at most");
     __shared__ __attribute__((aligned(16))) RecMeta image[PAFFY_NT / HDR_GROUP];
@@ -390,17 +399,50 @@ __global__ __launch_bounds__(PAFFY_NT) void k_header(const uint8_t *in, const ui
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (!live) return;
-    if (err == 0 && n_fields < 12) {
+    if (live && err == 0 && n_fields < 12) {
         err = PAFFY_ERR_FEW_FIELDS;
         if (gl == 0) m->err = err;
     }
     __builtin_amdgcn_wave_barrier();
-    uint32_t *dst = reinterpret_cast<uint32_t *>(meta + r);
-    dst[gl] = mw[gl];
-    if (gl + 32 < kWords) dst[32 + gl] = mw[32 + gl];
-    /* long cigars go straight to the sizing launch with the bigger LDS store (runs beside the main one) */
-    if (gl == 0 && err == 0 && (m->cg_len >> 1) > lvl0_max) big_list[atomicAdd(&info->b_count[0], 1u)] = r;
+    if (live) {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(meta + r);
+        dst[gl] = mw[gl];
+        if (gl + 32 < kWords) dst[32 + gl] = mw[32 + gl];
+        /* long cigars go straight to the sizing launch with the bigger LDS store (runs beside the main one) */
+        if (gl == 0 && err == 0 && (m->cg_len >> 1) > lvl0_max) big_list[atomicAdd(&info->b_count[0], 1u)] = r;
+    }
+    if (flat_rec) { /* kernel argument: the whole grid takes this branch or none of it does */
+        /* the flat sizing pass (flat_kernel.h): the record's cigar is pieces (its text cut at the 1 KiB boundaries of the batch) and chunks of
+           four pieces; their places in the summary array and the chunk list are handed out per workgroup, one atomic for its eight records */
+        __shared__ uint32_t s_np[PAFFY_NT / HDR_GROUP], s_nc[PAFFY_NT / HDR_GROUP];
+        __shared__ unsigned long long s_base;
+        uint32_t np = 0, nc = 0;
+        if (live && err == 0 && m->has_cg && m->cg_len > 0) {
+            np = ((m->cg_off + m->cg_len - 1u) >> FLAT_TILE_SHIFT) - (m->cg_off >> FLAT_TILE_SHIFT) + 1u;
+            nc = (np + FLAT_CHUNK_PIECES - 1u) / FLAT_CHUNK_PIECES;
+        }
+        if (gl == 0) {
+            s_np[g] = np;
+            s_nc[g] = nc;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long tp = 0, tc = 0;
+            for (uint32_t k = 0; k < PAFFY_NT / HDR_GROUP; k++) {
+                tp += s_np[k];
+                tc += s_nc[k];
+            }
+            s_base = (tp | tc) ? atomicAdd(&info->flat_alloc, (tp << 32) | tc) : 0ull;
+        }
+        __syncthreads();
+        uint32_t pbase = (uint32_t)(s_base >> 32), cbase = (uint32_t)(s_base & 0xffffffffull);
+        for (uint32_t k = 0; k < g; k++) {
+            pbase += s_np[k];
+            cbase += s_nc[k];
+        }
+        if (live && gl == 0) flat_rec[r] = make_uint2(pbase, cbase);
+        for (uint32_t j = gl; j < nc; j += HDR_GROUP) chunk_rec[cbase + j] = r;
+    }
 }
 
 /* ------------------------------------------------------------------ */
@@ -787,6 +829,7 @@ struct paffy_hip_ctx {
     bool plan_seq_lookup = false; /* rec_qseq / rec_tseq belong to the current plan */
     DevBuf seq_raw, pretty_off, pretty_out, pretty_err, host_in, host_out;
     DevBuf rec_stats; /* six sums per record of the PAFFY_STATS stage */
+    DevBuf flat_nd, flat_rec, flat_chunks, flat_sums, flat_done; /* the flat sizing pass (flat_kernel.h) */
     DevBuf bed_keys, bed_tab, bed_starts, bed_len, bed_off, bed_tiles;
     struct BedParams *bed_params = nullptr; /* host copy */
     uint64_t bed_runs = 0;
@@ -985,7 +1028,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     c->index_pool.clear();
     if (c->one_batch.p) (void)hipFree(c->one_batch.p);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
-                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->seq_raw, &c->pretty_off, &c->pretty_out, &c->pretty_err, &c->host_in, &c->host_out, &c->rec_stats, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
+                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->seq_raw, &c->pretty_off, &c->pretty_out, &c->pretty_err, &c->host_in, &c->host_out, &c->rec_stats, &c->flat_nd, &c->flat_rec, &c->flat_chunks, &c->flat_sums, &c->flat_done, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
                       &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts, &c->scan_part, &c->dedupe_keys, &c->emit_order, &c->order_cnt};
     for (DevBuf *b : bufs)
@@ -1016,7 +1059,7 @@ static int fetch_info(paffy_hip_ctx *c) {
 
 /* Separator index + header parse shared by plan and tile_plan. */
 static void index_drop(paffy_hip_ctx *c, const void *d_in);
-static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, uint32_t *n_lines_out, uint32_t lvl0_max = PAFFY_OPS_CAP) {
+static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, uint32_t *n_lines_out, uint32_t lvl0_max = PAFFY_OPS_CAP, bool flat = false) {
     index_drop(c, in); /* a kept index of this buffer describes what it held before */
     const uint32_t n_tiles = (len + SEP_TILE - 1) / SEP_TILE;
     c->indexed_in = nullptr; /* the index buffers are about to describe another batch */
@@ -1030,6 +1073,12 @@ static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, ui
        with exact sizes. The first batch of a context (no guess) takes the two-pass form, which sizes the buffers exactly. */
     uint32_t n_seps = 0, n_lines = 0;
     bool indexed = false;
+    /* the flat sizing pass wants the non-digit bytes of every 1 KiB tile of the text: the index kernels count them on their way */
+    uint16_t *nd = nullptr;
+    if (flat) {
+        if (ensure(c, c->flat_nd, sizeof(uint16_t) * (((size_t)len >> FLAT_TILE_SHIFT) + 2))) return PAFFY_E_HIP;
+        nd = static_cast<uint16_t *>(c->flat_nd.p);
+    }
     if (c->sep_guess_per_mib > 0 && !getenv("PAFFY_TWO_PASS_INDEX")) {
         const double mib = (double)len / (1 << 20) + 1.0;
         const size_t want_seps = (size_t)(c->sep_guess_per_mib * mib * 1.25) + 4096, want_lines = (size_t)(c->line_guess_per_mib * mib * 1.25) + 4096;
@@ -1039,7 +1088,7 @@ static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, ui
         const uint32_t cap_seps = (uint32_t)std::min<size_t>(c->sep_pos.cap / sizeof(uint32_t), 0x7fffffffu), cap_lines = (uint32_t)std::min<size_t>(c->nl_idx.cap / sizeof(uint32_t), 0x7fffffffu);
         HIPCHK(c, hipMemsetAsync(c->tile_counts.p, 0, sizeof(unsigned long long) * ((size_t)n_tiles + 1), c->stream));
         LAUNCH(c, "k_sep_index", k_sep_index, dim3(n_tiles), dim3(PAFFY_NT), 0, in, len, n_tiles, static_cast<unsigned long long *>(c->tile_counts.p),
-               static_cast<uint32_t *>(c->sep_pos.p), cap_seps, static_cast<uint32_t *>(c->nl_idx.p), cap_lines, static_cast<DevInfo *>(c->info.p));
+               static_cast<uint32_t *>(c->sep_pos.p), cap_seps, static_cast<uint32_t *>(c->nl_idx.p), cap_lines, static_cast<DevInfo *>(c->info.p), nd);
         if (fetch_info(c)) return PAFFY_E_HIP;
         n_seps = c->h_info->n_seps;
         n_lines = c->h_info->n_lines;
@@ -1047,7 +1096,7 @@ static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, ui
     }
     if (!indexed) {
         if (ensure(c, c->tile_counts, sizeof(uint2) * n_tiles)) return PAFFY_E_HIP;
-        LAUNCH(c, "k_sep_count", k_sep_count, dim3(n_tiles), dim3(PAFFY_NT), 0, in, len, static_cast<uint2 *>(c->tile_counts.p));
+        LAUNCH(c, "k_sep_count", k_sep_count, dim3(n_tiles), dim3(PAFFY_NT), 0, in, len, static_cast<uint2 *>(c->tile_counts.p), nd);
         LAUNCH(c, "k_scan_tiles", k_scan_tiles, dim3(1), dim3(PAFFY_NT), 0, static_cast<uint2 *>(c->tile_counts.p), n_tiles,
                static_cast<DevInfo *>(c->info.p));
         if (fetch_info(c)) return PAFFY_E_HIP;
@@ -1082,10 +1131,18 @@ static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, ui
     if (!indexed)
         LAUNCH(c, "k_sep_write", k_sep_write, dim3(n_tiles), dim3(PAFFY_NT), 0, in, len, static_cast<const uint2 *>(c->tile_counts.p),
                static_cast<uint32_t *>(c->sep_pos.p), static_cast<uint32_t *>(c->nl_idx.p));
+    if (flat && n_lines > 0) {
+        /* a record's cigar of L bytes is at most L / 1024 + 2 pieces and L / 4096 + 2 chunks */
+        const size_t max_pieces = ((size_t)len >> FLAT_TILE_SHIFT) + 2 * (size_t)n_lines + 8, max_chunks = ((size_t)len >> (FLAT_TILE_SHIFT + 2)) + 2 * (size_t)n_lines + 8;
+        if (ensure(c, c->flat_rec, sizeof(uint2) * (size_t)(n_lines + 1)) || ensure(c, c->flat_chunks, sizeof(uint32_t) * max_chunks) ||
+            ensure(c, c->flat_sums, sizeof(PieceSum) * max_pieces) || ensure(c, c->flat_done, (size_t)n_lines + 16))
+            return PAFFY_E_HIP;
+    }
     if (n_lines > 0)
         LAUNCH(c, "k_header", k_header, dim3((n_lines + PAFFY_NT / HDR_GROUP - 1) / (PAFFY_NT / HDR_GROUP)), dim3(PAFFY_NT), 0, in,
                static_cast<const uint32_t *>(c->sep_pos.p), static_cast<const uint32_t *>(c->nl_idx.p), n_lines,
-               static_cast<RecMeta *>(c->meta.p), static_cast<uint32_t *>(c->b_list.p), static_cast<DevInfo *>(c->info.p), lvl0_max);
+               static_cast<RecMeta *>(c->meta.p), static_cast<uint32_t *>(c->b_list.p), static_cast<DevInfo *>(c->info.p), lvl0_max,
+               flat ? static_cast<uint2 *>(c->flat_rec.p) : static_cast<uint2 *>(nullptr), flat ? static_cast<uint32_t *>(c->flat_chunks.p) : static_cast<uint32_t *>(nullptr));
 
     return 0;
 }
@@ -1162,8 +1219,12 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     static const uint32_t wave_env = getenv("PAFFY_WAVE_BYTES") ? (uint32_t)atoi(getenv("PAFFY_WAVE_BYTES")) : WAVE_MAX_BYTES;
     static const uint32_t wave_cap_env = getenv("PAFFY_WAVE_OPS") ? (uint32_t)atoi(getenv("PAFFY_WAVE_OPS")) : WAVE_OPS_CAP;
     const uint32_t wave_bytes = (need_seqs && add_not_last) ? 0u : wave_env;
+    /* the lean pipes are sized by the flat pass (flat_kernel.h): the text parsed in chunks whatever record they belong to, one wave per
+       record on the chunks' summaries; what it leaves (FLAT_F_IRREG and friends) goes through the record kernels below as before */
+    static const bool flat_off = getenv("PAFFY_NO_FLAT") != nullptr;
+    const bool flat = lean && nocheck_mask == 0 && n_stages > 0 && !flat_off;
     {
-        int rc = index_and_parse(c, in, len, &n_lines, lvl0_max);
+        int rc = index_and_parse(c, in, len, &n_lines, lvl0_max, flat);
         if (rc) return rc;
     }
     kp.lvl0_max = lvl0_max;
@@ -1211,8 +1272,58 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             HIPCHK(c, hipMemsetAsync(c->rec_stats.p, 0, sizeof(int64_t) * 6 * (size_t)n_lines, c->stream)); /* records that stop before the stage */
         }
 
-    if (n_lines > 0) {
-        { /* launch order of the sizing workgroups: long cigars first (out_len is scratch until the sizing pass fills it) */
+    auto post_scans = [&]() -> int {
+        /* the scan rides along: one host synchronisation per plan in the usual case (the arena was big enough) */
+        {
+            const uint32_t n_blocks = (n_lines + SCAN_BLOCK - 1) / SCAN_BLOCK;
+            if (ensure(c, c->scan_part, sizeof(int64_t) * 2 * (size_t)n_blocks)) return PAFFY_E_HIP;
+            LAUNCH(c, "k_scan_part", k_scan_part, dim3(n_blocks), dim3(PAFFY_NT), 0, kp.out_len, kp.out_rows, n_lines,
+                   static_cast<int64_t *>(c->out_off.p), static_cast<int64_t *>(c->scan_part.p), kp.info);
+            LAUNCH(c, "k_scan_fix", k_scan_fix, dim3(n_blocks), dim3(PAFFY_NT), 0, n_lines, n_blocks, static_cast<int64_t *>(c->out_off.p),
+                   static_cast<const int64_t *>(c->scan_part.p), kp.info);
+        }
+        {
+            if (ensure(c, c->emit_order, sizeof(uint32_t) * (size_t)n_lines)) return PAFFY_E_HIP;
+            if (ensure(c, c->order_cnt, sizeof(uint32_t) * 2 * ORDER_CLASSES)) return PAFFY_E_HIP;
+            uint32_t *cnt = static_cast<uint32_t *>(c->order_cnt.p);
+            HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * ORDER_CLASSES, c->stream));
+            const uint32_t g = (n_lines + PAFFY_NT - 1) / PAFFY_NT;
+            LAUNCH(c, "k_order_count", k_order_count, dim3(g), dim3(PAFFY_NT), 0, kp.out_len, n_lines, 14u, cnt);
+            LAUNCH(c, "k_order_scatter", k_order_scatter, dim3(g), dim3(PAFFY_NT), 0, kp.out_len, n_lines, 14u, cnt, cnt + ORDER_CLASSES,
+                   static_cast<uint32_t *>(c->emit_order.p));
+            kp.emit_order = static_cast<const uint32_t *>(c->emit_order.p);
+        }
+        return 0;
+    };
+    uint32_t flat_g_count = 0;
+    bool need_legacy = true;
+    if (flat && n_lines > 0) {
+        FlatParams fp;
+        fp.in = in;
+        fp.in_len = len;
+        fp.meta = kp.meta;
+        fp.flat_rec = static_cast<const uint2 *>(c->flat_rec.p);
+        fp.chunk_rec = static_cast<const uint32_t *>(c->flat_chunks.p);
+        fp.nd = static_cast<const uint16_t *>(c->flat_nd.p);
+        fp.sums = static_cast<PieceSum *>(c->flat_sums.p);
+        fp.ops_mirror = kp.ops_mirror;
+        fp.info = kp.info;
+        /* persistent waves over the chunks: eight workgroups of four waves per CU */
+        LAUNCH(c, "k_flat_parse", k_flat_parse, dim3(2048), dim3(64 * FLAT_PARSE_WAVES), 0, fp);
+        FlatSizeParams fs;
+        fs.P = kp;
+        fs.flat_rec = fp.flat_rec;
+        fs.sums = fp.sums;
+        fs.flat_done = static_cast<uint8_t *>(c->flat_done.p);
+        LAUNCH(c, "k_flat_size", k_flat_size, dim3((n_lines + FLAT_SIZE_WAVES - 1) / FLAT_SIZE_WAVES), dim3(64 * FLAT_SIZE_WAVES), 0, fs);
+        if (post_scans()) return PAFFY_E_HIP;
+        if (fetch_info(c)) return PAFFY_E_HIP;
+        flat_g_count = c->h_info->g_count;
+        need_legacy = c->h_info->flat_legacy > 0;
+        kp.flat_done = static_cast<const uint8_t *>(c->flat_done.p);
+    }
+    if (n_lines > 0 && need_legacy) {
+        if (!flat) { /* launch order of the sizing workgroups: long cigars first (out_len is scratch until the sizing pass fills it) */
             if (ensure(c, c->emit_order, sizeof(uint32_t) * (size_t)n_lines)) return PAFFY_E_HIP;
             if (ensure(c, c->order_cnt, sizeof(uint32_t) * 2 * ORDER_CLASSES)) return PAFFY_E_HIP;
             uint32_t *cnt = static_cast<uint32_t *>(c->order_cnt.p);
@@ -1279,26 +1390,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             if (kp.rec_stats)
                 LAUNCH(c, "k_stats_reduce", k_stats_reduce, dim3(std::min<uint32_t>(512u, (n_lines + PAFFY_NT - 1) / PAFFY_NT)), dim3(PAFFY_NT), 0, kp.rec_stats, n_lines,
                        static_cast<DevInfo *>(c->info.p)->stats);
-            /* the scan rides along: one host synchronisation per plan in the usual case (the arena was big enough) */
-            {
-                const uint32_t n_blocks = (n_lines + SCAN_BLOCK - 1) / SCAN_BLOCK;
-                if (ensure(c, c->scan_part, sizeof(int64_t) * 2 * (size_t)n_blocks)) return PAFFY_E_HIP;
-                LAUNCH(c, "k_scan_part", k_scan_part, dim3(n_blocks), dim3(PAFFY_NT), 0, kp.out_len, kp.out_rows, n_lines,
-                       static_cast<int64_t *>(c->out_off.p), static_cast<int64_t *>(c->scan_part.p), kp.info);
-                LAUNCH(c, "k_scan_fix", k_scan_fix, dim3(n_blocks), dim3(PAFFY_NT), 0, n_lines, n_blocks, static_cast<int64_t *>(c->out_off.p),
-                       static_cast<const int64_t *>(c->scan_part.p), kp.info);
-            }
-            {
-                if (ensure(c, c->emit_order, sizeof(uint32_t) * (size_t)n_lines)) return PAFFY_E_HIP;
-                if (ensure(c, c->order_cnt, sizeof(uint32_t) * 2 * ORDER_CLASSES)) return PAFFY_E_HIP;
-                uint32_t *cnt = static_cast<uint32_t *>(c->order_cnt.p);
-                HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * ORDER_CLASSES, c->stream));
-                const uint32_t g = (n_lines + PAFFY_NT - 1) / PAFFY_NT;
-                LAUNCH(c, "k_order_count", k_order_count, dim3(g), dim3(PAFFY_NT), 0, kp.out_len, n_lines, 14u, cnt);
-                LAUNCH(c, "k_order_scatter", k_order_scatter, dim3(g), dim3(PAFFY_NT), 0, kp.out_len, n_lines, 14u, cnt, cnt + ORDER_CLASSES,
-                       static_cast<uint32_t *>(c->emit_order.p));
-                kp.emit_order = static_cast<const uint32_t *>(c->emit_order.p);
-            }
+            if (post_scans()) return PAFFY_E_HIP;
             if (fetch_info(c)) return PAFFY_E_HIP;
             if (c->h_info->arena_used <= kp.arena_cap) {
                 if (lvl0_long && c->h_info->lvl0_over > 0) { /* denser cigars than the longer first level takes: back to the safe bound, for good */
@@ -1317,7 +1409,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
             DevInfo z = *c->h_info;
             z.arena_used = 0;
             z.w_count = 0;
-            z.g_count = 0;
+            z.g_count = flat_g_count; /* the records the flat pass left to the four-wave writers stay counted */
             z.b_count[1] = 0; /* b_count[0] was filled by k_header and stays */
             for (int k = 0; k < 6; k++) z.stats[k] = 0;
             z.first_err_key = ~0ull;
@@ -1329,7 +1421,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
                 return PAFFY_E_HIP;
             }
         }
-    } else if (fetch_info(c)) {
+    } else if (n_lines == 0 && fetch_info(c)) {
         return PAFFY_E_HIP;
     }
     if (c->profile) prof_collect(c);

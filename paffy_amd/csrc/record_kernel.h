@@ -3539,6 +3539,7 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_SIZE_OCC) void k_size_lds(KParams P
     uint32_t *ops_lds;
     RecLds L = carve_size_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds, P.ops_cap);
     const uint32_t rec = P.size_order ? P.size_order[blockIdx.x] : blockIdx.x; /* long cigars first */
+    if (P.flat_done && P.flat_done[rec]) return; /* sized by the flat pass (flat_kernel.h) */
     /* records whose cigar text promises more ops than this store holds were queued for level 1 by k_header */
     if ((P.meta[rec].cg_len >> 1) > P.lvl0_max && P.meta[rec].err == 0) return;
     /* short cigars belong to the one-wave build of this kernel (g64, launched first), everything else -- and what did not fit the
@@ -3555,7 +3556,8 @@ __global__ __launch_bounds__(PAFFY_NT, 2) void k_size_lds_long(KParams P) { /* t
     RecLds L = carve_size_lds(reinterpret_cast<uint8_t *>(smem4), &ops_lds, P.ops_cap);
     const uint32_t count = P.info->b_count[P.level - 1];
     for (uint32_t li = blockIdx.x; li < count; li += gridDim.x) {
-        size_lds_one<MASK>(P, P.b_list[P.level - 1][li], ops_lds, L);
+        const uint32_t rec = P.b_list[P.level - 1][li];
+        if (!(P.flat_done && P.flat_done[rec])) size_lds_one<MASK>(P, rec, ops_lds, L); /* not sized by the flat pass (flat_kernel.h) */
         __syncthreads();
     }
 }

@@ -54,6 +54,9 @@ struct DevInfo {
     /* the longer first store level (paffy_hip.hip: lvl0_long): records whose ops overflowed the first-level store although their cigar was
        short enough to start there, and -- while the safe bound is in force -- records of the second level that would have */
     uint32_t lvl0_over, lvl0_probe_dense;
+    /* flat sizing pass (flat_kernel.h): pieces << 32 | chunks handed out by k_header, and the records it left to the record kernels */
+    unsigned long long flat_alloc;
+    uint32_t flat_legacy, flat_pad;
 };
 
 /* What the stage list left of a record; written by the sizing pass, read by the emit pass. */
@@ -112,6 +115,7 @@ struct KParams {
     int64_t *rec_stats;         /* PAFFY_STATS: six sums per record (the order of paf_stats_calc's arguments), or NULL */
     uint32_t nocheck_mask;      /* bit i: stage i runs without the paf_check the command loops append (PAFFY_NO_CHECK) */
     uint32_t wave_max_bytes;    /* records with at most this many cigar bytes are sized by the one-wave kernel (0: none): the four-wave kernel skips them */
+    const uint8_t *flat_done;   /* flat sizing pass: 1 = the record has been sized there, the record kernels skip it (NULL: no flat pass) */
 };
 
 #endif

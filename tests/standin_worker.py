@@ -20,7 +20,10 @@ def tag(line, name, default):
 def main():
     args = sys.argv[1:]
     cmd = args[0]
-    inp, out = args[args.index("-i") + 1], args[args.index("-o") + 1]
+    # the launcher puts its own `-i <input> -o <output>` behind the user's options (one of which may have "-i" as its VALUE: `-l -i`)
+    at = len(args) - 1 - args[::-1].index("-o")
+    assert args[at - 2] == "-i", args
+    inp, out = args[at - 1], args[at + 1]
     with open(inp, "rb") as fh:
         data = fh.read()
     rg = os.environ.get("PAFFY_RANGE")
@@ -29,7 +32,7 @@ def main():
         data = data[a:b]
     if cmd == "tile":
         res, err = O.tile(data)
-        if not err.code and os.environ.get("PAFFY_ROWS_FILE"):
+        if not err.code and res and os.environ.get("PAFFY_ROWS_FILE"):  # like the worker of round 3: no output, no list (the launcher must cope)
             lines = data.splitlines(keepends=True)
             order = sorted(range(len(lines)), key=lambda k: (-tag(lines[k], b"s1", -1), -tag(lines[k], b"AS", 0), k))
             with open(os.environ["PAFFY_ROWS_FILE"], "wb") as fh:

@@ -57,3 +57,24 @@ def test_failing_record_with_two_workers(tmp_path):
     want, err = O.run([O.stage(O.INVERT)], data)
     p = paffy(["invert"], 2, data=data)
     assert err.code == O.ERR_STRAND and p.returncode == 1 and p.stdout == want
+
+
+def test_tile_with_one_query_name_and_with_no_input(tmp_path):
+    """fewer query names than workers (a per-contig split has one) and an empty input: the workers without lines are not started; the
+    output is one GPU's, an empty input gives an empty output and status 0 (round-3 advice: `worker %d left no output`)"""
+    data = tile_records(400, contigs=1)
+    src = tmp_path / "one.paf"
+    src.write_bytes(data)
+    want, err = O.tile(data)
+    assert err.code == 0
+    p = paffy(["tile", "-i", str(src)], 3)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout == want
+    empty = tmp_path / "empty.paf"
+    empty.write_bytes(b"")
+    for n in (1, 3):
+        p = paffy(["tile", "-i", str(empty)], n)
+        assert p.returncode == 0 and p.stdout == b"", (n, p.stderr[-2000:])
+    p = paffy(["trim", "-fi", str(src), "-t", "0.2"], 2)  # clustered flag in front of -i
+    q = paffy(["trim", "-f", "-t", "0.2", "-i", str(src)], 1)
+    assert p.returncode == 0 and q.returncode == 0 and p.stdout == q.stdout and len(p.stdout) > 0

@@ -108,3 +108,74 @@ def test_one_gpu_and_other_commands_become_the_worker(tmp_path):
     assert p.stdout == b"chain -i x\n"  # chain does not shard here: one worker
     p = subprocess.run([PAFFY, "tile", "-h"], env=dict(env, PAFFY_GPUS="4"), capture_output=True, timeout=30)
     assert p.stdout == b"tile -h\n"
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_tile_with_fewer_query_names_than_workers(tmp_path, n):
+    """one per-contig split of the input (the reference's own workflow, tests/paf_pipeline_test.sh:42-67) has ONE query name: all but one
+    worker have nothing to do -- they are not started, and the output is the one worker's"""
+    data = tile_records(200, contigs=1)
+    src = tmp_path / "in.paf"
+    src.write_bytes(data)
+    want, err = O.tile(data)
+    assert err.code == 0
+    p = run(["tile", "-i", str(src)], n, tmp=tmp_path)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout == want
+    assert os.listdir(tmp_path) == ["in.paf"]  # the private spool directory is gone
+
+
+def test_tile_of_an_empty_input_is_an_empty_output(tmp_path):
+    src = tmp_path / "in.paf"
+    src.write_bytes(b"")
+    p = run(["tile", "-i", str(src), "-o", str(tmp_path / "out.paf")], 3, tmp=tmp_path)
+    assert p.returncode == 0, p.stderr
+    assert (tmp_path / "out.paf").read_bytes() == b""
+    p = run(["tile"], 4, data=b"", tmp=tmp_path)
+    assert p.returncode == 0 and p.stdout == b""
+
+
+def test_option_spellings_mean_what_they_mean_to_the_worker(tmp_path):
+    """the launcher parses with getopt_long and the subcommand's own tables: abbreviated long options, a value that looks like an option,
+    attached values and clustered flags are what the single-GPU path makes of them"""
+    data = synth_lib.generate(0x5EED0003, 100, 0, 120, threads=1)
+    src = tmp_path / "in.paf"
+    src.write_bytes(data)
+    want = O.run([O.stage(O.INVERT)], data)[0]
+    for args in (["invert", "--input", str(src)], ["invert", "-l", "-i", "-i" + str(src)], ["invert", "--logLevel=-o", "--inputF=" + str(src)],
+                 ["invert", "-lDEBUG", "-i", str(src)]):
+        p = run(args, 3, tmp=tmp_path)
+        assert p.returncode == 0 and p.stdout == want, args
+    # a clustered flag in front of -i: `trim -fi in.paf` (the stand-in knows the identity trim only; what counts here is that the
+    # launcher found the input and handed -f on)
+    env = dict(os.environ, PAFFY_GPUS="2", PAFFY_WORKER="/bin/echo", PAFFY_TMPDIR=str(tmp_path))
+    p = subprocess.run([PAFFY, "trim", "-fi", str(src), "-t", "0.2"], env=env, capture_output=True, timeout=30)
+    lines = p.stdout.decode().splitlines()
+    assert len(lines) == 2 and all(l.startswith("trim -f -t 0.2 -i " + str(src) + " -o ") for l in lines), p.stdout
+    # something getopt_long rejects: one worker gets the command line as it is
+    p = subprocess.run([PAFFY, "invert", "-Z", "-i", str(src)], env=env, capture_output=True, timeout=30)
+    assert p.stdout == ("invert -Z -i " + str(src) + "\n").encode()
+
+
+def test_a_signal_takes_the_workers_and_the_spools_along(tmp_path):
+    import signal
+    import time
+
+    slow = tmp_path / "slow_worker.sh"
+    slow.write_text("#!/bin/sh\nsleep 60\n")
+    slow.chmod(0o755)
+    src = tmp_path / "in.paf"
+    src.write_bytes(synth_lib.generate(0x5EED0003, 50, 0, 20, threads=1))
+    env = dict(os.environ, PAFFY_GPUS="3", PAFFY_WORKER=str(slow), PAFFY_TMPDIR=str(tmp_path))
+    p = subprocess.Popen([PAFFY, "invert", "-i", str(src)], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for _ in range(100):
+        if any(f.startswith("paffy.") for f in os.listdir(tmp_path)):
+            break
+        time.sleep(0.05)
+    time.sleep(0.2)
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=10) == -signal.SIGTERM
+    time.sleep(0.2)
+    assert [f for f in os.listdir(tmp_path) if f.startswith("paffy.")] == []
+    alive = subprocess.run(["pgrep", "-f", str(slow)], capture_output=True).stdout.split()
+    assert alive == []
