@@ -340,6 +340,8 @@ def main():
             "cpu_baseline_all_cores": cpu_all,
             "end_to_end": e2e,
             "kernel_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kernels.items()},
+            # the lean pipes are sized by the flat pass (paffy_amd/csrc/flat_kernel.h); what it left to the record kernels in the last plan
+            "flat_pass": dict(zip(("records_left_to_record_kernels", "by_reason"), eng.flat_stats())),
         }
         print(json.dumps(line), flush=True)
     if dist:

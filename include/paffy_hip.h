@@ -299,6 +299,13 @@ int paffy_hip_stream_trim(paffy_hip_ctx *ctx);
  * meaningful when no record failed (a failing record ends the reference process before it prints anything).
  */
 int paffy_hip_plan_stats(paffy_hip_ctx *ctx, int64_t sums[6]);
+/*
+ * Diagnostics of the last paffy_hip_plan: the lean pipes (invert / identity trim / shatter / pass) are sized by the flat pass
+ * (paffy_amd/csrc/flat_kernel.h); *left = the records it left to the record kernels (-1: the plan did not take the flat pass),
+ * reasons[k] = how many for reason k (FLAT_WHY_* there). The outputs do not depend on who sized a record; the tests use this to
+ * know that the pass under test really ran.
+ */
+int paffy_hip_flat_stats(paffy_hip_ctx *ctx, int64_t *left, int64_t reasons[16]);
 /* The same six sums for every record of the batch (6 * n_records values, record by record): the numbers of the per-alignment line of
  * `paffy view` (paf_pretty_print, impl/paf.c:269-281). Returns n_records or a negative error. */
 int64_t paffy_hip_plan_record_stats(paffy_hip_ctx *ctx, int64_t cap_records, int64_t *sums);

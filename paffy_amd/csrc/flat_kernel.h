@@ -30,6 +30,7 @@
 #define FLAT_TILE_SHIFT 10u
 #define FLAT_CHUNK_PIECES 4u /* pieces (1 KiB of cigar text each) per parse work item */
 #define FLAT_P_CAP 512u      /* op letters a 1 KiB piece of a regular cigar can hold (two bytes per op at least) */
+#define FLAT_NO_CHUNK 0xffffffffu
 #define FLAT_F_IRREG 1u      /* the piece holds something the flat pass leaves to the record kernels */
 #define FLAT_F_NONPLAIN 2u   /* the piece holds = or X ops (paf_shatter asserts on them, impl/paf.c:649-651) */
 
@@ -49,8 +50,11 @@ struct FlatParams {
     const uint8_t *in;
     uint32_t in_len;
     const RecMeta *meta;
-    const uint2 *flat_rec;     /* per record: first piece, first chunk */
-    const uint32_t *chunk_rec; /* per chunk: its record */
+    /* Places without a scan or an atomic: piece p of record r has summary slot (cg_off >> 10) + r + p, its chunk c the list slot
+       (cg_off >> 12) + r + c -- records lie in text order, so a record's first tile is at or behind the last tile of the record before,
+       and the "+ r" keeps the slots of two records that share a tile apart. Slots no chunk maps to hold FLAT_NO_CHUNK. */
+    const uint32_t *chunk_rec; /* per chunk slot: its record */
+    uint32_t n_chunk_slots;
     const uint16_t *nd;        /* per 1 KiB tile of the text: bytes that are not digits */
     PieceSum *sums;
     uint32_t *ops_mirror;
@@ -69,24 +73,28 @@ __device__ __forceinline__ uint32_t nondigit16(const uint4 &v) { /* bit j: byte 
     return m;
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return wave_last_u32(wave_incl_scan_u32(v)); }
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint32_t lane_val(uint32_t x, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)l); }
 
 /* bytes of LDS per wave: 16 bytes in front of the tile (the text before it), the tile, the positions of its op letters */
 #define FLAT_PARSE_LDS (16u + FLAT_TILE + 2u * FLAT_P_CAP)
 #define FLAT_PARSE_WAVES 4u
 __global__ __launch_bounds__(64 * FLAT_PARSE_WAVES) void k_flat_parse(FlatParams F) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[FLAT_PARSE_WAVES][FLAT_PARSE_LDS];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    /* the wave's number, in a scalar register: everything derived from it (the chunk, its record, the tile addresses) is wave-uniform,
+       and the compiler only knows that when it is told */
+    const uint32_t lane = threadIdx.x & 63u, wave = uni(threadIdx.x >> 6);
     uint8_t *T = smem[wave];
     uint16_t *Pl = reinterpret_cast<uint16_t *>(T + 16u + FLAT_TILE);
-    const uint32_t n_chunks = (uint32_t)(F.info->flat_alloc & 0xffffffffull);
     const uint32_t n_waves = gridDim.x * FLAT_PARSE_WAVES;
-    for (uint32_t c = blockIdx.x * FLAT_PARSE_WAVES + wave; c < n_chunks; c += n_waves) {
+    for (uint32_t c = blockIdx.x * FLAT_PARSE_WAVES + wave; c < F.n_chunk_slots; c += n_waves) {
         const uint32_t rec = F.chunk_rec[c];
+        if (rec == FLAT_NO_CHUNK) continue;
         const uint32_t cg_off = F.meta[rec].cg_off, cg_end = cg_off + F.meta[rec].cg_len;
-        const uint2 fr = F.flat_rec[rec];
         const uint32_t tile_first = cg_off >> FLAT_TILE_SHIFT;
         const uint32_t np = ((cg_end - 1u) >> FLAT_TILE_SHIFT) - tile_first + 1u;
-        const uint32_t p0 = (c - fr.y) * FLAT_CHUNK_PIECES, p1 = p0 + FLAT_CHUNK_PIECES < np ? p0 + FLAT_CHUNK_PIECES : np;
+        const uint32_t p0 = (c - ((tile_first >> 2) + rec)) * FLAT_CHUNK_PIECES, p1 = p0 + FLAT_CHUNK_PIECES < np ? p0 + FLAT_CHUNK_PIECES : np;
+        PieceSum *const rec_sums = F.sums + (tile_first + rec);
         uint32_t tile = tile_first + p0;
         /* the 16 bytes in front of the chunk's first tile */
         __builtin_amdgcn_wave_barrier();
@@ -144,30 +152,36 @@ __global__ __launch_bounds__(64 * FLAT_PARSE_WAVES) void k_flat_parse(FlatParams
             const uint32_t top = total < FLAT_P_CAP ? total : FLAT_P_CAP;
             /* per lane at most eight ops of at most 8 191 bases: two 16-bit sums per register */
             uint32_t acc_mx = 0, acc_id = 0, acc_re = 0, nonplain = 0;
+            uint32_t before_first = (uint32_t)prev; /* the letter in front of the iteration's first op (lane 0 takes it) */
             for (uint32_t i = lane; i < top; i += 64u) {
-                const int32_t pos = (int32_t)Pl[i];
-                const int32_t before = i ? (int32_t)Pl[i - 1u] : prev;
-                const uint32_t k = (uint32_t)(pos - before - 1); /* digits in front of the letter */
+                const uint32_t pos = Pl[i];
+                /* the letter in front: the lane below's (active whenever this one is) */
+                const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)before_first, (int)pos, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                before_first = lane_val(pos, 63);
+                const uint32_t k = pos - before - 1u; /* digits in front of the letter */
                 /* the four bytes in front of the letter and the letter itself: two aligned words of the staged text */
-                const uint32_t a = 16u + (uint32_t)pos - 4u, sh = a & 3u;
+                const uint32_t a = 12u + pos, sh = a & 3u;
                 const uint32_t *wp = reinterpret_cast<const uint32_t *>(T + (a - sh));
                 const uint32_t d0 = wp[0], d1 = wp[1];
                 const uint32_t hi = __builtin_amdgcn_alignbyte(d1, d0, sh);
                 const uint32_t ch = (d1 >> (8u * sh)) & 0xffu;
                 const uint32_t kk = k < 4u ? k : 4u;
                 const uint32_t x = kk ? ((hi ^ 0x30303030u) & (0xffffffffu << (32u - 8u * kk))) : 0u;
-                const uint32_t len = swar4(x);
-                int code = op_code_of(ch);
+                const uint32_t pr = ((x << 3) + (x << 1) + (x >> 8)) & 0x00ff00ffu; /* swar4 without the 32-bit multiply: two 2-digit numbers */
+                const uint32_t len = __umul24(pr & 0xffu, 100u) + (pr >> 16);
+                /* letter -> code (impl/paf.c:96-103): '=' 0x3d, 'D' 0x44, 'I' 0x49, 'M' 0x4d, 'X' 0x58 lie 0, 7, 12, 16, 27 above '=' */
+                const uint32_t dl = ch - 0x3du;
+                const bool known = dl < 28u && ((0x08011081u >> dl) & 1u);
+                const uint32_t code = (0x04001023u >> (dl & 0x1cu)) & 7u;
                 const bool lead0 = kk >= 2u && ((hi >> (8u * (4u - kk))) & 0xffu) == (uint32_t)'0';
                 /* what the flat pass keeps: one to four digits without a leading zero, 1 <= length < 8192, a letter of MID=X */
-                bad |= ((k - 1u > 3u) | (len - 1u >= 8191u) | lead0 | (code < 0)) ? 1u : 0u;
-                code = code < 0 ? 0 : code;
-                dst[n + i] = (uint16_t)((len << 3) | (uint32_t)code);
+                bad |= ((k - 1u > 3u) | (len - 1u >= 8191u) | lead0 | !known) ? 1u : 0u;
+                dst[n + i] = (uint16_t)((len << 3) | code);
                 const uint32_t l16 = len & 0xffffu;
                 acc_mx += l16 << (((0x16u >> code) & 1u) << 4);                                     /* M = | X I D */
-                acc_id += (code == OP_I ? l16 : 0u) + (code == OP_D ? l16 << 16 : 0u);              /* I | D */
-                acc_re += code == OP_M ? 1u + ((kk - 1u) << 16) : 0u;                               /* rows | digits beyond the first */
-                nonplain |= code > OP_D ? 1u : 0u;
+                acc_id += (code == (uint32_t)OP_I ? l16 : 0u) + (code == (uint32_t)OP_D ? l16 << 16 : 0u); /* I | D */
+                acc_re += code == (uint32_t)OP_M ? 1u + ((kk - 1u) << 16) : 0u;                     /* rows | digits beyond the first */
+                nonplain |= code > (uint32_t)OP_D ? 1u : 0u;
             }
             const uint32_t s_m = wave_sum_u32(acc_mx & 0xffffu), s_x = wave_sum_u32(acc_mx >> 16);
             const uint32_t s_i = wave_sum_u32(acc_id & 0xffffu), s_d = wave_sum_u32(acc_id >> 16);
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(64 * FLAT_PARSE_WAVES) void k_flat_parse(FlatParams
                 if (prev < -64) prev = -64;
             }
             if (lane == 0) {
-                uint4 *o = reinterpret_cast<uint4 *>(F.sums + fr.x + p);
+                uint4 *o = reinterpret_cast<uint4 *>(rec_sums + p);
                 o[0] = make_uint4(total | (flags << 16), s_m, s_x, s_i);
                 o[1] = make_uint4(s_d, s_r, s_e, text_end);
             }
@@ -199,7 +213,6 @@ __global__ __launch_bounds__(64 * FLAT_PARSE_WAVES) void k_flat_parse(FlatParams
 
 struct FlatSizeParams {
     KParams P;
-    const uint2 *flat_rec;
     PieceSum *sums;
     uint8_t *flat_done;
 };
@@ -216,8 +229,6 @@ __device__ __forceinline__ FlatPre flat_sub(const FlatPre &a, const FlatPre &b) 
 }
 /* a word another lane of this wave has just stored: read past the L1 */
 __device__ __forceinline__ uint32_t flat_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
-__device__ __forceinline__ uint32_t lane_val(uint32_t x, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)l); }
 
 /* One record's pieces: their inclusive prefix sums, lane p = piece p for records of at most 64 pieces, in HBM (scanned in place) for longer ones. */
 struct FlatRec {
@@ -298,7 +309,18 @@ struct FlatView {
     __device__ __forceinline__ int64_t tt() const { return (int64_t)tm() + (int64_t)tx() - (int64_t)ins_v(); }
 };
 
-__device__ __forceinline__ int flat_check(const RecState &s, const FlatView &v) { /* paf_check, impl/paf.c:427-461 */
+/* what the transforms touch of a record: the rest of its fields is read again when the output is sized */
+struct FlatState {
+    int64_t qlen, qs, qe, tlen, ts, te;
+    bool same;
+};
+__device__ __forceinline__ void flat_invert(FlatState &s) { /* paf_invert, impl/paf.c:469-474 */
+    int64_t t;
+    t = s.qs; s.qs = s.ts; s.ts = t;
+    t = s.qe; s.qe = s.te; s.te = t;
+    t = s.qlen; s.qlen = s.tlen; s.tlen = t;
+}
+__device__ __forceinline__ int flat_check(const FlatState &s, const FlatView &v) { /* paf_check, impl/paf.c:427-461 */
     if (s.qs < 0 || s.qs >= s.qlen) return PAFFY_ERR_CHECK_QSTART;
     if (s.qs > s.qe || s.qe > s.qlen) return PAFFY_ERR_CHECK_QEND;
     if (s.ts < 0 || s.ts >= s.tlen) return PAFFY_ERR_CHECK_TSTART;
@@ -314,7 +336,7 @@ __device__ __forceinline__ int flat_check(const RecState &s, const FlatView &v) 
  * hold a hit (float32 conversions and the divide are off by less than 2e-7 relative) and is not looked at, the others are walked by
  * the wave, one op per lane, from the mirror.
  */
-__device__ __forceinline__ void flat_trim_prefix(const FlatRec &R, RecState &s, FlatView &v, float thr_f, float id_f, int64_t max_trim) {
+__device__ __forceinline__ void flat_trim_prefix(const FlatRec &R, FlatState &s, FlatView &v, float thr_f, float id_f, int64_t max_trim) {
     const double thr = (double)thr_f, idd = (double)id_f;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w_end = v.lo + v.n;
@@ -415,23 +437,104 @@ __device__ __forceinline__ void flat_trim_prefix(const FlatRec &R, RecState &s, 
     const uint32_t count = best != 0xffffffffu ? best : (uint32_t)trim_idx + 1u;
     if (count == 0) return;
     /* paf_trim_upto: the coordinates move over the dropped ops (impl/paf.c:842-861) */
-    const FlatView old = v;
-    if (!v.rev) {
-        v.lo += count;
-        v.wlo = R.raw_prefix(v.lo);
-    } else {
-        v.whi = R.raw_prefix(v.lo + v.n - count);
+    const int64_t old_tt = v.tt(), old_tq = v.tq();
+    {
+        const FlatPre cut = R.raw_prefix(v.rev ? v.lo + v.n - count : v.lo + count); /* the window's new end */
+        if (v.rev) {
+            v.whi = cut;
+        } else {
+            v.wlo = cut;
+            v.lo += count;
+        }
     }
     v.n -= count;
-    const int64_t d_t = old.tt() - v.tt(), d_q = old.tq() - v.tq();
+    const int64_t d_t = old_tt - v.tt(), d_q = old_tq - v.tq();
     s.ts += d_t;
     if (s.same) s.qs += d_q;
     else s.qe -= d_q;
 }
 
+/*
+ * Rows whose coordinates gain a digit inside the record. A row's bytes are a constant plus the digits of its two query and two target
+ * coordinates plus three times those of its length (paf_write_to_buffer, impl/paf.c:317-389, for the children of impl/paf.c:600-627); along
+ * the view the target coordinates only grow and the query coordinates only grow ('+') or only shrink ('-'), so the rows whose coordinate
+ * is at or above a power of ten B are a suffix or a prefix of the view's rows, and where it starts follows from the first op whose
+ * cumulative bases reach B's distance from the record's start. flat_find() finds that op: the piece by the summaries, the op by a walk
+ * of the piece. *rows_e = M ops of the view in front of the first view index E whose EXCLUSIVE cumulative bases are >= X (X > 0; all
+ * the view's M ops when there is none), *m_last = 1 when op E - 1 (the op whose inclusive sum reached X) is an M op.
+ */
+__device__ __forceinline__ void flat_find(const FlatRec &R, const FlatView &v, bool query, uint32_t X, uint32_t &rows_e, uint32_t &m_last) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w_end = v.lo + v.n;
+    const uint32_t nb = (R.np + 63u) >> 6;
+    /* the raw op kind that does not advance the coordinate: the view's D for the query, its I for the target (I <-> D under an invert) */
+    const bool skip_ins = query ? v.swp : !v.swp;
+    const uint32_t skip_code = skip_ins ? (uint32_t)OP_I : (uint32_t)OP_D;
+    const uint32_t lo_base = v.wlo.m + v.wlo.x - (skip_ins ? v.wlo.ins : v.wlo.del), hi_base = v.whi.m + v.whi.x - (skip_ins ? v.whi.ins : v.whi.del);
+    rows_e = v.whi.rows - v.wlo.rows;
+    m_last = 0;
+    for (uint32_t bi = 0; bi < nb; bi++) {
+        const uint32_t b = v.rev ? nb - 1u - bi : bi; /* pieces in view order */
+        const uint32_t p = b * 64u + lane;
+        uint32_t a_cnt = 0, a_base = 0, a_rows = 0, b_cnt = 0, b_base = 0, b_rows = 0;
+        if (p < R.np) {
+            if (R.in_regs) {
+                b_cnt = R.inc.cnt; b_base = R.inc.m + R.inc.x - (skip_ins ? R.inc.ins : R.inc.del); b_rows = R.inc.rows;
+            } else {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(R.ps + p);
+                b_cnt = flat_ld(q); b_base = flat_ld(q + 1) + flat_ld(q + 2) - flat_ld(q + (skip_ins ? 3 : 4)); b_rows = flat_ld(q + 5);
+            }
+        }
+        if (R.in_regs) {
+            a_cnt = dpp_mov_u32<0x138, 0xf, 0xf>(b_cnt); a_base = dpp_mov_u32<0x138, 0xf, 0xf>(b_base); a_rows = dpp_mov_u32<0x138, 0xf, 0xf>(b_rows);
+        } else if (p > 0 && p < R.np) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(R.ps + (p - 1u));
+            a_cnt = flat_ld(q); a_base = flat_ld(q + 1) + flat_ld(q + 2) - flat_ld(q + (skip_ins ? 3 : 4)); a_rows = flat_ld(q + 5);
+        }
+        if (a_cnt < v.lo) { a_cnt = v.lo; a_base = lo_base; a_rows = v.wlo.rows; }
+        if (a_cnt > w_end) { a_cnt = w_end; a_base = hi_base; a_rows = v.whi.rows; }
+        if (b_cnt < v.lo) { b_cnt = v.lo; b_base = lo_base; b_rows = v.wlo.rows; }
+        if (b_cnt > w_end) { b_cnt = w_end; b_base = hi_base; b_rows = v.whi.rows; }
+        const bool live = p < R.np && b_cnt > a_cnt;
+        /* cumulative bases at the piece's far end, in view order */
+        const uint32_t c_end = v.rev ? hi_base - a_base : b_base - lo_base;
+        const unsigned long long crossing = __ballot(live && c_end >= X);
+        if (!crossing) continue;
+        const uint32_t t = v.rev ? 63u - (uint32_t)__clzll((long long)crossing) : (uint32_t)__ffsll((long long)crossing) - 1u; /* the first in view order */
+        const uint32_t ra = lane_val(a_cnt, t), rb = lane_val(b_cnt, t);
+        uint32_t cum = v.rev ? hi_base - lane_val(b_base, t) : lane_val(a_base, t) - lo_base;        /* in front of the piece */
+        uint32_t rows = v.rev ? v.whi.rows - lane_val(b_rows, t) : lane_val(a_rows, t) - v.wlo.rows;
+        const uint32_t vb = v.rev ? w_end - rb : ra - v.lo, ve = v.rev ? w_end - ra : rb - v.lo;
+        for (uint32_t i0 = vb; i0 < ve; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            uint32_t len = 0, code = skip_code;
+            if (i < ve) {
+                const uint32_t w = R.ops[v.rev ? w_end - 1u - i : v.lo + i];
+                len = w >> 3;
+                code = w & 7u;
+            }
+            const uint32_t inc = wave_incl_scan_u32(code != skip_code ? len : 0u);
+            const unsigned long long is_m = __ballot(i < ve && code == (uint32_t)OP_M);
+            const unsigned long long hb = __ballot(i < ve && cum + inc >= X);
+            if (hb) {
+                const uint32_t hl = (uint32_t)__ffsll((long long)hb) - 1u;
+                rows_e = rows + (uint32_t)__popcll(is_m & ((2ull << hl) - 1ull));
+                m_last = (uint32_t)((is_m >> hl) & 1ull);
+                return;
+            }
+            cum += wave_last_u32(inc);
+            rows += (uint32_t)__popcll(is_m);
+        }
+        return; /* not reached: the piece's far end is at or above X */
+    }
+}
+
 /* what the record kernels take instead: nothing is written for the record but its mark */
-__device__ __forceinline__ void flat_leave(const FlatSizeParams &F, uint32_t rec) {
+enum { FLAT_WHY_HEADER = 0, FLAT_WHY_IRREG = 1, FLAT_WHY_SUMS = 2, FLAT_WHY_EMPTY = 3, FLAT_WHY_CHECK = 4, FLAT_WHY_TRIM_ASSERT = 5, FLAT_WHY_STAGE = 6,
+       FLAT_WHY_NONPLAIN = 7, FLAT_WHY_ROW_SHAPE = 8, FLAT_WHY_DIGITS = 9, FLAT_WHY_HEADER_LEN = 10 };
+__device__ __forceinline__ void flat_leave(const FlatSizeParams &F, uint32_t rec, int why) {
     if ((threadIdx.x & 63u) == 0) {
+        atomicAdd(&F.P.info->flat_reason[why], 1u);
         F.flat_done[rec] = 0;
         F.P.out_len[rec] = 0;
         F.P.out_rows[rec] = 0;
@@ -441,18 +544,35 @@ __device__ __forceinline__ void flat_leave(const FlatSizeParams &F, uint32_t rec
 }
 
 #define FLAT_SIZE_WAVES 4u
+#define FLAT_MAX_CROSS 6u /* powers of ten inside a record's query and target ranges together; more (coordinates of a few digits) go to the record kernels */
+/* digits beyond those of the record's start coordinates in the coordinates of the first ra rows of the view (flat_find) */
+__device__ __forceinline__ uint64_t flat_cross_digits(const uint32_t (*cross)[3], uint32_t n_cross, uint32_t ra) {
+    uint64_t extra = 0;
+    for (uint32_t c = 0; c < n_cross; c++) {
+        const uint32_t re = cross[c][0], ml = cross[c][1];
+        if (cross[c][2] == 0) { /* growing: rows from the crossing on; the row's end coordinate crosses one op earlier when that op is the row */
+            extra += (ra > re ? ra - re : 0u) + (ra > re - ml ? ra - (re - ml) : 0u);
+        } else { /* shrinking: rows in front of the crossing */
+            extra += (ra < re ? ra : re) + (ra < re - ml ? ra : re - ml);
+        }
+    }
+    return extra;
+}
 __global__ __launch_bounds__(64 * FLAT_SIZE_WAVES) void k_flat_size(FlatSizeParams F) {
     const KParams &P = F.P;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t rec = blockIdx.x * FLAT_SIZE_WAVES + (threadIdx.x >> 6);
+    const uint32_t rec = uni(blockIdx.x * FLAT_SIZE_WAVES + (threadIdx.x >> 6)); /* in a scalar register: the record's state is wave-uniform */
+    __shared__ uint32_t s_cross[FLAT_SIZE_WAVES][FLAT_MAX_CROSS][3]; /* per wave: the powers of ten inside a record's coordinate ranges (flat_find) */
+    const uint32_t wave_in_group = uni(threadIdx.x >> 6);
+    uint32_t n_cross = 0;
     if (rec >= P.n_rec) return;
     const RecMeta &m = P.meta[rec];
-    if (m.err || !m.has_cg || m.cg_len == 0) return flat_leave(F, rec);
+    if (m.err || !m.has_cg || m.cg_len == 0) return flat_leave(F, rec, FLAT_WHY_HEADER);
     const uint32_t cg_off = m.cg_off, cg_end = cg_off + m.cg_len;
-    const uint2 fr = F.flat_rec[rec];
     FlatRec R;
     R.np = ((cg_end - 1u) >> FLAT_TILE_SHIFT) - (cg_off >> FLAT_TILE_SHIFT) + 1u;
-    R.ps = F.sums + fr.x;
+    PieceSum *const rec_sums = F.sums + ((cg_off >> FLAT_TILE_SHIFT) + rec);
+    R.ps = rec_sums;
     R.ops = reinterpret_cast<const uint16_t *>(P.ops_mirror + (cg_off >> 1));
     R.in_regs = R.np <= 64u;
     const bool shatter_last = P.n_stages > 0 && P.stages[P.n_stages - 1].kind == PAFFY_SHATTER;
@@ -486,7 +606,7 @@ __global__ __launch_bounds__(64 * FLAT_SIZE_WAVES) void k_flat_size(FlatSizePara
             if (R.in_regs) {
                 R.inc = inc;
             } else if (p < R.np) {
-                uint4 *o = reinterpret_cast<uint4 *>(F.sums + fr.x + p);
+                uint4 *o = reinterpret_cast<uint4 *>(rec_sums + p);
                 o[0] = make_uint4(inc.cnt, inc.m, inc.x, inc.ins);
                 o[1] = make_uint4(inc.del, inc.rows, inc.extra, inc.text);
             }
@@ -496,24 +616,26 @@ __global__ __launch_bounds__(64 * FLAT_SIZE_WAVES) void k_flat_size(FlatSizePara
         R.n_ops = carry.cnt;
     }
     flags = (__any((flags & FLAT_F_IRREG) != 0) ? FLAT_F_IRREG : 0u) | (__any((flags & FLAT_F_NONPLAIN) != 0) ? FLAT_F_NONPLAIN : 0u);
-    if ((flags & FLAT_F_IRREG) || R.n_ops == 0 || tot_m + tot_x >= 0x7fffffffull || P.nocheck_mask) return flat_leave(F, rec);
+    if ((flags & FLAT_F_IRREG) || R.n_ops == 0) return flat_leave(F, rec, FLAT_WHY_IRREG);
+    if (tot_m + tot_x >= 0x7fffffffull || P.nocheck_mask) return flat_leave(F, rec, FLAT_WHY_SUMS);
     if (!R.in_regs) __threadfence(); /* the scanned sums are read back below by this wave (other lanes' stores): past the L1, flat_ld() */
-    RecState s;
-    load_state(m, s);
+    FlatState s;
+    s.qlen = m.qlen; s.qs = m.qs; s.qe = m.qe; s.tlen = m.tlen; s.ts = m.ts; s.te = m.te;
+    s.same = m.same_strand != 0;
     FlatView v;
     v.lo = 0; v.n = R.n_ops; v.rev = false; v.swp = false;
     v.wlo = R.piece_prefix(0);
     v.whi = R.piece_prefix(R.np);
-    bool swapped = false, shatter = false, checked = false;
+    bool swapped = false, shatter = false, checked = false, rewritten = false;
     for (int32_t si = 0; si < P.n_stages; si++) {
         const paffy_stage st = P.stages[si];
         if (si > 0) { /* what `paf_write | paf_parse` between two processes does to the record */
-            if (v.n == 0) return flat_leave(F, rec);
-            if (s.type == 0 && s.tile_level != -1) s.type = s.tile_level > 1 ? 'S' : 'P';
+            if (v.n == 0) return flat_leave(F, rec, FLAT_WHY_EMPTY);
+            rewritten = true; /* type: below, where the other fields are read */
         }
         int rc = 0;
         if (st.kind == PAFFY_INVERT) {
-            invert_state(s);
+            flat_invert(s);
             v.swp = !v.swp;
             if (!s.same) v.rev = !v.rev;
             swapped = !swapped;
@@ -529,80 +651,88 @@ __global__ __launch_bounds__(64 * FLAT_SIZE_WAVES) void k_flat_size(FlatSizePara
             for (int pass = 0; pass < 2; pass++) {
                 if (pass == 1) {
                     if (s.same && v.n == n_before) break;
-                    invert_state(s);
+                    flat_invert(s);
                     v.swp = !v.swp;
                     if (!s.same) v.rev = !v.rev;
                 }
                 flat_trim_prefix(R, s, v, thr_f, id_f, max_trim);
                 if (pass == 1) {
-                    invert_state(s);
+                    flat_invert(s);
                     v.swp = !v.swp;
                     if (!s.same) v.rev = !v.rev;
                 }
             }
             const uint32_t m2 = v.tm(), x2 = v.tx();
             const double final_identity = ratio_f32((int64_t)m2, (int64_t)m2 + (int64_t)x2);
-            rc = final_identity >= identity ? 0 : PAFFY_ERR_TRIM_IDENTITY_ASSERT;
-            if (!rc) rc = flat_check(s, v);
+            if (!(final_identity >= identity)) return flat_leave(F, rec, FLAT_WHY_TRIM_ASSERT);
+            rc = flat_check(s, v);
         } else if (st.kind == PAFFY_SHATTER) {
             shatter = true;
             break;
         } else if (st.kind != PAFFY_PASS) {
-            return flat_leave(F, rec);
+            return flat_leave(F, rec, FLAT_WHY_STAGE);
         }
-        if (rc) return flat_leave(F, rec);
+        if (rc) return flat_leave(F, rec, FLAT_WHY_CHECK);
         checked = st.kind != PAFFY_PASS;
     }
     RecPlan *plan = static_cast<RecPlan *>(P.rec_plan) + rec;
     int64_t bytes, rows;
     bool rows_kernel = false, line_kernel = false;
-    uint32_t chunk = ((v.n + 63u) / 64u) | 1u;
-    int64_t wq[4] = {0, 0, 0, 0}, wt[4] = {0, 0, 0, 0}, wo[4] = {0, 0, 0, 0};
+    uint32_t row_bytes1 = 0; /* shatter: bytes of a row whose length has one digit */
     const FlatPre win = flat_sub(v.whi, v.wlo);
+    if (shatter && !checked && flat_check(s, v)) return flat_leave(F, rec, FLAT_WHY_CHECK); /* every row of a record that passes paf_check passes its own (impl/paf.c:624) */
+    /* the record as the writers will see it */
+    RecState rs;
+    load_state(m, rs);
+    if (swapped) invert_state(rs);
+    rs.qs = s.qs; rs.qe = s.qe; rs.ts = s.ts; rs.te = s.te;
+    if (rewritten && rs.type == 0 && rs.tile_level != -1) rs.type = rs.tile_level > 1 ? 'S' : 'P';
     if (shatter) {
-        if (v.n == 0 || (flags & FLAT_F_NONPLAIN)) return flat_leave(F, rec);
-        if (!checked && flat_check(s, v)) return flat_leave(F, rec); /* every row of a record that passes paf_check passes its own (impl/paf.c:624) */
+        if (v.n == 0 || (flags & FLAT_F_NONPLAIN)) return flat_leave(F, rec, FLAT_WHY_NONPLAIN);
         ShatterConst k;
-        shatter_consts(s, k);
-        const uint32_t dq0 = (uint32_t)dec_len(s.qs), dt0 = (uint32_t)dec_len(s.ts);
-        if (!shatter_fits(k) || !shatter_fast_ok(s, k) || k.lenA > 48 || k.lenB > 48 || k.lenC > 48 || dq0 != (uint32_t)dec_len(s.qe) ||
-            dt0 != (uint32_t)dec_len(s.te) || s.qe - s.qs >= 0x7fffffffll || s.te - s.ts >= 0x7fffffffll)
-            return flat_leave(F, rec);
-        /* start and end coordinates print with the same number of digits: a row's size depends on its length only */
-        const uint32_t fixed = k.row_const + 2u * dq0 + 2u * dt0;
+        shatter_consts(rs, k);
+        const uint32_t dq0 = (uint32_t)dec_len(rs.qs), dt0 = (uint32_t)dec_len(rs.ts);
+        if (!shatter_fits(k) || !shatter_fast_ok(rs, k) || k.lenA > 48 || k.lenB > 48 || k.lenC > 48) return flat_leave(F, rec, FLAT_WHY_ROW_SHAPE);
+        if (rs.qe - rs.qs >= 0x7fffffffll || rs.te - rs.ts >= 0x7fffffffll) return flat_leave(F, rec, FLAT_WHY_DIGITS);
+        /* a row whose coordinates have the digits of the record's start coordinates and whose length has one */
+        row_bytes1 = k.row_const + 2u * dq0 + 2u * dt0 + 3u;
         rows = win.rows;
-        bytes = (int64_t)win.rows * (int64_t)(fixed + 3u) + 3ll * (int64_t)win.extra;
-        rows_kernel = v.n <= PAFFY_ROWS_MAX_OPS;
-        if (!rows_kernel) { /* the four-wave writer: bases consumed and bytes written in front of each wave's share of the view */
-            chunk = ((v.n + 255u) / 256u) | 1u;
-            for (uint32_t w = 1; w < 4; w++) {
-                const uint64_t at64 = 64ull * w * chunk;
-                const uint32_t at = at64 < v.n ? (uint32_t)at64 : v.n;
-                const FlatPre e = v.rev ? flat_sub(v.whi, R.raw_prefix(v.lo + v.n - at)) : flat_sub(R.raw_prefix(v.lo + at), v.wlo);
-                wq[w] = (int64_t)e.m + e.x - (v.swp ? e.ins : e.del);
-                wt[w] = (int64_t)e.m + e.x - (v.swp ? e.del : e.ins);
-                wo[w] = (int64_t)e.rows * (int64_t)(fixed + 3u) + 3ll * (int64_t)e.extra;
+        bytes = (int64_t)win.rows * (int64_t)row_bytes1 + 3ll * (int64_t)win.extra;
+        /* the powers of ten inside the record's two ranges (almost always none): the rows at or above one have a digit more */
+        if (dq0 != (uint32_t)dec_len(rs.qe) || dt0 != (uint32_t)dec_len(rs.te)) {
+#pragma unroll 1
+            for (uint32_t f = 0; f < 2; f++) { /* target, query */
+                const int64_t c_lo = f ? rs.qs : rs.ts, c_hi = f ? rs.qe : rs.te;
+                const bool falling = f == 1 && !rs.same; /* the query coordinates of a '-' record shrink along the view */
+#pragma unroll 1
+                for (int64_t B = 10; B <= c_hi; B *= 10) {
+                    if (B <= c_lo) continue;
+                    if (n_cross == FLAT_MAX_CROSS) return flat_leave(F, rec, FLAT_WHY_DIGITS);
+                    uint32_t re, ml;
+                    flat_find(R, v, f == 1, (uint32_t)(falling ? c_hi - B + 1 : B - c_lo), re, ml);
+                    if (lane == 0) {
+                        s_cross[wave_in_group][n_cross][0] = re;
+                        s_cross[wave_in_group][n_cross][1] = ml;
+                        s_cross[wave_in_group][n_cross][2] = falling ? 1u : 0u;
+                    }
+                    n_cross++;
+                }
             }
+            __builtin_amdgcn_wave_barrier();
+            bytes += (int64_t)flat_cross_digits(s_cross[wave_in_group], n_cross, win.rows);
         }
+        rows_kernel = v.n <= PAFFY_ROWS_MAX_OPS;
     } else {
-        if (v.n == 0) return flat_leave(F, rec);
-        const uint32_t lenH = header_len(s, false);
-        if (lenH > 3 * PAFFY_TMPL_MAX) return flat_leave(F, rec);
+        if (v.n == 0) return flat_leave(F, rec, FLAT_WHY_EMPTY);
+        const uint32_t lenH = header_len(rs, false);
+        if (lenH > 3 * PAFFY_TMPL_MAX) return flat_leave(F, rec, FLAT_WHY_HEADER_LEN);
         line_kernel = lenH + 8 <= PAFFY_TMPL_MAX && v.n <= PAFFY_ROWS_MAX_OPS;
         bytes = (int64_t)lenH + (int64_t)win.text + 1;
         rows = 1;
-        if (!line_kernel) {
-            chunk = ((v.n + 255u) / 256u) | 1u;
-            for (uint32_t w = 1; w < 4; w++) {
-                const uint64_t at64 = 64ull * w * chunk;
-                const uint32_t at = at64 < v.n ? (uint32_t)at64 : v.n;
-                const FlatPre e = v.rev ? flat_sub(v.whi, R.raw_prefix(v.lo + v.n - at)) : flat_sub(R.raw_prefix(v.lo + at), v.wlo);
-                wo[w] = (int64_t)e.text;
-            }
-        }
     }
+    const bool four_waves = shatter ? !rows_kernel : !line_kernel;
     if (lane == 0) {
-        if (shatter ? !rows_kernel : !line_kernel) atomicAdd(&P.info->g_count, 1u);
+        if (four_waves) atomicAdd(&P.info->g_count, 1u);
         F.flat_done[rec] = 1;
         P.status[rec] = (uint32_t)KLASS_LDS << 16;
         P.err_aux[rec] = 0;
@@ -611,13 +741,30 @@ __global__ __launch_bounds__(64 * FLAT_SIZE_WAVES) void k_flat_size(FlatSizePara
         P.out_rows[rec] = rows;
         plan->qs = s.qs; plan->qe = s.qe; plan->ts = s.ts; plan->te = s.te; plan->sub_lo = 0; plan->sub_hi = 0;
         plan->lo = v.lo; plan->n = v.n;
-        plan->flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | 8u | ((uint32_t)s.type << 8) | (shatter ? 16u : 0u) |
+        plan->flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | 8u | ((uint32_t)rs.type << 8) | (shatter ? 16u : 0u) |
                       (rows_kernel ? 64u : 0u) | (line_kernel ? 0x10000u : 0u) | 0x40000u;
-        plan->chunk = chunk;
-        for (int w = 0; w < 4; w++) {
-            plan->wq[w] = wq[w];
-            plan->wt[w] = wt[w];
-            plan->wo[w] = wo[w];
+        plan->chunk = four_waves ? (((v.n + 255u) / 256u) | 1u) : (((v.n + 63u) / 64u) | 1u);
+        for (int w = 0; w < 4; w++) plan->wq[w] = plan->wt[w] = plan->wo[w] = 0;
+    }
+    if (four_waves) {
+        /* the four-wave writers: bases consumed and bytes written in front of each wave's share of the view (wave w owns the view's ops
+           [64 w chunk, 64 (w + 1) chunk), as sweep_bounds() of record_kernel.h cuts them) */
+        const uint32_t chunk = ((v.n + 255u) / 256u) | 1u;
+#pragma unroll 1
+        for (uint32_t w = 1; w < 4; w++) {
+            const uint64_t at64 = 64ull * w * chunk;
+            const uint32_t at = at64 < v.n ? (uint32_t)at64 : v.n;
+            const FlatPre cut = R.raw_prefix(v.rev ? v.lo + v.n - at : v.lo + at);
+            const FlatPre e = v.rev ? flat_sub(v.whi, cut) : flat_sub(cut, v.wlo);
+            if (lane == 0) {
+                if (shatter) {
+                    plan->wq[w] = (int64_t)e.m + e.x - (v.swp ? e.ins : e.del);
+                    plan->wt[w] = (int64_t)e.m + e.x - (v.swp ? e.del : e.ins);
+                    plan->wo[w] = (int64_t)e.rows * (int64_t)row_bytes1 + 3ll * (int64_t)e.extra + (int64_t)flat_cross_digits(s_cross[wave_in_group], n_cross, e.rows);
+                } else {
+                    plan->wo[w] = (int64_t)e.text;
+                }
+            }
         }
     }
 }

@@ -284,7 +284,7 @@ __device__ int64_t parse_i64_dev(const uint8_t *in, uint32_t p, uint32_t e) {
  */
 #define HDR_GROUP 32u
 __global__ __launch_bounds__(PAFFY_NT) void k_header(const uint8_t *in, const uint32_t *sep_pos, const uint32_t *nl_idx, uint32_t n_lines,
-                                                      RecMeta *meta, uint32_t *big_list, DevInfo *info, uint32_t lvl0_max, uint2 *flat_rec, uint32_t *chunk_rec) {
+                                                      RecMeta *meta, uint32_t *big_list, DevInfo *info, uint32_t lvl0_max, uint32_t *chunk_rec) {
     constexpr uint32_t kWords = sizeof(RecMeta) / 4; /* 36 */
     static_assert(sizeof(RecMeta) % 4 == 0 && kWords > 32 && kWords <= 64, "the image is written as two words per lane at most");
     __shared__ __attribute__((aligned(16))) RecMeta image[PAFFY_NT / HDR_GROUP];
@@ -411,37 +411,14 @@ __global__ __launch_bounds__(PAFFY_NT) void k_header(const uint8_t *in, const ui
         /* long cigars go straight to the sizing launch with the bigger LDS store (runs beside the main one) */
         if (gl == 0 && err == 0 && (m->cg_len >> 1) > lvl0_max) big_list[atomicAdd(&info->b_count[0], 1u)] = r;
     }
-    if (flat_rec) { /* kernel argument: the whole grid takes this branch or none of it does */
+    if (chunk_rec && live && err == 0 && m->has_cg && m->cg_len > 0) {
         /* the flat sizing pass (flat_kernel.h): the record's cigar is pieces (its text cut at the 1 KiB boundaries of the batch) and chunks of
-           four pieces; their places in the summary array and the chunk list are handed out per workgroup, one atomic for its eight records */
-        __shared__ uint32_t s_np[PAFFY_NT / HDR_GROUP], s_nc[PAFFY_NT / HDR_GROUP];
-        __shared__ unsigned long long s_base;
-        uint32_t np = 0, nc = 0;
-        if (live && err == 0 && m->has_cg && m->cg_len > 0) {
-            np = ((m->cg_off + m->cg_len - 1u) >> FLAT_TILE_SHIFT) - (m->cg_off >> FLAT_TILE_SHIFT) + 1u;
-            nc = (np + FLAT_CHUNK_PIECES - 1u) / FLAT_CHUNK_PIECES;
-        }
-        if (gl == 0) {
-            s_np[g] = np;
-            s_nc[g] = nc;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long tp = 0, tc = 0;
-            for (uint32_t k = 0; k < PAFFY_NT / HDR_GROUP; k++) {
-                tp += s_np[k];
-                tc += s_nc[k];
-            }
-            s_base = (tp | tc) ? atomicAdd(&info->flat_alloc, (tp << 32) | tc) : 0ull;
-        }
-        __syncthreads();
-        uint32_t pbase = (uint32_t)(s_base >> 32), cbase = (uint32_t)(s_base & 0xffffffffull);
-        for (uint32_t k = 0; k < g; k++) {
-            pbase += s_np[k];
-            cbase += s_nc[k];
-        }
-        if (live && gl == 0) flat_rec[r] = make_uint2(pbase, cbase);
-        for (uint32_t j = gl; j < nc; j += HDR_GROUP) chunk_rec[cbase + j] = r;
+           four pieces; chunk c of record r stands at slot (cg_off >> 12) + r + c of the chunk list (records are in text order: no two
+           chunks share a slot, no scan or atomic hands the slots out) */
+        const uint32_t tf = m->cg_off >> FLAT_TILE_SHIFT;
+        const uint32_t np = ((m->cg_off + m->cg_len - 1u) >> FLAT_TILE_SHIFT) - tf + 1u;
+        const uint32_t nc = (np + FLAT_CHUNK_PIECES - 1u) / FLAT_CHUNK_PIECES;
+        for (uint32_t j = gl; j < nc; j += HDR_GROUP) chunk_rec[(tf >> 2) + r + j] = r;
     }
 }
 
@@ -866,6 +843,8 @@ struct paffy_hip_ctx {
     paffy_plan_info plan;
     /* profiling */
     bool profile = false;
+    int64_t flat_left = -1, flat_reasons[16] = {0}; /* paffy_hip_flat_stats */
+    uint32_t flat_chunk_slots = 0;
     bool lvl0_long_ok = false, lvl0_long_off = false; /* the longer first store level: shown safe by the batch before / overflowed once */
     /* device buffers of the two slots of a closed stream (paffy_hip_stream_close), taken again by the next paffy_hip_stream_open: a
        hipMalloc of the tens of GB a slot's output needs takes 16 ms most of the time and 0.5-2.6 s right behind the hipFree of the stream
@@ -1132,17 +1111,19 @@ static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, ui
         LAUNCH(c, "k_sep_write", k_sep_write, dim3(n_tiles), dim3(PAFFY_NT), 0, in, len, static_cast<const uint2 *>(c->tile_counts.p),
                static_cast<uint32_t *>(c->sep_pos.p), static_cast<uint32_t *>(c->nl_idx.p));
     if (flat && n_lines > 0) {
-        /* a record's cigar of L bytes is at most L / 1024 + 2 pieces and L / 4096 + 2 chunks */
-        const size_t max_pieces = ((size_t)len >> FLAT_TILE_SHIFT) + 2 * (size_t)n_lines + 8, max_chunks = ((size_t)len >> (FLAT_TILE_SHIFT + 2)) + 2 * (size_t)n_lines + 8;
-        if (ensure(c, c->flat_rec, sizeof(uint2) * (size_t)(n_lines + 1)) || ensure(c, c->flat_chunks, sizeof(uint32_t) * max_chunks) ||
-            ensure(c, c->flat_sums, sizeof(PieceSum) * max_pieces) || ensure(c, c->flat_done, (size_t)n_lines + 16))
+        /* summary slot of piece p of record r: (cg_off >> 10) + r + p; chunk slot of its chunk c: (cg_off >> 12) + r + c (flat_kernel.h) */
+        const size_t piece_slots = ((size_t)len >> FLAT_TILE_SHIFT) + (size_t)n_lines + 8, chunk_slots = ((size_t)len >> (FLAT_TILE_SHIFT + 2)) + (size_t)n_lines + 8;
+        if (ensure(c, c->flat_chunks, sizeof(uint32_t) * chunk_slots) || ensure(c, c->flat_sums, sizeof(PieceSum) * piece_slots) ||
+            ensure(c, c->flat_done, (size_t)n_lines + 16))
             return PAFFY_E_HIP;
+        HIPCHK(c, hipMemsetAsync(c->flat_chunks.p, 0xff, sizeof(uint32_t) * chunk_slots, c->stream)); /* FLAT_NO_CHUNK */
+        c->flat_chunk_slots = (uint32_t)chunk_slots;
     }
     if (n_lines > 0)
         LAUNCH(c, "k_header", k_header, dim3((n_lines + PAFFY_NT / HDR_GROUP - 1) / (PAFFY_NT / HDR_GROUP)), dim3(PAFFY_NT), 0, in,
                static_cast<const uint32_t *>(c->sep_pos.p), static_cast<const uint32_t *>(c->nl_idx.p), n_lines,
                static_cast<RecMeta *>(c->meta.p), static_cast<uint32_t *>(c->b_list.p), static_cast<DevInfo *>(c->info.p), lvl0_max,
-               flat ? static_cast<uint2 *>(c->flat_rec.p) : static_cast<uint2 *>(nullptr), flat ? static_cast<uint32_t *>(c->flat_chunks.p) : static_cast<uint32_t *>(nullptr));
+               flat ? static_cast<uint32_t *>(c->flat_chunks.p) : static_cast<uint32_t *>(nullptr));
 
     return 0;
 }
@@ -1182,6 +1163,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     c->planned = false;
     c->plan_is_tile = false;
     c->plan_is_bed = false;
+    c->flat_left = -1;
     memset(info, 0, sizeof(*info));
     info->in_bytes = in_len;
     memset(&c->plan, 0, sizeof(c->plan));
@@ -1302,8 +1284,8 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
         fp.in = in;
         fp.in_len = len;
         fp.meta = kp.meta;
-        fp.flat_rec = static_cast<const uint2 *>(c->flat_rec.p);
         fp.chunk_rec = static_cast<const uint32_t *>(c->flat_chunks.p);
+        fp.n_chunk_slots = c->flat_chunk_slots;
         fp.nd = static_cast<const uint16_t *>(c->flat_nd.p);
         fp.sums = static_cast<PieceSum *>(c->flat_sums.p);
         fp.ops_mirror = kp.ops_mirror;
@@ -1312,7 +1294,6 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
         LAUNCH(c, "k_flat_parse", k_flat_parse, dim3(2048), dim3(64 * FLAT_PARSE_WAVES), 0, fp);
         FlatSizeParams fs;
         fs.P = kp;
-        fs.flat_rec = fp.flat_rec;
         fs.sums = fp.sums;
         fs.flat_done = static_cast<uint8_t *>(c->flat_done.p);
         LAUNCH(c, "k_flat_size", k_flat_size, dim3((n_lines + FLAT_SIZE_WAVES - 1) / FLAT_SIZE_WAVES), dim3(64 * FLAT_SIZE_WAVES), 0, fs);
@@ -1320,6 +1301,8 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
         if (fetch_info(c)) return PAFFY_E_HIP;
         flat_g_count = c->h_info->g_count;
         need_legacy = c->h_info->flat_legacy > 0;
+        c->flat_left = c->h_info->flat_legacy;
+        for (int k = 0; k < 16; k++) c->flat_reasons[k] = c->h_info->flat_reason[k];
         kp.flat_done = static_cast<const uint8_t *>(c->flat_done.p);
     }
     if (n_lines > 0 && need_legacy) {
@@ -2516,6 +2499,14 @@ int paffy_hip_bed_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, const
     if (!rc) rc = paffy_hip_bed_add(c, d_in, in_len);
     if (!rc) rc = paffy_hip_bed_run(c, opts, info);
     return rc;
+}
+
+int paffy_hip_flat_stats(paffy_hip_ctx *c, int64_t *left, int64_t reasons[16]) {
+    if (!c || !left) return PAFFY_E_ARG;
+    *left = c->flat_left;
+    if (reasons)
+        for (int k = 0; k < 16; k++) reasons[k] = c->flat_left >= 0 ? c->flat_reasons[k] : 0;
+    return 0;
 }
 
 int paffy_hip_plan_stats(paffy_hip_ctx *c, int64_t sums[6]) {

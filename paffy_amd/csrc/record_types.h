@@ -54,9 +54,9 @@ struct DevInfo {
     /* the longer first store level (paffy_hip.hip: lvl0_long): records whose ops overflowed the first-level store although their cigar was
        short enough to start there, and -- while the safe bound is in force -- records of the second level that would have */
     uint32_t lvl0_over, lvl0_probe_dense;
-    /* flat sizing pass (flat_kernel.h): pieces << 32 | chunks handed out by k_header, and the records it left to the record kernels */
-    unsigned long long flat_alloc;
+    /* flat sizing pass (flat_kernel.h): the records it left to the record kernels */
     uint32_t flat_legacy, flat_pad;
+    uint32_t flat_reason[16]; /* why: FLAT_WHY_* of flat_kernel.h (diagnostics, paffy_hip_flat_stats) */
 };
 
 /* What the stage list left of a record; written by the sizing pass, read by the emit pass. */

@@ -145,6 +145,7 @@ def lib():
         L.paffy_hip_synth.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64)]
         L.paffy_hip_synth_contigs.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64)]
         L.paffy_hip_plan_stats.argtypes = [vp, C.POINTER(i64)]
+        L.paffy_hip_flat_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
         L.paffy_hip_bed_plan.argtypes = [vp, vp, i64, C.POINTER(BedOpts), C.POINTER(PlanInfo)]
         L.paffy_hip_synth4_setup.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, i64, i64, C.c_int]
         L.paffy_hip_synth4.argtypes = [vp, C.c_uint64, C.c_uint64, vp, i64, C.POINTER(i64)]
@@ -477,6 +478,12 @@ class Engine:
             raise PafError(f"record {info.error.record}: {L.paffy_hip_error_string(info.error.code).decode()}", info,
                            L.paffy_hip_error_exit_status(info.error.code))
         return out, info
+
+    def flat_stats(self):
+        """(records the flat sizing pass left to the record kernels in the last plan, or -1 when the plan did not take it; counts per reason)"""
+        left, why = C.c_int64(), (C.c_int64 * 16)()
+        self._check(lib().paffy_hip_flat_stats(self._ctx, C.byref(left), why), "paffy_hip_flat_stats")
+        return left.value, list(why)
 
     def plan_stats(self):
         """Sums of the STATS stage of the last plan (the last one, should a pipe hold several): (matches, mismatches, inserts, deletes, insert bases, delete bases)."""

@@ -18,6 +18,15 @@ LEAN_PIPES = ([O.SHATTER], [O.INVERT, O.TRIM_IDENTITY, O.SHATTER], [O.INVERT], [
               [O.TRIM_IDENTITY, O.SHATTER], [O.INVERT, O.INVERT, O.SHATTER])
 
 
+STATS = []  # (pipe, (records left to the record kernels, counts per reason)) of every run, in order
+
+
+def kept_all(n_runs=None):
+    """the flat pass took the last runs' records itself: the run exercised the code under test"""
+    runs = STATS[-n_runs:] if n_runs else STATS
+    return all(left == 0 for _, _, (left, _) in runs)
+
+
 @pytest.fixture(scope="module")
 def eng():
     import paffy_amd
@@ -25,6 +34,11 @@ def eng():
     e = paffy_amd.Engine()
     yield e
     e.close()
+    if os.environ.get("PAFFY_FLAT_STATS_OUT"):  # who sized what, run by run (diagnostics)
+        import json
+
+        with open(os.environ["PAFFY_FLAT_STATS_OUT"], "w") as fh:
+            json.dump([{"test": t, "pipe": p, "left": left, "why": why} for t, p, (left, why) in STATS], fh)
 
 
 def record(ops, strand="+", qname="hs.chr3", tname="pt.chr9", qlen=250_000_000, tlen=240_000_000, qs=None, ts=None, tags="tp:A:P\tAS:i:777\ts1:i:42",
@@ -60,6 +74,7 @@ def run_both(eng, data, pipes=LEAN_PIPES, params=None):
         gst = [paffy_amd.stage(k, *(params or {}).get(k, ())) for k in pipe]
         want, werr = O.run(ost, data)
         got, info = eng.run(gst, data, raise_on_error=False)
+        STATS.append((os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], tuple(pipe), eng.flat_stats()))
         assert info.error.code == werr.code, (pipe, info.error.code, werr.code, info.error.record, werr.record)
         assert len(got) == len(want) and hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest(), pipe
 
