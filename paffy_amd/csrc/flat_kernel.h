@@ -544,6 +544,7 @@ __device__ __forceinline__ void flat_leave(const FlatSizeParams &F, uint32_t rec
 }
 
 #define FLAT_SIZE_WAVES 4u
+#define FLAT_SEG_OPS (PAFFY_ROWS_MAX_OPS / 2u) /* ops of a segment of a long shatter record: one workgroup of k_emit_rows (about a megabyte of rows) */
 #define FLAT_MAX_CROSS 6u /* powers of ten inside a record's query and target ranges together; more (coordinates of a few digits) go to the record kernels */
 /* digits beyond those of the record's start coordinates in the coordinates of the first ra rows of the view (flat_find) */
 __device__ __forceinline__ uint64_t flat_cross_digits(const uint32_t (*cross)[3], uint32_t n_cross, uint32_t ra) {
@@ -730,7 +731,16 @@ __global__ __launch_bounds__(64 * FLAT_SIZE_WAVES) void k_flat_size(FlatSizePara
         bytes = (int64_t)lenH + (int64_t)win.text + 1;
         rows = 1;
     }
-    const bool four_waves = shatter ? !rows_kernel : !line_kernel;
+    /* a shatter record too long for one wave of the row writer: segments of FLAT_SEG_OPS ops, one workgroup of k_emit_rows each (EmitItem) */
+    const bool itemised = shatter && !rows_kernel;
+    const uint32_t n_seg = itemised ? (v.n + FLAT_SEG_OPS - 1u) / FLAT_SEG_OPS : 0u;
+    uint32_t item0 = 0;
+    if (itemised) {
+        if (lane == 0) item0 = atomicAdd(&P.info->n_items, n_seg);
+        item0 = uni(item0);
+        if (item0 + n_seg > P.items_cap) return flat_leave(F, rec, FLAT_WHY_ROW_SHAPE); /* cannot happen: the host sizes the list for every op of the text */
+    }
+    const bool four_waves = !shatter && !line_kernel;
     if (lane == 0) {
         if (four_waves) atomicAdd(&P.info->g_count, 1u);
         F.flat_done[rec] = 1;
@@ -742,13 +752,35 @@ __global__ __launch_bounds__(64 * FLAT_SIZE_WAVES) void k_flat_size(FlatSizePara
         plan->qs = s.qs; plan->qe = s.qe; plan->ts = s.ts; plan->te = s.te; plan->sub_lo = 0; plan->sub_hi = 0;
         plan->lo = v.lo; plan->n = v.n;
         plan->flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | 8u | ((uint32_t)rs.type << 8) | (shatter ? 16u : 0u) |
-                      (rows_kernel ? 64u : 0u) | (line_kernel ? 0x10000u : 0u) | 0x40000u;
+                      (rows_kernel ? 64u : 0u) | (line_kernel ? 0x10000u : 0u) | 0x40000u | (itemised ? 0x80000u : 0u);
         plan->chunk = four_waves ? (((v.n + 255u) / 256u) | 1u) : (((v.n + 63u) / 64u) | 1u);
         for (int w = 0; w < 4; w++) plan->wq[w] = plan->wt[w] = plan->wo[w] = 0;
     }
+    if (itemised) {
+#pragma unroll 1
+        for (uint32_t g = 0; g < n_seg; g++) {
+            const uint32_t at = g * FLAT_SEG_OPS; /* < v.n */
+            FlatPre e = flat_sub(v.whi, v.whi); /* zeros */
+            if (at) {
+                const FlatPre cut = R.raw_prefix(v.rev ? v.lo + v.n - at : v.lo + at);
+                e = v.rev ? flat_sub(v.whi, cut) : flat_sub(cut, v.wlo);
+            }
+            if (lane == 0) {
+                EmitItem it;
+                it.rec = rec;
+                it.wb = at;
+                it.we = at + FLAT_SEG_OPS < v.n ? at + FLAT_SEG_OPS : v.n;
+                it.pad = 0;
+                it.cq0 = (int64_t)e.m + e.x - (v.swp ? e.ins : e.del);
+                it.ct0 = (int64_t)e.m + e.x - (v.swp ? e.del : e.ins);
+                it.wo = (int64_t)e.rows * (int64_t)row_bytes1 + 3ll * (int64_t)e.extra + (int64_t)flat_cross_digits(s_cross[wave_in_group], n_cross, e.rows);
+                P.items[item0 + g] = it;
+            }
+        }
+    }
     if (four_waves) {
-        /* the four-wave writers: bases consumed and bytes written in front of each wave's share of the view (wave w owns the view's ops
-           [64 w chunk, 64 (w + 1) chunk), as sweep_bounds() of record_kernel.h cuts them) */
+        /* the four-wave line writer: text bytes in front of each wave's share of the view (wave w owns the view's ops [64 w chunk,
+           64 (w + 1) chunk), as sweep_bounds() of record_kernel.h cuts them) */
         const uint32_t chunk = ((v.n + 255u) / 256u) | 1u;
 #pragma unroll 1
         for (uint32_t w = 1; w < 4; w++) {
@@ -756,15 +788,7 @@ __global__ __launch_bounds__(64 * FLAT_SIZE_WAVES) void k_flat_size(FlatSizePara
             const uint32_t at = at64 < v.n ? (uint32_t)at64 : v.n;
             const FlatPre cut = R.raw_prefix(v.rev ? v.lo + v.n - at : v.lo + at);
             const FlatPre e = v.rev ? flat_sub(v.whi, cut) : flat_sub(cut, v.wlo);
-            if (lane == 0) {
-                if (shatter) {
-                    plan->wq[w] = (int64_t)e.m + e.x - (v.swp ? e.ins : e.del);
-                    plan->wt[w] = (int64_t)e.m + e.x - (v.swp ? e.del : e.ins);
-                    plan->wo[w] = (int64_t)e.rows * (int64_t)row_bytes1 + 3ll * (int64_t)e.extra + (int64_t)flat_cross_digits(s_cross[wave_in_group], n_cross, e.rows);
-                } else {
-                    plan->wo[w] = (int64_t)e.text;
-                }
-            }
+            if (lane == 0) plan->wo[w] = (int64_t)e.text;
         }
     }
 }

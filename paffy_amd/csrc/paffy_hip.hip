@@ -806,7 +806,7 @@ struct paffy_hip_ctx {
     bool plan_seq_lookup = false; /* rec_qseq / rec_tseq belong to the current plan */
     DevBuf seq_raw, pretty_off, pretty_out, pretty_err, host_in, host_out;
     DevBuf rec_stats; /* six sums per record of the PAFFY_STATS stage */
-    DevBuf flat_nd, flat_rec, flat_chunks, flat_sums, flat_done; /* the flat sizing pass (flat_kernel.h) */
+    DevBuf flat_nd, flat_rec, flat_chunks, flat_sums, flat_done, flat_items; /* the flat sizing pass (flat_kernel.h) */
     DevBuf bed_keys, bed_tab, bed_starts, bed_len, bed_off, bed_tiles;
     struct BedParams *bed_params = nullptr; /* host copy */
     uint64_t bed_runs = 0;
@@ -1007,7 +1007,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     c->index_pool.clear();
     if (c->one_batch.p) (void)hipFree(c->one_batch.p);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
-                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->seq_raw, &c->pretty_off, &c->pretty_out, &c->pretty_err, &c->host_in, &c->host_out, &c->rec_stats, &c->flat_nd, &c->flat_rec, &c->flat_chunks, &c->flat_sums, &c->flat_done, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
+                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->seq_raw, &c->pretty_off, &c->pretty_out, &c->pretty_err, &c->host_in, &c->host_out, &c->rec_stats, &c->flat_nd, &c->flat_rec, &c->flat_chunks, &c->flat_sums, &c->flat_done, &c->flat_items, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
                       &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts, &c->scan_part, &c->dedupe_keys, &c->emit_order, &c->order_cnt};
     for (DevBuf *b : bufs)
@@ -1292,6 +1292,12 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
         fp.info = kp.info;
         /* persistent waves over the chunks: eight workgroups of four waves per CU */
         LAUNCH(c, "k_flat_parse", k_flat_parse, dim3(2048), dim3(64 * FLAT_PARSE_WAVES), 0, fp);
+        /* segments of the shatter records too long for one wave of the row writer: a record of more than PAFFY_ROWS_MAX_OPS ops has
+           2 x that many cigar bytes at least, a segment holds half that many ops */
+        const size_t items_cap = ((size_t)len >> 15) + ((size_t)len >> 16) + 16;
+        if (ensure(c, c->flat_items, sizeof(EmitItem) * items_cap)) return PAFFY_E_HIP;
+        kp.items = static_cast<EmitItem *>(c->flat_items.p);
+        kp.items_cap = (uint32_t)items_cap;
         FlatSizeParams fs;
         fs.P = kp;
         fs.sums = fp.sums;
@@ -1300,6 +1306,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
         if (post_scans()) return PAFFY_E_HIP;
         if (fetch_info(c)) return PAFFY_E_HIP;
         flat_g_count = c->h_info->g_count;
+        kp.n_items = c->h_info->n_items;
         need_legacy = c->h_info->flat_legacy > 0;
         c->flat_left = c->h_info->flat_legacy;
         for (int k = 0; k < 16; k++) c->flat_reasons[k] = c->h_info->flat_reason[k];
@@ -2095,7 +2102,7 @@ int paffy_hip_emit(paffy_hip_ctx *c, void *d_out, int64_t out_cap) {
     kp.out = static_cast<uint8_t *>(d_out);
     const bool shatter = kp.n_stages > 0 && kp.stages[kp.n_stages - 1].kind == PAFFY_SHATTER;
     if (shatter) {
-        LAUNCH(c, "k_emit_rows", k_emit_rows, dim3(kp.n_rec), dim3(64), PAFFY_ROWS_LDS_BYTES + dbg_lds_pad(0), kp);
+        LAUNCH(c, "k_emit_rows", k_emit_rows, dim3(kp.n_rec + kp.n_items), dim3(64), PAFFY_ROWS_LDS_BYTES + dbg_lds_pad(0), kp);
         if (c->h_info->g_count > 0) LAUNCH(c, "k_emit_lds", k_emit_lds<true>, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
         if (c->h_info->w_count > 0) LAUNCH(c, "k_arena_emit", k_arena_emit<true>, dim3(2048), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
     } else {

@@ -3573,7 +3573,7 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_EMIT_OCC) void k_emit_lds(KParams P
     const uint32_t rec = blockIdx.x;
     if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return; /* nothing at or after the first failure */
     if ((P.status[rec] >> 16) != KLASS_LDS) return;
-    if (static_cast<const RecPlan *>(P.rec_plan)[rec].flags & (SHATTER ? 64u : 0x10000u)) return; /* k_emit_rows / k_emit_line has it */
+    if (static_cast<const RecPlan *>(P.rec_plan)[rec].flags & (SHATTER ? (64u | 0x80000u) : 0x10000u)) return; /* k_emit_rows / k_emit_line has it */
     OpsGlobal ops{emit_ops_of(P, rec, P.meta[rec], static_cast<const RecPlan *>(P.rec_plan)[rec]), emit_ops_half(static_cast<const RecPlan *>(P.rec_plan)[rec])};
 #if defined(PAFFY_ABL) && PAFFY_ABL == 22
     const unsigned long long c0 = clock64(), w0 = wall_clock64();
@@ -3651,11 +3651,21 @@ __device__ __forceinline__ void row_pieces_lanes(uint8_t *p, const RecState &s, 
 __global__ __launch_bounds__(64, PAFFY_ROWS_OCC) void k_emit_rows(KParams P) {
     extern __shared__ uint4 smem4[];
     uint8_t *smem = reinterpret_cast<uint8_t *>(smem4);
-    const uint32_t rec = P.emit_order ? P.emit_order[blockIdx.x] : blockIdx.x; /* long records first */
+    /* the first n_items workgroups write the segments of the long records (flat_kernel.h cuts a record of more than PAFFY_ROWS_MAX_OPS ops
+       into segments of a quarter of that: any length of record is just more workgroups, and they start first), the others one record each */
+    const bool is_item = blockIdx.x < P.n_items;
+    uint32_t rec, wb = 0, we = 0;
+    int64_t cq0 = 0, ct0 = 0, wo = 0;
+    if (is_item) {
+        const EmitItem &it = P.items[blockIdx.x];
+        rec = it.rec; wb = it.wb; we = it.we; cq0 = it.cq0; ct0 = it.ct0; wo = it.wo;
+    } else {
+        rec = P.emit_order ? P.emit_order[blockIdx.x - P.n_items] : blockIdx.x - P.n_items; /* long records first */
+    }
     if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return; /* nothing at or after the first failure */
     if ((P.status[rec] >> 16) != KLASS_LDS) return;
     const RecPlan &pl = static_cast<const RecPlan *>(P.rec_plan)[rec];
-    if (!(pl.flags & 64u)) return;
+    if (!(pl.flags & (is_item ? 0x80000u : 64u))) return;
     const RecMeta &m = P.meta[rec];
     RecState s;
     load_state(m, s);
@@ -3668,6 +3678,7 @@ __global__ __launch_bounds__(64, PAFFY_ROWS_OCC) void k_emit_rows(KParams P) {
     v.reset(ops, pl.n);
     v.lo = pl.lo; v.rev = pl.flags & 1u; v.swp = (pl.flags & 2u) != 0;
     v.sub_lo = pl.sub_lo; v.sub_hi = pl.sub_hi;
+    if (!is_item) we = v.n;
     ShatterConst k;
     shatter_consts(s, k);
     uint8_t *A = smem + PAFFY_WAVE_RING, *B = A + 64, *C = B + 64;
@@ -3676,8 +3687,8 @@ __global__ __launch_bounds__(64, PAFFY_ROWS_OCC) void k_emit_rows(KParams P) {
 #if defined(PAFFY_ABL) && PAFFY_ABL == 24 /* core clock against the 100 MHz wall clock inside the row kernel */
     const unsigned long long c0 = clock64(), w0 = wall_clock64();
 #endif
-    shatter_emit_fast(s, v, k, reinterpret_cast<const u32x4 *>(A), reinterpret_cast<const u32x4 *>(B), reinterpret_cast<const u32x4 *>(C), 0u, v.n, 0ll, 0ll,
-                      smem, P.out, (uint64_t)P.out_off[rec]);
+    shatter_emit_fast(s, v, k, reinterpret_cast<const u32x4 *>(A), reinterpret_cast<const u32x4 *>(B), reinterpret_cast<const u32x4 *>(C), wb, we, cq0, ct0,
+                      smem, P.out, (uint64_t)P.out_off[rec] + (uint64_t)wo);
 #if defined(PAFFY_ABL) && PAFFY_ABL == 24
     const unsigned long long c1 = clock64(), w1 = wall_clock64();
     if ((blockIdx.x & 16383u) == 99u && threadIdx.x == 0)

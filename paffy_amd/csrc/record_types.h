@@ -55,7 +55,8 @@ struct DevInfo {
        short enough to start there, and -- while the safe bound is in force -- records of the second level that would have */
     uint32_t lvl0_over, lvl0_probe_dense;
     /* flat sizing pass (flat_kernel.h): the records it left to the record kernels */
-    uint32_t flat_legacy, flat_pad;
+    uint32_t flat_legacy;
+    uint32_t n_items; /* EmitItem entries written (segments of the records too long for one wave of the row writer) */
     uint32_t flat_reason[16]; /* why: FLAT_WHY_* of flat_kernel.h (diagnostics, paffy_hip_flat_stats) */
 };
 
@@ -66,12 +67,20 @@ struct RecPlan {
     uint32_t flags; /* bit0 rev, bit1 swp, bit2 query/target swapped, bit3 has_cigar, bit4 shatter, bit5 direct, bit6 k_emit_rows,
                        bit7 dropped by a filter, bits 8-15 type, bit16 k_emit_line,
                        bit17 the 4-byte ops live in the arena block arena_off[rec] (rebuilt by add_mismatches), not in the mirror,
-                       bit18 the mirror holds 2-byte words (every length below 8192) */
+                       bit18 the mirror holds 2-byte words (every length below 8192),
+                       bit19 a long shatter record written as EmitItem segments by k_emit_rows */
     uint32_t chunk; /* ops per lane in the sizing sweep: wave w owns view ops [64*w*chunk, 64*(w+1)*chunk) */
     /* shatter: query / target bases consumed and output bytes produced before each wave's range */
     int64_t wq[4], wt[4], wo[4]; /* four waves: the emit workgroups; a one-wave sizing workgroup fills entry 0 and zeroes the rest */
 };
 
+
+/* A segment of a long shatter record for the one-wave row writer (k_emit_rows): the view's ops [wb, we), the bases consumed and the
+   bytes written in front of it. The flat sizing pass cuts records of more than PAFFY_ROWS_MAX_OPS ops into such segments. */
+struct EmitItem {
+    uint32_t rec, wb, we, pad;
+    int64_t cq0, ct0, wo;
+};
 
 struct KParams {
     const uint8_t *in;
@@ -115,6 +124,8 @@ struct KParams {
     int64_t *rec_stats;         /* PAFFY_STATS: six sums per record (the order of paf_stats_calc's arguments), or NULL */
     uint32_t nocheck_mask;      /* bit i: stage i runs without the paf_check the command loops append (PAFFY_NO_CHECK) */
     uint32_t wave_max_bytes;    /* records with at most this many cigar bytes are sized by the one-wave kernel (0: none): the four-wave kernel skips them */
+    EmitItem *items;            /* segments of long records, written by the flat sizing pass, emitted by k_emit_rows in front of the records */
+    uint32_t n_items, items_cap;
     const uint8_t *flat_done;   /* flat sizing pass: 1 = the record has been sized there, the record kernels skip it (NULL: no flat pass) */
 };
 
