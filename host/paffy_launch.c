@@ -120,6 +120,7 @@ typedef struct {
     char **pos; /* positional arguments (in argv order) */
     int n_pos;
     int ok;
+    char **copy; /* the permuted copy of argv that pos points into (freed by main) */
 } CmdLine;
 
 static const struct option k_common[] = {{"logLevel", required_argument, 0, 'l'}, {"inputFile", required_argument, 0, 'i'}, {"outputFile", required_argument, 0, 'o'},
@@ -165,6 +166,7 @@ static void parse_cmdline(int argc, char **argv, CmdLine *cl) {
         cl->opts[cl->n_opts++] = flag[n_flag++];
         if (optarg) cl->opts[cl->n_opts++] = optarg;
     }
+    cl->copy = v;
     cl->pos = v + optind; /* what getopt_long moved behind the options */
     cl->n_pos = cl->ok ? vc - optind : 0;
 }
@@ -594,6 +596,7 @@ int main(int argc, char **argv) {
         shard = cl.ok; /* -h, or something getopt_long would reject: the one worker says what the reference says */
     }
     if (!shard) { /* one GPU (or a command that does not shard): this process becomes the worker; it has not touched a GPU */
+        free(cl.copy);
         argv[0] = g_worker;
         execv(g_worker, argv);
         fprintf(stderr, "paffy: cannot start %s: %s\n", g_worker, strerror(errno));
@@ -626,6 +629,7 @@ int main(int argc, char **argv) {
         close(fd);
         in_path = g_stdin_spool;
     }
-    if (!strcmp(argv[1], "tile")) return run_tile(&cl, n, one_device, in_path, out_path);
-    return run_stream(argv[1], &cl, n, one_device, in_path, out_path);
+    const int rc = !strcmp(argv[1], "tile") ? run_tile(&cl, n, one_device, in_path, out_path) : run_stream(argv[1], &cl, n, one_device, in_path, out_path);
+    free(cl.copy);
+    return rc;
 }

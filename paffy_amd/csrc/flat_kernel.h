@@ -72,7 +72,31 @@ __device__ __forceinline__ uint32_t nondigit16(const uint4 &v) { /* bit j: byte 
     }
     return m;
 }
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return wave_last_u32(wave_incl_scan_u32(v)); }
+/* sum over the wave: six DPP adds leave it in lane 63 (an inclusive scan takes nine instructions) */
+__device__ __forceinline__ uint32_t wave_fold_u32(uint32_t x) {
+    x += dpp_mov_u32<DPP_ROW_SHR(1), 0xf, 0xf>(x);
+    x += dpp_mov_u32<DPP_ROW_SHR(2), 0xf, 0xf>(x);
+    x += dpp_mov_u32<DPP_ROW_SHR(4), 0xf, 0xf>(x);
+    x += dpp_mov_u32<DPP_ROW_SHR(8), 0xf, 0xf>(x);
+    x += dpp_mov_u32<DPP_BCAST15, 0xa, 0xf>(x);
+    x += dpp_mov_u32<DPP_BCAST31, 0xc, 0xf>(x);
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return wave_last_u32(wave_fold_u32(v)); }
+/* six sums at once, step by step: the chains are independent, so no DPP instruction waits for the one before it */
+__device__ __forceinline__ void wave_sum6_u32(uint32_t (&x)[6]) {
+#define FLAT_FOLD_STEP(CTRL, RM)                                                  \
+    _Pragma("unroll") for (int k = 0; k < 6; k++) x[k] += dpp_mov_u32<CTRL, RM, 0xf>(x[k]);
+    FLAT_FOLD_STEP(DPP_ROW_SHR(1), 0xf)
+    FLAT_FOLD_STEP(DPP_ROW_SHR(2), 0xf)
+    FLAT_FOLD_STEP(DPP_ROW_SHR(4), 0xf)
+    FLAT_FOLD_STEP(DPP_ROW_SHR(8), 0xf)
+    FLAT_FOLD_STEP(DPP_BCAST15, 0xa)
+    FLAT_FOLD_STEP(DPP_BCAST31, 0xc)
+#undef FLAT_FOLD_STEP
+#pragma unroll
+    for (int k = 0; k < 6; k++) x[k] = wave_last_u32(x[k]);
+}
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ uint32_t lane_val(uint32_t x, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)l); }
 
@@ -183,9 +207,9 @@ __global__ __launch_bounds__(64 * FLAT_PARSE_WAVES) void k_flat_parse(FlatParams
                 acc_re += code == (uint32_t)OP_M ? 1u + ((kk - 1u) << 16) : 0u;                     /* rows | digits beyond the first */
                 nonplain |= code > (uint32_t)OP_D ? 1u : 0u;
             }
-            const uint32_t s_m = wave_sum_u32(acc_mx & 0xffffu), s_x = wave_sum_u32(acc_mx >> 16);
-            const uint32_t s_i = wave_sum_u32(acc_id & 0xffffu), s_d = wave_sum_u32(acc_id >> 16);
-            const uint32_t s_r = wave_sum_u32(acc_re & 0xffffu), s_e = wave_sum_u32(acc_re >> 16);
+            uint32_t sums6[6] = {acc_mx & 0xffffu, acc_mx >> 16, acc_id & 0xffffu, acc_id >> 16, acc_re & 0xffffu, acc_re >> 16};
+            wave_sum6_u32(sums6);
+            const uint32_t s_m = sums6[0], s_x = sums6[1], s_i = sums6[2], s_d = sums6[3], s_r = sums6[4], s_e = sums6[5];
             const uint32_t flags = (__any(bad != 0) ? FLAT_F_IRREG : 0u) | (__any(nonplain != 0) ? FLAT_F_NONPLAIN : 0u);
             if (total) {
                 const int32_t last = (int32_t)Pl[top - 1u];
@@ -215,6 +239,7 @@ struct FlatSizeParams {
     KParams P;
     PieceSum *sums;
     uint8_t *flat_done;
+    uint32_t *defer; /* records k_flat_lane hands on to k_flat_size (DevInfo::flat_defer of them) */
 };
 
 /* prefix sums at a boundary between raw ops of a record (wave-uniform) */
@@ -288,8 +313,10 @@ struct FlatRec {
             se += code == (uint32_t)OP_M ? dg : 0u;
             st += dg + 2u;
         }
-        a.m += wave_sum_u32(sm); a.x += wave_sum_u32(sx); a.ins += wave_sum_u32(si); a.del += wave_sum_u32(sd);
-        a.rows += wave_sum_u32(sr); a.extra += wave_sum_u32(se);
+        uint32_t sums6[6] = {sm, sx, si, sd, sr, se};
+        wave_sum6_u32(sums6);
+        a.m += sums6[0]; a.x += sums6[1]; a.ins += sums6[2]; a.del += sums6[3];
+        a.rows += sums6[4]; a.extra += sums6[5];
         if (want_text) a.text += wave_sum_u32(st);
         a.cnt = r;
         return a;
@@ -328,6 +355,27 @@ __device__ __forceinline__ int flat_check(const FlatState &s, const FlatView &v)
     if (v.tq() != s.qe - s.qs) return PAFFY_ERR_CHECK_CIGAR_Q;
     if (v.tt() != s.te - s.ts) return PAFFY_ERR_CHECK_CIGAR_T;
     return 0;
+}
+
+/*
+ * (double)((float)num / (float)den) < thr and >= idd, thr = (double)thr_f, idd = (double)id_f -- the comparisons of impl/paf.c:832-833 and
+ * 886-887 -- decided without the division unless the quotient is within 4e-6 of the threshold: conversions, product and quotient are
+ * each off by at most 2^-24 relative, so a numerator below 0.999996 x threshold x denominator (above 1.000004 x) has its rounded quotient
+ * strictly below (above) the threshold. 0 / 0 takes the exact path (NaN compares false, as it does in the reference).
+ */
+__device__ __forceinline__ bool flat_ratio_lt(uint32_t num, uint32_t den, float thr_f, double thr) {
+    const float nf = __uint2float_rn(num), df = __uint2float_rn(den);
+    const float p = __fmul_rn(thr_f, df);
+    if (nf < __fmul_rn(p, 0.999996f)) return true;
+    if (nf > __fmul_rn(p, 1.000004f)) return false;
+    return (double)__fdiv_rn(nf, df) < thr;
+}
+__device__ __forceinline__ bool flat_ratio_ge(uint32_t num, uint32_t den, float id_f, double idd) {
+    const float nf = __uint2float_rn(num), df = __uint2float_rn(den);
+    const float p = __fmul_rn(id_f, df);
+    if (nf > __fmul_rn(p, 1.000004f)) return true;
+    if (nf < __fmul_rn(p, 0.999996f)) return false;
+    return (double)__fdiv_rn(nf, df) >= idd;
 }
 
 /*
@@ -380,9 +428,13 @@ __device__ __forceinline__ void flat_trim_prefix(const FlatRec &R, FlatState &s,
             flagged &= ~(1ull << t);
             const uint32_t ra = lane_val(a_cnt, t), rb = lane_val(b_cnt, t);
             uint32_t pm = lane_val(c_m, t), px = lane_val(c_x, t);
+            const uint32_t x_end = px + lane_val(chunk_x, t); /* mismatch bases in front of the piece's far end */
             const uint32_t vb = v.rev ? w_end - rb : ra - v.lo, ve = v.rev ? w_end - ra : rb - v.lo; /* view indices of the piece's ops */
             int32_t hit = -1;
             for (uint32_t i0 = vb; i0 < ve; i0 += 64u) {
+                /* the piece's bound again for what is left of it: once the prefix identity clears the threshold even with every
+                   mismatch still to come, nothing further on in this piece can hit (the first 64 or 128 ops decide most records) */
+                if (i0 != vb && pm > 0 && (double)pm >= thr * 1.00001 * (double)(pm + x_end)) break;
                 const uint32_t i = i0 + lane;
                 uint32_t len = 0, code = 0;
                 if (i < ve) {
@@ -393,7 +445,7 @@ __device__ __forceinline__ void flat_trim_prefix(const FlatRec &R, FlatState &s,
                 const uint32_t is_m = 0u - ((0x9u >> code) & 1u);
                 const uint32_t im = wave_incl_scan_u32(len & is_m), ix = wave_incl_scan_u32(len & ~is_m);
                 const uint32_t cm = pm + im, cx = px + ix;
-                const bool ok = i < ve && !(max_trim >= 0 && (int64_t)(cm + cx) > max_trim) && ratio_f32_u32(cm, cm + cx) < thr;
+                const bool ok = i < ve && !(max_trim >= 0 && (int64_t)(cm + cx) > max_trim) && flat_ratio_lt(cm, cm + cx, thr_f, thr);
                 const unsigned long long hb = __ballot(ok);
                 if (hb) {
                     const uint32_t hl = 63u - (uint32_t)__clzll((long long)hb);
@@ -427,7 +479,7 @@ __device__ __forceinline__ void flat_trim_prefix(const FlatRec &R, FlatState &s,
             const uint32_t vm = len & is_m, vx = len & ~is_m;
             const uint32_t im = wave_incl_scan_u32(vm), ix = wave_incl_scan_u32(vx);
             const uint32_t sm = hit_m - (pm + im - vm), sx = hit_x - (px + ix - vx); /* sums of [i, trim_idx] */
-            const bool ok = i <= (uint32_t)trim_idx && ratio_f32_u32(sm, sm + sx) >= idd;
+            const bool ok = i <= (uint32_t)trim_idx && flat_ratio_ge(sm, sm + sx, id_f, idd);
             const unsigned long long hb = __ballot(ok);
             if (hb) best = i0 + (uint32_t)__ffsll((long long)hb) - 1u;
             pm += wave_last_u32(im);
@@ -453,6 +505,332 @@ __device__ __forceinline__ void flat_trim_prefix(const FlatRec &R, FlatState &s,
     if (s.same) s.qs += d_q;
     else s.qe -= d_q;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------------ */
+/*
+ * k_flat_lane: the same sizing with ONE LANE per record, for the records that need little (at most FLAT_LANE_MAX_PIECES pieces, trims
+ * that look at a few hundred ops, rows whose coordinates keep their digit counts). What a wave does for a record -- scans, ballots,
+ * wave-uniform arithmetic repeated in 64 lanes -- a lane does here for its own record as plain sequential code over the pieces'
+ * summaries and a handful of ops, sixty-four records per wave: about a twentieth of the instructions (PMC on the wave kernel: 1 586
+ * VALU + 1 346 scalar instructions per record). Anything else -- long records, deep trims, a power of ten inside a coordinate range,
+ * whatever the flat pass leaves to the record kernels -- is put on a list for k_flat_size, which sizes it the way described above.
+ */
+#define FLAT_LANE_MAX_PIECES 12u
+#define FLAT_LANE_WALK_BUDGET 1024 /* ops a lane looks at one by one before it hands its record to a wave */
+
+struct LaneRec {
+    const PieceSum *ps;
+    const uint16_t *ops;
+    uint32_t np, n_ops;
+    int32_t budget;
+    bool want_text;
+    /* ops, matches and mismatches of the record's pieces: in LDS, [piece][thread] (read again and again by the trim's searches) */
+    uint32_t (*cnt)[256], (*m)[256], (*x)[256];
+};
+__device__ __forceinline__ FlatPre lane_piece(const PieceSum *ps, uint32_t p) { /* as parsed: cnt carries the flags */
+    const uint4 a = reinterpret_cast<const uint4 *>(ps + p)[0], b = reinterpret_cast<const uint4 *>(ps + p)[1];
+    FlatPre q;
+    q.cnt = a.x; q.m = a.y; q.x = a.z; q.ins = a.w; q.del = b.x; q.rows = b.y; q.extra = b.z; q.text = b.w;
+    return q;
+}
+__device__ __forceinline__ void lane_add_op(FlatPre &a, uint32_t w, bool want_text) {
+    const uint32_t len = w >> 3, code = w & 7u;
+    const uint32_t is_m = 0u - ((0x9u >> code) & 1u);
+    const uint32_t dg = (len >= 10u) + (len >= 100u) + (len >= 1000u);
+    a.m += len & is_m;
+    a.x += len & ~is_m;
+    a.ins += code == (uint32_t)OP_I ? len : 0u;
+    a.del += code == (uint32_t)OP_D ? len : 0u;
+    a.rows += code == (uint32_t)OP_M ? 1u : 0u;
+    a.extra += code == (uint32_t)OP_M ? dg : 0u;
+    if (want_text) a.text += dg + 2u;
+}
+/* Eight ops of the view at a time, one 16-byte load (a lane that asked for its ops one by one would wait for a load per op): view
+   indices [i, i + 8) -- the raw ops in front of the window's far end for a reversed view, read from the top. Ops past the window's end
+   belong to the neighbours in the mirror: loaded, never used. */
+struct LaneOps {
+    u32x4 w;
+    __device__ __forceinline__ void load(const uint16_t *ops, const FlatView &v, uint32_t i) {
+        const uint32_t w_end = v.lo + v.n;
+        const uint16_t *p = v.rev ? ops + (w_end - i) - 8u : ops + v.lo + i;
+        w = *reinterpret_cast<const u32x4_unaligned *>(p);
+    }
+    __device__ __forceinline__ uint32_t get(const FlatView &v, uint32_t k) const { /* op i + k, k = 0..7 */
+        const uint32_t j = v.rev ? 7u - k : k;
+        const uint32_t d = j < 4 ? (j < 2 ? w.x : w.y) : (j < 6 ? w.z : w.w);
+        return (j & 1u) ? d >> 16 : d & 0xffffu;
+    }
+};
+/* sums of raw ops [0, r): whole pieces from their summaries, the piece that holds the boundary walked from its nearer end */
+__device__ __forceinline__ FlatPre lane_raw_prefix(LaneRec &R, uint32_t r) {
+    FlatPre a;
+    a.cnt = a.m = a.x = a.ins = a.del = a.rows = a.extra = a.text = 0;
+    for (uint32_t p = 0; p < R.np; p++) {
+        const FlatPre q = lane_piece(R.ps, p);
+        const uint32_t cnt = q.cnt & 0xffffu;
+        if (a.cnt + cnt <= r) { /* the whole piece lies in front of the boundary */
+            a.cnt += cnt; a.m += q.m; a.x += q.x; a.ins += q.ins; a.del += q.del; a.rows += q.rows; a.extra += q.extra; a.text = q.text;
+            continue;
+        }
+        if (r - a.cnt <= a.cnt + cnt - r) { /* forwards from the piece's first op */
+            R.budget -= (int32_t)(r - a.cnt);
+            for (uint32_t i = a.cnt; i < r; i++) lane_add_op(a, R.ops[i], R.want_text);
+        } else { /* backwards from its last op */
+            FlatPre b;
+            b.cnt = b.m = b.x = b.ins = b.del = b.rows = b.extra = b.text = 0;
+            R.budget -= (int32_t)(a.cnt + cnt - r);
+            for (uint32_t i = r; i < a.cnt + cnt; i++) lane_add_op(b, R.ops[i], R.want_text);
+            a.m += q.m - b.m; a.x += q.x - b.x; a.ins += q.ins - b.ins; a.del += q.del - b.del; a.rows += q.rows - b.rows; a.extra += q.extra - b.extra;
+            a.text = q.text - b.text;
+        }
+        a.cnt = r;
+        return a;
+    }
+    return a; /* r == n_ops */
+}
+
+/* flat_trim_prefix for one lane: the pieces in view order, the ones that can hold a hit walked op by op */
+__device__ __forceinline__ void lane_trim_prefix(LaneRec &R, FlatState &s, FlatView &v, float thr_f, float id_f, int64_t max_trim, uint32_t tot_m, uint32_t tot_x) {
+    const double thr = (double)thr_f, idd = (double)id_f;
+    const uint32_t w_end = v.lo + v.n, tid = threadIdx.x;
+    int32_t trim_idx = -1;
+    uint32_t hit_m = 0, hit_x = 0;
+    /* prefix sums (count, matches, mismatches) at the near end of the current piece, in raw order */
+    uint32_t e_cnt = v.rev ? R.n_ops : 0u, e_m = v.rev ? tot_m : 0u, e_x = v.rev ? tot_x : 0u;
+    for (uint32_t k = 0; k < R.np && R.budget >= 0; k++) {
+        const uint32_t p = v.rev ? R.np - 1u - k : k;
+        const uint4 q = make_uint4(R.cnt[p][tid], R.m[p][tid], R.x[p][tid], 0);
+        const uint32_t cnt = q.x;
+        /* the piece's raw range and the prefix sums at its two ends */
+        uint32_t a_cnt, a_m, a_x, b_cnt, b_m, b_x;
+        if (v.rev) {
+            b_cnt = e_cnt; b_m = e_m; b_x = e_x;
+            e_cnt -= cnt; e_m -= q.y; e_x -= q.z;
+            a_cnt = e_cnt; a_m = e_m; a_x = e_x;
+        } else {
+            a_cnt = e_cnt; a_m = e_m; a_x = e_x;
+            e_cnt += cnt; e_m += q.y; e_x += q.z;
+            b_cnt = e_cnt; b_m = e_m; b_x = e_x;
+        }
+        if (a_cnt < v.lo) { a_cnt = v.lo; a_m = v.wlo.m; a_x = v.wlo.x; }
+        if (a_cnt > w_end) { a_cnt = w_end; a_m = v.whi.m; a_x = v.whi.x; }
+        if (b_cnt < v.lo) { b_cnt = v.lo; b_m = v.wlo.m; b_x = v.wlo.x; }
+        if (b_cnt > w_end) { b_cnt = w_end; b_m = v.whi.m; b_x = v.whi.x; }
+        if (b_cnt <= a_cnt) continue;
+        uint32_t pm = v.rev ? v.whi.m - b_m : a_m - v.wlo.m, px = v.rev ? v.whi.x - b_x : a_x - v.wlo.x; /* in front of the piece, in view order */
+        if (max_trim >= 0 && (int64_t)pm + (int64_t)px > max_trim) break; /* the sums only grow */
+        const uint32_t x_end = px + (b_x - a_x);
+        if (pm > 0 && (double)pm >= thr * 1.00001 * (double)(pm + x_end)) continue; /* cannot hold a hit (flat_trim_prefix) */
+        const uint32_t vb = v.rev ? w_end - b_cnt : a_cnt - v.lo, ve = v.rev ? w_end - a_cnt : b_cnt - v.lo;
+        bool stop = false;
+        for (uint32_t i0 = vb; i0 < ve && !stop; i0 += 8u) {
+            if (i0 != vb && pm > 0 && (double)pm >= thr * 1.00001 * (double)(pm + x_end)) break;
+            LaneOps blk;
+            blk.load(R.ops, v, i0);
+            R.budget -= 8;
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; j++) {
+                if (i0 + j < ve && !stop) {
+                    const uint32_t w = blk.get(v, j), len = w >> 3, code = w & 7u;
+                    if ((0x9u >> code) & 1u) pm += len;
+                    else px += len;
+                    if (max_trim >= 0 && (int64_t)(pm + px) > max_trim) {
+                        stop = true;
+                    } else if (flat_ratio_lt(pm, pm + px, thr_f, thr)) {
+                        trim_idx = (int32_t)(i0 + j);
+                        hit_m = pm;
+                        hit_x = px;
+                    }
+                }
+            }
+        }
+        if (stop) break;
+    }
+    if (trim_idx < 0 || R.budget < 0) return;
+    R.budget -= trim_idx + 1;
+    if (R.budget < 0) return;
+    uint32_t best = 0xffffffffu;
+    {
+        uint32_t pm = 0, px = 0;
+        for (uint32_t i0 = 0; i0 <= (uint32_t)trim_idx && best == 0xffffffffu; i0 += 8u) {
+            LaneOps blk;
+            blk.load(R.ops, v, i0);
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; j++) {
+                if (i0 + j <= (uint32_t)trim_idx && best == 0xffffffffu) {
+                    const uint32_t w = blk.get(v, j), len = w >> 3, code = w & 7u;
+                    const uint32_t sm = hit_m - pm, sx = hit_x - px; /* sums of [i, trim_idx] */
+                    if (flat_ratio_ge(sm, sm + sx, id_f, idd)) best = i0 + j;
+                    if ((0x9u >> code) & 1u) pm += len;
+                    else px += len;
+                }
+            }
+        }
+    }
+    const uint32_t count = best != 0xffffffffu ? best : (uint32_t)trim_idx + 1u;
+    if (count == 0) return;
+    const int64_t old_tt = v.tt(), old_tq = v.tq();
+    {
+        const FlatPre cut = lane_raw_prefix(R, v.rev ? v.lo + v.n - count : v.lo + count);
+        if (v.rev) {
+            v.whi = cut;
+        } else {
+            v.wlo = cut;
+            v.lo += count;
+        }
+    }
+    v.n -= count;
+    const int64_t d_t = old_tt - v.tt(), d_q = old_tq - v.tq();
+    s.ts += d_t;
+    if (s.same) s.qs += d_q;
+    else s.qe -= d_q;
+}
+
+__global__ __launch_bounds__(256) void k_flat_lane(FlatSizeParams F) {
+    __shared__ uint32_t s_cnt[FLAT_LANE_MAX_PIECES][256], s_m[FLAT_LANE_MAX_PIECES][256], s_x[FLAT_LANE_MAX_PIECES][256];
+    const KParams &P = F.P;
+    const uint32_t rec = blockIdx.x * 256u + threadIdx.x, tid = threadIdx.x;
+    if (rec >= P.n_rec) return;
+    bool done = false;
+    do { /* one pass; `break` = the record goes to k_flat_size */
+        const RecMeta &m = P.meta[rec];
+        if (m.err || !m.has_cg || m.cg_len == 0 || P.nocheck_mask) break;
+        const uint32_t cg_off = m.cg_off, cg_end = cg_off + m.cg_len;
+        LaneRec R;
+        R.np = ((cg_end - 1u) >> FLAT_TILE_SHIFT) - (cg_off >> FLAT_TILE_SHIFT) + 1u;
+        if (R.np > FLAT_LANE_MAX_PIECES) break;
+        R.ps = F.sums + ((cg_off >> FLAT_TILE_SHIFT) + rec);
+        R.ops = reinterpret_cast<const uint16_t *>(P.ops_mirror + (cg_off >> 1));
+        R.budget = FLAT_LANE_WALK_BUDGET;
+        R.cnt = s_cnt; R.m = s_m; R.x = s_x;
+        const bool shatter_last = P.n_stages > 0 && P.stages[P.n_stages - 1].kind == PAFFY_SHATTER;
+        R.want_text = !shatter_last;
+        FlatPre tot;
+        tot.cnt = tot.m = tot.x = tot.ins = tot.del = tot.rows = tot.extra = tot.text = 0;
+        uint32_t flags = 0;
+        for (uint32_t p0 = 0; p0 < R.np; p0 += 4u) { /* four pieces' loads in flight together */
+            FlatPre q[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++)
+                if (p0 + j < R.np) q[j] = lane_piece(R.ps, p0 + j);
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++)
+                if (p0 + j < R.np) {
+                    flags |= q[j].cnt >> 16;
+                    s_cnt[p0 + j][tid] = q[j].cnt & 0xffffu;
+                    s_m[p0 + j][tid] = q[j].m;
+                    s_x[p0 + j][tid] = q[j].x;
+                    tot.cnt += q[j].cnt & 0xffffu; tot.m += q[j].m; tot.x += q[j].x; tot.ins += q[j].ins; tot.del += q[j].del; tot.rows += q[j].rows;
+                    tot.extra += q[j].extra;
+                    tot.text = q[j].text;
+                }
+        }
+        R.n_ops = tot.cnt;
+        /* at most twelve pieces of 512 ops of 8 191 bases: the sums stay below 2^31 */
+        if ((flags & FLAT_F_IRREG) || R.n_ops == 0) break;
+        FlatState s;
+        s.qlen = m.qlen; s.qs = m.qs; s.qe = m.qe; s.tlen = m.tlen; s.ts = m.ts; s.te = m.te;
+        s.same = m.same_strand != 0;
+        FlatView v;
+        v.lo = 0; v.n = R.n_ops; v.rev = false; v.swp = false;
+        v.wlo.cnt = v.wlo.m = v.wlo.x = v.wlo.ins = v.wlo.del = v.wlo.rows = v.wlo.extra = v.wlo.text = 0;
+        v.whi = tot;
+        bool swapped = false, shatter = false, checked = false, rewritten = false, give_up = false;
+        for (int32_t si = 0; si < P.n_stages && !give_up; si++) {
+            const paffy_stage st = P.stages[si];
+            if (si > 0) {
+                if (v.n == 0) { give_up = true; break; }
+                rewritten = true;
+            }
+            int rc = 0;
+            if (st.kind == PAFFY_INVERT) {
+                flat_invert(s);
+                v.swp = !v.swp;
+                if (!s.same) v.rev = !v.rev;
+                swapped = !swapped;
+                rc = flat_check(s, v);
+            } else if (st.kind == PAFFY_TRIM_IDENTITY) {
+                const uint32_t mm = v.tm(), mx = v.tx();
+                const double identity = ratio_f32((int64_t)mm, (int64_t)mm + (int64_t)mx);
+                const double thr = __dsub_rn(identity, __dmul_rn(identity, (double)st.p0));
+                const int64_t max_trim = __float2ll_rz(__fmul_rn(__ll2float_rn((int64_t)mm + (int64_t)mx), st.p1));
+                const float thr_f = __double2float_rn(thr), id_f = __double2float_rn(identity);
+                const uint32_t n_before = v.n;
+#pragma unroll 1
+                for (int pass = 0; pass < 2; pass++) {
+                    if (pass == 1) {
+                        if (s.same && v.n == n_before) break;
+                        flat_invert(s);
+                        v.swp = !v.swp;
+                        if (!s.same) v.rev = !v.rev;
+                    }
+                    lane_trim_prefix(R, s, v, thr_f, id_f, max_trim, tot.m, tot.x);
+                    if (pass == 1) {
+                        flat_invert(s);
+                        v.swp = !v.swp;
+                        if (!s.same) v.rev = !v.rev;
+                    }
+                }
+                if (R.budget < 0) { give_up = true; break; }
+                const uint32_t m2 = v.tm(), x2 = v.tx();
+                const double final_identity = ratio_f32((int64_t)m2, (int64_t)m2 + (int64_t)x2);
+                if (!(final_identity >= identity)) { give_up = true; break; }
+                rc = flat_check(s, v);
+            } else if (st.kind == PAFFY_SHATTER) {
+                shatter = true;
+                break;
+            } else if (st.kind != PAFFY_PASS) {
+                give_up = true;
+                break;
+            }
+            if (rc) { give_up = true; break; }
+            checked = st.kind != PAFFY_PASS;
+        }
+        if (give_up || v.n == 0) break;
+        if (shatter && ((flags & FLAT_F_NONPLAIN) || (!checked && flat_check(s, v)))) break;
+        RecState rs;
+        load_state(m, rs);
+        if (swapped) invert_state(rs);
+        rs.qs = s.qs; rs.qe = s.qe; rs.ts = s.ts; rs.te = s.te;
+        if (rewritten && rs.type == 0 && rs.tile_level != -1) rs.type = rs.tile_level > 1 ? 'S' : 'P';
+        const FlatPre win = flat_sub(v.whi, v.wlo);
+        int64_t bytes, rows;
+        bool rows_kernel = false, line_kernel = false;
+        if (shatter) {
+            ShatterConst k;
+            shatter_consts(rs, k);
+            const uint32_t dq0 = (uint32_t)dec_len(rs.qs), dt0 = (uint32_t)dec_len(rs.ts);
+            if (!shatter_fits(k) || !shatter_fast_ok(rs, k) || k.lenA > 48 || k.lenB > 48 || k.lenC > 48 || dq0 != (uint32_t)dec_len(rs.qe) ||
+                dt0 != (uint32_t)dec_len(rs.te) || rs.qe - rs.qs >= 0x7fffffffll || rs.te - rs.ts >= 0x7fffffffll || v.n > PAFFY_ROWS_MAX_OPS)
+                break;
+            rows = win.rows;
+            bytes = (int64_t)win.rows * (int64_t)(k.row_const + 2u * dq0 + 2u * dt0 + 3u) + 3ll * (int64_t)win.extra;
+            rows_kernel = true;
+        } else {
+            const uint32_t lenH = header_len(rs, false);
+            if (lenH + 8 > PAFFY_TMPL_MAX || v.n > PAFFY_ROWS_MAX_OPS) break;
+            line_kernel = true;
+            bytes = (int64_t)lenH + (int64_t)win.text + 1;
+            rows = 1;
+        }
+        RecPlan *plan = static_cast<RecPlan *>(P.rec_plan) + rec;
+        F.flat_done[rec] = 1;
+        P.status[rec] = (uint32_t)KLASS_LDS << 16;
+        P.err_aux[rec] = 0;
+        P.n_ops[rec] = 0;
+        P.out_len[rec] = bytes;
+        P.out_rows[rec] = rows;
+        plan->qs = s.qs; plan->qe = s.qe; plan->ts = s.ts; plan->te = s.te; plan->sub_lo = 0; plan->sub_hi = 0;
+        plan->lo = v.lo; plan->n = v.n;
+        plan->flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | 8u | ((uint32_t)rs.type << 8) | (shatter ? 16u : 0u) |
+                      (rows_kernel ? 64u : 0u) | (line_kernel ? 0x10000u : 0u) | 0x40000u;
+        plan->chunk = ((v.n + 63u) / 64u) | 1u;
+        for (int w = 0; w < 4; w++) plan->wq[w] = plan->wt[w] = plan->wo[w] = 0;
+        done = true;
+    } while (false);
+    if (!done) F.defer[atomicAdd(&P.info->flat_defer, 1u)] = rec;
+}
+
 
 /*
  * Rows whose coordinates gain a digit inside the record. A row's bytes are a constant plus the digits of its two query and two target
@@ -559,14 +937,10 @@ __device__ __forceinline__ uint64_t flat_cross_digits(const uint32_t (*cross)[3]
     }
     return extra;
 }
-__global__ __launch_bounds__(64 * FLAT_SIZE_WAVES) void k_flat_size(FlatSizeParams F) {
+__device__ __forceinline__ void flat_size_one(const FlatSizeParams &F, uint32_t rec, uint32_t (*cross)[3]) {
     const KParams &P = F.P;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t rec = uni(blockIdx.x * FLAT_SIZE_WAVES + (threadIdx.x >> 6)); /* in a scalar register: the record's state is wave-uniform */
-    __shared__ uint32_t s_cross[FLAT_SIZE_WAVES][FLAT_MAX_CROSS][3]; /* per wave: the powers of ten inside a record's coordinate ranges (flat_find) */
-    const uint32_t wave_in_group = uni(threadIdx.x >> 6);
     uint32_t n_cross = 0;
-    if (rec >= P.n_rec) return;
     const RecMeta &m = P.meta[rec];
     if (m.err || !m.has_cg || m.cg_len == 0) return flat_leave(F, rec, FLAT_WHY_HEADER);
     const uint32_t cg_off = m.cg_off, cg_end = cg_off + m.cg_len;
@@ -712,15 +1086,15 @@ __global__ __launch_bounds__(64 * FLAT_SIZE_WAVES) void k_flat_size(FlatSizePara
                     uint32_t re, ml;
                     flat_find(R, v, f == 1, (uint32_t)(falling ? c_hi - B + 1 : B - c_lo), re, ml);
                     if (lane == 0) {
-                        s_cross[wave_in_group][n_cross][0] = re;
-                        s_cross[wave_in_group][n_cross][1] = ml;
-                        s_cross[wave_in_group][n_cross][2] = falling ? 1u : 0u;
+                        cross[n_cross][0] = re;
+                        cross[n_cross][1] = ml;
+                        cross[n_cross][2] = falling ? 1u : 0u;
                     }
                     n_cross++;
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            bytes += (int64_t)flat_cross_digits(s_cross[wave_in_group], n_cross, win.rows);
+            bytes += (int64_t)flat_cross_digits(cross, n_cross, win.rows);
         }
         rows_kernel = v.n <= PAFFY_ROWS_MAX_OPS;
     } else {
@@ -773,7 +1147,7 @@ __global__ __launch_bounds__(64 * FLAT_SIZE_WAVES) void k_flat_size(FlatSizePara
                 it.pad = 0;
                 it.cq0 = (int64_t)e.m + e.x - (v.swp ? e.ins : e.del);
                 it.ct0 = (int64_t)e.m + e.x - (v.swp ? e.del : e.ins);
-                it.wo = (int64_t)e.rows * (int64_t)row_bytes1 + 3ll * (int64_t)e.extra + (int64_t)flat_cross_digits(s_cross[wave_in_group], n_cross, e.rows);
+                it.wo = (int64_t)e.rows * (int64_t)row_bytes1 + 3ll * (int64_t)e.extra + (int64_t)flat_cross_digits(cross, n_cross, e.rows);
                 P.items[item0 + g] = it;
             }
         }
@@ -790,6 +1164,18 @@ __global__ __launch_bounds__(64 * FLAT_SIZE_WAVES) void k_flat_size(FlatSizePara
             const FlatPre e = v.rev ? flat_sub(v.whi, cut) : flat_sub(cut, v.wlo);
             if (lane == 0) plan->wo[w] = (int64_t)e.text;
         }
+    }
+}
+
+__global__ __launch_bounds__(64 * FLAT_SIZE_WAVES) void k_flat_size(FlatSizeParams F) {
+    __shared__ uint32_t s_cross[FLAT_SIZE_WAVES][FLAT_MAX_CROSS][3]; /* per wave: the powers of ten inside a record's coordinate ranges (flat_find) */
+    /* the records k_flat_lane handed on, one wave each (what derives from the wave's number is wave-uniform: told to the compiler, it
+       lives in scalar registers) */
+    const uint32_t wave_in_group = uni(threadIdx.x >> 6);
+    const uint32_t n_defer = F.P.info->flat_defer;
+    for (uint32_t li = uni(blockIdx.x * FLAT_SIZE_WAVES + (threadIdx.x >> 6)); li < n_defer; li += gridDim.x * FLAT_SIZE_WAVES) {
+        flat_size_one(F, uni(F.defer[li]), s_cross[wave_in_group]);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

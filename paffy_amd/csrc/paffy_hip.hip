@@ -1302,7 +1302,11 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
         fs.P = kp;
         fs.sums = fp.sums;
         fs.flat_done = static_cast<uint8_t *>(c->flat_done.p);
-        LAUNCH(c, "k_flat_size", k_flat_size, dim3((n_lines + FLAT_SIZE_WAVES - 1) / FLAT_SIZE_WAVES), dim3(64 * FLAT_SIZE_WAVES), 0, fs);
+        if (ensure(c, c->flat_rec, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+        fs.defer = static_cast<uint32_t *>(c->flat_rec.p);
+        /* one lane per record for the records that need little, one wave per record for the rest (a list whose length only the device knows) */
+        LAUNCH(c, "k_flat_lane", k_flat_lane, dim3((n_lines + 255) / 256), dim3(256), 0, fs);
+        LAUNCH(c, "k_flat_size", k_flat_size, dim3(std::min<uint32_t>(2048u, (n_lines + FLAT_SIZE_WAVES - 1) / FLAT_SIZE_WAVES)), dim3(64 * FLAT_SIZE_WAVES), 0, fs);
         if (post_scans()) return PAFFY_E_HIP;
         if (fetch_info(c)) return PAFFY_E_HIP;
         flat_g_count = c->h_info->g_count;

@@ -56,6 +56,7 @@ struct DevInfo {
     uint32_t lvl0_over, lvl0_probe_dense;
     /* flat sizing pass (flat_kernel.h): the records it left to the record kernels */
     uint32_t flat_legacy;
+    uint32_t flat_defer; /* records k_flat_lane handed on to k_flat_size */
     uint32_t n_items; /* EmitItem entries written (segments of the records too long for one wave of the row writer) */
     uint32_t flat_reason[16]; /* why: FLAT_WHY_* of flat_kernel.h (diagnostics, paffy_hip_flat_stats) */
 };

@@ -12,7 +12,7 @@ import oracle_lib as O
 import synth_lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PAFFY = os.path.join(ROOT, "bin", "paffy")
+PAFFY = os.environ.get("PAFFY_LAUNCHER") or os.path.join(ROOT, "bin", "paffy")  # tests/test_sanitizers.py points this at the ASan + UBSan build
 STANDIN = os.path.join(ROOT, "tests", "standin_worker.py")
 
 

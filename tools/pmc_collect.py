@@ -47,7 +47,7 @@ def main():
         json.dump(res, fh, indent=1, sort_keys=True)
     for k, e in res.items():
         w = e.get("SQ_WAVES", 0)
-        if w and ("k_emit" in k or "k_size" in k or "k_cov" in k):
+        if w and ("k_emit" in k or "k_size" in k or "k_cov" in k or "k_flat" in k or "k_sep" in k or "k_header" in k):
             print(k, {c: round(v / w, 1) for c, v in e.items() if c.startswith("SQ_") and c != "SQ_WAVES"})
 
 
