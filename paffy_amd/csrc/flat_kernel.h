@@ -41,7 +41,7 @@ struct PieceSum {
     uint32_t m, x;     /* bases of M and = ops; of X, I and D ops (the matches / mismatches of impl/paf.c:823-828) */
     uint32_t ins, del; /* bases of I ops, of D ops */
     uint32_t rows;     /* M ops */
-    uint32_t extra;    /* digits of the M ops' lengths beyond the first */
+    uint32_t extra;    /* digits of the M ops' lengths beyond the first; FlatParams::items_mode: 16-column chunks of the M ops */
     uint32_t text_end; /* offset from the cigar's first byte just behind the last op letter at or before the end of the piece */
 };
 static_assert(sizeof(PieceSum) == 32, "two 16-byte stores");
@@ -59,6 +59,7 @@ struct FlatParams {
     PieceSum *sums;
     uint32_t *ops_mirror;
     DevInfo *info;
+    uint32_t items_mode; /* add_mismatches (flat_add_kernel.h): PieceSum::extra counts the 16-column chunks of the M ops instead of their digits */
 };
 
 __device__ __forceinline__ uint32_t nondigit16(const uint4 &v) { /* bit j: byte j of the 16 is not an ASCII digit */
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(64 * FLAT_PARSE_WAVES) void k_flat_parse(FlatParams
                 const uint32_t l16 = len & 0xffffu;
                 acc_mx += l16 << (((0x16u >> code) & 1u) << 4);                                     /* M = | X I D */
                 acc_id += (code == (uint32_t)OP_I ? l16 : 0u) + (code == (uint32_t)OP_D ? l16 << 16 : 0u); /* I | D */
-                acc_re += code == (uint32_t)OP_M ? 1u + ((kk - 1u) << 16) : 0u;                     /* rows | digits beyond the first */
+                acc_re += code == (uint32_t)OP_M ? 1u + ((F.items_mode ? (len + 15u) >> 4 : kk - 1u) << 16) : 0u; /* rows | digits beyond the first (or 16-column chunks) */
                 nonplain |= code > (uint32_t)OP_D ? 1u : 0u;
             }
             uint32_t sums6[6] = {acc_mx & 0xffffu, acc_mx >> 16, acc_id & 0xffffu, acc_id >> 16, acc_re & 0xffffu, acc_re >> 16};

@@ -27,6 +27,7 @@
 #include "paf_synth_core.h"
 #include "record_groups.h"
 #include "flat_kernel.h"
+#include "flat_add_kernel.h"
 #include "coverage_kernel.h"
 #include "bed_kernel.h"
 
@@ -807,6 +808,8 @@ struct paffy_hip_ctx {
     DevBuf seq_raw, pretty_off, pretty_out, pretty_err, host_in, host_out;
     DevBuf rec_stats; /* six sums per record of the PAFFY_STATS stage */
     DevBuf flat_nd, flat_rec, flat_chunks, flat_sums, flat_done, flat_items; /* the flat sizing pass (flat_kernel.h) */
+    DevBuf add_pieces, add_scr_cnt, add_scr_off, add_new_cnt, add_new_off, add_text, add_bad, add_part, add_scratch, add_new_ops; /* flat_add_kernel.h */
+    uint32_t flat_piece_slots = 0;
     DevBuf bed_keys, bed_tab, bed_starts, bed_len, bed_off, bed_tiles;
     struct BedParams *bed_params = nullptr; /* host copy */
     uint64_t bed_runs = 0;
@@ -1007,7 +1010,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     c->index_pool.clear();
     if (c->one_batch.p) (void)hipFree(c->one_batch.p);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
-                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->seq_raw, &c->pretty_off, &c->pretty_out, &c->pretty_err, &c->host_in, &c->host_out, &c->rec_stats, &c->flat_nd, &c->flat_rec, &c->flat_chunks, &c->flat_sums, &c->flat_done, &c->flat_items, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
+                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->seq_raw, &c->pretty_off, &c->pretty_out, &c->pretty_err, &c->host_in, &c->host_out, &c->rec_stats, &c->flat_nd, &c->flat_rec, &c->flat_chunks, &c->flat_sums, &c->flat_done, &c->flat_items, &c->add_pieces, &c->add_scr_cnt, &c->add_scr_off, &c->add_new_cnt, &c->add_new_off, &c->add_text, &c->add_bad, &c->add_part, &c->add_scratch, &c->add_new_ops, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
                       &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts, &c->scan_part, &c->dedupe_keys, &c->emit_order, &c->order_cnt};
     for (DevBuf *b : bufs)
@@ -1118,6 +1121,7 @@ static int index_and_parse(paffy_hip_ctx *c, const uint8_t *in, uint32_t len, ui
             return PAFFY_E_HIP;
         HIPCHK(c, hipMemsetAsync(c->flat_chunks.p, 0xff, sizeof(uint32_t) * chunk_slots, c->stream)); /* FLAT_NO_CHUNK */
         c->flat_chunk_slots = (uint32_t)chunk_slots;
+        c->flat_piece_slots = (uint32_t)piece_slots;
     }
     if (n_lines > 0)
         LAUNCH(c, "k_header", k_header, dim3((n_lines + PAFFY_NT / HDR_GROUP - 1) / (PAFFY_NT / HDR_GROUP)), dim3(PAFFY_NT), 0, in,
@@ -1204,7 +1208,9 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     /* the lean pipes are sized by the flat pass (flat_kernel.h): the text parsed in chunks whatever record they belong to, one wave per
        record on the chunks' summaries; what it leaves (FLAT_F_IRREG and friends) goes through the record kernels below as before */
     static const bool flat_off = getenv("PAFFY_NO_FLAT") != nullptr;
-    const bool flat = lean && nocheck_mask == 0 && n_stages > 0 && !flat_off;
+    /* `paffy add_mismatches` alone (BASELINE cfg4): the same parse, the encoder on the pieces (flat_add_kernel.h) */
+    const bool flat_add = n_stages == 1 && stages[0].kind == PAFFY_ADD_MISMATCHES && nocheck_mask == 0 && !flat_off && c->n_seqs > 0;
+    const bool flat = (lean && nocheck_mask == 0 && n_stages > 0 && !flat_off) || flat_add;
     {
         int rc = index_and_parse(c, in, len, &n_lines, lvl0_max, flat);
         if (rc) return rc;
@@ -1279,7 +1285,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     };
     uint32_t flat_g_count = 0;
     bool need_legacy = true;
-    if (flat && n_lines > 0) {
+    if (flat_add && n_lines > 0) {
         FlatParams fp;
         fp.in = in;
         fp.in_len = len;
@@ -1290,6 +1296,89 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
         fp.sums = static_cast<PieceSum *>(c->flat_sums.p);
         fp.ops_mirror = kp.ops_mirror;
         fp.info = kp.info;
+        fp.items_mode = 1;
+        LAUNCH(c, "k_flat_parse", k_flat_parse, dim3(2048), dim3(64 * FLAT_PARSE_WAVES), 0, fp);
+        const uint32_t n_slots = c->flat_piece_slots, n_sblocks = (n_slots + SCAN32_BLOCK - 1) / SCAN32_BLOCK;
+        if (ensure(c, c->add_pieces, sizeof(AddPiece) * (size_t)n_slots) || ensure(c, c->add_scr_cnt, sizeof(uint32_t) * (size_t)n_slots) ||
+            ensure(c, c->add_scr_off, sizeof(uint64_t) * (size_t)n_slots) || ensure(c, c->add_new_cnt, sizeof(uint32_t) * (size_t)n_slots) ||
+            ensure(c, c->add_new_off, sizeof(uint64_t) * (size_t)n_slots) || ensure(c, c->add_text, sizeof(uint32_t) * (size_t)n_slots) ||
+            ensure(c, c->add_bad, sizeof(uint32_t) * (size_t)(n_lines + 1)) || ensure(c, c->add_part, sizeof(uint64_t) * (size_t)(n_sblocks + 1)))
+            return PAFFY_E_HIP;
+        /* item words + passed-through ops, and the new 4-byte ops: about 2.4 and 2.9 bytes per byte of text for 2 %-divergent sequences; a
+           batch that needs more is encoded again with what it asked for (the totals come back with the plan's one synchronisation) */
+        size_t scr_words = std::max<size_t>(c->add_scratch.cap / 4, (size_t)len + ((size_t)1 << 20)), new_words = std::max<size_t>(c->add_new_ops.cap / 4, (size_t)len + ((size_t)1 << 20));
+        for (int attempt = 0;; attempt++) {
+            if (ensure(c, c->add_scratch, 4 * scr_words) || ensure(c, c->add_new_ops, 4 * new_words)) return PAFFY_E_HIP;
+            AddParams ap;
+            ap.P = kp;
+            ap.sums = fp.sums;
+            ap.pieces = static_cast<AddPiece *>(c->add_pieces.p);
+            ap.n_piece_slots = n_slots;
+            ap.scr_cnt = static_cast<uint32_t *>(c->add_scr_cnt.p);
+            ap.scr_off = static_cast<const uint64_t *>(c->add_scr_off.p);
+            ap.scratch = static_cast<uint32_t *>(c->add_scratch.p);
+            ap.scr_cap = c->add_scratch.cap / 4;
+            ap.new_cnt = static_cast<uint32_t *>(c->add_new_cnt.p);
+            ap.new_off = static_cast<const uint64_t *>(c->add_new_off.p);
+            ap.new_ops = static_cast<uint32_t *>(c->add_new_ops.p);
+            ap.new_cap = c->add_new_ops.cap / 4;
+            ap.text_cnt = static_cast<uint32_t *>(c->add_text.p);
+            ap.rec_bad = static_cast<uint32_t *>(c->add_bad.p);
+            ap.flat_done = static_cast<uint8_t *>(c->flat_done.p);
+            { /* segments of the lines that become more than PAFFY_ROWS_MAX_OPS ops */
+                const size_t items_cap = new_words / (PAFFY_ROWS_MAX_OPS / 4u) + ((size_t)len >> 14) + 64;
+                if (ensure(c, c->flat_items, sizeof(EmitItem) * items_cap)) return PAFFY_E_HIP;
+                kp.items = static_cast<EmitItem *>(c->flat_items.p);
+                kp.items_cap = (uint32_t)items_cap;
+                ap.P = kp;
+            }
+            HIPCHK(c, hipMemsetAsync(c->add_pieces.p, 0xff, sizeof(AddPiece) * (size_t)n_slots, c->stream)); /* rec = FLAT_NO_CHUNK */
+            HIPCHK(c, hipMemsetAsync(c->add_scr_cnt.p, 0, sizeof(uint32_t) * (size_t)n_slots, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->add_new_cnt.p, 0, sizeof(uint32_t) * (size_t)n_slots, c->stream));
+            LAUNCH(c, "k_add_prep", k_add_prep, dim3((n_lines + 255) / 256), dim3(256), 0, ap);
+            LAUNCH(c, "k_scan32_part", k_scan32_part, dim3(n_sblocks), dim3(256), 0, ap.scr_cnt, n_slots, static_cast<uint64_t *>(c->add_scr_off.p), static_cast<uint64_t *>(c->add_part.p));
+            LAUNCH(c, "k_scan32_fix", k_scan32_fix, dim3(n_sblocks), dim3(256), 0, n_slots, n_sblocks, static_cast<uint64_t *>(c->add_scr_off.p), static_cast<const uint64_t *>(c->add_part.p),
+                   reinterpret_cast<uint64_t *>(&static_cast<DevInfo *>(c->info.p)->add_scr_total));
+            LAUNCH(c, "k_add_count", k_add_count, dim3(2048), dim3(64 * ADD_WAVES), 0, ap);
+            LAUNCH(c, "k_scan32_part", k_scan32_part, dim3(n_sblocks), dim3(256), 0, ap.new_cnt, n_slots, static_cast<uint64_t *>(c->add_new_off.p), static_cast<uint64_t *>(c->add_part.p));
+            LAUNCH(c, "k_scan32_fix", k_scan32_fix, dim3(n_sblocks), dim3(256), 0, n_slots, n_sblocks, static_cast<uint64_t *>(c->add_new_off.p), static_cast<const uint64_t *>(c->add_part.p),
+                   reinterpret_cast<uint64_t *>(&static_cast<DevInfo *>(c->info.p)->add_new_total));
+            LAUNCH(c, "k_add_fill", k_add_fill, dim3(2048), dim3(64 * ADD_WAVES), 0, ap);
+            LAUNCH(c, "k_add_final", k_add_final, dim3((n_lines + 255) / 256), dim3(256), 0, ap);
+            kp.new_ops = ap.new_ops;
+            if (post_scans()) return PAFFY_E_HIP;
+            if (fetch_info(c)) return PAFFY_E_HIP;
+            kp.n_items = c->h_info->n_items;
+            if (c->h_info->add_scr_total <= ap.scr_cap && c->h_info->add_new_total <= ap.new_cap) break;
+            if (attempt == 2) {
+                c->last_error = "add_mismatches: the scratch demand kept growing";
+                return PAFFY_E_HIP;
+            }
+            scr_words = std::max<size_t>(scr_words, (size_t)c->h_info->add_scr_total + ((size_t)c->h_info->add_scr_total >> 3) + 1024);
+            new_words = std::max<size_t>(new_words, (size_t)c->h_info->add_new_total + ((size_t)c->h_info->add_new_total >> 3) + 1024);
+            DevInfo z = *c->h_info; /* once more: nothing of the first try counts */
+            z.flat_legacy = 0;
+            z.n_items = 0;
+            z.out_bytes = z.out_rows = 0;
+            HIPCHK(c, hipMemcpyAsync(c->info.p, &z, sizeof(z), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        need_legacy = c->h_info->flat_legacy > 0;
+        c->flat_left = c->h_info->flat_legacy;
+        for (int k = 0; k < 16; k++) c->flat_reasons[k] = 0;
+        kp.flat_done = static_cast<const uint8_t *>(c->flat_done.p);
+    } else if (flat && n_lines > 0) {
+        FlatParams fp;
+        fp.in = in;
+        fp.in_len = len;
+        fp.meta = kp.meta;
+        fp.chunk_rec = static_cast<const uint32_t *>(c->flat_chunks.p);
+        fp.n_chunk_slots = c->flat_chunk_slots;
+        fp.nd = static_cast<const uint16_t *>(c->flat_nd.p);
+        fp.sums = static_cast<PieceSum *>(c->flat_sums.p);
+        fp.ops_mirror = kp.ops_mirror;
+        fp.info = kp.info;
+        fp.items_mode = 0;
         /* persistent waves over the chunks: eight workgroups of four waves per CU */
         LAUNCH(c, "k_flat_parse", k_flat_parse, dim3(2048), dim3(64 * FLAT_PARSE_WAVES), 0, fp);
         /* segments of the shatter records too long for one wave of the row writer: a record of more than PAFFY_ROWS_MAX_OPS ops has
@@ -2110,7 +2199,7 @@ int paffy_hip_emit(paffy_hip_ctx *c, void *d_out, int64_t out_cap) {
         if (c->h_info->g_count > 0) LAUNCH(c, "k_emit_lds", k_emit_lds<true>, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
         if (c->h_info->w_count > 0) LAUNCH(c, "k_arena_emit", k_arena_emit<true>, dim3(2048), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
     } else {
-        LAUNCH(c, "k_emit_line", k_emit_line, dim3(kp.n_rec), dim3(64), PAFFY_LINE_LDS_BYTES, kp);
+        LAUNCH(c, "k_emit_line", k_emit_line, dim3(kp.n_rec + kp.n_items), dim3(64), PAFFY_LINE_LDS_BYTES, kp);
         if (c->h_info->g_count > 0) LAUNCH(c, "k_emit_lds<line>", k_emit_lds<false>, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
         if (c->h_info->w_count > 0) LAUNCH(c, "k_arena_emit<line>", k_arena_emit<false>, dim3(2048), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
     }

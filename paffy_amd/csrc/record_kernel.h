@@ -3487,6 +3487,8 @@ __device__ __forceinline__ RecLds carve_emit_lds(uint8_t *smem) {
 __device__ __forceinline__ uint32_t mirror_index(const RecMeta &m) { return m.cg_off >> 1; }
 /* the 4-byte ops the emit pass reads for an LDS-class record */
 __device__ __forceinline__ const uint32_t *emit_ops_of(const KParams &P, uint32_t rec, const RecMeta &m, const RecPlan &pl) {
+    /* bit 20: the ops stand in new_ops[] (flat_add_kernel.h: the new cigars of all records back to back), arena_off counts its 4-byte words */
+    if (pl.flags & 0x100000u) return P.new_ops + P.arena_off[rec];
     return (pl.flags & 0x20000u) ? reinterpret_cast<const uint32_t *>(P.arena + P.arena_off[rec]) : P.ops_mirror + mirror_index(m);
 }
 __device__ __forceinline__ bool emit_ops_half(const RecPlan &pl) { return (pl.flags & 0x60000u) == 0x40000u; } /* the mirror, in 2-byte words */
@@ -3573,7 +3575,7 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_EMIT_OCC) void k_emit_lds(KParams P
     const uint32_t rec = blockIdx.x;
     if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return; /* nothing at or after the first failure */
     if ((P.status[rec] >> 16) != KLASS_LDS) return;
-    if (static_cast<const RecPlan *>(P.rec_plan)[rec].flags & (SHATTER ? (64u | 0x80000u) : 0x10000u)) return; /* k_emit_rows / k_emit_line has it */
+    if (static_cast<const RecPlan *>(P.rec_plan)[rec].flags & (SHATTER ? (64u | 0x80000u) : (0x10000u | 0x80000u))) return; /* k_emit_rows / k_emit_line has it */
     OpsGlobal ops{emit_ops_of(P, rec, P.meta[rec], static_cast<const RecPlan *>(P.rec_plan)[rec]), emit_ops_half(static_cast<const RecPlan *>(P.rec_plan)[rec])};
 #if defined(PAFFY_ABL) && PAFFY_ABL == 22
     const unsigned long long c0 = clock64(), w0 = wall_clock64();
@@ -3704,11 +3706,21 @@ __global__ __launch_bounds__(64, PAFFY_ROWS_OCC) void k_emit_rows(KParams P) {
 __global__ __launch_bounds__(64, PAFFY_EMIT_OCC) void k_emit_line(KParams P) {
     extern __shared__ uint4 smem4[];
     uint8_t *smem = reinterpret_cast<uint8_t *>(smem4);
-    const uint32_t rec = P.emit_order ? P.emit_order[blockIdx.x] : blockIdx.x; /* long records first */
+    /* the first n_items workgroups write the segments of the long lines (flat_add_kernel.h cuts the cigar of a record that becomes more
+       than PAFFY_ROWS_MAX_OPS ops into segments: the header goes with the first), the others one record each */
+    const bool is_item = blockIdx.x < P.n_items;
+    uint32_t rec, wb = 0, we = 0;
+    int64_t wo = 0;
+    if (is_item) {
+        const EmitItem &it = P.items[blockIdx.x];
+        rec = it.rec; wb = it.wb; we = it.we; wo = it.wo;
+    } else {
+        rec = P.emit_order ? P.emit_order[blockIdx.x - P.n_items] : blockIdx.x - P.n_items; /* long records first */
+    }
     if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return;
     if ((P.status[rec] >> 16) != KLASS_LDS) return;
     const RecPlan &pl = static_cast<const RecPlan *>(P.rec_plan)[rec];
-    if (!(pl.flags & 0x10000u)) return; /* long header or dropped: k_emit_lds<line> */
+    if (!(pl.flags & (is_item ? 0x80000u : 0x10000u))) return; /* long header or dropped: k_emit_lds<line> */
     const RecMeta &m = P.meta[rec];
     RecState s;
     load_state(m, s);
@@ -3724,12 +3736,14 @@ __global__ __launch_bounds__(64, PAFFY_EMIT_OCC) void k_emit_line(KParams P) {
     const bool nl_in_header = !(s.has_cigar && v.n > 0);
     const uint32_t lenH = header_len_wave(s, nl_in_header);
     uint64_t *H = reinterpret_cast<uint64_t *>(smem + PAFFY_WAVE_RING);
-    {
+    const bool with_header = !is_item || wb == 0;
+    if (with_header) {
         Piece w{(uint8_t *)H, 0, PAFFY_TMPL_MAX, false};
         build_header(w, s, P.in, nl_in_header);
     }
     __builtin_amdgcn_wave_barrier();
-    write_emit_range(v, 0u, nl_in_header ? 0u : v.n, true, H, lenH, smem, P.out, (uint64_t)P.out_off[rec]);
+    if (!is_item) we = nl_in_header ? 0u : v.n;
+    write_emit_range(v, wb, we, with_header, H, lenH, smem, P.out, (uint64_t)P.out_off[rec] + (with_header ? 0ull : (uint64_t)lenH + (uint64_t)wo));
 }
 
 /* Arena class: records whose ops do not fit LDS; persistent workgroups walk the list. */

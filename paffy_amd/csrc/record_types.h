@@ -59,6 +59,7 @@ struct DevInfo {
     uint32_t flat_defer; /* records k_flat_lane handed on to k_flat_size */
     uint32_t n_items; /* EmitItem entries written (segments of the records too long for one wave of the row writer) */
     uint32_t flat_reason[16]; /* why: FLAT_WHY_* of flat_kernel.h (diagnostics, paffy_hip_flat_stats) */
+    unsigned long long add_scr_total, add_new_total; /* flat_add_kernel.h: words of scratch / of new ops the batch needs */
 };
 
 /* What the stage list left of a record; written by the sizing pass, read by the emit pass. */
@@ -125,6 +126,7 @@ struct KParams {
     int64_t *rec_stats;         /* PAFFY_STATS: six sums per record (the order of paf_stats_calc's arguments), or NULL */
     uint32_t nocheck_mask;      /* bit i: stage i runs without the paf_check the command loops append (PAFFY_NO_CHECK) */
     uint32_t wave_max_bytes;    /* records with at most this many cigar bytes are sized by the one-wave kernel (0: none): the four-wave kernel skips them */
+    const uint32_t *new_ops;    /* flat_add_kernel.h: the rebuilt cigars of all records, 4-byte ops back to back (RecPlan flag bit 20: arena_off counts words of it) */
     EmitItem *items;            /* segments of long records, written by the flat sizing pass, emitted by k_emit_rows in front of the records */
     uint32_t n_items, items_cap;
     const uint8_t *flat_done;   /* flat sizing pass: 1 = the record has been sized there, the record kernels skip it (NULL: no flat pass) */

@@ -168,3 +168,60 @@ def test_alternating_columns_grow_the_arena(eng):
         assert werr.code == 0 and info.error.code == 0 and got == want
     assert want.count(b"1X") > 100_000
     e2.close()
+
+
+def test_long_lines_and_a_scratch_demand_that_outgrows_the_first_guess(eng):
+    """`add_mismatches` alone goes through the flat pass (paffy_amd/csrc/flat_add_kernel.h): pieces of cigar text encoded one wave each.
+    Records of tens of thousands of ops become lines of more than 32 768 ops -- written as segments by the one-wave line writer -- on
+    both strands; records whose M ops meet alternating columns become fifty times their ops -- the scratch and the new ops outgrow what
+    the first try allowed and the batch is encoded again; a missing sequence and a record that leaves its sequence are the record
+    kernels' to report, between records the flat pass keeps."""
+    import random
+
+    from test_gpu_flat import random_ops, record
+
+    rng = random.Random(77)
+    n = 3_000_000
+    t = "".join(rng.choice("ACGT") for _ in range(n))
+    q = list(t)
+    for i in range(0, n, 37):  # a substitution every 37 bases, some lower case
+        q[i] = "ACGT"["ACGT".index(q[i]) ^ 1]
+    for i in range(0, n, 101):
+        q[i] = q[i].lower()
+    q = "".join(q)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "a": "t", "c": "g", "g": "c", "t": "a"}
+    qrc = "".join(comp[c] for c in reversed(q))
+    seqs = {"tt": t, "qf": q, "qr": qrc, "alt": "AC" * 200_000, "aaa": "A" * 400_000}
+    eng.set_sequences(seqs)
+    recs = []
+    for k, n_ops in enumerate([300, 20_000, 45_000, 70_000, 1200]):
+        ops = random_ops(rng, n_ops, lens=(1, 5, 30, 60, 110), indel=(1, 2, 3))
+        span_q = sum(L for L, c in ops if c in "MI")
+        span_t = sum(L for L, c in ops if c in "MD")
+        s0 = rng.randrange(0, 1000)
+        recs.append(record(ops, "+", qname="qf", tname="tt", qlen=n, tlen=n, qs=s0, ts=s0 + 3))
+        recs.append(record(ops, "-", qname="qr", tname="tt", qlen=n, tlen=n, qs=n - s0 - span_q, ts=s0 + 3))
+        assert s0 + 3 + span_t < n
+    for k in range(3):  # fifty ops per M op: 2 500 M ops of 50 alternating columns each
+        ops = [(50, "M") if i % 2 == 0 else (1, "I") for i in range(4999)]
+        recs.append(record(ops, "+", qname="aaa", tname="alt", qlen=400_000, tlen=400_000, qs=10 + k, ts=20 + k))
+    good = recs[0]
+    missing = good.replace("qf\t", "nope\t", 1)
+    outside = record([(40, "M")], "+", qname="qf", tname="tt", qlen=n + 100, tlen=n, qs=n + 10, ts=5)
+    stages = [S(O.ADD_MISMATCHES)]
+    data = "".join(recs).encode()
+    e2 = type(eng)()  # a fresh context: its buffers start at the first guess
+    e2.set_sequences(seqs)
+    want, werr = O.run(stages, data, seqs)
+    got, info = e2.run(gs(stages), data, raise_on_error=False)
+    assert werr.code == 0 and info.error.code == 0
+    assert got == want
+    left, _ = e2.flat_stats()
+    assert left == 0, left  # the flat pass took every record: long lines and the second try included
+    assert max(line.count(b"=") + line.count(b"X") for line in want.split(b"\n")) > 100_000
+    for bad in (missing, outside):
+        d2 = (good + bad + good).encode()
+        w, e = O.run(stages, d2, seqs)
+        g, i = e2.run(gs(stages), d2, raise_on_error=False)
+        assert (i.error.code, i.error.record) == (e.code, e.record) and e.code != 0 and g == w
+    e2.close()
