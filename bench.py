@@ -71,7 +71,9 @@ def main():
                          "the writers of batch k (1 = one context, batches strictly one after the other; default 2, 1 for the workload with genomes)")
     ap.add_argument("--keep-cache", action="store_true", help="cfg5: do not return torch's cached blocks to the driver between steps (experiments only)")
     ap.add_argument("--tile-text-batch", type=int, default=200_000, help="cfg5: records per text batch handed to the library (each batch stays below 2 GiB)")
-    ap.add_argument("--verify", action="store_true", help="cfg5: gather the ordered output of the last step on rank 0 and compare it with a one-process tile of the same records (small --batch only)")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed region, gather the ordered output of the last step(s) on rank 0 (the batches travel there in batch order: RCCL send / recv with the "
+                         "nccl backend) and compare it with a one-process pass over the same records; small --batch only. cfg5: the tile of the last step")
     ap.add_argument("--rehearse", action="store_true",
                     help="plumbing rehearsal without a GPU: ranks, rendezvous, the per-step size exchange and the reductions run, the hot path does not (value is null)")
     args = ap.parse_args()
@@ -226,6 +228,9 @@ def main():
         kernels = eng.profile_read()
         eng.profile(False)
 
+    verified = None
+    if args.verify:
+        verified = verify_stream(args, wl, eng, stages, rank, world, dist, dev if (dist is None or args.dist_backend == "nccl") else "cpu", mine, batches)
     if dist:
         red_dev = dev if args.dist_backend == "nccl" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -331,7 +336,7 @@ def main():
                        "sharding": "batch b of the stream on rank b % N; per step one all-gather of the output sizes (8 B per rank) inside the timed "
                                    "region gives every rank the offset of its bytes in the ordered output; the bytes themselves stay on their GPU"},
             "ordered_write": {"mode": "per-rank offsets from an all-gather of the step's output sizes", "total_bytes": ordered_total,
-                              "rank0_first_offsets": [int(x) for x in my_offsets[:4].tolist()]},
+                              "rank0_first_offsets": [int(x) for x in my_offsets[:4].tolist()], "verified_against_one_process": verified},
             "whole_path_GBps_per_gpu": round(((job_in + job_out) / world + extra_per_base * aligned_per_record * args.batch * args.steps) / elapsed / 1e9, 1),
             "roofline": roofline,
             "roofline_by_kernel": {k: v for k, v in by_kernel.items() if "+" in k or kernels[k][0] >= 0.05 * max(x[0] for x in kernels.values())},
@@ -416,10 +421,17 @@ def bench_tile(args, wl, rank, world, dist, dev):
     kernels = eng.profile_read()
     eng.profile(False)
     red = dev if (dist is not None and args.dist_backend == "nccl") else "cpu"
+    # what every rank ended up owning in the last step: the partition by query contig (heaviest contig to the lightest rank) bounds the
+    # N-GPU efficiency before any link does, so the line shows it
+    mine_load = torch.tensor([sum(n for _, n in worker.keep), int(last[0]["keys"].shape[0])], dtype=torch.int64, device=red)
+    loads = mine_load.reshape(1, 2)
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        loads = torch.zeros(world, 2, dtype=torch.int64, device=red)
+        dist.all_gather_into_tensor(loads, mine_load)
+    loads = loads.cpu().tolist()
     verified = None
     if args.verify:
         res, out, batches, first = last
@@ -445,8 +457,12 @@ def bench_tile(args, wl, rank, world, dist, dev):
         if kernels and step_ms > 0:
             dom = max(kernels, key=lambda k: kernels[k][0])
             ach = per_step / (step_ms * 1e-3) / 1e9
+            traffic = tile_step_traffic(args, kernels)
             roofline = {"bound": "hbm", "kernel": f"all kernels of one step on one rank (dominant: {dom})", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tile_step_traffic(args, kernels), "step_kernels_ms": round(step_ms, 4), "dominant_kernel": dom,
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        # the honest second figure: the bytes the step's kernels really moved (PMC pass of this workload) over the same time
+                        "traffic_frac": (round(traffic / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+                        "step_kernels_ms": round(step_ms, 4), "dominant_kernel": dom,
                         "dominant_avg_kernel_ms": round(kernels[dom][0] / max(1, kernels[dom][1]), 4), "algorithmic_bytes_per_launch": int(per_step),
                         "note": "algorithmic bytes = input lines + output lines + 4 B per aligned base (SURVEY 8d counts the counter of every aligned base as 2 B read + 2 B "
                                 "written in HBM; here a slice's counters live in LDS while its records are walked, so the walk itself moves one bit per base)"}
@@ -466,6 +482,8 @@ def bench_tile(args, wl, rank, world, dist, dev):
                                    "then an all-gather of 32 B per record places every line in the ordered output; all inside the timed region"},
             "ordered_write": {"mode": "per-line offsets from the all-gathered keys; lines written by their owner", "total_bytes": int(last[0]["total"]),
                               "verified_against_one_process": verified},
+            "rank_load_last_step": {"text_bytes": [int(x[0]) for x in loads], "records": [int(x[1]) for x in loads],
+                                    "max_over_mean_bytes": round(max(x[0] for x in loads) * len(loads) / max(1, sum(x[0] for x in loads)), 4)},
             "phase_ms_last_step": last[0].get("timing") or None, "ms_each_step": each,
             "hbm": {"in_use_after_last_step_GB": round(hbm_used_after_step / 1e9, 2), "peak_in_use_GB": (round(last[0]["hbm_peak"] / 1e9, 2) if last[0].get("hbm_peak") else None),
                     "peak_live_GB": (round(last[0]["hbm_live_peak"] / 1e9, 2) if last[0].get("hbm_live_peak") else None),
@@ -608,6 +626,51 @@ class SizeExchange:
         return offs, int(ends[-1].item()) if flat.numel() else 0
 
 
+def verify_stream(args, wl, eng, stages, rank, world, dist, comm, mine, batches, last=2):
+    """The ordered write of the stream workloads, checked: the outputs of every rank's last `last` timed batches travel to rank 0 in batch
+    order (shard.gather_to_writer: point-to-point sends, RCCL over xGMI with the nccl backend; per-batch sizes from an all-reduce) and
+    rank 0 compares each with its own pass over the same records of the stream. Returns True / False on rank 0, None elsewhere."""
+    import torch
+
+    from paffy_amd import shard
+
+    n_batches = (args.warmup + args.steps) * world
+    take = [k for k in range(args.warmup + max(0, args.steps - last), args.warmup + args.steps)]
+    local = {}
+    for k in take:
+        b, _, _ = mine[k]
+        buf, nbytes, _ = batches[k]
+        info = eng.plan(stages, buf, nbytes)
+        out = eng.alloc_out(info.out_bytes)
+        eng.emit(out)
+        eng.sync()
+        local[b] = out[: info.out_bytes]
+    if dist is None:
+        sizes = [0] * n_batches
+        for b, t in local.items():
+            sizes[b] = int(t.numel())
+    else:
+        sizes = shard.gather_batch_sizes(dist, {b: int(t.numel()) for b, t in local.items()}, n_batches, device=comm)
+    got = {}
+    if dist is None:
+        got = dict(local)
+    else:
+        shard.gather_to_writer(dist, rank, world, {b: (t if str(t.device) == str(comm) else t.to(comm)) for b, t in local.items()}, sizes,
+                               lambda b, t: got.__setitem__(b, t.clone()), device=comm)
+    if rank != 0:
+        return None
+    ok = len(got) == sum(1 for s in sizes if s > 0)
+    for b in sorted(got):
+        r0 = (b * args.batch) % max(1, wl["total"] - args.batch + 1)
+        buf, nbytes = eng.synth4(r0, args.batch) if wl.get("genomes") else eng.synth(wl["seed"], wl["mean_ops"], r0, args.batch)
+        info = eng.plan(stages, buf, nbytes)
+        ref = eng.alloc_out(info.out_bytes)
+        eng.emit(ref)
+        eng.sync()
+        ok = ok and info.out_bytes == sizes[b] and bool(torch.equal(ref[: info.out_bytes].cpu(), got[b].cpu()))
+    return bool(ok)
+
+
 def rehearse(args):
     """`--rehearse`: everything of the N-rank run but the hot path -- rendezvous, barriers, the per-step size exchange, the
     max-over-ranks reduction and the JSON line -- on CPU tensors over gloo. The hot path has no CPU implementation, so nothing is
@@ -635,15 +698,35 @@ def rehearse(args):
     want = [sum(1000 * (j + 1) * world + world * (world - 1) // 2 for j in range(i)) + sum(1000 * (i + 1) + r for r in range(rank))
             for i in range(args.steps)]
     ok = [int(x) for x in offs.tolist()] == want
+    verified = None
+    if args.verify:
+        # the --verify plumbing without a GPU: stand-in outputs (batch b = its size in bytes of (b * 31 + position) mod 251) travel to rank 0
+        # in batch order over gloo and must arrive as one process would have written them
+        from paffy_amd import shard
+
+        def standin(b, n):
+            return ((torch.arange(n, dtype=torch.int64) + 31 * b) % 251).to(torch.uint8)
+
+        n_b = args.steps * world
+        local = {i * world + rank: standin(i * world + rank, 1000 * (i + 1) + rank) for i in range(args.steps)}
+        if dist:
+            sizes = shard.gather_batch_sizes(dist, {b: int(t.numel()) for b, t in local.items()}, n_b)
+            got = {}
+            shard.gather_to_writer(dist, rank, world, local, sizes, lambda b, t: got.__setitem__(b, t.clone()))
+        else:
+            sizes = [int(local[b].numel()) for b in range(n_b)]
+            got = local
+        if rank == 0:
+            verified = sorted(got) == list(range(n_b)) and all(torch.equal(got[b], standin(b, sizes[b])) for b in got) and sum(sizes) == total
     if rank == 0:
         print(json.dumps({"metric": "PAF records/sec (shatter+invert+trim pipe); % HBM roofline at 1/2/4/8 GPU", "value": None, "unit": "records/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(t.item()) / max(1, args.steps) * 1e3, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "none", "rehearsal": True,
                           "ordered_write": {"mode": "per-rank offsets from an all-gather of the step's output sizes", "offsets_ok": ok,
-                                            "total_bytes": total}}), flush=True)
+                                            "total_bytes": total, "verified_against_one_process": verified}}), flush=True)
     if dist:
         dist.destroy_process_group()
-    return 0 if ok else 1
+    return 0 if ok and verified is not False else 1
 
 
 def tile_step_traffic(args, kernels):

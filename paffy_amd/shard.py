@@ -175,7 +175,7 @@ def big_buffer_bytes(n):
     return (n + unit - 1) // unit * unit
 
 
-def _pairwise_exchange(dist, rank, world, src, send_counts, dst, recv_counts, chunk, recv_offsets=None):
+def _pairwise_exchange(dist, rank, world, src, send_counts, dst, recv_counts, chunk, recv_offsets=None, verify=True):
     """dst <- what every rank holds for this rank in src (both flat, grouped by peer, counts in elements): the all-to-all as explicit
     sends and receives per peer in pieces of at most `chunk` elements, the rank's own part as a plain copy. Over the nccl backend
     these are RCCL send / recv pairs -- point-to-point over xGMI, which is what the fabric is. Why not all_to_all_single: one call
@@ -190,6 +190,8 @@ def _pairwise_exchange(dist, rank, world, src, send_counts, dst, recv_counts, ch
         re = [ro[r] + int(recv_counts[r]) for r in range(world)]
     if send_counts[rank]:
         dst[ro[rank]: re[rank]].copy_(src[so[rank]: so[rank + 1]])
+    if verify:
+        sent = _edge_sums(src, so[:-1], so[1:])
     rounds = max([0] + [(int(c) + chunk - 1) // chunk for r, c in enumerate(send_counts) if r != rank] +
                  [(int(c) + chunk - 1) // chunk for r, c in enumerate(recv_counts) if r != rank])
     for k in range(rounds):
@@ -205,6 +207,35 @@ def _pairwise_exchange(dist, rank, world, src, send_counts, dst, recv_counts, ch
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+    if verify:
+        # every posted byte arrived: the sender's fingerprint of each part (element count, sums over its first and last 64 Ki elements)
+        # travels as a 24-byte all-to-all and must equal what the receiver finds where the part landed. An RCCL collective that returns
+        # without its bytes (tools/probes/rccl_a2a_sizes.py saw one do that from 768 MiB per peer on) fails here, loudly, not downstream.
+        import torch
+
+        theirs = torch.zeros_like(sent)
+        dist.all_to_all_single(theirs, sent)
+        got = _edge_sums(dst, ro[:world], re[:world])
+        if not torch.equal(theirs.cpu(), got.cpu()):
+            bad = [r for r in range(world) if not torch.equal(theirs[r].cpu(), got[r].cpu())]
+            raise RuntimeError(f"_pairwise_exchange: rank {rank} did not receive what ranks {bad} sent (fingerprints differ)")
+
+
+EDGE_ELEMENTS = 1 << 16
+
+
+def _edge_sums(buf, starts, ends):
+    """int64 [parts, 3]: (elements, sum of the first EDGE_ELEMENTS, sum of the last EDGE_ELEMENTS) of buf[start:end] for every part"""
+    import torch
+
+    out = torch.zeros(len(starts), 3, dtype=torch.int64, device=buf.device)
+    for r, (a, b) in enumerate(zip(starts, ends)):
+        a, b = int(a), int(b)
+        if b > a:
+            out[r, 0] = b - a
+            out[r, 1] = buf[a: min(b, a + EDGE_ELEMENTS)].to(torch.int64).sum()
+            out[r, 2] = buf[max(a, b - EDGE_ELEMENTS): b].to(torch.int64).sum()
+    return out
 
 
 def exchange_lines(dist, send_buf, send_bytes, send_gidx, send_records, comm_device="cpu", pieces=None):

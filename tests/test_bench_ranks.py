@@ -38,3 +38,14 @@ def test_gpus_beyond_the_visible_devices_is_an_error():
     # no --rehearse / --one-device here: this container has no GPU, so two ranks cannot get a device each
     rc, lines, err = _run("--gpus", "2", "--steps", "1")
     assert rc != 0 and not lines and "device(s) visible" in err
+
+
+def test_verify_gathers_the_ordered_output_on_rank_zero():
+    """`--verify` for the stream workloads (cfg3): the ranks' batch outputs travel to rank 0 in batch order (shard.gather_to_writer) and
+    are compared with what one process writes. Without a GPU the rehearsal sends stand-in outputs through the same calls over gloo."""
+    for n in ("2", "3"):
+        rc, lines, err = _run("--gpus", n, "--rehearse", "--verify", "--workload", "cfg3", "--steps", "3", "--warmup", "0")
+        assert rc == 0, err
+        assert lines[0]["ordered_write"]["verified_against_one_process"] is True and lines[0]["ordered_write"]["offsets_ok"] is True
+    rc, lines, err = _run("--rehearse", "--verify", "--steps", "2")
+    assert rc == 0 and lines[0]["ordered_write"]["verified_against_one_process"] is True, err

@@ -256,3 +256,66 @@ def test_one_rank_group_tiles_padded_pieces_in_place(tmp_path):
     want, err = O.tile("".join(_tile_data(150)).encode())
     assert err.code == 0
     assert (tmp_path / "tiled.paf").read_bytes() == want
+
+
+class _LossyDist:
+    """torch.distributed with a batch_isend_irecv that 'delivers' one receive as zeros -- what an RCCL call that returns without its bytes
+    looks like (tools/probes/rccl_a2a_sizes.py saw all_to_all_single do that from 768 MiB per peer on)."""
+
+    def __init__(self, lose_on_rank):
+        self.lose_on_rank = lose_on_rank
+
+    def __getattr__(self, name):
+        return getattr(dist, name)
+
+    def batch_isend_irecv(self, ops):
+        reqs = dist.batch_isend_irecv(ops)
+        for r in reqs:
+            r.wait()
+        if dist.get_rank() == self.lose_on_rank:
+            for op in ops:
+                if op.op is dist.irecv:
+                    op.tensor.zero_()
+                    break
+        return []
+
+
+def _exchange_worker(rank, world, port, lossy, result):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    counts = [[0, 70_000, 5], [300_000, 0, 0], [9, 150_000, 0]]  # elements rank r sends to rank d
+    send = torch.randint(1, 255, (sum(counts[rank]),), dtype=torch.uint8, generator=g)
+    recv_counts = [counts[r][rank] for r in range(world)]
+    dst = torch.zeros(sum(recv_counts), dtype=torch.uint8)
+    d = _LossyDist(1) if lossy else dist
+    try:
+        shard._pairwise_exchange(d, rank, world, send, counts[rank], dst, recv_counts, 64 << 10)
+        ok = True
+    except RuntimeError as e:
+        ok = "fingerprints differ" not in str(e)
+    # what should have arrived: every sender's part for this rank, in sender order
+    want = []
+    for r in range(world):
+        gr = torch.Generator().manual_seed(100 + r)
+        sr = torch.randint(1, 255, (sum(counts[r]),), dtype=torch.uint8, generator=gr)
+        at = sum(counts[r][:rank])
+        want.append(sr[at: at + counts[r][rank]])
+    result[rank] = (ok, bool(torch.equal(dst, torch.cat(want))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lossy", [False, True])
+def test_pairwise_exchange_checks_that_every_posted_byte_arrived(lossy):
+    """three ranks, parts of 0 to 300 000 elements in pieces of 64 Ki: the exchange delivers them; with a receive lost on rank 1 the
+    fingerprints of the parts (count, sums over their first and last 64 Ki elements) differ there and the exchange raises"""
+    world = 3
+    with mp.Manager() as mgr:
+        result = mgr.dict()
+        mp.spawn(_exchange_worker, args=(world, _free_port(), lossy, result), nprocs=world, join=True)
+        res = dict(result)
+    if not lossy:
+        assert all(ok and same for ok, same in res.values()), res
+    else:
+        assert res[1][0] is False and res[0][0] and res[2][0], res  # rank 1 noticed, the others got what was sent
