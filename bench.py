@@ -429,8 +429,9 @@ def bench_tile(args, wl, rank, world, dist, dev):
         t = torch.tensor([elapsed], dtype=torch.float64, device=red)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        loads = torch.zeros(world, 2, dtype=torch.int64, device=red)
-        dist.all_gather_into_tensor(loads, mine_load)
+        flat_loads = torch.zeros(world * 2, dtype=torch.int64, device=red)
+        dist.all_gather_into_tensor(flat_loads, mine_load)
+        loads = flat_loads.reshape(world, 2)
     loads = loads.cpu().tolist()
     verified = None
     if args.verify:

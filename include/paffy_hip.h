@@ -290,7 +290,10 @@ int paffy_hip_stream_read(paffy_hip_stream *stream, const char **piece, int64_t 
 void paffy_hip_stream_close(paffy_hip_stream *stream);
 /* A closed stream leaves the device buffers of its two slots (input text, output) with the context; the context's next stream takes them
    again instead of allocating (a hipMalloc of the tens of GB a slot's output needs takes 16 ms most of the time and seconds right behind
-   the hipFree of the stream before). paffy_hip_stream_trim frees them; paffy_hip_destroy does too. */
+   the hipFree of the stream before). paffy_hip_stream_trim frees them; paffy_hip_destroy does too, and so do the whole-input commands when
+   they begin (tile_begin / bed_begin / chain_begin: the memory is theirs to use). A context that is destroyed while a stream of its is still
+   open detaches the stream: paffy_hip_stream_close stays valid afterwards (it then frees the stream's own buffers), every other stream call
+   needs the context. */
 int paffy_hip_stream_trim(paffy_hip_ctx *ctx);
 
 /*

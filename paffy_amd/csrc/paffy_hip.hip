@@ -854,6 +854,8 @@ struct paffy_hip_ctx {
        before (tools/probes/d2h_pieces.py) */
     void *kept_slot_buf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; /* [slot][0 = input, 1 = output] */
     size_t kept_slot_cap[2][2] = {{0, 0}, {0, 0}};
+    std::vector<struct paffy_hip_stream *> open_streams; /* streams of this context that are open: paffy_hip_destroy detaches them (a stream closed later frees
+                                                           its buffers itself instead of leaving them with a context that is gone) */
     std::string profile_only; /* when not empty: only launches of this kernel are bracketed (paffy_hip_profile_only) */
     std::vector<hipEvent_t> event_pool;
     std::vector<ProfEntry> prof;
@@ -988,6 +990,7 @@ int paffy_hip_create(paffy_hip_ctx **out, int device) {
     return 0;
 }
 
+static void stream_detach(struct paffy_hip_stream *s);
 static void cov_free(paffy_hip_ctx *c); /* coverage_host.h state */
 static void dedupe_free(paffy_hip_ctx *c); /* dedupe_host.h state */
 static void index_drop(paffy_hip_ctx *c, const void *d_in);
@@ -996,6 +999,8 @@ static void chain_free(paffy_hip_ctx *c);
 
 void paffy_hip_destroy(paffy_hip_ctx *c) {
     if (!c) return;
+    for (paffy_hip_stream *st : c->open_streams) stream_detach(st); /* streams still open: they close later without this context */
+    c->open_streams.clear();
     prof_collect(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     c->event_pool.clear();
@@ -1602,6 +1607,7 @@ static int lines_plan(paffy_hip_ctx *c, CovState &S, uint64_t n) {
  * Any failing record means nothing is written (the reference writes only after the last record).
  */
 int paffy_hip_tile_begin(paffy_hip_ctx *c) {
+    if (c) (void)paffy_hip_stream_trim(c); /* a closed stream's slot buffers (tens of GB) are this command's to use */
     if (!c) return PAFFY_E_ARG;
     c->planned = false;
     index_drop_all(c); /* indexes kept by paffy_hip_query_names for batches that were never split */
@@ -1652,6 +1658,7 @@ int paffy_hip_tile_plan(paffy_hip_ctx *c, const void *d_in, int64_t in_len, paff
  * the output lines (cn / s1 tags set, cigar text verbatim) are written by paffy_hip_emit or paffy_hip_emit_lines.
  */
 int paffy_hip_chain_begin(paffy_hip_ctx *c) {
+    if (c) (void)paffy_hip_stream_trim(c); /* a closed stream's slot buffers (tens of GB) are this command's to use */
     if (!c) return PAFFY_E_ARG;
     c->planned = false;
     index_drop_all(c); /* indexes kept by paffy_hip_query_names for batches that were never split */
@@ -2294,6 +2301,8 @@ struct paffy_hip_stream {
     int n_issued = 0, n_returned = 0;
 };
 
+static void stream_detach(paffy_hip_stream *s) { s->c = nullptr; }
+
 int paffy_hip_stream_trim(paffy_hip_ctx *c) {
     if (!c) return PAFFY_E_ARG;
     for (int k = 0; k < 2; k++)
@@ -2310,6 +2319,7 @@ int paffy_hip_stream_open(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n
         return PAFFY_E_ARG;
     paffy_hip_stream *s = new paffy_hip_stream();
     s->c = c;
+    c->open_streams.push_back(s);
     s->n_stages = n_stages;
     for (int32_t i = 0; i < n_stages; i++) s->stages[i] = stages[i];
     bool ok = hipStreamCreateWithFlags(&s->s_h2d, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&s->s_d2h, hipStreamNonBlocking) == hipSuccess;
@@ -2339,6 +2349,14 @@ int paffy_hip_stream_open(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n
 }
 
 void paffy_hip_stream_close(paffy_hip_stream *s) {
+    if (s && s->c) { /* no longer an open stream of its context */
+        auto &v = s->c->open_streams;
+        for (size_t k = 0; k < v.size(); k++)
+            if (v[k] == s) {
+                v.erase(v.begin() + (long)k);
+                break;
+            }
+    }
     if (!s) return;
     (void)hipDeviceSynchronize();
     for (int k = 0; k < 2; k++) {
@@ -2480,6 +2498,7 @@ static int scan64(paffy_hip_ctx *c, const int64_t *in, uint64_t n, int64_t *out,
  * reference iterates a sonLib hash: its order is not defined). Any failing record means no output.
  */
 int paffy_hip_bed_begin(paffy_hip_ctx *c, const paffy_bed_opts *opts) {
+    if (c) (void)paffy_hip_stream_trim(c); /* a closed stream's slot buffers (tens of GB) are this command's to use */
     if (!c || !opts) return PAFFY_E_ARG;
     c->planned = false;
     index_drop_all(c);

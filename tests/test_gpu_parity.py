@@ -249,3 +249,26 @@ def test_error_paths(eng):
         got, info = check(eng, stages, ok + bad + ok)
         assert info.error.code != 0 and info.error.record == 1
         assert got == O.run(stages, ok)[0]
+
+
+def test_a_stream_closed_after_its_context_was_destroyed():
+    """round-3 advice: paffy_hip_stream_close left the slots' device buffers with a context that could be gone. A context now knows its open
+    streams and detaches them when it is destroyed; closing such a stream frees its own buffers."""
+    import ctypes as C
+
+    import paffy_amd
+    from paffy_amd import engine
+
+    L = engine.lib()
+    ctx, st = C.c_void_p(), C.c_void_p()
+    assert L.paffy_hip_create(C.byref(ctx), 0) == 0
+    stages = (engine.Stage * 1)(paffy_amd.stage(paffy_amd.INVERT))
+    assert L.paffy_hip_stream_open(ctx, stages, 1, 1 << 20, 1 << 20, C.byref(st)) == 0
+    L.paffy_hip_destroy(ctx)
+    L.paffy_hip_stream_close(st)  # must neither crash nor touch the freed context
+    # and the usual order still leaves the buffers with the context for its next stream
+    assert L.paffy_hip_create(C.byref(ctx), 0) == 0
+    for _ in range(2):
+        assert L.paffy_hip_stream_open(ctx, stages, 1, 1 << 20, 1 << 20, C.byref(st)) == 0
+        L.paffy_hip_stream_close(st)
+    L.paffy_hip_destroy(ctx)

@@ -197,3 +197,21 @@ def test_longer_first_store_level_and_its_way_back():
         assert info.error.code == werr.code == 0, i
         assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest(), i
     eng.close()
+
+
+def test_one_wave_writers_on_both_sides_of_their_op_limit(eng):
+    """round-3 advice: PAFFY_ROWS_MAX_OPS went from 16 384 to 32 768 ops after the soak. Cigars of 16 385, 20 000, 32 768 and 32 769 view ops
+    (and their neighbours) through a shatter pipe and a line-writing pipe the RECORD kernels size (the fixed trim keeps them off the flat
+    pass) and through the flat pass's own pipes: the one-wave writers k_emit_rows / k_emit_line below the limit, the four-wave writers
+    and the segments of the flat pass above it, byte for byte against the oracle."""
+    rng = random.Random(45)
+    recs = []
+    for k, n_ops in enumerate([16383, 16385, 20001, 32767, 32769, 32771, 40001]):  # make_record ends on an M op: odd counts
+        recs.append(make_record(rng, "hs.chr5", "pt.chr8", 240000000, 240000000, n_ops, "+-"[k & 1], [1, 7, 30, 120]))
+    data = "".join(recs).encode()
+    run_both(eng, data, ([O.TRIM_FIXED, O.SHATTER], [O.TRIM_FIXED], [O.REMOVE_MISMATCHES, O.INVERT], [O.SHATTER], [O.INVERT], [O.INVERT, O.TRIM_IDENTITY, O.SHATTER]))
+    import re
+
+    # the view's op count decides: the records really stand on both sides of 32 768
+    counts = [len(re.findall(rb"[MID]", r.split(b"cg:Z:")[1])) for r in data.splitlines()]
+    assert min(counts) < 16384 < sorted(counts)[1] and any(c == 32767 for c in counts) and any(c == 32769 for c in counts)
