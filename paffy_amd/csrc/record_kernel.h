@@ -1174,11 +1174,23 @@ __device__ __forceinline__ uint32_t mismatch_count_wave(const KParams &P, const 
     uint32_t nm_written = 0; /* ops other than M seen so far: they are kept as they are, in nm_list */
     uint32_t nm_run = 0;     /* how many of them since the last M op (wave-uniform) */
     int64_t first_bad = INT64_MAX;
+    /* ops in the HBM mirror (flat_add_kernel.h: one wave per piece): the op words of a window are requested a window ahead -- a window is
+       the op load, the scans and one or two rounds of sequence loads, each a round trip the wave would otherwise sit through in turn */
+    typename std::conditional<std::is_same<OPS, OpsGlobal>::value, uint32_t, int>::type raw_ahead = 0;
+    if constexpr (std::is_same<OPS, OpsGlobal>::value)
+        if (wb + lane < we) raw_ahead = v.ops.raw(v.raw_index(wb + lane));
     for (uint32_t base = wb; base < we; base += 64) {
         const uint32_t i = base + lane;
         int64_t len = 0;
         int op = OP_I;
-        if (i < we) v.get(i, len, op);
+        if constexpr (std::is_same<OPS, OpsGlobal>::value) {
+            const uint32_t raw_now = raw_ahead;
+            raw_ahead = 0;
+            if (i + 64u < we) raw_ahead = v.ops.raw(v.raw_index(i + 64u));
+            if (i < we) v.decode(raw_now, v.raw_index(i), len, op);
+        } else {
+            if (i < we) v.get(i, len, op);
+        }
         const uint32_t dq = (i < we && op != OP_D) ? (uint32_t)len : 0u, dt = (i < we && op != OP_I) ? (uint32_t)len : 0u;
         const uint32_t qinc = wave_incl_scan_u32(dq), tinc = wave_incl_scan_u32(dt);
         const uint32_t qrel = qinc - dq, trel = tinc - dt; /* columns in front of this op, from the window's first */
