@@ -358,6 +358,30 @@ __device__ __forceinline__ int flat_check(const FlatState &s, const FlatView &v)
     return 0;
 }
 
+/* `paffy filter` on a record's totals (impl/paf_filter.c:120-156, paf_stats_calc impl/paf.c:236-260): true = the record passes the thresholds */
+__device__ __forceinline__ bool flat_filter_pass(const KParams &P, const RecMeta &m, const FlatView &v) {
+    const int64_t mm = v.tm(), mx = v.tx();
+    const int64_t all = mm + mx;
+    const int64_t ins = all - v.tt(), del = all - v.tq();
+    const double identity = ratio_f32(mm, mm + (mx - ins - del));
+    const double identity_with_gaps = ratio_f32(mm, all);
+    const int64_t f_as = P.filter.min_alignment_score, f_cs = P.filter.min_chain_score, f_tl = P.filter.max_tile_level;
+    const double f_id = P.filter.min_identity, f_idg = P.filter.min_identity_with_gaps;
+    return m.score >= f_as && m.chain_score >= f_cs && (f_tl == -1 || m.tile_level <= f_tl) && identity >= f_id && identity_with_gaps >= f_idg;
+}
+/* a record a filter stage drops: no output, later stages never see it */
+__device__ __forceinline__ void flat_dropped(const KParams &P, uint8_t *flat_done, uint32_t rec) {
+    RecPlan *dp = static_cast<RecPlan *>(P.rec_plan) + rec;
+    flat_done[rec] = 1;
+    P.status[rec] = (uint32_t)KLASS_LDS << 16;
+    P.err_aux[rec] = 0;
+    P.n_ops[rec] = 0;
+    P.out_len[rec] = 0;
+    P.out_rows[rec] = 0;
+    dp->flags = 128u;
+    dp->n = 0;
+}
+
 /*
  * (double)((float)num / (float)den) < thr and >= idd, thr = (double)thr_f, idd = (double)id_f -- the comparisons of impl/paf.c:832-833 and
  * 886-887 -- decided without the division unless the quotient is within 4e-6 of the threshold: conversions, product and quotient are
@@ -780,12 +804,17 @@ __global__ __launch_bounds__(256) void k_flat_lane(FlatSizeParams F) {
             } else if (st.kind == PAFFY_SHATTER) {
                 shatter = true;
                 break;
+            } else if (st.kind == PAFFY_FILTER) {
+                if (flat_filter_pass(P, m, v) == (P.filter.invert != 0)) {
+                    flat_dropped(P, F.flat_done, rec);
+                    return;
+                }
             } else if (st.kind != PAFFY_PASS) {
                 give_up = true;
                 break;
             }
             if (rc) { give_up = true; break; }
-            checked = st.kind != PAFFY_PASS;
+            checked = st.kind != PAFFY_PASS && st.kind != PAFFY_FILTER;
         }
         if (give_up || v.n == 0) break;
         if (shatter && ((flags & FLAT_F_NONPLAIN) || (!checked && flat_check(s, v)))) break;
@@ -1045,11 +1074,16 @@ __device__ __forceinline__ void flat_size_one(const FlatSizeParams &F, uint32_t 
         } else if (st.kind == PAFFY_SHATTER) {
             shatter = true;
             break;
+        } else if (st.kind == PAFFY_FILTER) {
+            if (flat_filter_pass(P, m, v) == (P.filter.invert != 0)) {
+                if (lane == 0) flat_dropped(P, F.flat_done, rec);
+                return;
+            }
         } else if (st.kind != PAFFY_PASS) {
             return flat_leave(F, rec, FLAT_WHY_STAGE);
         }
         if (rc) return flat_leave(F, rec, FLAT_WHY_CHECK);
-        checked = st.kind != PAFFY_PASS;
+        checked = st.kind != PAFFY_PASS && st.kind != PAFFY_FILTER;
     }
     RecPlan *plan = static_cast<RecPlan *>(P.rec_plan) + rec;
     int64_t bytes, rows;

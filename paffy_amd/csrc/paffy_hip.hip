@@ -1215,7 +1215,9 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     static const bool flat_off = getenv("PAFFY_NO_FLAT") != nullptr;
     /* `paffy add_mismatches` alone (BASELINE cfg4): the same parse, the encoder on the pieces (flat_add_kernel.h) */
     const bool flat_add = n_stages == 1 && stages[0].kind == PAFFY_ADD_MISMATCHES && nocheck_mask == 0 && !flat_off && c->n_seqs > 0;
-    const bool flat = (lean && nocheck_mask == 0 && n_stages > 0 && !flat_off) || flat_add;
+    bool lean_or_filter = n_stages > 0; /* the flat pass also knows `paffy filter` (a predicate on the sums it keeps anyway) */
+    for (int32_t i = 0; i < n_stages; i++) lean_or_filter = lean_or_filter && (((PAFFY_MASK_LEAN | (1u << PAFFY_FILTER)) >> stages[i].kind) & 1u);
+    const bool flat = (lean_or_filter && nocheck_mask == 0 && !flat_off) || flat_add;
     {
         int rc = index_and_parse(c, in, len, &n_lines, lvl0_max, flat);
         if (rc) return rc;
