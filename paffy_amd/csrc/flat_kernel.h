@@ -540,6 +540,88 @@ __device__ __forceinline__ void flat_trim_prefix(const FlatRec &R, FlatState &s,
  * VALU + 1 346 scalar instructions per record). Anything else -- long records, deep trims, a power of ten inside a coordinate range,
  * whatever the flat pass leaves to the record kernels -- is put on a list for k_flat_size, which sizes it the way described above.
  */
+/*
+ * The three constant pieces of a shatter record's rows (A = qname \t qlen \t | B = \t strand \t tname \t tlen \t | C = \t mapq tags \tcg:Z:,
+ * paf_shatter2 + paf_write, impl/paf.c:600-627, 317-368), at most 48 bytes each, left in the record's 144 bytes of P.row_pieces (3 x 48,
+ * zero filled) by the sizing pass. In the row writer this was every wave's prologue -- 64 lanes for thirteen items, 0.16 ms of a cfg3
+ * step and 0.09 ms of a cfg2 step --; in the lane kernel ONE lane's few hundred instructions are shared by the 64 records of its wave:
+ * the names come with three 16-byte loads each, the text is put together byte by byte in the lane's column of the kernel's LDS (36
+ * dwords; the summaries that lived there are no longer needed) and leaves as nine 16-byte stores. RecPlan flag bit 21 tells the row writer that the
+ * block is there; for the records of the wave kernel (one in eight on cfg3) it builds the pieces itself as before (row_pieces_lanes).
+ */
+#define FLAT_F_ROW_PIECES 0x200000u
+#define FLAT_ROW_PIECES_BYTES 144u
+struct LanePieceSink {
+    uint32_t (*S)[256];
+    uint32_t tid;
+    __device__ __forceinline__ void put(uint32_t piece, uint32_t n, uint32_t c) const { reinterpret_cast<uint8_t *>(&S[12u * piece + (n >> 2)][tid])[n & 3u] = (uint8_t)c; }
+    __device__ __forceinline__ uint32_t dec(uint32_t piece, uint32_t n, int64_t val) const {
+        uint64_t u = val < 0 ? 0ull - (uint64_t)val : (uint64_t)val;
+        if (val < 0) put(piece, n++, '-');
+        const uint32_t d = (uint32_t)dec_len((int64_t)(u > 0x7fffffffffffffffull ? 0x7fffffffffffffffull : u)); /* |INT64_MIN|: 19 digits like INT64_MAX */
+        if ((u >> 32) == 0) {
+            uint32_t w = (uint32_t)u;
+            for (uint32_t i = d; i-- > 0;) { put(piece, n + i, '0' + w % 10u); w /= 10u; }
+        } else {
+            for (uint32_t i = d; i-- > 0;) { put(piece, n + i, '0' + (uint32_t)(u % 10ull)); u /= 10ull; }
+        }
+        return n + d;
+    }
+    __device__ __forceinline__ uint32_t tag(uint32_t piece, uint32_t n, char a, char b, char t) const {
+        put(piece, n, '\t'); put(piece, n + 1, (uint8_t)a); put(piece, n + 2, (uint8_t)b); put(piece, n + 3, ':'); put(piece, n + 4, (uint8_t)t); put(piece, n + 5, ':');
+        return n + 6;
+    }
+};
+__device__ __forceinline__ void lane_row_pieces(uint32_t (*S)[256], uint32_t tid, uint8_t *dst, const RecState &s, const uint8_t *in) { /* lenA, lenB, lenC <= 48 */
+    u32x4 qn[3], tn[3];
+#pragma unroll
+    for (uint32_t j = 0; j < 3; j++) { /* at most 15 bytes beyond a name: the line's later columns */
+        qn[j] = u32x4{0, 0, 0, 0};
+        tn[j] = u32x4{0, 0, 0, 0};
+        if (16u * j < s.qn_len) qn[j] = *reinterpret_cast<const u32x4_unaligned *>(in + s.qn_off + 16u * j);
+        if (16u * j < s.tn_len) tn[j] = *reinterpret_cast<const u32x4_unaligned *>(in + s.tn_off + 16u * j);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 36; j++) S[j][tid] = 0;
+    const uint32_t qd[12] = {qn[0].x, qn[0].y, qn[0].z, qn[0].w, qn[1].x, qn[1].y, qn[1].z, qn[1].w, qn[2].x, qn[2].y, qn[2].z, qn[2].w};
+    const uint32_t td[12] = {tn[0].x, tn[0].y, tn[0].z, tn[0].w, tn[1].x, tn[1].y, tn[1].z, tn[1].w, tn[2].x, tn[2].y, tn[2].z, tn[2].w};
+    /* whole dwords of the names; what a name's last dword holds beyond its end (at most three bytes) is covered by the tab, digit and tab that follow */
+#pragma unroll
+    for (uint32_t j = 0; j < 12; j++)
+        if (4u * j < s.qn_len) S[j][tid] = qd[j];
+    uint32_t prev = ((uint32_t)'\t' | ((uint32_t)(s.same ? '+' : '-') << 8) | ((uint32_t)'\t' << 16)) << 8; /* B = \t strand \t tname ...: the name starts at byte 3 */
+#pragma unroll
+    for (uint32_t j = 0; j < 12; j++) {
+        if (4u * j < s.tn_len + 3u) S[12 + j][tid] = __builtin_amdgcn_alignbyte(td[j], prev, 1);
+        prev = td[j];
+    }
+    const LanePieceSink k{S, tid};
+    uint32_t n = s.qn_len;
+    k.put(0, n++, '\t');
+    n = k.dec(0, n, s.qlen);
+    k.put(0, n++, '\t');
+    n = 3u + s.tn_len;
+    k.put(1, n++, '\t');
+    n = k.dec(1, n, s.tlen);
+    k.put(1, n++, '\t');
+    n = 0;
+    k.put(2, n++, '\t');
+    n = k.dec(2, n, s.mapq);
+    if (s.type != 0 || s.tile_level != -1) { /* impl/paf.c:343-348 */
+        n = k.tag(2, n, 't', 'p', 'A');
+        k.put(2, n++, s.type ? s.type : (uint8_t)(s.tile_level > 1 ? 'S' : 'P'));
+    }
+    if (s.score != 2147483647ll) n = k.dec(2, k.tag(2, n, 'A', 'S', 'i'), s.score); /* INT_MAX guard, impl/paf.c:349 */
+    if (s.tile_level != -1) n = k.dec(2, k.tag(2, n, 't', 'l', 'i'), s.tile_level);
+    if (s.chain_id != -1) n = k.dec(2, k.tag(2, n, 'c', 'n', 'i'), s.chain_id);
+    n = k.tag(2, n, 's', '1', 'i'); /* the children carry s1:i:0 (calloc, impl/paf.c:601) */
+    k.put(2, n++, '0');
+    k.tag(2, n, 'c', 'g', 'Z');
+#pragma unroll
+    for (uint32_t q = 0; q < 9; q++)
+        reinterpret_cast<uint4 *>(dst)[q] = make_uint4(S[4 * q][tid], S[4 * q + 1][tid], S[4 * q + 2][tid], S[4 * q + 3][tid]);
+}
+
 #define FLAT_LANE_MAX_PIECES 12u
 #define FLAT_LANE_WALK_BUDGET 1024 /* ops a lane looks at one by one before it hands its record to a wave */
 
@@ -712,7 +794,9 @@ __device__ __forceinline__ void lane_trim_prefix(LaneRec &R, FlatState &s, FlatV
 }
 
 __global__ __launch_bounds__(256) void k_flat_lane(FlatSizeParams F) {
-    __shared__ uint32_t s_cnt[FLAT_LANE_MAX_PIECES][256], s_m[FLAT_LANE_MAX_PIECES][256], s_x[FLAT_LANE_MAX_PIECES][256];
+    __shared__ uint32_t s_all[3 * FLAT_LANE_MAX_PIECES][256]; /* per lane: count / M / X sums of its record's pieces, at the end the row pieces' text */
+    static_assert(3 * FLAT_LANE_MAX_PIECES >= 36, "lane_row_pieces() needs 36 dwords per lane");
+    uint32_t (*s_cnt)[256] = s_all, (*s_m)[256] = s_all + FLAT_LANE_MAX_PIECES, (*s_x)[256] = s_all + 2 * FLAT_LANE_MAX_PIECES;
     const KParams &P = F.P;
     const uint32_t rec = blockIdx.x * 256u + threadIdx.x, tid = threadIdx.x;
     if (rec >= P.n_rec) return;
@@ -852,10 +936,12 @@ __global__ __launch_bounds__(256) void k_flat_lane(FlatSizeParams F) {
         P.out_rows[rec] = rows;
         plan->qs = s.qs; plan->qe = s.qe; plan->ts = s.ts; plan->te = s.te; plan->sub_lo = 0; plan->sub_hi = 0;
         plan->lo = v.lo; plan->n = v.n;
+        const bool pieces = rows_kernel && P.row_pieces != nullptr;
         plan->flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | 8u | ((uint32_t)rs.type << 8) | (shatter ? 16u : 0u) |
-                      (rows_kernel ? 64u : 0u) | (line_kernel ? 0x10000u : 0u) | 0x40000u;
+                      (rows_kernel ? 64u : 0u) | (line_kernel ? 0x10000u : 0u) | 0x40000u | (pieces ? FLAT_F_ROW_PIECES : 0u);
         plan->chunk = ((v.n + 63u) / 64u) | 1u;
         for (int w = 0; w < 4; w++) plan->wq[w] = plan->wt[w] = plan->wo[w] = 0;
+        if (pieces) lane_row_pieces(s_all, tid, P.row_pieces + (uint64_t)FLAT_ROW_PIECES_BYTES * rec, rs, P.in);
         done = true;
     } while (false);
     if (!done) F.defer[atomicAdd(&P.info->flat_defer, 1u)] = rec;

@@ -807,7 +807,7 @@ struct paffy_hip_ctx {
     bool plan_seq_lookup = false; /* rec_qseq / rec_tseq belong to the current plan */
     DevBuf seq_raw, pretty_off, pretty_out, pretty_err, host_in, host_out;
     DevBuf rec_stats; /* six sums per record of the PAFFY_STATS stage */
-    DevBuf flat_nd, flat_rec, flat_chunks, flat_sums, flat_done, flat_items; /* the flat sizing pass (flat_kernel.h) */
+    DevBuf flat_nd, flat_rec, flat_chunks, flat_sums, flat_done, flat_items, flat_pieces; /* the flat sizing pass (flat_kernel.h) */
     DevBuf add_pieces, add_scr_cnt, add_scr_off, add_new_cnt, add_new_off, add_text, add_bad, add_part, add_scratch, add_new_ops; /* flat_add_kernel.h */
     uint32_t flat_piece_slots = 0;
     DevBuf bed_keys, bed_tab, bed_starts, bed_len, bed_off, bed_tiles;
@@ -1015,7 +1015,7 @@ void paffy_hip_destroy(paffy_hip_ctx *c) {
     c->index_pool.clear();
     if (c->one_batch.p) (void)hipFree(c->one_batch.p);
     DevBuf *bufs[] = {&c->tile_counts, &c->sep_pos, &c->nl_idx, &c->meta, &c->out_len, &c->out_rows, &c->status, &c->err_aux,
-                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->seq_raw, &c->pretty_off, &c->pretty_out, &c->pretty_err, &c->host_in, &c->host_out, &c->rec_stats, &c->flat_nd, &c->flat_rec, &c->flat_chunks, &c->flat_sums, &c->flat_done, &c->flat_items, &c->add_pieces, &c->add_scr_cnt, &c->add_scr_off, &c->add_new_cnt, &c->add_new_off, &c->add_text, &c->add_bad, &c->add_part, &c->add_scratch, &c->add_new_ops, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
+                      &c->n_ops, &c->arena_off, &c->out_off, &c->w_list, &c->b_list, &c->b_list1, &c->arena, &c->info, &c->synth_sizes, &c->rec_plan, &c->ops_mirror, &c->seq_blob, &c->seq_table, &c->seq_names, &c->seq_name_off, &c->synth4_contigs, &c->synth4_q, &c->synth4_t, &c->seq_comp, &c->seq_raw, &c->pretty_off, &c->pretty_out, &c->pretty_err, &c->host_in, &c->host_out, &c->rec_stats, &c->flat_nd, &c->flat_rec, &c->flat_chunks, &c->flat_sums, &c->flat_done, &c->flat_items, &c->flat_pieces, &c->add_pieces, &c->add_scr_cnt, &c->add_scr_off, &c->add_new_cnt, &c->add_new_off, &c->add_text, &c->add_bad, &c->add_part, &c->add_scratch, &c->add_new_ops, &c->bed_keys, &c->bed_tab, &c->bed_starts, &c->bed_len, &c->bed_off, &c->bed_tiles,
                       &c->rec_qseq, &c->rec_tseq, &c->tile_keys, &c->tile_order, &c->tile_rank, &c->tile_coff, &c->tile_cbase,
                       &c->tile_cov, &c->tile_level, &c->tile_len, &c->tile_items, &c->tile_slots, &c->tile_parts, &c->scan_part, &c->dedupe_keys, &c->emit_order, &c->order_cnt};
     for (DevBuf *b : bufs)
@@ -1394,6 +1394,17 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
         if (ensure(c, c->flat_items, sizeof(EmitItem) * items_cap)) return PAFFY_E_HIP;
         kp.items = static_cast<EmitItem *>(c->flat_items.p);
         kp.items_cap = (uint32_t)items_cap;
+        /* the constant pieces of a shatter record's rows, 144 bytes per record (lane_row_pieces, flat_kernel.h) */
+        static const bool no_pieces = getenv("PAFFY_NO_ROW_PIECES") != nullptr;
+        const bool has_shatter = [&] {
+            for (int32_t i = 0; i < n_stages; i++)
+                if (stages[i].kind == PAFFY_SHATTER) return true;
+            return false;
+        }();
+        if (has_shatter && !no_pieces) {
+            if (ensure(c, c->flat_pieces, FLAT_ROW_PIECES_BYTES * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
+            kp.row_pieces = static_cast<uint8_t *>(c->flat_pieces.p);
+        }
         FlatSizeParams fs;
         fs.P = kp;
         fs.sums = fp.sums;

@@ -3696,7 +3696,14 @@ __global__ __launch_bounds__(64, PAFFY_ROWS_OCC) void k_emit_rows(KParams P) {
     ShatterConst k;
     shatter_consts(s, k);
     uint8_t *A = smem + PAFFY_WAVE_RING, *B = A + 64, *C = B + 64;
+#if !defined(PAFFY_ABL) || PAFFY_ABL != 41 /* 41: without the per-record pieces (their cost) */
+    if (pl.flags & 0x200000u) { /* the flat sizing pass left the pieces in HBM (row_pieces_serial, flat_kernel.h) */
+        if (threadIdx.x < 48) /* 3 x 48 bytes there, 3 x 64 zero filled bytes here */
+            reinterpret_cast<uint32_t *>(A)[threadIdx.x] =
+                (threadIdx.x & 15u) < 12u ? reinterpret_cast<const uint32_t *>(P.row_pieces + 144ull * rec)[12u * (threadIdx.x >> 4) + (threadIdx.x & 15u)] : 0u;
+    } else
     row_pieces_lanes(A, s, P.in); /* A = qname \t qlen \t | B = \t strand \t tname \t tlen \t | C = \t mapq tags \tcg:Z: -- 64 bytes each, zero filled */
+#endif
     __builtin_amdgcn_wave_barrier();
 #if defined(PAFFY_ABL) && PAFFY_ABL == 24 /* core clock against the 100 MHz wall clock inside the row kernel */
     const unsigned long long c0 = clock64(), w0 = wall_clock64();

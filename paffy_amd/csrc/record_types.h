@@ -129,6 +129,7 @@ struct KParams {
     const uint32_t *new_ops;    /* flat_add_kernel.h: the rebuilt cigars of all records, 4-byte ops back to back (RecPlan flag bit 20: arena_off counts words of it) */
     EmitItem *items;            /* segments of long records, written by the flat sizing pass, emitted by k_emit_rows in front of the records */
     uint32_t n_items, items_cap;
+    uint8_t *row_pieces;        /* flat sizing pass: the three constant pieces of a record's rows, 3 x 48 zero filled bytes per record (RecPlan flag bit 21; NULL: none) */
     const uint8_t *flat_done;   /* flat sizing pass: 1 = the record has been sized there, the record kernels skip it (NULL: no flat pass) */
 };
 

@@ -199,3 +199,41 @@ def test_no_flat_switch_gives_the_same_bytes(eng, human_chimp):
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PAFFY_NO_FLAT="1"), capture_output=True, text=True, check=True).stdout.strip()
     got, _ = eng.run([__import__("paffy_amd").stage(k) for k in (O.INVERT, O.TRIM_IDENTITY, O.SHATTER)], human_chimp)
     assert out == hashlib.sha256(got).hexdigest()
+
+
+def test_row_pieces_of_the_sizing_pass(eng):
+    """The constant pieces of a record's rows (name and length columns, mapq and tags) are put together by the sizing pass, one lane per
+    record (lane_row_pieces, flat_kernel.h), and copied by the row writer: names of every length the one-wave row writer takes (pieces
+    of at most 48 bytes; longer ones take the general writer), every tag present or absent, negative and many-digit values, both
+    strands, with and without an invert in front (the names swap), next to each other in one batch."""
+    rng = random.Random(77)
+    lines = []
+    tag_sets = ["", "tp:A:P", "tp:A:S\tAS:i:-5", "AS:i:2147483646\ts1:i:9", "tl:i:3", "tl:i:1\tcn:i:12\ts1:i:-7", "tp:A:I\tAS:i:0\ttl:i:2\tcn:i:4000000000\ts1:i:1",
+                "AS:i:-2147483648", "cn:i:0"]
+    for k in range(1200):
+        nq, nt = rng.choice((1, 2, 7, 15, 16, 17, 31, 32, 33, 40, 43, 44, 45, 46, 60)), rng.choice((1, 3, 12, 13, 16, 28, 29, 36, 37, 38, 39, 40, 41, 55))
+        qname = "".join(rng.choice("abcXYZ_.|0123456789") for _ in range(nq))
+        tname = "".join(rng.choice("abcXYZ_.|0123456789") for _ in range(nt))
+        qlen, tlen = rng.choice((5000, 99_999, 100_000, 4_000_000_000, 250_000_000)), rng.choice((7000, 9_999_999, 10_000_000, 5_000_000_000))
+        line = record(random_ops(rng, rng.choice((1, 3, 20, 90)), lens=(1, 5, 30), indel=(1, 4)), strand=rng.choice("+-"), qname=qname, tname=tname, qlen=qlen, tlen=tlen,
+                      tags=rng.choice(tag_sets), rng=rng)
+        mapq = rng.choice(("0", "7", "60", "255"))
+        cols = line.split("\t")
+        cols[11] = mapq
+        lines.append("\t".join(c for c in cols if c != ""))
+
+    def fits(line):  # both ways round (the invert swaps the names): name, tab, length, tab <= 48 and tab, strand, tab, name, tab, length, tab <= 48
+        c = line.rstrip("\n").split("\t")
+        tags = [t for t in c[12:-1] if not t.startswith("s1:")]
+        if any(t.startswith("tl:") for t in tags) and not any(t.startswith("tp:") for t in tags):
+            tags.append("tp:A:P")  # a tile level makes a type (impl/paf.c:343-348)
+        len_c = 1 + len(c[11]) + sum(1 + len(t) for t in tags) + 7 + 6  # \t mapq tags \ts1:i:0 \tcg:Z:
+        first_ok = min(len(c[0]) + len(c[1]), len(c[5]) + len(c[6])) + 2 >= 16  # the one-wave row writer wants a first piece of a whole 16 bytes
+        return first_ok and len_c <= 48 and all(len(a) + len(b) + 5 <= 48 for a, b in ((c[0], c[1]), (c[5], c[6]), (c[0], c[6]), (c[5], c[1])))
+
+    pipes = ([O.SHATTER], [O.INVERT, O.SHATTER], [O.INVERT, O.TRIM_IDENTITY, O.SHATTER])
+    short = [l for l in lines if fits(l)]
+    assert 100 < len(short) < len(lines)
+    run_both(eng, "".join(short).encode(), pipes=pipes)
+    assert kept_all(3)
+    run_both(eng, "".join(lines).encode(), pipes=pipes)  # the longer names among them: those records take the general row writer
