@@ -623,7 +623,10 @@ __device__ __forceinline__ void lane_row_pieces(uint32_t (*S)[256], uint32_t tid
 }
 
 #define FLAT_LANE_MAX_PIECES 12u
-#define FLAT_LANE_WALK_BUDGET 1024 /* ops a lane looks at one by one before it hands its record to a wave */
+#ifndef FLAT_LANE_WALK_BUDGET
+#define FLAT_LANE_WALK_BUDGET 1024
+#endif
+/* ops a lane looks at one by one before it hands its record to a wave */
 
 struct LaneRec {
     const PieceSum *ps;
@@ -661,6 +664,18 @@ struct LaneOps {
         const uint32_t w_end = v.lo + v.n;
         const uint16_t *p = v.rev ? ops + (w_end - i) - 8u : ops + v.lo + i;
         w = *reinterpret_cast<const u32x4_unaligned *>(p);
+    }
+    __device__ __forceinline__ void sums(uint32_t &m, uint32_t &x) const { /* bases of the eight ops: in M and = ops, in the others */
+        const uint32_t d[4] = {w.x, w.y, w.z, w.w};
+        uint32_t all = 0;
+        m = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t lo = d[k] & 0xffffu, hi = d[k] >> 16;
+            all += (lo >> 3) + (hi >> 3);
+            m += ((lo >> 3) & (0u - ((0x9u >> (lo & 7u)) & 1u))) + ((hi >> 3) & (0u - ((0x9u >> (hi & 7u)) & 1u)));
+        }
+        x = all - m;
     }
     __device__ __forceinline__ uint32_t get(const FlatView &v, uint32_t k) const { /* op i + k, k = 0..7 */
         const uint32_t j = v.rev ? 7u - k : k;
@@ -735,6 +750,19 @@ __device__ __forceinline__ void lane_trim_prefix(LaneRec &R, FlatState &s, FlatV
             LaneOps blk;
             blk.load(R.ops, v, i0);
             R.budget -= 8;
+            if (i0 + 8u <= ve && pm > 0) {
+                /* a whole block of eight ops: a prefix that ends inside it has at least the matches in front of the block and at most the
+                   mismatches in front of it plus the block's, so when even that ratio is not below the threshold (the margin of the
+                   piece bound above) none of the eight is a hit and their sums are all the walk needs of them -- an eighth of the
+                   instructions of the op-by-op look. Past the first few blocks of an end that is the usual case. */
+                uint32_t bm, bx;
+                blk.sums(bm, bx);
+                if ((double)pm >= thr * 1.00001 * (double)(pm + px + bx) && !(max_trim >= 0 && (int64_t)pm + (int64_t)px + (int64_t)bm + (int64_t)bx > max_trim)) {
+                    pm += bm;
+                    px += bx;
+                    continue;
+                }
+            }
 #pragma unroll
             for (uint32_t j = 0; j < 8u; j++) {
                 if (i0 + j < ve && !stop) {
