@@ -745,10 +745,15 @@ __device__ __forceinline__ void lane_trim_prefix(LaneRec &R, FlatState &s, FlatV
         if (pm > 0 && (double)pm >= thr * 1.00001 * (double)(pm + x_end)) continue; /* cannot hold a hit (flat_trim_prefix) */
         const uint32_t vb = v.rev ? w_end - b_cnt : a_cnt - v.lo, ve = v.rev ? w_end - a_cnt : b_cnt - v.lo;
         bool stop = false;
-        for (uint32_t i0 = vb; i0 < ve && !stop; i0 += 8u) {
+        /* the blocks' loads run three ahead of their use: a lane's sixteen bytes are a cache line of their own, and with one load in flight
+           the walk was waiting for it most of the time */
+        LaneOps blk, ahead1, ahead2, ahead3;
+        blk.load(R.ops, v, vb);
+        if (vb + 8u < ve) ahead1.load(R.ops, v, vb + 8u);
+        if (vb + 16u < ve) ahead2.load(R.ops, v, vb + 16u);
+        for (uint32_t i0 = vb; i0 < ve && !stop; i0 += 8u, blk = ahead1, ahead1 = ahead2, ahead2 = ahead3) {
             if (i0 != vb && pm > 0 && (double)pm >= thr * 1.00001 * (double)(pm + x_end)) break;
-            LaneOps blk;
-            blk.load(R.ops, v, i0);
+            if (i0 + 24u < ve) ahead3.load(R.ops, v, i0 + 24u);
             R.budget -= 8;
             if (i0 + 8u <= ve && pm > 0) {
                 /* a whole block of eight ops: a prefix that ends inside it has at least the matches in front of the block and at most the
@@ -827,6 +832,9 @@ __global__ __launch_bounds__(256) void k_flat_lane(FlatSizeParams F) {
     uint32_t (*s_cnt)[256] = s_all, (*s_m)[256] = s_all + FLAT_LANE_MAX_PIECES, (*s_x)[256] = s_all + 2 * FLAT_LANE_MAX_PIECES;
     const KParams &P = F.P;
     const uint32_t rec = blockIdx.x * 256u + threadIdx.x, tid = threadIdx.x;
+#if defined(PAFFY_ABL) && PAFFY_ABL == 51
+    const unsigned long long abl_w0 = wall_clock64();
+#endif
     if (rec >= P.n_rec) return;
     bool done = false;
     do { /* one pass; `break` = the record goes to k_flat_size */
@@ -973,6 +981,13 @@ __global__ __launch_bounds__(256) void k_flat_lane(FlatSizeParams F) {
         done = true;
     } while (false);
     if (!done) F.defer[atomicAdd(&P.info->flat_defer, 1u)] = rec;
+#if defined(PAFFY_ABL) && PAFFY_ABL == 51 /* how long the waves of the lane kernel live: histogram of log2(ticks of the 100 MHz wall clock) in DevInfo::flat_reason */
+    {
+        const unsigned long long dt = wall_clock64() - abl_w0;
+        const uint32_t b = dt ? 63u - (uint32_t)__clzll((long long)dt) : 0u;
+        if ((threadIdx.x & 63u) == 0) atomicAdd(&P.info->flat_reason[b < 15u ? b : 15u], 1u);
+    }
+#endif
 }
 
 

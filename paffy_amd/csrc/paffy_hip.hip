@@ -63,6 +63,40 @@ __device__ __forceinline__ void sep_masks(const uint8_t *in, uint32_t in_len, ui
     }
 }
 
+/*
+ * The same masks and the non-digit count with fewer instructions (the one-pass index spends most of its time on them: 2 700 VALU
+ * instructions per wave, two thirds of them here). Per 4-byte word: bytes 9 and 10 are the bytes b < 0x80 with ((b | 0x80) - 9) & 0xfe
+ * == 0x80 -- one subtraction without borrows between the bytes, one zero-byte test -- and the newlines among them have bit 0 of the
+ * difference set; the four flag bits of a word (bit 7 of each byte) are gathered by one multiplication; non-digit bytes are counted on
+ * the flags themselves; the newline mask is only put together in the (few) rounds in which a lane of the wave has one.
+ */
+__device__ __forceinline__ void sep_masks_nd(const uint4 &v, uint32_t in_len, uint32_t g, uint32_t &tabs_nl, uint32_t &nl, uint32_t &nondigits) {
+    /* v: the 16 bytes at g (a multiple of 16), loaded by the caller -- all the loads of a workgroup's tile are issued before the first is looked at */
+    tabs_nl = nl = nondigits = 0;
+    if (g >= in_len) return;
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t nlf[4], any_nl = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        nondigits += (uint32_t)__popc(nondigit4(w[k]));
+        const uint32_t u = (w[k] | 0x80808080u) - 0x09090909u;                       /* per byte: 0x80 for a tab, 0x81 for a newline; no borrows */
+        const uint32_t z = ((u ^ 0x80808080u) & 0xfefefefeu) | (w[k] & 0x80808080u); /* zero byte <=> tab or newline */
+        const uint32_t f = ~(((z & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z) & 0x80808080u;   /* bit 7 of every zero byte */
+        nlf[k] = f & (u << 7);
+        any_nl |= nlf[k];
+        tabs_nl |= ((f * 0x00204081u) >> 28) << (4 * k); /* bits 7, 15, 23, 31 -> 28 .. 31: the other partial products stay below bit 24 */
+    }
+    if (any_nl) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) nl |= ((nlf[k] * 0x00204081u) >> 28) << (4 * k);
+    }
+    if (in_len - g < 16u) { /* the text ends inside these 16 bytes */
+        const uint32_t keep = (1u << (in_len - g)) - 1u;
+        tabs_nl &= keep;
+        nl &= keep; /* (the non-digit count takes the 16 bytes as loaded, like sep_masks<true>: no cigar reaches beyond the text) */
+    }
+}
+
 __global__ __launch_bounds__(PAFFY_NT) void k_sep_count(const uint8_t *in, uint32_t in_len, uint2 *tile_counts, uint16_t *nd) {
     __shared__ int64_t scratch_mem[2 * PAFFY_NWAVE * 4];
     BlockComm scratch{scratch_mem, 0};
@@ -70,7 +104,9 @@ __global__ __launch_bounds__(PAFFY_NT) void k_sep_count(const uint8_t *in, uint3
     int64_t acc[2] = {0, 0};
     for (uint32_t off = threadIdx.x * 16; off < SEP_TILE; off += PAFFY_NT * 16) {
         uint32_t a, b, c;
-        sep_masks<true>(in, in_len, tile0 + off, a, b, &c);
+        uint4 txt = make_uint4(0, 0, 0, 0);
+        if (tile0 + off < in_len) txt = *reinterpret_cast<const uint4 *>(in + tile0 + off);
+        sep_masks_nd(txt, in_len, tile0 + off, a, b, c);
         acc[0] += __popc(a);
         acc[1] += __popc(b);
         c = wave_sum_u32(c); /* a wave's 64 x 16 bytes are one 1 KiB tile */
@@ -169,10 +205,17 @@ __global__ __launch_bounds__(PAFFY_NT) void k_sep_index(const uint8_t *in, uint3
     const uint32_t tile = s_tile, tile0 = tile * SEP_TILE;
     unsigned long long *status = state + 1;
     uint32_t m[16];
+    uint4 txt[16]; /* the tile's sixteen loads in flight together: one at a time, each waited for, was most of the kernel's time */
+#pragma unroll
+    for (uint32_t it = 0; it < 16; it++) {
+        const uint32_t g = tile0 + it * (PAFFY_NT * 16u) + tid * 16u;
+        txt[it] = make_uint4(0, 0, 0, 0);
+        if (g < in_len) txt[it] = *reinterpret_cast<const uint4 *>(in + g);
+    }
 #pragma unroll
     for (uint32_t it = 0; it < 16; it++) {
         uint32_t a, b, c;
-        sep_masks<true>(in, in_len, tile0 + it * (PAFFY_NT * 16u) + tid * 16u, a, b, &c);
+        sep_masks_nd(txt[it], in_len, tile0 + it * (PAFFY_NT * 16u) + tid * 16u, a, b, c);
         c = wave_sum_u32(c); /* a wave's 64 x 16 bytes are one 1 KiB tile */
         if (lane == 0 && nd && tile0 + it * (PAFFY_NT * 16u) + tid * 16u < in_len) nd[(tile0 + it * (PAFFY_NT * 16u) + tid * 16u) >> FLAT_TILE_SHIFT] = (uint16_t)c;
         m[it] = a | (b << 16);
