@@ -3693,6 +3693,9 @@ __global__ __launch_bounds__(64, PAFFY_ROWS_OCC) void k_emit_rows(KParams P) {
     v.lo = pl.lo; v.rev = pl.flags & 1u; v.swp = (pl.flags & 2u) != 0;
     v.sub_lo = pl.sub_lo; v.sub_hi = pl.sub_hi;
     if (!is_item) we = v.n;
+#if defined(PAFFY_ABL) && PAFFY_ABL == 42 /* 42: one window per record (what a record costs before and after its rows) */
+    if (we > wb + 128u) we = wb + 128u;
+#endif
     ShatterConst k;
     shatter_consts(s, k);
     uint8_t *A = smem + PAFFY_WAVE_RING, *B = A + 64, *C = B + 64;
