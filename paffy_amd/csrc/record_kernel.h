@@ -2424,8 +2424,13 @@ __device__ __forceinline__ void shatter_emit_fast(const RecState &s, const View<
     const bool pre_ok = row_pre_ok(rc);
     /* digit bases: forward strand q = (qs + cq) + dq; reverse strand q0 = (qe - cq - total) + (total - dq - len) */
     DigitBase bq, bt;
+#if defined(PAFFY_ABL) && PAFFY_ABL == 43 /* 43: without the two digit bases' divisions and texts (their cost; the rows come out wrong) */
+    bq.P = 1; bq.W = (uint32_t)cq0; bq.t0 = 0x31; bq.t1 = 0x32; bq.n0 = bq.n1 = 1;
+    bt.P = 1; bt.W = (uint32_t)ct0; bt.t0 = 0x31; bt.t1 = 0x32; bt.n0 = bt.n1 = 1;
+#else
     bq.set(s.same ? (uint64_t)(s.qs + cq0) : (uint64_t)(s.qe - cq0));
     bt.set((uint64_t)(s.ts + ct0));
+#endif
     const uint32_t cap_bytes = PAFFY_WAVE_RING - 48 - PAFFY_FLUSH_GRAN; /* a carried rest of up to a granule in front */
     const uint32_t rows_cap = cap_bytes / k.row_max; /* >= 1: shatter_fast_ok */
     const uint32_t w_safe = rows_cap < 128 ? rows_cap : 128;
