@@ -544,65 +544,20 @@ __global__ __launch_bounds__(COV_NT, 4) void k_cov_walk(CovParams P, uint16_t *b
     const uint32_t rot = ((((lane >> 2) ^ (lane >> 3)) & 1u) << 1) | (((lane >> 1) ^ (lane >> 3)) & 1u);
     const uint32_t wa = 8u * lane + wave, wb = wa + COV_NT;          /* my two words of the slice ... */
     const uint32_t pa = wave * (COV_WORDS / 8u) + lane, pb = pa + 64u; /* ... and where their counters are */
-    /*
-     * What an entry needs from HBM is a chain of three loads -- its (slice, entry) pair, the entry's range and bitmap offset, this thread's
-     * two bitmap words -- and every wave of the workgroup used to sit through all three at the top of every entry, in front of a barrier
-     * (a fifth of an entry's time). They run ahead now: while entry j is walked the bitmap words of entry j + 1, the fields of entry j + 2
-     * and the pair of entry j + 3 are on their way.
-     */
-    struct Fields {
-        int64_t lo, hi;
-        uint64_t bm_off;
-        uint32_t pair_base, first_slice;
-    };
-    struct Words {
-        uint32_t w_lo, w_hi;
-        const uint32_t *bmw;
-        bool ha, hb;
-        uint32_t ba, bb;
-    };
-    auto load_fields = [&](uint32_t e) {
-        const CovEntry &E = P.entries[e];
-        Fields f;
-        f.lo = E.lo; f.hi = E.hi; f.bm_off = E.bm_off; f.pair_base = E.pair_base; f.first_slice = E.first_slice;
-        return f;
-    };
-    auto load_words = [&](const Fields &f) {
-        Words w;
-        const int64_t lo = f.lo > s_lo ? f.lo : s_lo, hi = f.hi < s_lo + (int64_t)COV_SLICE ? f.hi : s_lo + (int64_t)COV_SLICE;
-        w.w_lo = (uint32_t)((lo - s_lo) >> 5);
-        w.w_hi = (uint32_t)((hi - 1 - s_lo) >> 5) + 1u; /* slice words the entry touches */
-        /* slice word w is word (s_lo >> 5) + w - (E.lo >> 5) of the entry's bitmap */
-        w.bmw = P.bitmap + ((int64_t)(f.bm_off - P.bm_base) + ((s_lo >> 5) - (f.lo >> 5)));
-        w.ha = wa >= w.w_lo && wa < w.w_hi;
-        w.hb = wb >= w.w_lo && wb < w.w_hi;
-        /* every thread loads a word, its own or the nearest one of the entry (w_lo < w_hi: the entry touches the slice): a load that is
-           issued on every path can be counted, and the wait for an older load then leaves the younger ones in flight (a conditional
-           load makes the compiler wait for everything) */
-        const uint32_t ca = wa < w.w_lo ? w.w_lo : (wa >= w.w_hi ? w.w_hi - 1u : wa), cb = wb < w.w_lo ? w.w_lo : (wb >= w.w_hi ? w.w_hi - 1u : wb);
-        w.ba = w.bmw[ca];
-        w.bb = w.bmw[cb];
-        return w;
-    };
-    const uint32_t p_last = p1 - 1u; /* p0 < p1: an item has an entry */
-    Fields f_cur = load_fields((uint32_t)P.pairs[p0]), f_nxt = load_fields((uint32_t)P.pairs[p0 + 1 < p1 ? p0 + 1 : p_last]);
-    uint32_t e_nn = (uint32_t)P.pairs[p0 + 2 < p1 ? p0 + 2 : p_last];
-    Words w_cur = load_words(f_cur);
     for (uint32_t p = p0; p < p1; p++) {
         const uint32_t j = p - p0;
-        /* requests for the entries behind this one (what they need has been here since the entry before); past the item's last entry
-           they ask for the last entry's again */
-        const Words w_nxt = load_words(f_nxt);
-        const Fields f_nn = load_fields(e_nn);
-        const uint32_t e_n3 = (uint32_t)P.pairs[p + 3 < p1 ? p + 3 : p_last];
-        const Fields E = f_cur;
-        const uint32_t w_lo = w_cur.w_lo, w_hi = w_cur.w_hi;
-        const uint32_t *bmw = w_cur.bmw;
+        const uint32_t e = (uint32_t)P.pairs[p];
+        const CovEntry &E = P.entries[e];
+        const int64_t lo = E.lo > s_lo ? E.lo : s_lo, hi = E.hi < s_lo + (int64_t)COV_SLICE ? E.hi : s_lo + (int64_t)COV_SLICE;
+        const uint32_t w_lo = (uint32_t)((lo - s_lo) >> 5), w_hi = (uint32_t)((hi - 1 - s_lo) >> 5) + 1u; /* slice words the entry touches */
+        /* slice word w is word (s_lo >> 5) + w - (E.lo >> 5) of the entry's bitmap */
+        const uint32_t *bmw = P.bitmap + ((int64_t)(E.bm_off - P.bm_base) + ((s_lo >> 5) - (E.lo >> 5)));
         uint32_t *copy = L.hist[j & 1u][lane & (COV_COPIES - 1u)];
         uint32_t tmin = 0xffffffffu, tmax = 0;
-        const bool ha = w_cur.ha, hb = w_cur.hb;
-        const uint32_t ba = ha ? w_cur.ba : 0u, bb = hb ? w_cur.bb : 0u;
-        f_cur = f_nxt; f_nxt = f_nn; e_nn = e_n3; w_cur = w_nxt; /* (values: the loop body below works on its own copies) */
+        const bool ha = wa >= w_lo && wa < w_hi, hb = wb >= w_lo && wb < w_hi;
+        uint32_t ba = 0, bb = 0;
+        if (ha) ba = bmw[wa]; /* words in front of the entry's bitmap are never read: wa >= w_lo */
+        if (hb) bb = bmw[wb];
         if (ha) cov_word<HIST>(L, pa, ba, rot, copy, tmin, tmax);
         if (hb) cov_word<HIST>(L, pb, bb, rot, copy, tmin, tmax);
         if (!HIST) continue; /* to_bed: nothing is shared between entries */
