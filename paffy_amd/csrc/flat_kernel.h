@@ -745,15 +745,15 @@ __device__ __forceinline__ void lane_trim_prefix(LaneRec &R, FlatState &s, FlatV
         if (pm > 0 && (double)pm >= thr * 1.00001 * (double)(pm + x_end)) continue; /* cannot hold a hit (flat_trim_prefix) */
         const uint32_t vb = v.rev ? w_end - b_cnt : a_cnt - v.lo, ve = v.rev ? w_end - a_cnt : b_cnt - v.lo;
         bool stop = false;
-        /* the blocks' loads run three ahead of their use: a lane's sixteen bytes are a cache line of their own, and with one load in flight
-           the walk was waiting for it most of the time */
-        LaneOps blk, ahead1, ahead2, ahead3;
-        blk.load(R.ops, v, vb);
-        if (vb + 8u < ve) ahead1.load(R.ops, v, vb + 8u);
-        if (vb + 16u < ve) ahead2.load(R.ops, v, vb + 16u);
-        for (uint32_t i0 = vb; i0 < ve && !stop; i0 += 8u, blk = ahead1, ahead1 = ahead2, ahead2 = ahead3) {
+        /* a block's load is requested while the block before it is looked at (a lane's sixteen bytes are a cache line of their own).
+           One block ahead, taken before the next request: the compiler waits for every outstanding load at the first use of any
+           (s_waitcnt vmcnt(0) behind a loop's back edge), so a deeper queue in plain C++ only waits for its newest request */
+        LaneOps nxt;
+        nxt.load(R.ops, v, vb);
+        for (uint32_t i0 = vb; i0 < ve && !stop; i0 += 8u) {
             if (i0 != vb && pm > 0 && (double)pm >= thr * 1.00001 * (double)(pm + x_end)) break;
-            if (i0 + 24u < ve) ahead3.load(R.ops, v, i0 + 24u);
+            const LaneOps blk = nxt;
+            if (i0 + 8u < ve) nxt.load(R.ops, v, i0 + 8u);
             R.budget -= 8;
             if (i0 + 8u <= ve && pm > 0) {
                 /* a whole block of eight ops: a prefix that ends inside it has at least the matches in front of the block and at most the
