@@ -204,6 +204,38 @@ def test_header_lines_of_many_tokens(eng):
     check(eng, PIPES["pass"], lines[0] + lines[1] + bad_tp + lines[2], "bad tp in round 2")
 
 
+def test_integer_columns_at_every_alignment(eng):
+    """str_to_int64 (impl/paf.c:37-48) in the header kernel reads a column's digits from aligned 8-byte words (parse_i64_words): columns
+    of 1 to 19 digits and a sign starting at every byte alignment, digits followed by other characters (the number stops there), a sign
+    alone, a '+', columns of more than twenty characters (the byte-by-byte form), tag values of every length -- and the text's last
+    line without a newline, its last column ending with the buffer (no word beyond the text is read)."""
+    import random
+
+    rng = random.Random(11)
+    lines = []
+    for k in range(400):
+        qn = "q" * rng.randrange(1, 18)  # shifts the alignment of everything behind it
+        nd = rng.choice([1, 2, 7, 8, 9, 15, 16, 17, 18, 19])
+        big = rng.randrange(10 ** (nd - 1), 10 ** nd) if nd > 1 else rng.randrange(1, 10)
+        big = min(big, 2 ** 62)
+        qlen = big + 10
+        qs = big
+        score = rng.choice([0, 5, -5, 123456789012, -(2 ** 62), 2 ** 62, 99999999, 100000000])
+        s1 = rng.choice(["7", "-7", "0012", "12ab", "-", "+5", "", "1" * 25, "-" + "9" * 22, "4x", "18446744073709551615"])
+        tl = rng.choice(["1", "2", "30"])
+        cn = rng.choice(["0", "65535", "4294967296"])
+        lines.append(f"{qn}\t{qlen}\t{qs}\t{qs + 5}\t{rng.choice('+-')}\tt\t{10 ** rng.randrange(3, 18)}\t7\t12\t5\t5\t{rng.choice([0, 9, 60, 255])}"
+                     f"\tAS:i:{score}\ttl:i:{tl}\tcn:i:{cn}\tcg:Z:5M\ts1:i:{s1}\n".encode())
+    data = b"".join(lines)
+    for name in ("pass", "invert", "shatter"):
+        check(eng, PIPES[name], data, name)
+        for cut in (1, 2, 9):  # the last column ends with the buffer, at several alignments
+            check(eng, PIPES[name], data[:-cut] if data[-cut - 1:-cut].isdigit() else data[:-1], name)
+    tail = b"q\t100\t0\t5\t+\tt\t100\t0\t5\t5\t5\t60\tcg:Z:5M\ts1:i:1234567"
+    for n in range(1, 8):
+        check(eng, PIPES["pass"], lines[0] + tail[:len(tail) - 7 + n], "tag value of %d digits at the end of the text" % n)
+
+
 def test_one_pass_separator_index_follows_the_density(eng):
     """Round 3: from the second batch of a context on the separator index is ONE pass over the text whose buffers are sized by the batch
     before (k_sep_index: tile tickets, decoupled look-back); a denser batch is indexed again with exact sizes. One engine, batches of
