@@ -41,7 +41,7 @@ struct PieceSum {
     uint32_t m, x;     /* bases of M and = ops; of X, I and D ops (the matches / mismatches of impl/paf.c:823-828) */
     uint32_t ins, del; /* bases of I ops, of D ops */
     uint32_t rows;     /* M ops */
-    uint32_t extra;    /* digits of the M ops' lengths beyond the first; FlatParams::items_mode: 16-column chunks of the M ops */
+    uint32_t extra;    /* digits of the M ops' lengths beyond the first; or the 16-column chunks of the M ops; or the I ops (k_flat_parse's MODE) */
     uint32_t text_end; /* offset from the cigar's first byte just behind the last op letter at or before the end of the piece */
 };
 static_assert(sizeof(PieceSum) == 32, "two 16-byte stores");
@@ -59,7 +59,7 @@ struct FlatParams {
     PieceSum *sums;
     uint32_t *ops_mirror;
     DevInfo *info;
-    uint32_t items_mode; /* add_mismatches (flat_add_kernel.h): PieceSum::extra counts the 16-column chunks of the M ops instead of their digits */
+    uint32_t items_mode; /* the MODE of k_flat_parse: what PieceSum::extra counts (the host picks the instantiation by it) */
 };
 
 __device__ __forceinline__ uint32_t nondigit16(const uint4 &v) { /* bit j: byte j of the 16 is not an ASCII digit */
@@ -104,6 +104,9 @@ __device__ __forceinline__ uint32_t lane_val(uint32_t x, uint32_t l) { return (u
 /* bytes of LDS per wave: 16 bytes in front of the tile (the text before it), the tile, the positions of its op letters */
 #define FLAT_PARSE_LDS (16u + FLAT_TILE + 2u * FLAT_P_CAP)
 #define FLAT_PARSE_WAVES 4u
+/* MODE = what PieceSum::extra counts: 0 the digits of the M ops' lengths beyond the first (shatter's row bytes), 1 the 16-column chunks of the M
+   ops (add_mismatches, flat_add_kernel.h), 2 the I ops (the counts of paf_stats_calc, impl/paf.c:236-260) */
+template <uint32_t MODE>
 __global__ __launch_bounds__(64 * FLAT_PARSE_WAVES) void k_flat_parse(FlatParams F) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[FLAT_PARSE_WAVES][FLAT_PARSE_LDS];
     /* the wave's number, in a scalar register: everything derived from it (the chunk, its record, the tile addresses) is wave-uniform,
@@ -205,7 +208,8 @@ __global__ __launch_bounds__(64 * FLAT_PARSE_WAVES) void k_flat_parse(FlatParams
                 const uint32_t l16 = len & 0xffffu;
                 acc_mx += l16 << (((0x16u >> code) & 1u) << 4);                                     /* M = | X I D */
                 acc_id += (code == (uint32_t)OP_I ? l16 : 0u) + (code == (uint32_t)OP_D ? l16 << 16 : 0u); /* I | D */
-                acc_re += code == (uint32_t)OP_M ? 1u + ((F.items_mode ? (len + 15u) >> 4 : kk - 1u) << 16) : 0u; /* rows | digits beyond the first (or 16-column chunks) */
+                if (MODE == 2u) acc_re += (code == (uint32_t)OP_M ? 1u : 0u) + (code == (uint32_t)OP_I ? 1u << 16 : 0u); /* rows | I ops */
+                else acc_re += code == (uint32_t)OP_M ? 1u + ((MODE == 1u ? (len + 15u) >> 4 : kk - 1u) << 16) : 0u; /* rows | digits beyond the first (or 16-column chunks) */
                 nonplain |= code > (uint32_t)OP_D ? 1u : 0u;
             }
             uint32_t sums6[6] = {acc_mx & 0xffffu, acc_mx >> 16, acc_id & 0xffffu, acc_id >> 16, acc_re & 0xffffu, acc_re >> 16};
@@ -264,6 +268,7 @@ struct FlatRec {
     FlatPre inc; /* in_regs: lane p holds the sums of pieces [0, p] */
     const uint16_t *ops;
     bool want_text;
+    bool extra_icount; /* PieceSum::extra counts I ops (a pipe with a stats stage), not digits */
 
     __device__ __forceinline__ FlatPre piece_prefix(uint32_t j) const { /* pieces [0, j) */
         FlatPre r;
@@ -311,7 +316,7 @@ struct FlatRec {
             si += code == (uint32_t)OP_I ? len : 0u;
             sd += code == (uint32_t)OP_D ? len : 0u;
             sr += code == (uint32_t)OP_M ? 1u : 0u;
-            se += code == (uint32_t)OP_M ? dg : 0u;
+            se += extra_icount ? (code == (uint32_t)OP_I ? 1u : 0u) : (code == (uint32_t)OP_M ? dg : 0u);
             st += dg + 2u;
         }
         uint32_t sums6[6] = {sm, sx, si, sd, sr, se};
@@ -388,6 +393,21 @@ __device__ __forceinline__ void flat_dropped(const KParams &P, uint8_t *flat_don
  * each off by at most 2^-24 relative, so a numerator below 0.999996 x threshold x denominator (above 1.000004 x) has its rounded quotient
  * strictly below (above) the threshold. 0 / 0 takes the exact path (NaN compares false, as it does in the reference).
  */
+/* paf_stats_calc (impl/paf.c:236-260) of the view from its sums: matches (M and =), mismatches (X), inserts, deletes, insert bases, delete
+   bases -- the order of the record kernels' rec_stats. The I ops are what PieceSum::extra counts in a pipe with a stats stage; the other
+   ops that are not M are the D ops as long as the cigar is plain (the caller leaves = and X to the record kernels); an inverted view
+   has them swapped. */
+__device__ __forceinline__ void flat_stats(const KParams &P, uint32_t rec, const FlatView &v) {
+    const uint32_t n_i = v.whi.extra - v.wlo.extra, n_other = (v.whi.cnt - v.wlo.cnt) - (v.whi.rows - v.wlo.rows);
+    const uint32_t n_d = n_other - n_i;
+    int64_t *o = P.rec_stats + 6ull * rec;
+    o[0] = (int64_t)v.tm();
+    o[1] = (int64_t)v.tx() - (int64_t)(v.whi.ins - v.wlo.ins) - (int64_t)(v.whi.del - v.wlo.del);
+    o[2] = (int64_t)(v.swp ? n_d : n_i);
+    o[3] = (int64_t)(v.swp ? n_i : n_d);
+    o[4] = (int64_t)v.ins_v();
+    o[5] = (int64_t)v.del_v();
+}
 __device__ __forceinline__ bool flat_ratio_lt(uint32_t num, uint32_t den, float thr_f, double thr) {
     const float nf = __uint2float_rn(num), df = __uint2float_rn(den);
     const float p = __fmul_rn(thr_f, df);
@@ -634,6 +654,7 @@ struct LaneRec {
     uint32_t np, n_ops;
     int32_t budget;
     bool want_text;
+    bool extra_icount;
     /* ops, matches and mismatches of the record's pieces: in LDS, [piece][thread] (read again and again by the trim's searches) */
     uint32_t (*cnt)[256], (*m)[256], (*x)[256];
 };
@@ -643,7 +664,7 @@ __device__ __forceinline__ FlatPre lane_piece(const PieceSum *ps, uint32_t p) { 
     q.cnt = a.x; q.m = a.y; q.x = a.z; q.ins = a.w; q.del = b.x; q.rows = b.y; q.extra = b.z; q.text = b.w;
     return q;
 }
-__device__ __forceinline__ void lane_add_op(FlatPre &a, uint32_t w, bool want_text) {
+__device__ __forceinline__ void lane_add_op(FlatPre &a, uint32_t w, bool want_text, bool extra_icount) {
     const uint32_t len = w >> 3, code = w & 7u;
     const uint32_t is_m = 0u - ((0x9u >> code) & 1u);
     const uint32_t dg = (len >= 10u) + (len >= 100u) + (len >= 1000u);
@@ -652,7 +673,7 @@ __device__ __forceinline__ void lane_add_op(FlatPre &a, uint32_t w, bool want_te
     a.ins += code == (uint32_t)OP_I ? len : 0u;
     a.del += code == (uint32_t)OP_D ? len : 0u;
     a.rows += code == (uint32_t)OP_M ? 1u : 0u;
-    a.extra += code == (uint32_t)OP_M ? dg : 0u;
+    a.extra += extra_icount ? (code == (uint32_t)OP_I ? 1u : 0u) : (code == (uint32_t)OP_M ? dg : 0u);
     if (want_text) a.text += dg + 2u;
 }
 /* Eight ops of the view at a time, one 16-byte load (a lane that asked for its ops one by one would wait for a load per op): view
@@ -696,12 +717,12 @@ __device__ __forceinline__ FlatPre lane_raw_prefix(LaneRec &R, uint32_t r) {
         }
         if (r - a.cnt <= a.cnt + cnt - r) { /* forwards from the piece's first op */
             R.budget -= (int32_t)(r - a.cnt);
-            for (uint32_t i = a.cnt; i < r; i++) lane_add_op(a, R.ops[i], R.want_text);
+            for (uint32_t i = a.cnt; i < r; i++) lane_add_op(a, R.ops[i], R.want_text, R.extra_icount);
         } else { /* backwards from its last op */
             FlatPre b;
             b.cnt = b.m = b.x = b.ins = b.del = b.rows = b.extra = b.text = 0;
             R.budget -= (int32_t)(a.cnt + cnt - r);
-            for (uint32_t i = r; i < a.cnt + cnt; i++) lane_add_op(b, R.ops[i], R.want_text);
+            for (uint32_t i = r; i < a.cnt + cnt; i++) lane_add_op(b, R.ops[i], R.want_text, R.extra_icount);
             a.m += q.m - b.m; a.x += q.x - b.x; a.ins += q.ins - b.ins; a.del += q.del - b.del; a.rows += q.rows - b.rows; a.extra += q.extra - b.extra;
             a.text = q.text - b.text;
         }
@@ -850,6 +871,7 @@ __global__ __launch_bounds__(256) void k_flat_lane(FlatSizeParams F) {
         R.cnt = s_cnt; R.m = s_m; R.x = s_x;
         const bool shatter_last = P.n_stages > 0 && P.stages[P.n_stages - 1].kind == PAFFY_SHATTER;
         R.want_text = !shatter_last;
+        R.extra_icount = P.rec_stats != nullptr;
         FlatPre tot;
         tot.cnt = tot.m = tot.x = tot.ins = tot.del = tot.rows = tot.extra = tot.text = 0;
         uint32_t flags = 0;
@@ -929,12 +951,15 @@ __global__ __launch_bounds__(256) void k_flat_lane(FlatSizeParams F) {
                     flat_dropped(P, F.flat_done, rec);
                     return;
                 }
+            } else if (st.kind == PAFFY_STATS) {
+                if (flags & FLAT_F_NONPLAIN) { give_up = true; break; }
+                flat_stats(P, rec, v);
             } else if (st.kind != PAFFY_PASS) {
                 give_up = true;
                 break;
             }
             if (rc) { give_up = true; break; }
-            checked = st.kind != PAFFY_PASS && st.kind != PAFFY_FILTER;
+            if (st.kind != PAFFY_STATS) checked = st.kind != PAFFY_PASS && st.kind != PAFFY_FILTER;
         }
         if (give_up || v.n == 0) break;
         if (shatter && ((flags & FLAT_F_NONPLAIN) || (!checked && flat_check(s, v)))) break;
@@ -1111,6 +1136,7 @@ __device__ __forceinline__ void flat_size_one(const FlatSizeParams &F, uint32_t 
     R.in_regs = R.np <= 64u;
     const bool shatter_last = P.n_stages > 0 && P.stages[P.n_stages - 1].kind == PAFFY_SHATTER;
     R.want_text = !shatter_last;
+    R.extra_icount = P.rec_stats != nullptr;
     /* the pieces' sums become inclusive prefix sums: in registers for a record of at most 64 pieces, in place in HBM for a longer one */
     uint32_t flags = 0;
     unsigned long long tot_m = 0, tot_x = 0;
@@ -1208,11 +1234,14 @@ __device__ __forceinline__ void flat_size_one(const FlatSizeParams &F, uint32_t 
                 if (lane == 0) flat_dropped(P, F.flat_done, rec);
                 return;
             }
+        } else if (st.kind == PAFFY_STATS) {
+            if (flags & FLAT_F_NONPLAIN) return flat_leave(F, rec, FLAT_WHY_NONPLAIN);
+            if (lane == 0) flat_stats(P, rec, v);
         } else if (st.kind != PAFFY_PASS) {
             return flat_leave(F, rec, FLAT_WHY_STAGE);
         }
         if (rc) return flat_leave(F, rec, FLAT_WHY_CHECK);
-        checked = st.kind != PAFFY_PASS && st.kind != PAFFY_FILTER;
+        if (st.kind != PAFFY_STATS) checked = st.kind != PAFFY_PASS && st.kind != PAFFY_FILTER;
     }
     RecPlan *plan = static_cast<RecPlan *>(P.rec_plan) + rec;
     int64_t bytes, rows;

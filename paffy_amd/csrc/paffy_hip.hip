@@ -1290,7 +1290,15 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
     /* `paffy add_mismatches` alone (BASELINE cfg4): the same parse, the encoder on the pieces (flat_add_kernel.h) */
     const bool flat_add = n_stages == 1 && stages[0].kind == PAFFY_ADD_MISMATCHES && nocheck_mask == 0 && !flat_off && c->n_seqs > 0;
     bool lean_or_filter = n_stages > 0; /* the flat pass also knows `paffy filter` (a predicate on the sums it keeps anyway) */
-    for (int32_t i = 0; i < n_stages; i++) lean_or_filter = lean_or_filter && (((PAFFY_MASK_LEAN | (1u << PAFFY_FILTER)) >> stages[i].kind) & 1u);
+    /* ... and the stats stage of `paffy view -s` (paf_stats_calc, impl/paf.c:236-260: sums the pieces' summaries hold, with the I ops counted
+       where a shatter pipe counts the digits of its rows -- so not both in one pipe) */
+    bool has_stats = false, has_shatter_stage = false;
+    for (int32_t i = 0; i < n_stages; i++) {
+        has_stats = has_stats || stages[i].kind == PAFFY_STATS;
+        has_shatter_stage = has_shatter_stage || stages[i].kind == PAFFY_SHATTER;
+    }
+    const uint32_t flat_kinds = PAFFY_MASK_LEAN | (1u << PAFFY_FILTER) | (has_shatter_stage ? 0u : 1u << PAFFY_STATS);
+    for (int32_t i = 0; i < n_stages; i++) lean_or_filter = lean_or_filter && ((flat_kinds >> stages[i].kind) & 1u);
     const bool flat = (lean_or_filter && nocheck_mask == 0 && !flat_off) || flat_add;
     {
         int rc = index_and_parse(c, in, len, &n_lines, lvl0_max, flat);
@@ -1378,7 +1386,7 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
         fp.ops_mirror = kp.ops_mirror;
         fp.info = kp.info;
         fp.items_mode = 1;
-        LAUNCH(c, "k_flat_parse", k_flat_parse, dim3(2048), dim3(64 * FLAT_PARSE_WAVES), 0, fp);
+        LAUNCH(c, "k_flat_parse", k_flat_parse<1u>, dim3(2048), dim3(64 * FLAT_PARSE_WAVES), 0, fp);
         const uint32_t n_slots = c->flat_piece_slots, n_sblocks = (n_slots + SCAN32_BLOCK - 1) / SCAN32_BLOCK;
         if (ensure(c, c->add_pieces, sizeof(AddPiece) * (size_t)n_slots) || ensure(c, c->add_scr_cnt, sizeof(uint32_t) * (size_t)n_slots) ||
             ensure(c, c->add_scr_off, sizeof(uint64_t) * (size_t)n_slots) || ensure(c, c->add_new_cnt, sizeof(uint32_t) * (size_t)n_slots) ||
@@ -1459,9 +1467,10 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
         fp.sums = static_cast<PieceSum *>(c->flat_sums.p);
         fp.ops_mirror = kp.ops_mirror;
         fp.info = kp.info;
-        fp.items_mode = 0;
+        fp.items_mode = has_stats ? 2u : 0u;
         /* persistent waves over the chunks: eight workgroups of four waves per CU */
-        LAUNCH(c, "k_flat_parse", k_flat_parse, dim3(2048), dim3(64 * FLAT_PARSE_WAVES), 0, fp);
+        if (has_stats) LAUNCH(c, "k_flat_parse", k_flat_parse<2u>, dim3(2048), dim3(64 * FLAT_PARSE_WAVES), 0, fp);
+        else LAUNCH(c, "k_flat_parse", k_flat_parse<0u>, dim3(2048), dim3(64 * FLAT_PARSE_WAVES), 0, fp);
         /* segments of the shatter records too long for one wave of the row writer: a record of more than PAFFY_ROWS_MAX_OPS ops has
            2 x that many cigar bytes at least, a segment holds half that many ops */
         const size_t items_cap = ((size_t)len >> 15) + ((size_t)len >> 16) + 16;
@@ -1496,6 +1505,11 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
         c->flat_left = c->h_info->flat_legacy;
         for (int k = 0; k < 16; k++) c->flat_reasons[k] = c->h_info->flat_reason[k];
         kp.flat_done = static_cast<const uint8_t *>(c->flat_done.p);
+        if (kp.rec_stats && !need_legacy) { /* the batch's sums (the record kernels' launch chain does this when it runs) */
+            LAUNCH(c, "k_stats_reduce", k_stats_reduce, dim3(std::min<uint32_t>(512u, (n_lines + PAFFY_NT - 1) / PAFFY_NT)), dim3(PAFFY_NT), 0, kp.rec_stats, n_lines,
+                   static_cast<DevInfo *>(c->info.p)->stats);
+            if (fetch_info(c)) return PAFFY_E_HIP;
+        }
     }
     if (n_lines > 0 && need_legacy) {
         if (!flat) { /* launch order of the sizing workgroups: long cigars first (out_len is scratch until the sizing pass fills it) */

@@ -237,3 +237,37 @@ def test_row_pieces_of_the_sizing_pass(eng):
     run_both(eng, "".join(short).encode(), pipes=pipes)
     assert kept_all(3)
     run_both(eng, "".join(lines).encode(), pipes=pipes)  # the longer names among them: those records take the general row writer
+
+
+def test_stats_stage_from_the_summaries(eng):
+    """paf_stats_calc (impl/paf.c:236-260; `paffy view -s`) of every record as a stage of a pipe the flat pass takes: the six sums come from
+    the pieces' summaries (the I ops counted where a shatter pipe counts digits) -- of the whole record, of what an identity trim leaves of it
+    (the cut ops summed by a walk), of an inverted record (inserts and deletes swap). Records with = and X ops go to the record kernels."""
+    import paffy_amd
+
+    rng = random.Random(5)
+    lines = []
+    for k in range(900):
+        n = rng.choice((1, 2, 3, 9, 40, 150, 700, 2500))
+        lines.append(record(random_ops(rng, n), strand=rng.choice("+-"), rng=rng))
+    lines.append(record(random_ops(rng, 30_000), strand="-", rng=rng))  # more than 64 pieces
+    plain = "".join(lines).encode()
+    eqx = plain + record([(5, "="), (2, "X"), (3, "I"), (4, "="), (1, "D"), (6, "M")], rng=rng).encode() * 3
+
+    def oracle_sums(out):
+        acc = [0] * 6
+        for ln in out.splitlines():
+            f = ln.split(b"cg:Z:")
+            if len(f) > 1:
+                acc = O.cigar_stats(f[1].split(b"\t")[0].decode(), acc, zero=False)
+        return acc
+
+    for data, all_flat in ((plain, True), (eqx, False)):
+        buf = eng.to_device(data)
+        for pipe in ([], [O.INVERT], [O.TRIM_IDENTITY], [O.INVERT, O.TRIM_IDENTITY], [O.INVERT, O.INVERT]):
+            want, werr = O.run([O.stage(k) for k in pipe] or [O.stage(O.PASS)], data)
+            assert werr.code == 0
+            info = eng.plan([paffy_amd.stage(k) for k in pipe] + [paffy_amd.stage(paffy_amd.STATS)], buf, len(data))
+            assert info.error.code == 0 and list(eng.plan_stats()) == oracle_sums(want), pipe
+            left, why = eng.flat_stats()
+            assert (left == 0) == all_flat, (pipe, left, why)
