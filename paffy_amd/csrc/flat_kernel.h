@@ -642,7 +642,9 @@ __device__ __forceinline__ void lane_row_pieces(uint32_t (*S)[256], uint32_t tid
         reinterpret_cast<uint4 *>(dst)[q] = make_uint4(S[4 * q][tid], S[4 * q + 1][tid], S[4 * q + 2][tid], S[4 * q + 3][tid]);
 }
 
+#ifndef FLAT_LANE_MAX_PIECES
 #define FLAT_LANE_MAX_PIECES 12u
+#endif
 #ifndef FLAT_LANE_WALK_BUDGET
 #define FLAT_LANE_WALK_BUDGET 1024
 #endif
