@@ -281,7 +281,25 @@ def main():
         O.set_filter(**f)
         eng.set_filter(**f)
         want, werr = O.run([O.stage(k, *params) for k in pipe], data)
-        got, info = eng.run([paffy_amd.stage(k, *params) for k in pipe], data, raise_on_error=False)
+        gpu_pipe = [paffy_amd.stage(k, *params) for k in pipe]
+        stats_at = None
+        if rng.random() < 0.3:  # a stats stage (paffy view -s) somewhere in front of the shatter: the output is the same, the six sums are checked
+            stats_at = rng.randrange(len(pipe) + (0 if pipe and pipe[-1] == O.SHATTER else 1))
+            gpu_pipe.insert(stats_at, paffy_amd.stage(paffy_amd.STATS))
+        got, info = eng.run(gpu_pipe, data, raise_on_error=False)
+        if stats_at is not None and werr.code == 0 and info.error.code == 0:
+            upto, uerr = O.run([O.stage(k, *params) for k in pipe[:stats_at]] or [O.stage(O.PASS)], data)
+            acc = [0] * 6
+            for ln in upto.splitlines():
+                cg = ln.split(b"cg:Z:")
+                if len(cg) > 1:
+                    acc = O.cigar_stats(cg[1].split(b"\t")[0].decode(), acc, zero=False)
+            if uerr.code == 0 and list(eng.plan_stats()) != acc:
+                print("STATS MISMATCH", dict(pipe=pipe, stats_at=stats_at, params=params, filter=f, gpu=list(eng.plan_stats()), cpu=acc))
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "fuzz_fail.paf"), "wb") as fh:
+                    fh.write(data)
+                sys.exit(1)
         if info.error.code != werr.code or (werr.code and info.error.record != werr.record) or got != want:
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             with open(os.path.join(ROOT, "gpurun_out", "fuzz_fail.paf"), "wb") as fh:
