@@ -689,16 +689,20 @@ struct LaneOps {
         w = *reinterpret_cast<const u32x4_unaligned *>(p);
     }
     __device__ __forceinline__ void sums(uint32_t &m, uint32_t &x) const { /* bases of the eight ops: in M and = ops, in the others */
+        /* two ops per word, both halves at once: lengths below 8 192, so four of them add up inside a half. An op is a match (M 0, = 3)
+           when bit 2 of its code is clear and bits 1 and 0 agree */
         const uint32_t d[4] = {w.x, w.y, w.z, w.w};
-        uint32_t all = 0;
-        m = 0;
+        uint32_t all2 = 0, x2 = 0;
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) {
-            const uint32_t lo = d[k] & 0xffffu, hi = d[k] >> 16;
-            all += (lo >> 3) + (hi >> 3);
-            m += ((lo >> 3) & (0u - ((0x9u >> (lo & 7u)) & 1u))) + ((hi >> 3) & (0u - ((0x9u >> (hi & 7u)) & 1u)));
+            const uint32_t len2 = (d[k] >> 3) & 0x1fff1fffu, c = d[k] & 0x00070007u;
+            const uint32_t nm = ((c ^ (c >> 1)) | (c >> 2)) & 0x00010001u; /* 1 in a half whose op is not a match */
+            all2 += len2;
+            x2 += len2 & (nm * 0x1fffu); /* the product stays below 2^30: the 24-bit multiply */
         }
-        x = all - m;
+        const uint32_t all = (all2 & 0xffffu) + (all2 >> 16);
+        x = (x2 & 0xffffu) + (x2 >> 16);
+        m = all - x;
     }
     __device__ __forceinline__ uint32_t get(const FlatView &v, uint32_t k) const { /* op i + k, k = 0..7 */
         const uint32_t j = v.rev ? 7u - k : k;
