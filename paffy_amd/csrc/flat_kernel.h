@@ -655,6 +655,9 @@ struct LaneRec {
     const uint16_t *ops;
     uint32_t np, n_ops;
     int32_t budget;
+#if defined(PAFFY_ABL) && PAFFY_ABL == 52
+    uint32_t *abl; /* [4]: blocks skipped / looked at op by op, ops of the second search, ops summed for a cut */
+#endif
     bool want_text;
     bool extra_icount;
     /* ops, matches and mismatches of the record's pieces: in LDS, [piece][thread] (read again and again by the trim's searches) */
@@ -723,11 +726,17 @@ __device__ __forceinline__ FlatPre lane_raw_prefix(LaneRec &R, uint32_t r) {
         }
         if (r - a.cnt <= a.cnt + cnt - r) { /* forwards from the piece's first op */
             R.budget -= (int32_t)(r - a.cnt);
+#if defined(PAFFY_ABL) && PAFFY_ABL == 52
+            R.abl[3] += r - a.cnt;
+#endif
             for (uint32_t i = a.cnt; i < r; i++) lane_add_op(a, R.ops[i], R.want_text, R.extra_icount);
         } else { /* backwards from its last op */
             FlatPre b;
             b.cnt = b.m = b.x = b.ins = b.del = b.rows = b.extra = b.text = 0;
             R.budget -= (int32_t)(a.cnt + cnt - r);
+#if defined(PAFFY_ABL) && PAFFY_ABL == 52
+            R.abl[3] += a.cnt + cnt - r;
+#endif
             for (uint32_t i = r; i < a.cnt + cnt; i++) lane_add_op(b, R.ops[i], R.want_text, R.extra_icount);
             a.m += q.m - b.m; a.x += q.x - b.x; a.ins += q.ins - b.ins; a.del += q.del - b.del; a.rows += q.rows - b.rows; a.extra += q.extra - b.extra;
             a.text = q.text - b.text;
@@ -792,9 +801,15 @@ __device__ __forceinline__ void lane_trim_prefix(LaneRec &R, FlatState &s, FlatV
                 if ((double)pm >= thr * 1.00001 * (double)(pm + px + bx) && !(max_trim >= 0 && (int64_t)pm + (int64_t)px + (int64_t)bm + (int64_t)bx > max_trim)) {
                     pm += bm;
                     px += bx;
+#if defined(PAFFY_ABL) && PAFFY_ABL == 52
+                    R.abl[0]++;
+#endif
                     continue;
                 }
             }
+#if defined(PAFFY_ABL) && PAFFY_ABL == 52
+            R.abl[1]++;
+#endif
 #pragma unroll
             for (uint32_t j = 0; j < 8u; j++) {
                 if (i0 + j < ve && !stop) {
@@ -815,6 +830,9 @@ __device__ __forceinline__ void lane_trim_prefix(LaneRec &R, FlatState &s, FlatV
     }
     if (trim_idx < 0 || R.budget < 0) return;
     R.budget -= trim_idx + 1;
+#if defined(PAFFY_ABL) && PAFFY_ABL == 52
+    R.abl[2] += (uint32_t)trim_idx + 1u;
+#endif
     if (R.budget < 0) return;
     uint32_t best = 0xffffffffu;
     {
@@ -863,6 +881,9 @@ __global__ __launch_bounds__(256) void k_flat_lane(FlatSizeParams F) {
     const unsigned long long abl_w0 = wall_clock64();
 #endif
     if (rec >= P.n_rec) return;
+#if defined(PAFFY_ABL) && PAFFY_ABL == 52 /* what the trim walks of a wave consist of: sums over its lanes in DevInfo::flat_reason[0..3], the longest lane's in [4..7] */
+    uint32_t abl_cnt[4] = {0, 0, 0, 0};
+#endif
     bool done = false;
     do { /* one pass; `break` = the record goes to k_flat_size */
         const RecMeta &m = P.meta[rec];
@@ -874,6 +895,9 @@ __global__ __launch_bounds__(256) void k_flat_lane(FlatSizeParams F) {
         R.ps = F.sums + ((cg_off >> FLAT_TILE_SHIFT) + rec);
         R.ops = reinterpret_cast<const uint16_t *>(P.ops_mirror + (cg_off >> 1));
         R.budget = FLAT_LANE_WALK_BUDGET;
+#if defined(PAFFY_ABL) && PAFFY_ABL == 52
+        R.abl = abl_cnt;
+#endif
         R.cnt = s_cnt; R.m = s_m; R.x = s_x;
         const bool shatter_last = P.n_stages > 0 && P.stages[P.n_stages - 1].kind == PAFFY_SHATTER;
         R.want_text = !shatter_last;
@@ -1012,6 +1036,17 @@ __global__ __launch_bounds__(256) void k_flat_lane(FlatSizeParams F) {
         done = true;
     } while (false);
     if (!done) F.defer[atomicAdd(&P.info->flat_defer, 1u)] = rec;
+#if defined(PAFFY_ABL) && PAFFY_ABL == 52
+    for (int k = 0; k < 4; k++) {
+        atomicAdd(&P.info->flat_reason[k], abl_cnt[k]);
+        uint32_t mx = abl_cnt[k];
+        for (int d = 32; d; d >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)mx, d);
+            mx = o > mx ? o : mx;
+        }
+        if ((threadIdx.x & 63u) == 0) atomicAdd(&P.info->flat_reason[4 + k], mx);
+    }
+#endif
 #if defined(PAFFY_ABL) && PAFFY_ABL == 51 /* how long the waves of the lane kernel live: histogram of log2(ticks of the 100 MHz wall clock) in DevInfo::flat_reason */
     {
         const unsigned long long dt = wall_clock64() - abl_w0;
