@@ -334,8 +334,9 @@ struct FlatView {
     uint32_t lo, n;
     bool rev, swp;
     FlatPre wlo, whi;
-    __device__ __forceinline__ uint32_t tm() const { return whi.m - wlo.m; }
-    __device__ __forceinline__ uint32_t tx() const { return whi.x - wlo.x; }
+    uint32_t cut_m = 0, cut_x = 0; /* bases a fixed trim has cut from the window's end ops (M / = ops, X ops): the ops stay, shortened */
+    __device__ __forceinline__ uint32_t tm() const { return whi.m - wlo.m - cut_m; }
+    __device__ __forceinline__ uint32_t tx() const { return whi.x - wlo.x - cut_x; }
     __device__ __forceinline__ uint32_t ins_v() const { return swp ? whi.del - wlo.del : whi.ins - wlo.ins; } /* I <-> D under an invert */
     __device__ __forceinline__ uint32_t del_v() const { return swp ? whi.ins - wlo.ins : whi.del - wlo.del; }
     __device__ __forceinline__ int64_t tq() const { return (int64_t)tm() + (int64_t)tx() - (int64_t)del_v(); }
@@ -1132,6 +1133,76 @@ __device__ __forceinline__ void flat_find(const FlatRec &R, const FlatView &v, b
     }
 }
 
+/*
+ * The op a fixed trim stops at (cigar_trim / cigar_trim_back, impl/paf.c:518-576, on the front of the view: the back is the front of the
+ * reversed view): ops are popped while the front op is an indel or fewer than `end` aligned bases (M, =, X) are gone, i.e. up to the first
+ * aligned op whose inclusive sum of aligned bases exceeds `end` -- that op stays, shortened by what is missing. Found like flat_find():
+ * the piece by the summaries, the op by a walk of the piece. The view's LAST op counts `far_cut` bases less (the cut the other end has
+ * made already; the summaries do not know it, so the last piece may be walked in vain). Returns false when no op stops the trim (it
+ * takes everything); else *idx = the op's view index, *tb = the aligned bases in front of it, *len its length (less far_cut), *code.
+ */
+__device__ __forceinline__ bool flat_find_aligned(const FlatRec &R, const FlatView &v, uint32_t end, uint32_t far_cut, uint32_t &idx, uint32_t &tb, uint32_t &len_out,
+                                                   uint32_t &code_out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w_end = v.lo + v.n;
+    const uint32_t nb = (R.np + 63u) >> 6;
+    const uint32_t lo_base = v.wlo.m + v.wlo.x - v.wlo.ins - v.wlo.del, hi_base = v.whi.m + v.whi.x - v.whi.ins - v.whi.del;
+    for (uint32_t bi = 0; bi < nb; bi++) {
+        const uint32_t b = v.rev ? nb - 1u - bi : bi; /* pieces in view order */
+        const uint32_t p = b * 64u + lane;
+        uint32_t a_cnt = 0, a_base = 0, b_cnt = 0, b_base = 0;
+        if (p < R.np) {
+            if (R.in_regs) {
+                b_cnt = R.inc.cnt; b_base = R.inc.m + R.inc.x - R.inc.ins - R.inc.del;
+            } else {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(R.ps + p);
+                b_cnt = flat_ld(q); b_base = flat_ld(q + 1) + flat_ld(q + 2) - flat_ld(q + 3) - flat_ld(q + 4);
+            }
+        }
+        if (R.in_regs) {
+            a_cnt = dpp_mov_u32<0x138, 0xf, 0xf>(b_cnt); a_base = dpp_mov_u32<0x138, 0xf, 0xf>(b_base);
+        } else if (p > 0 && p < R.np) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(R.ps + (p - 1u));
+            a_cnt = flat_ld(q); a_base = flat_ld(q + 1) + flat_ld(q + 2) - flat_ld(q + 3) - flat_ld(q + 4);
+        }
+        if (a_cnt < v.lo) { a_cnt = v.lo; a_base = lo_base; }
+        if (a_cnt > w_end) { a_cnt = w_end; a_base = hi_base; }
+        if (b_cnt < v.lo) { b_cnt = v.lo; b_base = lo_base; }
+        if (b_cnt > w_end) { b_cnt = w_end; b_base = hi_base; }
+        const bool live = p < R.np && b_cnt > a_cnt;
+        const uint32_t c_end = v.rev ? hi_base - a_base : b_base - lo_base; /* aligned bases through the piece's far end, in view order */
+        const unsigned long long crossing = __ballot(live && c_end > end);
+        if (!crossing) continue;
+        const uint32_t t = v.rev ? 63u - (uint32_t)__clzll((long long)crossing) : (uint32_t)__ffsll((long long)crossing) - 1u; /* the first in view order */
+        const uint32_t ra = lane_val(a_cnt, t), rb = lane_val(b_cnt, t);
+        uint32_t cum = v.rev ? hi_base - lane_val(b_base, t) : lane_val(a_base, t) - lo_base; /* in front of the piece */
+        const uint32_t vb = v.rev ? w_end - rb : ra - v.lo, ve = v.rev ? w_end - ra : rb - v.lo;
+        for (uint32_t i0 = vb; i0 < ve; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            uint32_t len = 0, code = (uint32_t)OP_I;
+            if (i < ve) {
+                const uint32_t w = R.ops[v.rev ? w_end - 1u - i : v.lo + i];
+                len = (w >> 3) - (i == v.n - 1u ? far_cut : 0u);
+                code = w & 7u;
+            }
+            const bool al = code != (uint32_t)OP_I && code != (uint32_t)OP_D;
+            const uint32_t inc = wave_incl_scan_u32(al ? len : 0u);
+            const unsigned long long hb = __ballot(i < ve && al && cum + inc > end);
+            if (hb) {
+                const uint32_t hl = (uint32_t)__ffsll((long long)hb) - 1u;
+                idx = i0 + hl;
+                len_out = lane_val(len, hl);
+                code_out = lane_val(code, hl);
+                tb = cum + lane_val(inc, hl) - len_out;
+                return true;
+            }
+            cum += wave_last_u32(inc);
+        }
+        return false; /* the last piece, its sums too large by far_cut */
+    }
+    return false;
+}
+
 /* what the record kernels take instead: nothing is written for the record but its mark */
 enum { FLAT_WHY_HEADER = 0, FLAT_WHY_IRREG = 1, FLAT_WHY_SUMS = 2, FLAT_WHY_EMPTY = 3, FLAT_WHY_CHECK = 4, FLAT_WHY_TRIM_ASSERT = 5, FLAT_WHY_STAGE = 6,
        FLAT_WHY_NONPLAIN = 7, FLAT_WHY_ROW_SHAPE = 8, FLAT_WHY_DIGITS = 9, FLAT_WHY_HEADER_LEN = 10 };
@@ -1162,6 +1233,16 @@ __device__ __forceinline__ uint64_t flat_cross_digits(const uint32_t (*cross)[3]
     }
     return extra;
 }
+/* digits the end ops of a fixed trim's window lost with the bases cut from them (lengths below 8 192): len / amt [0] the view's first op, [1]
+   its last; `one`: they are the same op; `first_only`: the first op's share (the text in front of a later op) */
+__device__ __forceinline__ uint32_t flat_cut_digits(const uint32_t *len, const uint32_t *amt, bool one, bool first_only) {
+    auto dl = [](uint32_t x) { return 1u + (x >= 10u) + (x >= 100u) + (x >= 1000u); };
+    if (one) return dl(len[0]) - dl(len[0] - amt[0] - amt[1]);
+    const uint32_t a = dl(len[0]) - dl(len[0] - amt[0]);
+    return first_only ? a : a + dl(len[1]) - dl(len[1] - amt[1]);
+}
+/* FIXED: the instantiation for pipes that end with a fixed trim (`paffy trim -f`); the others do not carry its code */
+template <bool FIXED>
 __device__ __forceinline__ void flat_size_one(const FlatSizeParams &F, uint32_t rec, uint32_t (*cross)[3]) {
     const KParams &P = F.P;
     const uint32_t lane = threadIdx.x & 63u;
@@ -1228,6 +1309,8 @@ __device__ __forceinline__ void flat_size_one(const FlatSizeParams &F, uint32_t 
     v.wlo = R.piece_prefix(0);
     v.whi = R.piece_prefix(R.np);
     bool swapped = false, shatter = false, checked = false, rewritten = false;
+    uint32_t fx_amt[2] = {0, 0}, fx_len[2] = {1, 1}; /* fixed trim: bases cut from the op it stops at and that op's length, front / back of the view */
+    uint32_t sub_lo = 0, sub_hi = 0;                 /* ... as the writers want them: cut from the window's raw first / last op */
     for (int32_t si = 0; si < P.n_stages; si++) {
         const paffy_stage st = P.stages[si];
         if (si > 0) { /* what `paf_write | paf_parse` between two processes does to the record */
@@ -1240,6 +1323,50 @@ __device__ __forceinline__ void flat_size_one(const FlatSizeParams &F, uint32_t 
             v.swp = !v.swp;
             if (!s.same) v.rev = !v.rev;
             swapped = !swapped;
+            rc = flat_check(s, v);
+        } else if (FIXED && st.kind == PAFFY_TRIM_FIXED) {
+            /* paf_trim_end_fraction + paf_trim_ends (impl/paf.c:578-598), the pipe's last stage (the host sees to that): half of the fraction of
+               the aligned bases goes at either end. The ops in front of the op a cut stops at leave the window as in the identity trim; the op
+               itself stays, shorter (FlatView::cut_m / cut_x for the sums, sub_lo / sub_hi for the writers) */
+            const float pct = st.p1;
+            if (!(pct >= 0.0f && pct <= 1.0f)) return flat_leave(F, rec, FLAT_WHY_STAGE); /* the record kernels report the assert */
+            const int64_t aligned = (int64_t)v.tm() + (int64_t)v.tx() - (int64_t)(v.whi.ins - v.wlo.ins) - (int64_t)(v.whi.del - v.wlo.del);
+            const uint32_t end = (uint32_t)__double2ll_rz((double)__fmul_rn(__ll2float_rn(aligned), pct) / 2.0);
+#pragma unroll 1
+            for (int pass = 0; pass < 2; pass++) {
+                if (pass == 1) v.rev = !v.rev; /* the back is the front of the reversed view */
+                uint32_t idx = 0, tb = 0, len = 1, code = 0;
+                if (!flat_find_aligned(R, v, end, pass == 1 ? fx_amt[0] : 0u, idx, tb, len, code)) return flat_leave(F, rec, FLAT_WHY_EMPTY); /* nothing is left */
+                const uint32_t amt = tb < end ? end - tb : 0u;
+                const int64_t old_tt = v.tt(), old_tq = v.tq();
+                if (idx) {
+                    const FlatPre cut = R.raw_prefix(v.rev ? v.lo + v.n - idx : v.lo + idx);
+                    if (v.rev) {
+                        v.whi = cut;
+                    } else {
+                        v.wlo = cut;
+                        v.lo += idx;
+                    }
+                    v.n -= idx;
+                }
+                if (code == (uint32_t)OP_X) v.cut_x += amt;
+                else v.cut_m += amt;
+                if (v.rev) sub_hi += amt;
+                else sub_lo += amt;
+                const int64_t d_t = old_tt - v.tt(), d_q = old_tq - v.tq();
+                if (pass == 0) {
+                    s.ts += d_t;
+                    if (s.same) s.qs += d_q;
+                    else s.qe -= d_q;
+                } else {
+                    s.te -= d_t;
+                    if (s.same) s.qe -= d_q;
+                    else s.qs += d_q;
+                }
+                fx_amt[pass] = amt;
+                fx_len[pass] = len;
+            }
+            v.rev = !v.rev;
             rc = flat_check(s, v);
         } else if (st.kind == PAFFY_TRIM_IDENTITY) { /* paf_trim_unreliable_tails, impl/paf.c:906-953 */
             const uint32_t mm = v.tm(), mx = v.tx();
@@ -1338,6 +1465,7 @@ __device__ __forceinline__ void flat_size_one(const FlatSizeParams &F, uint32_t 
         line_kernel = lenH + 8 <= PAFFY_TMPL_MAX && v.n <= PAFFY_ROWS_MAX_OPS;
         bytes = (int64_t)lenH + (int64_t)win.text + 1;
         rows = 1;
+        if (FIXED) bytes -= (int64_t)flat_cut_digits(fx_len, fx_amt, v.n == 1u, false); /* the shortened end ops may have lost digits */
     }
     /* a shatter record too long for one wave of the row writer: segments of FLAT_SEG_OPS ops, one workgroup of k_emit_rows each (EmitItem) */
     const bool itemised = shatter && !rows_kernel;
@@ -1357,7 +1485,7 @@ __device__ __forceinline__ void flat_size_one(const FlatSizeParams &F, uint32_t 
         P.n_ops[rec] = 0;
         P.out_len[rec] = bytes;
         P.out_rows[rec] = rows;
-        plan->qs = s.qs; plan->qe = s.qe; plan->ts = s.ts; plan->te = s.te; plan->sub_lo = 0; plan->sub_hi = 0;
+        plan->qs = s.qs; plan->qe = s.qe; plan->ts = s.ts; plan->te = s.te; plan->sub_lo = (int64_t)sub_lo; plan->sub_hi = (int64_t)sub_hi;
         plan->lo = v.lo; plan->n = v.n;
         plan->flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | 8u | ((uint32_t)rs.type << 8) | (shatter ? 16u : 0u) |
                       (rows_kernel ? 64u : 0u) | (line_kernel ? 0x10000u : 0u) | 0x40000u | (itemised ? 0x80000u : 0u);
@@ -1396,19 +1524,22 @@ __device__ __forceinline__ void flat_size_one(const FlatSizeParams &F, uint32_t 
             const uint32_t at = at64 < v.n ? (uint32_t)at64 : v.n;
             const FlatPre cut = R.raw_prefix(v.rev ? v.lo + v.n - at : v.lo + at);
             const FlatPre e = v.rev ? flat_sub(v.whi, cut) : flat_sub(cut, v.wlo);
-            if (lane == 0) plan->wo[w] = (int64_t)e.text;
+            /* (a fixed trim's shortened first op: the digits it lost are missing in front of every later wave's share) */
+            if (lane == 0) plan->wo[w] = (int64_t)e.text - (FIXED && at ? (int64_t)flat_cut_digits(fx_len, fx_amt, v.n == 1u, true) : 0ll);
         }
     }
 }
 
+template <bool FIXED>
 __global__ __launch_bounds__(64 * FLAT_SIZE_WAVES) void k_flat_size(FlatSizeParams F) {
     __shared__ uint32_t s_cross[FLAT_SIZE_WAVES][FLAT_MAX_CROSS][3]; /* per wave: the powers of ten inside a record's coordinate ranges (flat_find) */
     /* the records k_flat_lane handed on, one wave each (what derives from the wave's number is wave-uniform: told to the compiler, it
        lives in scalar registers) */
     const uint32_t wave_in_group = uni(threadIdx.x >> 6);
-    const uint32_t n_defer = F.P.info->flat_defer;
+    /* FIXED: every record (the lane kernel does not know the fixed trim and is not launched) */
+    const uint32_t n_defer = FIXED ? F.P.n_rec : F.P.info->flat_defer;
     for (uint32_t li = uni(blockIdx.x * FLAT_SIZE_WAVES + (threadIdx.x >> 6)); li < n_defer; li += gridDim.x * FLAT_SIZE_WAVES) {
-        flat_size_one(F, uni(F.defer[li]), s_cross[wave_in_group]);
+        flat_size_one<FIXED>(F, FIXED ? li : uni(F.defer[li]), s_cross[wave_in_group]);
         __builtin_amdgcn_wave_barrier();
     }
 }

@@ -1297,8 +1297,11 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
         has_stats = has_stats || stages[i].kind == PAFFY_STATS;
         has_shatter_stage = has_shatter_stage || stages[i].kind == PAFFY_SHATTER;
     }
+    /* ... and a fixed trim (`paffy trim -f`) as the pipe's last stage: the wave kernel finds the two ops it stops at (flat_find_aligned) */
+    const bool fixed_last = n_stages > 0 && stages[n_stages - 1].kind == PAFFY_TRIM_FIXED;
     const uint32_t flat_kinds = PAFFY_MASK_LEAN | (1u << PAFFY_FILTER) | (has_shatter_stage ? 0u : 1u << PAFFY_STATS);
-    for (int32_t i = 0; i < n_stages; i++) lean_or_filter = lean_or_filter && ((flat_kinds >> stages[i].kind) & 1u);
+    for (int32_t i = 0; i < n_stages; i++)
+        lean_or_filter = lean_or_filter && (((flat_kinds >> stages[i].kind) & 1u) || (fixed_last && i == n_stages - 1));
     const bool flat = (lean_or_filter && nocheck_mask == 0 && !flat_off) || flat_add;
     {
         int rc = index_and_parse(c, in, len, &n_lines, lvl0_max, flat);
@@ -1495,8 +1498,12 @@ int paffy_hip_plan(paffy_hip_ctx *c, const paffy_stage *stages, int32_t n_stages
         if (ensure(c, c->flat_rec, sizeof(uint32_t) * (size_t)(n_lines + 1))) return PAFFY_E_HIP;
         fs.defer = static_cast<uint32_t *>(c->flat_rec.p);
         /* one lane per record for the records that need little, one wave per record for the rest (a list whose length only the device knows) */
-        LAUNCH(c, "k_flat_lane", k_flat_lane, dim3((n_lines + 255) / 256), dim3(256), 0, fs);
-        LAUNCH(c, "k_flat_size", k_flat_size, dim3(std::min<uint32_t>(2048u, (n_lines + FLAT_SIZE_WAVES - 1) / FLAT_SIZE_WAVES)), dim3(64 * FLAT_SIZE_WAVES), 0, fs);
+        if (fixed_last) { /* one wave per record for all of them */
+            LAUNCH(c, "k_flat_size", k_flat_size<true>, dim3(std::min<uint32_t>(2048u, (n_lines + FLAT_SIZE_WAVES - 1) / FLAT_SIZE_WAVES)), dim3(64 * FLAT_SIZE_WAVES), 0, fs);
+        } else {
+            LAUNCH(c, "k_flat_lane", k_flat_lane, dim3((n_lines + 255) / 256), dim3(256), 0, fs);
+            LAUNCH(c, "k_flat_size", k_flat_size<false>, dim3(std::min<uint32_t>(2048u, (n_lines + FLAT_SIZE_WAVES - 1) / FLAT_SIZE_WAVES)), dim3(64 * FLAT_SIZE_WAVES), 0, fs);
+        }
         if (post_scans()) return PAFFY_E_HIP;
         if (fetch_info(c)) return PAFFY_E_HIP;
         flat_g_count = c->h_info->g_count;

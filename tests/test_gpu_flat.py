@@ -271,3 +271,27 @@ def test_stats_stage_from_the_summaries(eng):
             assert info.error.code == 0 and list(eng.plan_stats()) == oracle_sums(want), pipe
             left, why = eng.flat_stats()
             assert (left == 0) == all_flat, (pipe, left, why)
+
+
+def test_fixed_trim_as_the_last_stage(eng):
+    """`paffy trim -f` (paf_trim_end_fraction + paf_trim_ends, impl/paf.c:578-598) as the last stage of a pipe the flat pass takes: the wave
+    kernel finds the op either cut stops at (flat_find_aligned) and shortens it. Every fraction from nothing to everything, cuts that fall
+    on an op boundary (the indels behind it go too), in the record's only op, in the same op from both ends, behind an invert and an
+    identity trim, = and X ops (aligned bases like M), short and very long records (pieces in registers / scanned in HBM)."""
+    rng = random.Random(21)
+    lines = []
+    for k in range(500):
+        n = rng.choice((1, 1, 2, 3, 4, 9, 40, 150, 700, 2500))
+        lines.append(record(random_ops(rng, n, lens=(1, 2, 3, 10, 11, 99, 100, 101, 999, 1000, 1001), indel=(1, 2, 3, 10)), strand=rng.choice("+-"), rng=rng))
+    lines.append(record(random_ops(rng, 30_000), strand="-", rng=rng))
+    lines.append(record([(10, "M")], rng=rng))
+    lines.append(record([(10, "M"), (3, "I"), (10, "M")], strand="-", rng=rng))
+    lines.append(record([(4, "M"), (2, "D"), (2, "I"), (4, "M"), (1, "I"), (4, "M")], rng=rng))
+    lines.append(record([(5, "="), (2, "X"), (3, "I"), (4, "="), (1, "D"), (6, "M"), (1, "X")], rng=rng))
+    data = "".join(lines).encode()
+    for frac in (0.0, 0.05, 0.1, 0.3333, 0.5, 0.9, 1.0):
+        params = {O.TRIM_FIXED: (0.05, frac)}
+        run_both(eng, data, pipes=([O.TRIM_FIXED], [O.INVERT, O.TRIM_FIXED], [O.TRIM_IDENTITY, O.TRIM_FIXED], [O.INVERT, O.TRIM_IDENTITY, O.PASS, O.TRIM_FIXED]), params=params)
+    left = [x for _, _, (x, _) in STATS[-28:]]
+    assert all(x == 0 for x in left[:24]), left  # fractions up to 0.9: every record stays with the flat pass
+    assert all(0 < x < 300 for x in left[24:]), left  # 1.0: the records it empties go to the record kernels (they write a cg tag without ops)

@@ -16,7 +16,7 @@ def main():
     ap.add_argument("--records", type=int, default=200000)
     ap.add_argument("--mean-ops", type=int, default=2048)
     ap.add_argument("--contigs", type=int, default=24, help="contigs of the synthetic stream (chain: fewer contigs = larger groups)")
-    ap.add_argument("--cmd", default="tile", choices=["tile", "invert", "trim", "shatter", "remove", "filter", "add", "dedupe", "bed", "stats", "chain"])
+    ap.add_argument("--cmd", default="tile", choices=["tile", "invert", "trim", "trimf", "shatter", "remove", "filter", "add", "dedupe", "bed", "stats", "chain"])
     a = ap.parse_args()
     import torch
 
@@ -58,7 +58,7 @@ def main():
             paffy_amd.engine.lib().paffy_hip_dedupe_reset(eng._ctx)
             info = eng.dedupe_plan(buf, nbytes, True)
         else:
-            info = eng.tile_plan(buf, nbytes) if a.cmd == "tile" else eng.plan([paffy_amd.stage(kinds[a.cmd])], buf, nbytes)
+            info = eng.tile_plan(buf, nbytes) if a.cmd == "tile" else eng.plan([paffy_amd.stage(paffy_amd.TRIM_FIXED, 0.05, 0.1) if a.cmd == "trimf" else paffy_amd.stage(kinds[a.cmd])], buf, nbytes)
         out = eng.alloc_out(info.out_bytes)
         eng.emit(out)
         eng.sync()
