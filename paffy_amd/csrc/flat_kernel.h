@@ -571,6 +571,8 @@ __device__ __forceinline__ void flat_trim_prefix(const FlatRec &R, FlatState &s,
  * block is there; for the records of the wave kernel (one in eight on cfg3) it builds the pieces itself as before (row_pieces_lanes).
  */
 #define FLAT_F_ROW_PIECES 0x200000u
+#define FLAT_F_COPY 0x400000u       /* RecPlan flag bit 22: the line's cigar is a stretch of the input text, written by k_emit_copy (wq[0] = first byte from cg_off, wt[0] = bytes) */
+#define FLAT_COPY_MAX (1u << 18)    /* bytes of cigar text one wave copies; longer lines take the writers that split a record */
 #define FLAT_ROW_PIECES_BYTES 144u
 struct LanePieceSink {
     uint32_t (*S)[256];
@@ -1001,7 +1003,7 @@ __global__ __launch_bounds__(256) void k_flat_lane(FlatSizeParams F) {
         if (rewritten && rs.type == 0 && rs.tile_level != -1) rs.type = rs.tile_level > 1 ? 'S' : 'P';
         const FlatPre win = flat_sub(v.whi, v.wlo);
         int64_t bytes, rows;
-        bool rows_kernel = false, line_kernel = false;
+        bool rows_kernel = false, line_kernel = false, copy = false;
         if (shatter) {
             ShatterConst k;
             shatter_consts(rs, k);
@@ -1014,8 +1016,12 @@ __global__ __launch_bounds__(256) void k_flat_lane(FlatSizeParams F) {
             rows_kernel = true;
         } else {
             const uint32_t lenH = header_len(rs, false);
-            if (lenH + 8 > PAFFY_TMPL_MAX || v.n > PAFFY_ROWS_MAX_OPS) break;
-            line_kernel = true;
+            if (lenH + 8 > PAFFY_TMPL_MAX) break;
+            /* a window that is not reversed is a stretch of the record's own cigar text (what the flat pass keeps is text as paf_write
+               would print it: no leading zeros, lengths below 8 192, letters MID=X): the copy writer takes the line */
+            copy = !v.rev && win.text <= FLAT_COPY_MAX;
+            if (!copy && v.n > PAFFY_ROWS_MAX_OPS) break;
+            line_kernel = !copy;
             bytes = (int64_t)lenH + (int64_t)win.text + 1;
             rows = 1;
         }
@@ -1030,9 +1036,13 @@ __global__ __launch_bounds__(256) void k_flat_lane(FlatSizeParams F) {
         plan->lo = v.lo; plan->n = v.n;
         const bool pieces = rows_kernel && P.row_pieces != nullptr;
         plan->flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | 8u | ((uint32_t)rs.type << 8) | (shatter ? 16u : 0u) |
-                      (rows_kernel ? 64u : 0u) | (line_kernel ? 0x10000u : 0u) | 0x40000u | (pieces ? FLAT_F_ROW_PIECES : 0u);
+                      (rows_kernel ? 64u : 0u) | (line_kernel ? 0x10000u : 0u) | 0x40000u | (pieces ? FLAT_F_ROW_PIECES : 0u) | (copy ? FLAT_F_COPY : 0u);
         plan->chunk = ((v.n + 63u) / 64u) | 1u;
         for (int w = 0; w < 4; w++) plan->wq[w] = plan->wt[w] = plan->wo[w] = 0;
+        if (copy) { /* the stretch of text: from this byte of the cigar, this many */
+            plan->wq[0] = (int64_t)v.wlo.text;
+            plan->wt[0] = (int64_t)win.text;
+        }
         if (pieces) lane_row_pieces(s_all, tid, P.row_pieces + (uint64_t)FLAT_ROW_PIECES_BYTES * rec, rs, P.in);
         done = true;
     } while (false);
@@ -1413,7 +1423,7 @@ __device__ __forceinline__ void flat_size_one(const FlatSizeParams &F, uint32_t 
     }
     RecPlan *plan = static_cast<RecPlan *>(P.rec_plan) + rec;
     int64_t bytes, rows;
-    bool rows_kernel = false, line_kernel = false;
+    bool rows_kernel = false, line_kernel = false, copy = false;
     uint32_t row_bytes1 = 0; /* shatter: bytes of a row whose length has one digit */
     const FlatPre win = flat_sub(v.whi, v.wlo);
     if (shatter && !checked && flat_check(s, v)) return flat_leave(F, rec, FLAT_WHY_CHECK); /* every row of a record that passes paf_check passes its own (impl/paf.c:624) */
@@ -1462,7 +1472,9 @@ __device__ __forceinline__ void flat_size_one(const FlatSizeParams &F, uint32_t 
         if (v.n == 0) return flat_leave(F, rec, FLAT_WHY_EMPTY);
         const uint32_t lenH = header_len(rs, false);
         if (lenH > 3 * PAFFY_TMPL_MAX) return flat_leave(F, rec, FLAT_WHY_HEADER_LEN);
-        line_kernel = lenH + 8 <= PAFFY_TMPL_MAX && v.n <= PAFFY_ROWS_MAX_OPS;
+        /* a window that is not reversed, with whole end ops, is a stretch of the record's own cigar text: the copy writer (see k_flat_lane) */
+        copy = lenH + 8 <= PAFFY_TMPL_MAX && !v.rev && (sub_lo | sub_hi) == 0 && win.text <= FLAT_COPY_MAX;
+        line_kernel = !copy && lenH + 8 <= PAFFY_TMPL_MAX && v.n <= PAFFY_ROWS_MAX_OPS;
         bytes = (int64_t)lenH + (int64_t)win.text + 1;
         rows = 1;
         if (FIXED) bytes -= (int64_t)flat_cut_digits(fx_len, fx_amt, v.n == 1u, false); /* the shortened end ops may have lost digits */
@@ -1476,7 +1488,7 @@ __device__ __forceinline__ void flat_size_one(const FlatSizeParams &F, uint32_t 
         item0 = uni(item0);
         if (item0 + n_seg > P.items_cap) return flat_leave(F, rec, FLAT_WHY_ROW_SHAPE); /* cannot happen: the host sizes the list for every op of the text */
     }
-    const bool four_waves = !shatter && !line_kernel;
+    const bool four_waves = !shatter && !line_kernel && !copy;
     if (lane == 0) {
         if (four_waves) atomicAdd(&P.info->g_count, 1u);
         F.flat_done[rec] = 1;
@@ -1488,9 +1500,13 @@ __device__ __forceinline__ void flat_size_one(const FlatSizeParams &F, uint32_t 
         plan->qs = s.qs; plan->qe = s.qe; plan->ts = s.ts; plan->te = s.te; plan->sub_lo = (int64_t)sub_lo; plan->sub_hi = (int64_t)sub_hi;
         plan->lo = v.lo; plan->n = v.n;
         plan->flags = (v.rev ? 1u : 0u) | (v.swp ? 2u : 0u) | (swapped ? 4u : 0u) | 8u | ((uint32_t)rs.type << 8) | (shatter ? 16u : 0u) |
-                      (rows_kernel ? 64u : 0u) | (line_kernel ? 0x10000u : 0u) | 0x40000u | (itemised ? 0x80000u : 0u);
+                      (rows_kernel ? 64u : 0u) | (line_kernel ? 0x10000u : 0u) | 0x40000u | (itemised ? 0x80000u : 0u) | (copy ? FLAT_F_COPY : 0u);
         plan->chunk = four_waves ? (((v.n + 255u) / 256u) | 1u) : (((v.n + 63u) / 64u) | 1u);
         for (int w = 0; w < 4; w++) plan->wq[w] = plan->wt[w] = plan->wo[w] = 0;
+        if (copy) {
+            plan->wq[0] = (int64_t)v.wlo.text;
+            plan->wt[0] = (int64_t)win.text;
+        }
     }
     if (itemised) {
 #pragma unroll 1

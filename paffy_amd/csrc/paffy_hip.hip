@@ -2315,6 +2315,8 @@ int paffy_hip_emit(paffy_hip_ctx *c, void *d_out, int64_t out_cap) {
         if (c->h_info->w_count > 0) LAUNCH(c, "k_arena_emit", k_arena_emit<true>, dim3(2048), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
     } else {
         LAUNCH(c, "k_emit_line", k_emit_line, dim3(kp.n_rec + kp.n_items), dim3(64), PAFFY_LINE_LDS_BYTES, kp);
+        /* the lines of the flat pass whose cigar is a stretch of the input's (a workgroup without such a record ends at once) */
+        if (kp.flat_done && !kp.new_ops) LAUNCH(c, "k_emit_copy", k_emit_copy, dim3(kp.n_rec), dim3(64), PAFFY_COPY_LDS_BYTES, kp);
         if (c->h_info->g_count > 0) LAUNCH(c, "k_emit_lds<line>", k_emit_lds<false>, dim3(kp.n_rec), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
         if (c->h_info->w_count > 0) LAUNCH(c, "k_arena_emit<line>", k_arena_emit<false>, dim3(2048), dim3(PAFFY_NT), PAFFY_EMIT_LDS_BYTES, kp);
     }

@@ -3592,7 +3592,7 @@ __global__ __launch_bounds__(PAFFY_NT, PAFFY_EMIT_OCC) void k_emit_lds(KParams P
     const uint32_t rec = blockIdx.x;
     if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return; /* nothing at or after the first failure */
     if ((P.status[rec] >> 16) != KLASS_LDS) return;
-    if (static_cast<const RecPlan *>(P.rec_plan)[rec].flags & (SHATTER ? (64u | 0x80000u) : (0x10000u | 0x80000u))) return; /* k_emit_rows / k_emit_line has it */
+    if (static_cast<const RecPlan *>(P.rec_plan)[rec].flags & (SHATTER ? (64u | 0x80000u) : (0x10000u | 0x80000u | 0x400000u))) return; /* k_emit_rows / k_emit_line / k_emit_copy has it */
     OpsGlobal ops{emit_ops_of(P, rec, P.meta[rec], static_cast<const RecPlan *>(P.rec_plan)[rec]), emit_ops_half(static_cast<const RecPlan *>(P.rec_plan)[rec])};
 #if defined(PAFFY_ABL) && PAFFY_ABL == 22
     const unsigned long long c0 = clock64(), w0 = wall_clock64();
@@ -3771,6 +3771,77 @@ __global__ __launch_bounds__(64, PAFFY_EMIT_OCC) void k_emit_line(KParams P) {
     __builtin_amdgcn_wave_barrier();
     if (!is_item) we = nl_in_header ? 0u : v.n;
     write_emit_range(v, wb, we, with_header, H, lenH, smem, P.out, (uint64_t)P.out_off[rec] + (with_header ? 0ull : (uint64_t)lenH + (uint64_t)wo));
+}
+
+/*
+ * Copy kernel: one wave per record for the whole-line pipes of the flat pass whose window of ops is not reversed (every pipe's + strand
+ * records; all records when no invert stands in the pipe): the line's cigar is then a stretch of the input's own cigar text -- what the
+ * flat pass keeps is text as paf_write prints it (impl/paf.c:381-385: no leading zeros, lengths below 8 192, letters MID=X) -- with I and D
+ * swapped under an invert (impl/paf.c:469-490). No op is looked at: the header as k_emit_line builds it, then 16 bytes per lane and
+ * step from the text (RecPlan flag bit 22; wq[0] = first byte from the cigar's start, wt[0] = bytes), a newline. k_emit_line formats
+ * 64 ops (176 bytes) in 107 instructions; this moves a kilobyte in about fifty.
+ */
+#define PAFFY_COPY_LDS_BYTES (PAFFY_TMPL_MAX + 64)
+__device__ __forceinline__ uint32_t swap_id4(uint32_t w) { /* 'I' (0x49) <-> 'D' (0x44) in four bytes of cigar text */
+    const uint32_t hit = (~nonzero4(w ^ 0x49494949u) | ~nonzero4(w ^ 0x44444444u)) & 0x80808080u;
+    const uint32_t m = hit >> 7;
+    return w ^ (m | (m << 2) | (m << 3)); /* 0x0d per hit */
+}
+__global__ __launch_bounds__(64, 8) void k_emit_copy(KParams P) {
+    extern __shared__ uint4 smem4[];
+    uint8_t *H = reinterpret_cast<uint8_t *>(smem4);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t rec = P.emit_order ? P.emit_order[blockIdx.x] : blockIdx.x;
+    if (rec >= (uint32_t)(P.info->first_err_key >> 16)) return;
+    if ((P.status[rec] >> 16) != KLASS_LDS) return;
+    const RecPlan &pl = static_cast<const RecPlan *>(P.rec_plan)[rec];
+    if (!(pl.flags & 0x400000u)) return;
+    const RecMeta &m = P.meta[rec];
+    RecState s;
+    load_state(m, s);
+    if (pl.flags & 4u) invert_state(s);
+    s.qs = pl.qs; s.qe = pl.qe; s.ts = pl.ts; s.te = pl.te;
+    s.has_cigar = true;
+    s.type = (uint8_t)(pl.flags >> 8);
+    const uint32_t lenH = header_len_wave(s, false);
+    Piece w{H, 0, PAFFY_TMPL_MAX, false};
+    build_header(w, s, P.in, false);
+    __builtin_amdgcn_wave_barrier();
+    uint8_t *out = P.out + P.out_off[rec];
+    for (uint32_t b = lane * 16u; b < lenH; b += 1024u) {
+        if (b + 16u <= lenH) {
+            *reinterpret_cast<u32x4_unaligned *>(out + b) = *reinterpret_cast<const u32x4 *>(H + b);
+        } else {
+            for (uint32_t k = b; k < lenH; k++) out[k] = H[k];
+        }
+    }
+    const uint8_t *src = P.in + m.cg_off + (uint32_t)pl.wq[0];
+    const uint32_t n = (uint32_t)pl.wt[0];
+    const bool swp = (pl.flags & 2u) != 0;
+    uint8_t *dst = out + lenH;
+    for (uint32_t i0 = 0; i0 < n; i0 += 4096u) { /* four loads of a lane in flight */
+        u32x4 t[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t i = i0 + k * 1024u + lane * 16u;
+            t[k] = u32x4{0, 0, 0, 0};
+            if (i + 16u <= n) t[k] = *reinterpret_cast<const u32x4_unaligned *>(src + i);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t i = i0 + k * 1024u + lane * 16u;
+            if (i + 16u <= n) {
+                if (swp) t[k] = u32x4{swap_id4(t[k].x), swap_id4(t[k].y), swap_id4(t[k].z), swap_id4(t[k].w)};
+                *reinterpret_cast<u32x4_unaligned *>(dst + i) = t[k];
+            } else if (i < n) { /* the text's last bytes */
+                for (uint32_t j = i; j < n; j++) {
+                    const uint8_t c = src[j];
+                    dst[j] = swp ? (c == 'I' ? (uint8_t)'D' : (c == 'D' ? (uint8_t)'I' : c)) : c;
+                }
+            }
+        }
+    }
+    if (lane == 0) dst[n] = '\n';
 }
 
 /* Arena class: records whose ops do not fit LDS; persistent workgroups walk the list. */
