@@ -1473,7 +1473,7 @@ __device__ __forceinline__ void flat_size_one(const FlatSizeParams &F, uint32_t 
         const uint32_t lenH = header_len(rs, false);
         if (lenH > 3 * PAFFY_TMPL_MAX) return flat_leave(F, rec, FLAT_WHY_HEADER_LEN);
         /* a window that is not reversed, with whole end ops, is a stretch of the record's own cigar text: the copy writer (see k_flat_lane) */
-        copy = lenH + 8 <= PAFFY_TMPL_MAX && !v.rev && (sub_lo | sub_hi) == 0 && win.text <= FLAT_COPY_MAX;
+        copy = lenH + 8 <= PAFFY_TMPL_MAX && !v.rev && win.text <= FLAT_COPY_MAX; /* (a fixed trim's shortened end ops are written anew, the stretch between them copied) */
         line_kernel = !copy && lenH + 8 <= PAFFY_TMPL_MAX && v.n <= PAFFY_ROWS_MAX_OPS;
         bytes = (int64_t)lenH + (int64_t)win.text + 1;
         rows = 1;
@@ -1506,6 +1506,19 @@ __device__ __forceinline__ void flat_size_one(const FlatSizeParams &F, uint32_t 
         if (copy) {
             plan->wq[0] = (int64_t)v.wlo.text;
             plan->wt[0] = (int64_t)win.text;
+            if (FIXED && (sub_lo | sub_hi)) {
+                /* the window's first / last op as the cuts left them: new length (0: untouched) and the bytes of its text in the input */
+                auto dl = [](uint32_t x) { return 1u + (x >= 10u) + (x >= 100u) + (x >= 1000u); };
+                const bool one = v.n == 1u;
+                if (fx_amt[0] || (one && fx_amt[1])) {
+                    plan->wq[1] = (int64_t)(fx_len[0] - fx_amt[0] - (one ? fx_amt[1] : 0u));
+                    plan->wq[2] = (int64_t)(dl(fx_len[0]) + 1u);
+                }
+                if (!one && fx_amt[1]) {
+                    plan->wt[1] = (int64_t)(fx_len[1] - fx_amt[1]);
+                    plan->wt[2] = (int64_t)(dl(fx_len[1]) + 1u);
+                }
+            }
         }
     }
     if (itemised) {

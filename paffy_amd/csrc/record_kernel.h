@@ -3816,9 +3816,36 @@ __global__ __launch_bounds__(64, 8) void k_emit_copy(KParams P) {
         }
     }
     const uint8_t *src = P.in + m.cg_off + (uint32_t)pl.wq[0];
-    const uint32_t n = (uint32_t)pl.wt[0];
+    uint32_t n = (uint32_t)pl.wt[0];
     const bool swp = (pl.flags & 2u) != 0;
     uint8_t *dst = out + lenH;
+    /* end ops a fixed trim has shortened (wq[1] / wt[1] = new length of the first / last op, wq[2] / wt[2] = bytes of its text in the
+       input): written anew by lane 0, the stretch between them copied */
+    const uint32_t head_len = (uint32_t)pl.wq[1], head_in = (uint32_t)pl.wq[2], tail_len = (uint32_t)pl.wt[1], tail_in = (uint32_t)pl.wt[2];
+    if (head_len | tail_len) {
+        auto put_op = [&](uint8_t *p, uint32_t len, uint8_t letter) -> uint32_t { /* lengths below 8 192 */
+            const uint32_t d = 1u + (len >= 10u) + (len >= 100u) + (len >= 1000u);
+            uint32_t x = len;
+            for (uint32_t k = d; k-- > 0;) { p[k] = (uint8_t)('0' + x % 10u); x /= 10u; }
+            p[d] = swp ? (letter == 'I' ? (uint8_t)'D' : (letter == 'D' ? (uint8_t)'I' : letter)) : letter;
+            return d + 1u;
+        };
+        uint32_t head_out = 0;
+        if (head_len) {
+            const uint8_t letter = src[head_in - 1u];
+            head_out = 1u + (head_len >= 10u) + (head_len >= 100u) + (head_len >= 1000u) + 1u;
+            if (lane == 0) put_op(dst, head_len, letter);
+        }
+        const uint32_t n_mid = n - head_in - tail_in;
+        if (tail_len && lane == 0) put_op(dst + head_out + n_mid, tail_len, src[n - 1u]);
+        const uint32_t tail_out = tail_len ? 1u + (tail_len >= 10u) + (tail_len >= 100u) + (tail_len >= 1000u) + 1u : 0u;
+        if (lane == 0) dst[head_out + n_mid + tail_out] = '\n';
+        src += head_in;
+        dst += head_out;
+        n = n_mid;
+    } else if (lane == 0) {
+        dst[n] = '\n';
+    }
     for (uint32_t i0 = 0; i0 < n; i0 += 4096u) { /* four loads of a lane in flight */
         u32x4 t[4];
 #pragma unroll
@@ -3841,7 +3868,6 @@ __global__ __launch_bounds__(64, 8) void k_emit_copy(KParams P) {
             }
         }
     }
-    if (lane == 0) dst[n] = '\n';
 }
 
 /* Arena class: records whose ops do not fit LDS; persistent workgroups walk the list. */
