@@ -70,7 +70,10 @@ struct RecPlan {
                        bit7 dropped by a filter, bits 8-15 type, bit16 k_emit_line,
                        bit17 the 4-byte ops live in the arena block arena_off[rec] (rebuilt by add_mismatches), not in the mirror,
                        bit18 the mirror holds 2-byte words (every length below 8192),
-                       bit19 a long shatter record written as EmitItem segments by k_emit_rows */
+                       bit19 a long shatter record written as EmitItem segments by k_emit_rows,
+                       bit20 the 4-byte ops are words of new_ops[] (flat add_mismatches), bit21 the row pieces are in row_pieces[],
+                       bit22 the line's cigar is a stretch of the input's text: k_emit_copy (wq[0] = first byte from cg_off, wt[0] = bytes;
+                       wq[1] / wt[1] = new length of a first / last op a fixed trim shortened, wq[2] / wt[2] = bytes of that op's text) */
     uint32_t chunk; /* ops per lane in the sizing sweep: wave w owns view ops [64*w*chunk, 64*(w+1)*chunk) */
     /* shatter: query / target bases consumed and output bytes produced before each wave's range */
     int64_t wq[4], wt[4], wo[4]; /* four waves: the emit workgroups; a one-wave sizing workgroup fills entry 0 and zeroes the rest */
