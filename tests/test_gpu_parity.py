@@ -236,6 +236,25 @@ def test_integer_columns_at_every_alignment(eng):
         check(eng, PIPES["pass"], lines[0] + tail[:len(tail) - 7 + n], "tag value of %d digits at the end of the text" % n)
 
 
+def test_a_stats_stage_is_a_process_of_its_own(eng):
+    """`paffy view -s` behind another command is a second process: what reaches it has been through `paf_write | paf_parse`, so a record whose
+    cigar a fixed trim has emptied arrives without its cg tag (impl/paf.c:71-73: cigar_parse("") is NULL) -- the output of a pipe with a stats
+    stage equals the oracle's with a pass stage in its place, not the pipe without it (found by the soak, round 4)."""
+    import paffy_amd
+
+    rec = kat_line("q", 100, 0, 5, "+", "t", 100, 0, 4, 4, 5, 60, "2M1I2M", "tp:A:S\tAS:i:35114")
+    keep = kat_line("q2", 100, 0, 50, "-", "t", 100, 0, 48, 48, 50, 60, "20M1I10M1I18M")
+    data = rec + keep
+    trim_all = S(O.TRIM_FIXED, 0.05, 1.0)
+    want_plain, _ = O.run([trim_all], data)
+    want_pass, _ = O.run([trim_all, S(O.PASS)], data)
+    assert want_plain != want_pass and b"cg:Z:\n" in want_plain  # the emptied cigar keeps its tag only without the boundary
+    got, info = eng.run([paffy_amd.Stage(O.TRIM_FIXED, 0.05, 1.0), paffy_amd.stage(paffy_amd.STATS)], data, raise_on_error=False)
+    assert info.error.code == 0 and got == want_pass
+    got, info = eng.run([paffy_amd.Stage(O.TRIM_FIXED, 0.05, 1.0)], data, raise_on_error=False)
+    assert info.error.code == 0 and got == want_plain
+
+
 def test_one_pass_separator_index_follows_the_density(eng):
     """Round 3: from the second batch of a context on the separator index is ONE pass over the text whose buffers are sized by the batch
     before (k_sep_index: tile tickets, decoupled look-back); a denser batch is indexed again with exact sizes. One engine, batches of
